@@ -1,0 +1,616 @@
+// bam_records.hip -- BAM record boundary discovery + column unpack for MI355X (gfx950).
+//
+// Replaces, for the read_bam scan (src/bam_reader.c:722-1038):
+//   htslib sam.c:779-855 bam_read1 (framing + validation), sam.c:675-730 bam_tag2cigar,
+//   sam.c:4124-4134 sam_read1_bam (tid range), sam.c:4785-4855 aux walk (RG lookup), and the
+//   column writers bam_reader.c:785-918 (QNAME..SAMPLE_ID).
+//
+// The inflated BAM stream is a linked list (next = cur + 4 + block_size).  It is cut into
+// fixed TILE-byte tiles; one LANE per tile speculates the first record start inside its tile
+// (same predicates bam_read1 enforces, chained 3 deep) and walks to the tile end.  A fix-up
+// kernel then proves continuity tile-to-tile (end of tile t-1's chain == start of tile t) and
+// re-walks only the tiles whose speculation was wrong, so the result is exact.  Row ids come
+// from a prefix sum of per-tile counts; string columns are written with a length pass +
+// prefix sums + a 16-lanes-per-record write pass.  Integer/byte work only.
+#include "dhts_common.h"
+
+#define REC_OK 0
+#define REC_INVALID 1
+#define REC_INCOMPLETE 2
+#define NONE64 0xffffffffffffffffull
+
+struct BamStream {
+    const uint8_t *u;      // inflated bytes (this batch, carry included)
+    uint64_t ulen;         // valid bytes
+    int32_t n_ref;
+    int32_t final_batch;   // 1: no more data follows (an incomplete tail is a truncation)
+};
+
+__device__ __forceinline__ uint32_t ldu32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// bam_cigar_type (htslib/sam.h:139-148): bit0 = consumes query
+#define CIG_QUERY(op) ((0x3C1A7u >> ((op) << 1)) & 1u)
+
+__device__ __forceinline__ int aux_size(uint8_t t) {
+    switch (t) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    default: return 0;
+    }
+}
+// htslib sam.c:4785-4809 skip_aux.  s points at the type byte.  Returns next tag position
+// (end if exhausted) or NONE64 on corrupt data.
+__device__ uint64_t aux_skip(const uint8_t *u, uint64_t s, uint64_t end) {
+    if (s >= end) return end;
+    uint8_t t = u[s]; ++s;
+    if (t == 'Z' || t == 'H') {
+        while (s < end && u[s] != 0) s++;
+        return s < end ? s + 1 : end;
+    }
+    if (t == 'B') {
+        if (end - s < 5) return NONE64;
+        int sz = aux_size(u[s]); if (u[s] == 'Z' || u[s] == 'H' || u[s] == 'B') sz = u[s];   // aux_type2size returns the letter itself
+        ++s;
+        uint64_t n = ldu32(u + s); s += 4;
+        if (sz == 0 || end - s < (uint64_t)sz * n) return NONE64;
+        return s + (uint64_t)sz * n;
+    }
+    int sz = aux_size(t);
+    if (sz == 0) return NONE64;
+    if (end - s < (uint64_t)sz) return NONE64;
+    return s + sz;
+}
+// htslib sam.c:4834-4855 bam_aux_get: returns offset of the type byte, NONE64 if absent; *bad on corrupt aux.
+__device__ uint64_t aux_find(const uint8_t *u, uint64_t aux, uint64_t end, uint8_t t0, uint8_t t1, bool *bad,
+                             uint64_t skip_beg, uint64_t skip_end) {
+    *bad = false;
+    // [skip_beg, skip_end) = a CG tag removed by bam_tag2cigar (sam.c:716-720); the walk behaves as if spliced out
+    uint64_t eff_len = (end - aux) - (skip_end - skip_beg);
+    if (eff_len <= 2) return NONE64;
+    uint64_t s = aux;
+    if (s == skip_beg) s = skip_end;
+    s += 2;
+    for (;;) {
+        if (u[s - 2] == t0 && u[s - 1] == t1) {
+            uint64_t e = aux_skip(u, s, end);
+            if (e == NONE64) { *bad = true; return NONE64; }
+            if ((u[s] == 'Z' || u[s] == 'H') && u[e - 1] != 0) { *bad = true; return NONE64; }
+            return s;
+        }
+        uint64_t nx = aux_skip(u, s, end);
+        if (nx == NONE64) { *bad = true; return NONE64; }
+        if (nx == skip_beg) nx = skip_end;
+        if (end - nx <= 2) return NONE64;
+        s = nx + 2;
+    }
+}
+
+struct RecInfo {
+    uint32_t block_len, l_qname, n_cigar, flag, mapq;
+    int32_t tid, pos, l_seq, mtid, mpos, tlen;
+    uint64_t cig_off;      // absolute offset of the effective CIGAR (CG-swapped if needed)
+    uint32_t n_cigar_eff;
+    uint64_t cg_beg, cg_end;   // spliced-out CG tag, or (0,0)
+};
+
+// Restates bam_read1's checks.  `full` adds the CIGAR/qlen test, the CG swap and the tid range test.
+__device__ int rec_check(const BamStream &st, uint64_t o, RecInfo &r, bool full) {
+    const uint8_t *u = st.u;
+    if (st.ulen - o < 4) return REC_INCOMPLETE;
+    int32_t block_len = (int32_t)ldu32(u + o);
+    if (block_len < 32) return REC_INVALID;                           // sam.c:794
+    if (st.ulen - o - 4 < 32) return REC_INCOMPLETE;
+    const uint8_t *x = u + o + 4;
+    r.block_len = (uint32_t)block_len;
+    r.tid = (int32_t)ldu32(x); r.pos = (int32_t)ldu32(x + 4);
+    uint32_t x2 = ldu32(x + 8), x3 = ldu32(x + 12);
+    r.mapq = (x2 >> 8) & 0xff; r.l_qname = x2 & 0xff;
+    r.flag = x3 >> 16; r.n_cigar = x3 & 0xffff;
+    r.l_seq = (int32_t)ldu32(x + 16); r.mtid = (int32_t)ldu32(x + 20); r.mpos = (int32_t)ldu32(x + 24); r.tlen = (int32_t)ldu32(x + 28);
+    uint64_t body = (uint64_t)r.block_len - 32;
+    if (r.l_seq < 0 || r.l_qname < 1) return REC_INVALID;             // sam.c:820
+    if (((uint64_t)r.n_cigar << 2) + r.l_qname + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq > body) return REC_INVALID;  // :821-823
+    if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
+    r.cig_off = o + 36 + r.l_qname; r.n_cigar_eff = r.n_cigar; r.cg_beg = r.cg_end = 0;
+    if (!full) {
+        // speculation filter only: cheap header-range sanity (not part of exactness)
+        if (r.tid < -1 || r.tid >= st.n_ref || r.mtid < -1 || r.mtid >= st.n_ref) return REC_INVALID;
+        return REC_OK;
+    }
+    uint64_t end = o + 4 + r.block_len;
+    uint64_t aux = r.cig_off + 4ull * r.n_cigar + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq;
+    // long-CIGAR swap (sam.c:675-730)
+    if (r.n_cigar > 0 && ldu32(u + r.cig_off) == (4u | ((uint32_t)r.l_seq << 4)) && r.tid >= 0 && r.pos >= 0) {
+        bool bad; uint64_t cg = aux_find(u, aux, end, 'C', 'G', &bad, 0, 0);
+        if (cg == NONE64 && bad) return REC_INVALID;
+        if (cg != NONE64 && u[cg] == 'B' && (u[cg + 1] == 'I' || u[cg + 1] == 'i')) {
+            uint32_t cgl = ldu32(u + cg + 2);
+            if (cgl >= r.n_cigar && cgl < (1u << 29)) {
+                r.cig_off = cg + 6; r.n_cigar_eff = cgl; r.cg_beg = cg - 2; r.cg_end = cg + 6 + 4ull * cgl;
+            }
+        }
+    }
+    if (r.n_cigar_eff > 0) {                                           // sam.c:842-852
+        int64_t qlen = 0;
+        for (uint32_t k = 0; k < r.n_cigar_eff; k++) { uint32_t c = ldu32(u + r.cig_off + 4ull * k); if (CIG_QUERY(c & 0xf)) qlen += c >> 4; }
+        if (r.l_seq > 0 && !(r.flag & 4) && qlen != r.l_seq) return REC_INVALID;
+    }
+    if (r.tid >= st.n_ref || r.tid < -1 || r.mtid >= st.n_ref || r.mtid < -1) return REC_INVALID;   // sam.c:4127-4131
+    return REC_OK;
+}
+
+struct TileOut {
+    uint64_t *first;     // first record start in tile (absolute offset in this batch buffer) or NONE64
+    uint64_t *end_next;  // where the chain leaves the tile (start of the first record at/after tile end, or stuck position)
+    uint32_t *count;     // records starting in this tile
+    int32_t *err;        // 0, or 1 = chain stopped on an invalid record at end_next
+};
+
+__device__ void tile_walk(const BamStream &st, uint64_t start, uint64_t tile_end, uint64_t &end_next, uint32_t &count, int &err) {
+    uint64_t o = start; uint32_t c = 0; err = 0;
+    while (o < tile_end) {
+        RecInfo r; int rc = rec_check(st, o, r, true);
+        if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }   // truncated tail = read error (sam.c:790-791,833-835)
+        if (rc == REC_INVALID) { err = 1; break; }
+        c++; o += 4ull + r.block_len;
+    }
+    end_next = o; count = c;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+bam_tile_speculate(BamStream st, uint64_t start0, uint32_t tile_bytes, int64_t ntiles, TileOut out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    uint64_t tb = (uint64_t)t * tile_bytes, te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
+    uint64_t first = NONE64;
+    if (t == 0 && start0 != NONE64) first = start0;
+    else {
+        // a shard that begins mid-stream speculates its very first record too; its tile 0 keeps looking past the tile
+        const uint64_t se = (t == 0) ? st.ulen : te;
+        for (uint64_t o = tb; o < se; o++) {
+            RecInfo r;
+            if (rec_check(st, o, r, false) != REC_OK) continue;
+            // chain two more records (or run off the buffer) before trusting the candidate
+            uint64_t o2 = o + 4ull + r.block_len; bool good = true;
+            for (int k = 0; k < 2 && good; k++) {
+                RecInfo r2; int rc = rec_check(st, o2, r2, false);
+                if (rc == REC_INVALID) good = false;
+                else if (rc == REC_INCOMPLETE) break;
+                else o2 += 4ull + r2.block_len;
+            }
+            if (good) { first = o; break; }
+        }
+    }
+    uint64_t en = NONE64; uint32_t cnt = 0; int err = 0;
+    if (first != NONE64 && first < te) tile_walk(st, first, te, en, cnt, err);
+    else if (first != NONE64) { en = first; }            // t == 0 with start0 beyond the tile
+    out.first[t] = (first != NONE64 && first < te) ? first : NONE64;
+    out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
+}
+
+// One round of continuity proof + repair.  nfixed counts the tiles changed this round.
+extern "C" __global__ void __launch_bounds__(256)
+bam_tile_fix(BamStream st, uint32_t tile_bytes, int64_t ntiles, TileOut out, uint32_t *nfixed) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles || t == 0) return;
+    uint64_t p = *(volatile uint64_t *)&out.end_next[t - 1];
+    if (p == NONE64) return;                             // predecessor unresolved: it is repaired first
+    if (*(volatile int32_t *)&out.err[t - 1]) return;    // chain already stopped before this tile
+    uint64_t tb = (uint64_t)t * tile_bytes, te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
+    if (p >= te && t + 1 < ntiles) {
+        // tile lies inside a record that started earlier
+        if (out.first[t] == NONE64 && out.end_next[t] == p && out.count[t] == 0 && out.err[t] == 0) return;
+        out.first[t] = NONE64; out.count[t] = 0; out.err[t] = 0; out.end_next[t] = p;
+        atomicAdd(nfixed, 1u);
+        return;
+    }
+    if (p >= te) {                                       // last tile, chain already past it
+        if (out.first[t] == NONE64 && out.end_next[t] == p && out.count[t] == 0) return;
+        out.first[t] = NONE64; out.count[t] = 0; out.err[t] = 0; out.end_next[t] = p;
+        atomicAdd(nfixed, 1u);
+        return;
+    }
+    if (out.first[t] == p) return;
+    uint64_t en; uint32_t cnt; int err;
+    tile_walk(st, p, te, en, cnt, err);
+    out.first[t] = p; out.count[t] = cnt; out.err[t] = err; out.end_next[t] = en;
+    atomicAdd(nfixed, 1u);
+}
+
+// Sequential fallback (pathological inputs only): one thread proves/repairs every tile in order.
+extern "C" __global__ void bam_tile_fix_seq(BamStream st, uint32_t tile_bytes, int64_t ntiles, TileOut out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int64_t t = 1; t < ntiles; t++) {
+        if (out.err[t - 1]) return;
+        uint64_t p = out.end_next[t - 1];
+        uint64_t tb = (uint64_t)t * tile_bytes, te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
+        if (p >= te) { out.first[t] = NONE64; out.count[t] = 0; out.err[t] = 0; out.end_next[t] = p; continue; }
+        if (out.first[t] == p) continue;
+        uint64_t en; uint32_t cnt; int err;
+        tile_walk(st, p, te, en, cnt, err);
+        out.first[t] = p; out.count[t] = cnt; out.err[t] = err; out.end_next[t] = en;
+    }
+}
+
+// Single-workgroup finalize: first error tile E, exclusive prefix of counts (cut after E), totals.
+// res[0] = total rows, res[1] = stream position after the last good record (carry start),
+// res[2] = 1 if the chain stopped on an error, res[3] = E (or ntiles)
+extern "C" __global__ void __launch_bounds__(1024)
+bam_tile_finalize(int64_t ntiles, TileOut out, uint32_t *rowbase, uint64_t *res) {
+    __shared__ uint32_t sh[1024];
+    __shared__ unsigned long long shE;
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) { shE = (unsigned long long)ntiles; carry = 0; }
+    __syncthreads();
+    for (int64_t t = tid; t < ntiles; t += 1024) if (out.err[t]) atomicMin(&shE, (unsigned long long)t);
+    __syncthreads();
+    const int64_t E = (int64_t)shE;
+    for (int64_t base = 0; base < ntiles; base += 1024) {
+        int64_t t = base + tid;
+        uint32_t v = (t < ntiles && t <= E) ? out.count[t] : 0;
+        sh[tid] = v; __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) { uint32_t a = (tid >= d) ? sh[tid - d] : 0; __syncthreads(); sh[tid] += a; __syncthreads(); }
+        if (t < ntiles) rowbase[t] = carry + sh[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        res[0] = carry;
+        int64_t last = (E < ntiles) ? E : ntiles - 1;
+        res[1] = out.end_next[last];
+        res[2] = (E < ntiles) ? 1 : 0;
+        res[3] = (uint64_t)E;
+    }
+}
+
+// second walk: record offsets by row id
+extern "C" __global__ void __launch_bounds__(256)
+bam_tile_offsets(BamStream st, uint32_t tile_bytes, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res,
+                 uint32_t *rec_off) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles || (uint64_t)t > res[3]) return;
+    uint64_t o = out.first[t]; if (o == NONE64) return;
+    uint32_t n = out.count[t], row = rowbase[t];
+    for (uint32_t k = 0; k < n; k++) { rec_off[row + k] = (uint32_t)o; o += 4ull + ldu32(st.u + o); }
+}
+
+// ------------------------------------------------------------------------------------
+// column unpack
+// ------------------------------------------------------------------------------------
+struct BamDict {
+    int32_t n_rg;
+    const uint32_t *rg_off;     // n_rg+1 offsets into rg_bytes (@RG ID strings, header order, first ID wins)
+    const uint8_t *rg_bytes;
+};
+
+struct BamCols {
+    // fixed-width, DuckDB physical types (src/bam_reader.c:514-526)
+    uint16_t *flag; int64_t *pos; int32_t *mapq; int64_t *pnext; int64_t *tlen;
+    int32_t *tid, *mtid;        // dictionary ids behind RNAME / RNEXT (names resolved by sam_hdr_tid2name on the host mirror)
+    int32_t *rg_idx;            // dictionary id behind SAMPLE_ID (-1 = NULL)
+    uint64_t *rg_valid;         // validity words of READ_GROUP_ID
+    // var-width: reserved length per row (scanned into offsets) and actual length
+    uint32_t *len_qname, *len_cigar, *len_seq, *len_qual, *len_rg;
+    // per-row scratch for the write pass
+    uint32_t *cig_rel;          // effective CIGAR offset relative to the record start
+    uint32_t *ncig_eff;
+    uint32_t *rg_rel;           // RG value offset relative to the record start
+};
+
+__device__ __forceinline__ uint32_t ndigits(uint32_t v) {
+    return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) + (v >= 10000000) + (v >= 100000000);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+bam_core_unpack(BamStream st, BamDict dict, const uint32_t *rec_off, int64_t nrows, uint32_t colmask, BamCols c) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = row < nrows;
+    bool rgv = false;
+    if (act) {
+        const uint8_t *u = st.u;
+        uint64_t o = rec_off[row];
+        RecInfo r; rec_check(st, o, r, true);
+        c.flag[row] = (uint16_t)r.flag;                            // bam_reader.c:792-796
+        c.pos[row] = (int64_t)r.pos + 1;                           // :807-811
+        c.mapq[row] = (int32_t)r.mapq;                             // :813-817
+        c.pnext[row] = (int64_t)r.mpos + 1;                        // :845-849
+        c.tlen[row] = (int64_t)r.tlen;                             // :851-855
+        c.tid[row] = r.tid; c.mtid[row] = r.mtid;
+        // QNAME: C string up to the first NUL within l_qname bytes (:785-790, sam.c:827-829)
+        uint32_t ql = 0; const uint8_t *qn = u + o + 36;
+        while (ql < r.l_qname && qn[ql] != 0) ql++;
+        c.len_qname[row] = ql;
+        // CIGAR text length (:819-834, cigar_to_kstring 375-383)
+        uint32_t cl = 0;
+        for (uint32_t k = 0; k < r.n_cigar_eff; k++) cl += ndigits(ldu32(u + r.cig_off + 4ull * k) >> 4) + 1;
+        c.len_cigar[row] = r.n_cigar_eff ? cl : 1;
+        c.cig_rel[row] = (uint32_t)(r.cig_off - o); c.ncig_eff[row] = r.n_cigar_eff;
+        // SEQ / QUAL reserved lengths (:857-877)
+        uint64_t seq = o + 36 + r.l_qname + 4ull * r.n_cigar;
+        uint64_t qual = seq + (((uint64_t)r.l_seq + 1) >> 1);
+        c.len_seq[row] = r.l_seq > 0 ? (uint32_t)r.l_seq : 1;
+        c.len_qual[row] = (r.l_seq > 0 && u[qual] != 255) ? (uint32_t)r.l_seq : 1;
+        // READ_GROUP_ID / SAMPLE_ID (:879-918)
+        uint64_t aux = qual + (uint64_t)r.l_seq, end = o + 4ull + r.block_len;
+        bool bad; uint64_t rg = aux_find(u, aux, end, 'R', 'G', &bad, r.cg_beg, r.cg_end);
+        uint32_t rl = 0; int32_t rgi = -1;
+        if (rg != NONE64 && (u[rg] == 'Z' || u[rg] == 'H')) {     // bam_aux2Z sam.c:5134-5141
+            rgv = true;
+            const uint8_t *z = u + rg + 1;
+            while (z[rl] != 0) rl++;
+            for (int32_t k = 0; k < dict.n_rg; k++) {
+                uint32_t a = dict.rg_off[k], b = dict.rg_off[k + 1];
+                if (b - a != rl) continue;
+                bool eq = true;
+                for (uint32_t q = 0; q < rl; q++) if (dict.rg_bytes[a + q] != z[q]) { eq = false; break; }
+                if (eq) { rgi = k; break; }
+            }
+            c.rg_rel[row] = (uint32_t)(rg + 1 - o);
+        } else c.rg_rel[row] = 0;
+        c.len_rg[row] = rl; c.rg_idx[row] = rgi;
+    }
+    uint64_t m = __ballot(rgv);
+    if ((threadIdx.x & 63) == 0 && ((row >> 6) << 6) < nrows) c.rg_valid[row >> 6] = m;
+}
+
+// ---- generic multi-array exclusive scan (u32 in; u32 or u64 out), 3 launches for up to 8 arrays at once ----
+#define SCAN_ITEMS 4096     /* per workgroup: 256 threads x 16 */
+struct ScanArgs { const uint32_t *in[8]; uint32_t *out32[8]; uint64_t *out64[8]; uint64_t *partial[8]; uint64_t *total[8]; int64_t n; int narr; };
+
+extern "C" __global__ void __launch_bounds__(256) scan_reduce(ScanArgs a) {
+    __shared__ uint32_t sh[256];
+    const int arr = blockIdx.y; const uint32_t *in = a.in[arr];
+    int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (int k = 0; k < 16; k++) { int64_t i = base + k * 256 + threadIdx.x; if (i < a.n) s += in[i]; }
+    sh[threadIdx.x] = s; __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) a.partial[arr][blockIdx.x] = sh[0];
+}
+extern "C" __global__ void __launch_bounds__(1024) scan_partials(ScanArgs a, int64_t nparts) {
+    __shared__ uint64_t sh[1024]; __shared__ uint64_t carry;
+    const int arr = blockIdx.x; uint64_t *p = a.partial[arr];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nparts; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        uint64_t v = i < nparts ? p[i] : 0;
+        sh[threadIdx.x] = v; __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) { uint64_t t = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+        if (i < nparts) p[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.total[arr] = carry;
+}
+extern "C" __global__ void __launch_bounds__(256) scan_apply(ScanArgs a) {
+    __shared__ uint32_t sh[256];
+    const int arr = blockIdx.y; const uint32_t *in = a.in[arr]; uint32_t *o32 = a.out32[arr]; uint64_t *o64 = a.out64[arr];
+    int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS + (int64_t)threadIdx.x * 16;
+    uint32_t v[16]; uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { int64_t i = base + k; v[k] = i < a.n ? in[i] : 0; s += v[k]; }
+    sh[threadIdx.x] = s; __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { uint32_t t = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+    uint64_t run = a.partial[arr][blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int64_t i = base + k;
+        if (i <= a.n) { if (o32) o32[i] = (uint32_t)run; if (o64) o64[i] = run; }     // i == n writes the total (off[n])
+        run += v[k];
+    }
+}
+
+// ---- string write pass: 16 lanes per record ----
+struct BamStrOut {
+    const uint32_t *off_qname, *off_cigar, *off_seq, *off_qual, *off_rg;
+    uint8_t *qname, *cigar, *seq, *qual, *rg;
+    uint32_t *alen_qual;     // actual QUAL length (the reference assigns through a NUL-terminated API: byte 223 (+33 == 0) truncates)
+};
+
+__device__ __forceinline__ void group_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int gl) {
+    for (uint32_t b = gl * 16; b < n; b += 256) {
+        if (b + 16 <= n) { uint4 v; __builtin_memcpy(&v, src + b, 16); __builtin_memcpy(dst + b, &v, 16); }
+        else for (uint32_t k = b; k < n; k++) dst[k] = src[k];
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t colmask, BamCols c, BamStrOut s) {
+    const int gl = threadIdx.x & 15;                                  // lane within the 16-lane group
+    int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    bool act = row < nrows;
+    const uint8_t *u = st.u;
+    uint64_t o = act ? rec_off[row] : 0;
+    uint32_t x2 = act ? ldu32(u + o + 12) : 0, x3 = act ? ldu32(u + o + 16) : 0;
+    uint32_t l_qname = x2 & 0xff, n_cigar = x3 & 0xffff;
+    int32_t l_seq = act ? (int32_t)ldu32(u + o + 20) : 0;
+    if (act) {
+        // QNAME
+        group_copy(s.qname + s.off_qname[row], u + o + 36, c.len_qname[row], gl);
+        // READ_GROUP_ID
+        uint32_t rl = c.len_rg[row];
+        if (rl) group_copy(s.rg + s.off_rg[row], u + o + c.rg_rel[row], rl, gl);
+        // SEQ: 4-bit -> "=ACMGRSVTWYHKDBN" (hts.c:260), high nibble first (sam.h:325); 8 packed bytes -> 16 chars per lane
+        const uint8_t *seq = u + o + 36 + l_qname + 4ull * n_cigar;
+        uint8_t *dseq = s.seq + s.off_seq[row];
+        if (l_seq <= 0) { if (gl == 0) dseq[0] = '*'; }
+        else {
+            const uint64_t NT_LO = ((uint64_t)'=') | ((uint64_t)'A' << 8) | ((uint64_t)'C' << 16) | ((uint64_t)'M' << 24) |
+                                   ((uint64_t)'G' << 32) | ((uint64_t)'R' << 40) | ((uint64_t)'S' << 48) | ((uint64_t)'V' << 56);
+            const uint64_t NT_HI = ((uint64_t)'T') | ((uint64_t)'W' << 8) | ((uint64_t)'Y' << 16) | ((uint64_t)'H' << 24) |
+                                   ((uint64_t)'K' << 32) | ((uint64_t)'D' << 40) | ((uint64_t)'B' << 48) | ((uint64_t)'N' << 56);
+            for (uint32_t b = gl * 16; b < (uint32_t)l_seq; b += 256) {
+                uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
+                uint64_t pk; __builtin_memcpy(&pk, seq + (b >> 1), 8);            // may read past the field; the buffer is padded
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    uint32_t byte = (uint32_t)(pk >> (8 * (k >> 1))) & 0xff;
+                    uint32_t nib = (k & 1) ? (byte & 0xf) : (byte >> 4);
+                    uint32_t ch = (uint32_t)(((nib & 8) ? NT_HI : NT_LO) >> (8 * (nib & 7))) & 0xff;
+                    if ((k & 3) == 0) w[k >> 2] = ch; else w[k >> 2] |= ch << (8 * (k & 3));
+                }
+                if (n == 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(dseq + b, &v, 16); }
+                else for (uint32_t k = 0; k < n; k++) dseq[b + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+    }
+    // QUAL (+33), truncated at the first byte that becomes NUL
+    {
+        const uint8_t *qual = u + o + 36 + l_qname + 4ull * n_cigar + (((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) >> 1);
+        uint32_t firstnul = 0xffffffffu;
+        bool star = act && !(l_seq > 0 && qual[0] != 255);
+        uint8_t *dq = act ? s.qual + s.off_qual[row] : nullptr;
+        if (act && star) { if (gl == 0) dq[0] = '*'; }
+        else if (act) {
+            for (uint32_t b = gl * 16; b < (uint32_t)l_seq; b += 256) {
+                uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
+                uint32_t w[4]; __builtin_memcpy(w, qual + b, 16);                  // padded buffer
+                bool z = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t x = w[k];
+                    uint32_t t = ((x & 0x7f7f7f7fu) + 0x21212121u) ^ (x & 0x80808080u);   // bytewise +33 without cross-byte carry
+                    w[k] = t;
+                    z |= (((t - 0x01010101u) & ~t & 0x80808080u) != 0);
+                }
+                if (z) for (uint32_t k = 0; k < n; k++) if (((w[k >> 2] >> (8 * (k & 3))) & 0xff) == 0) { if (firstnul == 0xffffffffu) firstnul = b + k; }
+                if (n == 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(dq + b, &v, 16); }
+                else for (uint32_t k = 0; k < n; k++) dq[b + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { uint32_t t = __shfl_xor(firstnul, d, 64); firstnul = t < firstnul ? t : firstnul; }
+        if (act && gl == 0) s.alen_qual[row] = star ? 1u : (firstnul != 0xffffffffu ? firstnul : (uint32_t)l_seq);
+    }
+    // CIGAR text: 16 ops per pass, group prefix sum of the per-op text widths
+    {
+        uint32_t ne = act ? c.ncig_eff[row] : 0;
+        const uint8_t *cig = u + o + (act ? c.cig_rel[row] : 0);
+        uint8_t *dc = act ? s.cigar + s.off_cigar[row] : nullptr;
+        if (act && ne == 0 && gl == 0) dc[0] = '*';
+        // trip count must be uniform across the 16-lane group (it is: ne is per-row) but groups differ: use max over the wave
+        uint32_t nmax = ne;
+#pragma unroll
+        for (int d = 32; d >= 16; d >>= 1) { uint32_t t = __shfl_xor(nmax, d, 64); nmax = t > nmax ? t : nmax; }
+        uint32_t base = 0;
+        for (uint32_t k0 = 0; k0 < nmax; k0 += 16) {
+            uint32_t k = k0 + gl; bool has = k < ne;
+            uint32_t op = has ? ldu32(cig + 4ull * k) : 0;
+            uint32_t ol = op >> 4, w = has ? ndigits(ol) + 1 : 0;
+            uint32_t inc = w;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { uint32_t t = __shfl_up(inc, d, 16); if (gl >= d) inc += t; }
+            uint32_t tot = __shfl(inc, 15, 16);
+            if (has) {
+                uint32_t p = base + inc - w, nd = w - 1;
+                for (uint32_t q = 0; q < nd; q++) { dc[p + nd - 1 - q] = (uint8_t)('0' + ol % 10); ol /= 10; }
+                const uint64_t CG_LO = ((uint64_t)'M') | ((uint64_t)'I' << 8) | ((uint64_t)'D' << 16) | ((uint64_t)'N' << 24) |
+                                       ((uint64_t)'S' << 32) | ((uint64_t)'H' << 40) | ((uint64_t)'P' << 48) | ((uint64_t)'=' << 56);
+                const uint64_t CG_HI = ((uint64_t)'X') | ((uint64_t)'B' << 8) | 0x3f3f3f3f3f3f0000ull;       // sam.h:112 BAM_CIGAR_STR, '?' beyond
+                uint32_t oc = op & 0xf;
+                dc[p + nd] = (uint8_t)(((oc & 8) ? CG_HI : CG_LO) >> (8 * (oc & 7)));
+            }
+            base += tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BGZF block discovery on resident bytes: signature scan + chain proof
+// ------------------------------------------------------------------------------------
+// One wave owns a 64 KiB span and sweeps it in 1 KiB coalesced pieces (16 B per lane); a lane tests its
+// 16 byte positions for the 4-byte magic with byte-aligns, then the remaining signature bytes on a hit.
+// pass 1 counts per span; pass 2 (after a prefix sum over spans) writes the candidates in file order.
+__device__ __forceinline__ bool bgzf_sig_rest(const uint8_t *p) {
+    // htslib bgzf.c:896-903 check_header == 0 (ID1 ID2 CM FLG.FEXTRA already matched): XLEN==6, 'B','C', SLEN==2
+    return p[10] == 6 && p[11] == 0 && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0;
+}
+__device__ __forceinline__ uint32_t sig_hits16(const uint8_t *d, uint64_t n, uint64_t pos, int lane) {
+    // returns a 16-bit mask of signature starts in [pos, pos+16)
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    if (pos + 16 <= n) { uint4 v = *(const uint4 *)(d + pos); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else for (uint64_t k = pos; k < n && k < pos + 16; k++) w[(k - pos) >> 2] |= (uint32_t)d[k] << (8 * ((k - pos) & 3));
+    uint32_t nx = __shfl_down(w[0], 1, 64);
+    if (lane == 63) { nx = 0; for (uint64_t k = pos + 16; k < n && k < pos + 20; k++) nx |= (uint32_t)d[k] << (8 * (k - pos - 16)); }
+    w[4] = nx;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t lo = w[j >> 2], hi = w[(j >> 2) + 1];
+        uint32_t v = (j & 3) ? ((lo >> (8 * (j & 3))) | (hi << (32 - 8 * (j & 3)))) : lo;
+        if ((v & 0x04ffffffu) == 0x04088b1fu) m |= 1u << j;           // 1f 8b 08, FLG has FEXTRA
+    }
+    uint32_t out = 0;
+    while (m) { int j = __ffs(m) - 1; m &= m - 1; if (pos + j + 18 <= n && bgzf_sig_rest(d + pos + j)) out |= 1u << j; }
+    return out;
+}
+extern "C" __global__ void __launch_bounds__(256)
+bgzf_sig_count(const uint8_t *d, uint64_t n, uint32_t *cnt) {
+    const int lane = threadIdx.x & 63;
+    int64_t span = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t b = (uint64_t)span * 65536;
+    if (b >= n) return;
+    uint32_t c = 0;
+    for (uint64_t p = b; p < b + 65536 && p < n; p += 1024) c += __popc(sig_hits16(d, n, p + lane * 16, lane));
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k, 64);
+    if (lane == 0) cnt[span] = c;
+}
+extern "C" __global__ void __launch_bounds__(256)
+bgzf_sig_write(const uint8_t *d, uint64_t n, const uint32_t *base, uint64_t *cand) {
+    const int lane = threadIdx.x & 63;
+    int64_t span = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t b = (uint64_t)span * 65536;
+    if (b >= n) return;
+    uint32_t w = base[span];
+    for (uint64_t p = b; p < b + 65536 && p < n; p += 1024) {
+        uint32_t m = sig_hits16(d, n, p + lane * 16, lane);
+        uint32_t c = __popc(m), inc = c;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) { uint32_t t = __shfl_up(inc, k, 64); if (lane >= k) inc += t; }
+        uint32_t at = w + inc - c;
+        while (m) { int j = __ffs(m) - 1; m &= m - 1; cand[at++] = p + lane * 16 + j; }
+        w += __shfl(inc, 63, 64);
+    }
+}
+// Sequential restatement of the htslib chain walk (bgzf.c:1155-1236); used only when the parallel proof fails
+// (corrupt or unusual files).  res[0] = number of good blocks, res[1] = status (0 clean end, -1 bad header, -2 short block).
+extern "C" __global__ void bgzf_chain_walk_seq(const uint8_t *d, uint64_t n, uint64_t *coff, uint32_t *clen, uint32_t *isize,
+                                               int64_t cap, int64_t *res) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t o = 0; int64_t k = 0; int64_t status = 0;
+    while (o < n && k < cap) {
+        if (n - o < 18) { status = -1; break; }
+        const uint8_t *p = d + o;
+        if (!(p[0] == 31 && p[1] == 139 && p[2] == 8 && (p[3] & 4) && bgzf_sig_rest(p))) { status = -1; break; }
+        uint32_t bl = ((uint32_t)p[16] | ((uint32_t)p[17] << 8)) + 1;
+        if (bl < 18) { status = -1; break; }
+        if (o + bl > n) { status = -2; break; }
+        coff[k] = o; clen[k] = bl; isize[k] = bl >= 26 ? ldu32(p + bl - 4) : 0;
+        k++; o += bl;
+    }
+    res[0] = k; res[1] = status;
+}
+// chain proof: candidate i must start exactly where candidate i-1 ends; fills the block table.
+// bad[0] counts violations (then the host falls back to a sequential chain walk).
+extern "C" __global__ void __launch_bounds__(256)
+bgzf_chain_check(const uint8_t *d, uint64_t n, const uint64_t *cand, int64_t ncand, uint32_t *clen, uint32_t *isize, uint32_t *bad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand) return;
+    uint64_t o = cand[i];
+    uint32_t bl = ((uint32_t)d[o + 16] | ((uint32_t)d[o + 17] << 8)) + 1;
+    bool ok = true;
+    if (i == 0 && o != 0) ok = false;
+    if (o + bl > n || bl < 26) ok = false;
+    if (ok) { if (i + 1 < ncand) ok = (cand[i + 1] == o + bl); else ok = (o + bl == n); }
+    clen[i] = bl;
+    isize[i] = ok ? ldu32(d + o + bl - 4) : 0;
+    if (!ok) atomicAdd(bad, 1u);
+}

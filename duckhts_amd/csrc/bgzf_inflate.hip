@@ -1,0 +1,472 @@
+// bgzf_inflate.hip -- BGZF block inflate for MI355X (gfx950), written from RFC 1951/1952.
+//
+// Replaces htslib bgzf.c:762-824 (bgzf_uncompress/inflate_block over zlib) and the CRC
+// compare at bgzf.c:793-801.  Two kernels, both integer/bit work:
+//
+//  phase A  bgzf_huff_decode : ONE LANE PER BGZF BLOCK (64 independent DEFLATE streams per
+//           wave64).  Each lane walks its stream with canonical-code arithmetic (no big
+//           LUTs): the 15 left-justified code limits of the literal/length and distance
+//           alphabets live in VGPRs, the sorted symbol lists in LDS ([entry][lane] layout,
+//           ~40 KB per wave => 4 waves per CU).  Output is append-only: literal bytes and
+//           one 32-bit token per LZ77 match.  No loads depend on earlier stores, so lanes
+//           never stall on the LZ77 window.
+//  phase B  bgzf_lz_resolve  : ONE WAVE PER BGZF BLOCK.  Tokens are consumed 64 at a time
+//           (coalesced), wave prefix sums give every token's destination, literals are
+//           placed lane-parallel, matches are replayed by the whole wave in the LDS window
+//           (64 KiB, the full block), then the block is CRC-32'd from LDS (slice-by-4,
+//           per-lane chunks combined with x^(8n) mod P) and flushed to HBM with 16-byte
+//           coalesced stores.
+#include "dhts_common.h"
+
+// ------------------------------------------------------------------------------------
+// phase A
+// ------------------------------------------------------------------------------------
+#define A_LSYM_LO 0                      /* u8  [288][64] */
+#define A_LSYM_HI (A_LSYM_LO + 288 * 64) /* u32 [9][64]   */
+#define A_DSYM (A_LSYM_HI + 9 * 64 * 4)  /* u8  [32][64]  */
+#define A_LBASE (A_DSYM + 32 * 64)       /* u16 [16][64]  */
+#define A_DBASE (A_LBASE + 16 * 64 * 2)  /* u16 [16][64]  */
+#define A_CNT (A_DBASE + 16 * 64 * 2)    /* u16 [16][64]  */
+#define A_LENS (A_CNT + 16 * 64 * 2)     /* u8  [160][64] nibble-packed code lengths */
+#define A_CLSYM (A_LENS + 160 * 64)      /* u8  [32][64]  */
+#define A_LDS_BYTES (A_CLSYM + 32 * 64)
+
+struct BitR {
+    const uint8_t *p;   // stream base (deflate payload start)
+    uint32_t pos;       // next byte to load
+    uint32_t lim;       // bytes that may be touched (payload + trailer)
+    uint64_t buf;
+    uint32_t cnt;
+};
+
+__device__ __forceinline__ uint32_t ld32_guard(const uint8_t *p, uint32_t pos, uint32_t lim) {
+    if (pos + 4 <= lim) { uint32_t v; __builtin_memcpy(&v, p + pos, 4); return v; }
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) if (pos + k < lim) v |= (uint32_t)p[pos + k] << (8 * k);
+    return v;
+}
+__device__ __forceinline__ void br_refill(BitR &b) {
+    if (b.cnt <= 32) { b.buf |= (uint64_t)ld32_guard(b.p, b.pos, b.lim) << b.cnt; b.pos += 4; b.cnt += 32; }
+}
+__device__ __forceinline__ uint32_t br_take(BitR &b, uint32_t n) {   // n <= 32, caller refilled
+    uint32_t v = (uint32_t)b.buf & (uint32_t)((1ull << n) - 1);
+    b.buf >>= n; b.cnt -= n;
+    return v;
+}
+
+// 15 left-justified limits: lim[L-1] = (first_code[L] + count[L]) << (15 - L)
+struct Limits { uint32_t v[15]; };
+
+__device__ __forceinline__ uint32_t code_len(const Limits &lm, uint32_t w15) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 15; i++) c += (w15 >= lm.v[i]) ? 1u : 0u;
+    return c + 1;   // 16 => invalid code
+}
+
+// builds limits (registers) + base table (LDS, [L][lane]) from cnt[L] (LDS); leaves cnt[L] = first
+// symbol index of length L (offs) for the placement pass.  Returns the Kraft remainder `left`
+// (0 complete, >0 incomplete, <0 over-subscribed).
+__device__ __forceinline__ int build_limits(Limits &lm, uint16_t *cnt, uint16_t *base, int lane, int maxlen) {
+    uint32_t first = 0, offs = 0; int left = 1;
+#pragma unroll
+    for (int L = 1; L <= 15; L++) {
+        uint32_t c = (L <= maxlen) ? cnt[L * 64 + lane] : 0;
+        left = (left << 1) - (int)c;
+        base[L * 64 + lane] = (uint16_t)(offs - first);
+        lm.v[L - 1] = (first + c) << (15 - L);
+        if (L <= maxlen) cnt[L * 64 + lane] = (uint16_t)offs;
+        offs += c;
+        first = (first + c) << 1;
+    }
+    return left;
+}
+
+__device__ __forceinline__ uint32_t get_len(const uint8_t *lens, int lane, uint32_t i) {
+    uint32_t b = lens[(i >> 1) * 64 + lane];
+    return (i & 1) ? (b >> 4) : (b & 15);
+}
+__device__ __forceinline__ void set_len(uint8_t *lens, int lane, uint32_t i, uint32_t v) {
+    uint32_t idx = (i >> 1) * 64 + lane;
+    uint32_t b = lens[idx];
+    lens[idx] = (uint8_t)((i & 1) ? ((b & 0x0f) | (v << 4)) : ((b & 0xf0) | v));
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                 uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *lsym_lo = smem + A_LSYM_LO;
+    uint32_t *lsym_hi = (uint32_t *)(smem + A_LSYM_HI);
+    uint8_t *dsym = smem + A_DSYM;
+    uint16_t *lbase = (uint16_t *)(smem + A_LBASE);
+    uint16_t *dbase = (uint16_t *)(smem + A_DBASE);
+    uint16_t *cnt = (uint16_t *)(smem + A_CNT);
+    uint8_t *lens = smem + A_LENS;
+    uint8_t *clsym = smem + A_CLSYM;
+
+    const int lane = threadIdx.x;
+    const int64_t s = (int64_t)blockIdx.x * 64 + lane;
+    if (s >= nblk) return;
+    const int64_t bi = blk0 + s;
+    const uint32_t clen = tab.clen[bi];
+    uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
+    uint32_t *tok = tok_all + (size_t)s * DHTS_TOK_STRIDE;
+
+    BitR br;
+    br.p = comp + tab.coff[bi] + 18;
+    br.pos = 0; br.buf = 0; br.cnt = 0;
+    br.lim = clen >= 18 ? clen - 18 : 0;          // payload + 8-byte trailer are readable
+    const uint32_t payload_bits = clen >= 26 ? (clen - 26) * 8 : 0;
+
+    uint32_t nlit = 0, ntok = 0, outpos = 0, run = 0, litbuf = 0;
+    int status = clen >= 26 ? 0 : DHTS_BLK_ERR_INFLATE;
+    bool last = (status != 0);
+    Limits ll, dl;
+
+#define EMIT_LIT(byte_)                                                                              \
+    do {                                                                                             \
+        if (outpos >= 65536u) { status = DHTS_BLK_ERR_INFLATE; }                                     \
+        else {                                                                                       \
+            litbuf |= (uint32_t)(byte_) << (8 * (nlit & 3)); nlit++; outpos++;                       \
+            if ((nlit & 3) == 0) { *(uint32_t *)(lit + nlit - 4) = litbuf; litbuf = 0; }             \
+            if (++run == DHTS_TOK_PURE) { tok[ntok++] = DHTS_TOK_PURE << 23; run = 0; }              \
+        }                                                                                            \
+    } while (0)
+
+    while (!last && status == 0) {
+        br_refill(br);
+        last = br_take(br, 1) != 0;
+        uint32_t type = br_take(br, 2);
+        if (type == 0) {
+            // ---- stored block ----
+            br_take(br, br.cnt & 7);                         // to byte boundary
+            br_refill(br);
+            uint32_t len = br_take(br, 16);
+            br_refill(br);
+            uint32_t nlen = br_take(br, 16);
+            if ((len ^ 0xffffu) != nlen) { status = DHTS_BLK_ERR_INFLATE; break; }
+            for (uint32_t k = 0; k < len && status == 0; k++) {
+                br_refill(br);
+                uint32_t b = br_take(br, 8);
+                EMIT_LIT(b);
+            }
+            if (br.pos * 8 - br.cnt > payload_bits) status = DHTS_BLK_ERR_INFLATE;
+            continue;
+        }
+        if (type == 3) { status = DHTS_BLK_ERR_INFLATE; break; }
+
+        uint32_t nl, nd;
+        if (type == 1) {
+            // ---- fixed code lengths (RFC 1951 3.2.6) ----
+            nl = 288; nd = 30;
+            for (uint32_t i = 0; i < 288; i++) set_len(lens, lane, i, i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+            for (uint32_t i = 0; i < 30; i++) set_len(lens, lane, 288 + i, 5);
+        } else {
+            // ---- dynamic: code-length code, then the two length vectors (3.2.7) ----
+            br_refill(br);
+            nl = br_take(br, 5) + 257; nd = br_take(br, 5) + 1;
+            uint32_t nc = br_take(br, 4) + 4;
+            if (nl > 286 || nd > 30) { status = DHTS_BLK_ERR_INFLATE; break; }
+            uint32_t cl[19];
+#pragma unroll
+            for (int i = 0; i < 19; i++) cl[i] = 0;
+            {
+                // order 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 -- static indices keep cl[] in VGPRs
+                const int ORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+#pragma unroll
+                for (int i = 0; i < 19; i++) {
+                    if ((i & 7) == 0) br_refill(br);
+                    uint32_t v = (uint32_t)i < nc ? br_take(br, 3) : 0;
+                    cl[ORD[i]] = v;
+                }
+            }
+            // canonical code for the CL alphabet (max length 7)
+            uint32_t ccount[8];
+#pragma unroll
+            for (int L = 0; L < 8; L++) ccount[L] = 0;
+#pragma unroll
+            for (int i = 0; i < 19; i++) {
+#pragma unroll
+                for (int L = 1; L < 8; L++) ccount[L] += (cl[i] == (uint32_t)L) ? 1u : 0u;
+            }
+            uint32_t climit[7], cbase[7], coffs[8];
+            {
+                uint32_t first = 0, offs = 0; int left = 1;
+#pragma unroll
+                for (int L = 1; L <= 7; L++) {
+                    left = (left << 1) - (int)ccount[L];
+                    cbase[L - 1] = offs - first;
+                    climit[L - 1] = (first + ccount[L]) << (7 - L);
+                    coffs[L] = offs;
+                    offs += ccount[L];
+                    first = (first + ccount[L]) << 1;
+                }
+                if (left != 0) { status = DHTS_BLK_ERR_INFLATE; break; }   // CL code must be complete
+            }
+#pragma unroll
+            for (int i = 0; i < 19; i++) {
+#pragma unroll
+                for (int L = 1; L < 8; L++) {
+                    if (cl[i] == (uint32_t)L) { clsym[coffs[L] * 64 + lane] = (uint8_t)i; coffs[L]++; }
+                }
+            }
+            // decode nl+nd code lengths
+            uint32_t idx = 0, total = nl + nd, prev = 0;
+            while (idx < total) {
+                br_refill(br);
+                uint32_t w7 = __brev((uint32_t)br.buf) >> 25;
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) c += (w7 >= climit[i]) ? 1u : 0u;
+                if (c >= 7) { status = DHTS_BLK_ERR_INFLATE; break; }
+                uint32_t L = c + 1;
+                uint32_t cb = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) cb = (c == (uint32_t)i) ? cbase[i] : cb;
+                uint32_t sym = clsym[((cb + (w7 >> (7 - L))) & 31) * 64 + lane];
+                br_take(br, L);
+                if (sym < 16) { set_len(lens, lane, idx++, sym); prev = sym; }
+                else {
+                    uint32_t rep, val = 0;
+                    if (sym == 16) { if (idx == 0) { status = DHTS_BLK_ERR_INFLATE; break; } val = prev; rep = 3 + br_take(br, 2); }
+                    else if (sym == 17) rep = 3 + br_take(br, 3);
+                    else rep = 11 + br_take(br, 7);
+                    if (idx + rep > total) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    for (uint32_t k = 0; k < rep; k++) set_len(lens, lane, idx++, val);
+                    prev = val;
+                }
+            }
+            if (status != 0) break;
+            if (get_len(lens, lane, 256) == 0) { status = DHTS_BLK_ERR_INFLATE; break; }
+        }
+
+        // ---- canonical tables: literal/length ----
+#pragma unroll
+        for (int L = 0; L < 16; L++) cnt[L * 64 + lane] = 0;
+        for (uint32_t i = 0; i < nl; i++) { uint32_t l = get_len(lens, lane, i); cnt[l * 64 + lane]++; }
+        uint32_t nz_l = nl - cnt[0 * 64 + lane];
+        int left = build_limits(ll, cnt, lbase, lane, 15);
+        if (left < 0 || (left > 0 && nz_l != 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
+        for (int k = 0; k < 9; k++) lsym_hi[k * 64 + lane] = 0;
+        for (uint32_t i = 0; i < nl; i++) {
+            uint32_t l = get_len(lens, lane, i);
+            if (l) {
+                uint32_t o = cnt[l * 64 + lane]; cnt[l * 64 + lane] = (uint16_t)(o + 1);
+                lsym_lo[o * 64 + lane] = (uint8_t)i;
+                if (i & 256) lsym_hi[(o >> 5) * 64 + lane] |= 1u << (o & 31);
+            }
+        }
+        // ---- canonical tables: distance ----
+#pragma unroll
+        for (int L = 0; L < 16; L++) cnt[L * 64 + lane] = 0;
+        for (uint32_t i = 0; i < nd; i++) { uint32_t l = get_len(lens, lane, nl + i); cnt[l * 64 + lane]++; }
+        uint32_t nz_d = nd - cnt[0 * 64 + lane];
+        left = build_limits(dl, cnt, dbase, lane, 15);
+        if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
+        for (uint32_t i = 0; i < nd; i++) {
+            uint32_t l = get_len(lens, lane, nl + i);
+            if (l) { uint32_t o = cnt[l * 64 + lane]; cnt[l * 64 + lane] = (uint16_t)(o + 1); dsym[(o & 31) * 64 + lane] = (uint8_t)i; }
+        }
+
+        // ---- symbol loop ----
+        for (;;) {
+            br_refill(br);
+            uint32_t w = __brev((uint32_t)br.buf) >> 17;
+            uint32_t L = code_len(ll, w);
+            if (L > 15) { status = DHTS_BLK_ERR_INFLATE; break; }
+            uint32_t o = (uint32_t)(uint16_t)(lbase[L * 64 + lane] + (uint16_t)(w >> (15 - L)));
+            if (o >= 288) { status = DHTS_BLK_ERR_INFLATE; break; }
+            uint32_t sym = lsym_lo[o * 64 + lane] | (((lsym_hi[(o >> 5) * 64 + lane] >> (o & 31)) & 1u) << 8);
+            br_take(br, L);
+            if (sym < 256) {
+                EMIT_LIT(sym);
+                if (status != 0) break;
+            } else if (sym == 256) {
+                break;
+            } else {
+                uint32_t i = sym - 257;
+                if (i >= 29) { status = DHTS_BLK_ERR_INFLATE; break; }
+                uint32_t eb = (i < 8 || i == 28) ? 0 : (i >> 2) - 1;
+                uint32_t len = (i < 8) ? 3 + i : (i == 28) ? 258 : 3 + ((4 + (i & 3)) << eb);
+                len += br_take(br, eb);
+                br_refill(br);
+                uint32_t wd = __brev((uint32_t)br.buf) >> 17;
+                uint32_t Ld = code_len(dl, wd);
+                if (Ld > 15) { status = DHTS_BLK_ERR_INFLATE; break; }
+                uint32_t od = (uint32_t)(uint16_t)(dbase[Ld * 64 + lane] + (uint16_t)(wd >> (15 - Ld)));
+                if (od >= 30) { status = DHTS_BLK_ERR_INFLATE; break; }
+                uint32_t ds = dsym[od * 64 + lane];
+                br_take(br, Ld);
+                if (ds >= 30) { status = DHTS_BLK_ERR_INFLATE; break; }
+                uint32_t deb = (ds < 4) ? 0 : (ds >> 1) - 1;
+                uint32_t dist = (ds < 4) ? 1 + ds : 1 + ((2 + (ds & 1)) << deb);
+                dist += br_take(br, deb);
+                if (dist > outpos || outpos + len > 65536u) { status = DHTS_BLK_ERR_INFLATE; break; }
+                tok[ntok++] = (run << 23) | ((len - 3) << 15) | (dist - 1);
+                run = 0; outpos += len;
+            }
+            if (br.pos * 8 - br.cnt > payload_bits + 64) { status = DHTS_BLK_ERR_INFLATE; break; }   // ran off the payload
+        }
+        if (status == 0 && br.pos * 8 - br.cnt > payload_bits) status = DHTS_BLK_ERR_INFLATE;
+    }
+    if (nlit & 3) *(uint32_t *)(lit + (nlit & ~3u)) = litbuf;
+    InflateMeta m; m.ntok = ntok; m.nlit = nlit; m.outlen = outpos; m.status = status;
+    meta[s] = m;
+#undef EMIT_LIT
+}
+
+// ------------------------------------------------------------------------------------
+// phase B
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+    return v;
+}
+
+// multiply two polynomials mod the reflected CRC-32 polynomial (bit 31 = x^0)
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        p ^= (b & 0x80000000u) ? a : 0u;
+        a = (a >> 1) ^ ((a & 1u) ? 0xEDB88320u : 0u);
+        b <<= 1;
+    }
+    return p;
+}
+
+#define B_WIN 0                          /* u8 [65536 + 64] */
+#define B_CRCT (65536 + 64)              /* u32 [4][256] slice-by-4 tables */
+#define B_STAGE (B_CRCT + 4096)          /* u8 [1024] literal staging */
+#define B_LDS_BYTES (B_STAGE + 1024)
+
+extern "C" __global__ void __launch_bounds__(64)
+bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
+                const InflateMeta *__restrict__ meta, uint8_t *__restrict__ out, uint64_t out_base,
+                int32_t *__restrict__ blk_status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *win = smem + B_WIN;
+    uint32_t *crct = (uint32_t *)(smem + B_CRCT);
+    uint8_t *stage = smem + B_STAGE;
+    const int lane = threadIdx.x;
+    const int64_t s = blockIdx.x;
+    if (s >= nblk) return;
+    const int64_t bi = blk0 + s;
+    const InflateMeta m = meta[s];
+    const uint32_t isize = tab.isize[bi];
+    const uint32_t clen = tab.clen[bi];
+
+    // slice-by-4 tables (built per workgroup: 4 entries per lane per table)
+    for (int k = lane; k < 256; k += 64) {
+        uint32_t c = (uint32_t)k;
+#pragma unroll
+        for (int j = 0; j < 8; j++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+        crct[k] = c;
+    }
+    __syncthreads();
+    for (int k = lane; k < 256; k += 64) {
+        uint32_t c = crct[k];
+        c = crct[c & 0xff] ^ (c >> 8); crct[256 + k] = c;
+        c = crct[c & 0xff] ^ (c >> 8); crct[512 + k] = c;
+        c = crct[c & 0xff] ^ (c >> 8); crct[768 + k] = c;
+    }
+    __syncthreads();
+
+    int st = m.status;
+    if (st == 0 && m.outlen != isize) st = DHTS_BLK_ERR_ISIZE;   // htslib does not test ISIZE; we flag it
+    if (st != 0) { if (lane == 0) blk_status[bi] = st; return; }
+
+    const uint32_t *tok = tok_all + (size_t)s * DHTS_TOK_STRIDE;
+    const uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
+    uint32_t outpos = 0, litpos = 0;
+
+    for (uint32_t t0 = 0; t0 < m.ntok; t0 += 64) {
+        uint32_t t = (t0 + lane < m.ntok) ? tok[t0 + lane] : 0xffffffffu;
+        uint32_t lrun = (t == 0xffffffffu) ? 0 : (t >> 23);
+        bool pure = (lrun == DHTS_TOK_PURE) || (t == 0xffffffffu);
+        uint32_t mlen = pure ? 0 : ((t >> 15) & 255u) + 3;
+        uint32_t mdist = (t & 0x7fffu) + 1;
+        uint32_t adv_i = wave_incl_scan(lrun + mlen, lane);
+        uint32_t lit_i = wave_incl_scan(lrun, lane);
+        uint32_t tot_adv = __shfl(adv_i, 63, 64), tot_lit = __shfl(lit_i, 63, 64);
+        uint32_t dst = outpos + adv_i - (lrun + mlen);       // where this token's literals start
+        uint32_t lsrc = lit_i - lrun;                        // offset into this batch's literal bytes
+        // literals: stage the batch's literal bytes through LDS in 1 KiB pieces (coalesced), then lane-parallel placement
+        for (uint32_t base = 0; base < tot_lit; base += 1024) {
+            uint32_t nst = tot_lit - base < 1024 ? tot_lit - base : 1024;
+            for (uint32_t k = lane * 4; k < nst; k += 256) {
+                uint32_t v; __builtin_memcpy(&v, lit + litpos + base + k, 4);   // litpos+base+k is 4-aligned only by luck; bytes beyond nlit are padding
+                *(uint32_t *)(stage + k) = v;
+            }
+            __syncthreads();
+            uint32_t lo = lsrc > base ? lsrc : base, hi = lsrc + lrun < base + nst ? lsrc + lrun : base + nst;
+            for (uint32_t q = lo; q < hi; q++) win[dst + (q - lsrc)] = stage[q - base];
+            __syncthreads();
+        }
+        // matches, in stream order, each replayed by the whole wave
+        uint64_t mm = __ballot(mlen > 0);
+        while (mm) {
+            int i = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1;
+            uint32_t d0 = __shfl(dst + lrun, i, 64), l0 = __shfl(mlen, i, 64), di = __shfl(mdist, i, 64);
+            uint32_t src0 = d0 - di;
+            if (l0 <= di) { for (uint32_t k = lane; k < l0; k += 64) win[d0 + k] = win[src0 + k]; }
+            else { for (uint32_t k = lane; k < l0; k += 64) win[d0 + k] = win[src0 + (k % di)]; }
+            __syncthreads();
+        }
+        outpos += tot_adv; litpos += tot_lit;
+    }
+    // trailing literals
+    {
+        uint32_t rem = m.nlit - litpos;
+        for (uint32_t k = lane; k < rem; k += 64) win[outpos + k] = lit[litpos + k];
+        outpos += rem;
+    }
+    __syncthreads();
+    if (outpos != m.outlen) { if (lane == 0) blk_status[bi] = DHTS_BLK_ERR_INFLATE; return; }
+
+    // ---- CRC-32 of win[0..outlen): per-lane chunk, then combine ----
+    const uint32_t n = m.outlen;
+    const uint32_t chunk = ((n + 63) / 64 + 3) & ~3u;          // multiple of 4
+    uint32_t beg = lane * chunk; if (beg > n) beg = n;
+    uint32_t end = beg + chunk; if (end > n) end = n;
+    uint32_t c = (lane == 0) ? 0xffffffffu : 0u;
+    uint32_t q = beg;
+    for (; q + 4 <= end; q += 4) {
+        uint32_t v = *(const uint32_t *)(win + q) ^ c;
+        c = crct[768 + (v & 0xff)] ^ crct[512 + ((v >> 8) & 0xff)] ^ crct[256 + ((v >> 16) & 0xff)] ^ crct[v >> 24];
+    }
+    for (; q < end; q++) c = crct[(c ^ win[q]) & 0xff] ^ (c >> 8);
+    // advance lane's register by the bytes that follow its chunk: multiply by x^(8*after) mod P
+    {
+        uint32_t after = n - end;
+        uint32_t pw = 0x80000000u;                               // x^0
+        uint32_t sq = 0x00800000u;                               // x^8 (reflected: bit 31-8)
+        while (after) {
+            if (after & 1) pw = crc_mulmod(pw, sq);
+            sq = crc_mulmod(sq, sq);
+            after >>= 1;
+        }
+        c = crc_mulmod(c, pw);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
+    c ^= 0xffffffffu;
+    uint32_t want; __builtin_memcpy(&want, comp + tab.coff[bi] + clen - 8, 4);
+    if (c != want) st = DHTS_BLK_ERR_CRC;
+    if (lane == 0) blk_status[bi] = st;
+    if (st != 0) return;
+
+    // ---- flush to the inflated stream: 16-byte coalesced stores over the aligned interior ----
+    uint8_t *dstp = out + (tab.uoff[bi] - out_base);
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dstp & 15)) & 15); if (head > n) head = n;
+    for (uint32_t k = lane; k < head; k += 64) dstp[k] = win[k];
+    uint32_t body = (n - head) & ~15u;
+    for (uint32_t k = lane * 16; k < body; k += 64 * 16) {
+        uint4 v; __builtin_memcpy(&v, win + head + k, 16);
+        *(uint4 *)(dstp + head + k) = v;
+    }
+    for (uint32_t k = head + body + lane; k < n; k += 64) dstp[k] = win[k];
+}

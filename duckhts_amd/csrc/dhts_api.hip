@@ -1,0 +1,670 @@
+// dhts_api.hip -- host side of the thin C ABI (include/duckhts_amd.h): HBM residency, one HIP
+// stream per context (= per GPU), kernel orchestration for BGZF index / inflate / BAM unpack.
+// Single translation unit with the kernels (no -fgpu-rdc needed).
+#include "../../include/duckhts_amd.h"
+#include "bgzf_inflate.hip"
+#include "bam_records.hip"
+
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+
+#define TILE_BYTES 8192u
+#define PAD_BYTES 256u
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) return -1;
+        cap = want; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct dhts_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // resident compressed bytes
+    DevBuf comp; uint64_t comp_len = 0;
+    // block table
+    int64_t n_blocks = 0; int bgzf_status = 0;
+    DevBuf coff, clen, isize, uoff, blk_status;
+    std::vector<uint64_t> h_coff, h_uoff; std::vector<uint32_t> h_clen, h_isize;
+    // inflate scratch
+    DevBuf lit, tok, meta;
+    // inflated stream double buffer (carry moves between them)
+    DevBuf ubuf[2]; int ucur = 0; uint64_t carry_len = 0;
+    // tiles
+    DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed;
+    // rows
+    DevBuf rec_off, c_flag, c_pos, c_mapq, c_pnext, c_tlen, c_tid, c_mtid, c_rgidx, c_rgvalid;
+    DevBuf l_qname, l_cigar, l_seq, l_qual, l_rg, cig_rel, ncig_eff, rg_rel, alen_qual;
+    DevBuf o_qname, o_cigar, o_seq, o_qual, o_rg, scan_partial, scan_total;
+    DevBuf a_qname, a_cigar, a_seq, a_qual, a_rg;
+    // header
+    bool bam_open = false;
+    std::vector<std::string> ref_name; std::vector<const char *> ref_name_p; std::vector<uint32_t> ref_len;
+    std::string text;
+    std::vector<std::string> rg_id, rg_sm; std::vector<char> rg_has_sm; std::vector<const char *> rg_id_p, rg_sm_p;
+    uint64_t first_rec_uoff = 0;
+    DevBuf d_rg_off, d_rg_bytes;
+    // scan position
+    int64_t shard_b0 = 0, shard_b1 = 0;   // block range of this shard
+    int shard_rank = 0, shard_world = 1;
+    int64_t next_block = 0; bool stream_done = false; bool first_batch = true;
+    int64_t halo_limit = 0;
+    // timing
+    bool timing = false;
+    double k_ms[DHTS_K_COUNT] = {0}; int64_t k_n[DHTS_K_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static int fail(dhts_ctx *c, const char *fmt, ...) {
+    char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return -1;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define ENSURE(c, buf, n) do { if ((buf).ensure(n) != 0) return fail(c, "hipMalloc of %zu bytes failed", (size_t)(n)); } while (0)
+
+// ---- kernel timing with HIP events on the context's stream --------------------------------
+static hipEvent_t ev_get(dhts_ctx *c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct KTimer {
+    dhts_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+    KTimer(dhts_ctx *c_, int id_) : c(c_), id(id_) { if (c->timing) { a = ev_get(c); b = ev_get(c); (void)hipEventRecord(a, c->stream); } }
+    ~KTimer() { if (c->timing) { (void)hipEventRecord(b, c->stream); c->pending.push_back({id, {a, b}}); } }
+};
+static void timing_collect(dhts_ctx *c) {
+    for (auto &p : c->pending) {
+        float ms = 0; (void)hipEventSynchronize(p.second.second);
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) { c->k_ms[p.first] += ms; c->k_n[p.first]++; }
+        c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
+    }
+    c->pending.clear();
+}
+
+extern "C" {
+
+int dhts_abi_version(void) { return DHTS_ABI_VERSION; }
+
+int dhts_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+dhts_ctx *dhts_create(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    dhts_ctx *c = new dhts_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    // the LDS-window kernel needs more than the default dynamic LDS limit
+    if (hipFuncSetAttribute((const void *)bgzf_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bgzf_huff_decode, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c; return nullptr;     // no gfx950 code object for this device
+    }
+    return c;
+}
+
+void dhts_destroy(dhts_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    timing_collect(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    DevBuf *all[] = {&c->comp, &c->coff, &c->clen, &c->isize, &c->uoff, &c->blk_status, &c->lit, &c->tok, &c->meta, &c->ubuf[0], &c->ubuf[1],
+                     &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
+                     &c->c_mapq, &c->c_pnext, &c->c_tlen, &c->c_tid, &c->c_mtid, &c->c_rgidx, &c->c_rgvalid, &c->l_qname, &c->l_cigar, &c->l_seq,
+                     &c->l_qual, &c->l_rg, &c->cig_rel, &c->ncig_eff, &c->rg_rel, &c->alen_qual, &c->o_qname, &c->o_cigar, &c->o_seq, &c->o_qual,
+                     &c->o_rg, &c->scan_partial, &c->scan_total, &c->a_qname, &c->a_cigar, &c->a_seq, &c->a_qual, &c->a_rg, &c->d_rg_off, &c->d_rg_bytes};
+    for (auto b : all) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no context (no MI355X device or code object)"; }
+
+static void reset_file_state(dhts_ctx *c) {
+    c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
+    c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
+}
+
+int dhts_open_host(dhts_ctx *c, const void *bytes, uint64_t n) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_file_state(c);
+    ENSURE(c, c->comp, n + PAD_BYTES);
+    HIPCHK(c, hipMemcpyAsync(c->comp.p, bytes, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->comp_len = n;
+    return 0;
+}
+
+int dhts_open_tiled(dhts_ctx *c, const void *head, uint64_t n_head, const void *body, uint64_t n_body, int reps, const void *tail, uint64_t n_tail) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_file_state(c);
+    uint64_t n = n_head + n_body * (uint64_t)reps + n_tail;
+    ENSURE(c, c->comp, n + PAD_BYTES);
+    uint8_t *d = (uint8_t *)c->comp.p;
+    if (n_head) HIPCHK(c, hipMemcpyAsync(d, head, n_head, hipMemcpyHostToDevice, c->stream));
+    if (n_body && reps > 0) {
+        HIPCHK(c, hipMemcpyAsync(d + n_head, body, n_body, hipMemcpyHostToDevice, c->stream));
+        for (int r = 1; r < reps; r++) HIPCHK(c, hipMemcpyAsync(d + n_head + n_body * (uint64_t)r, d + n_head, n_body, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (n_tail) HIPCHK(c, hipMemcpyAsync(d + n_head + n_body * (uint64_t)reps, tail, n_tail, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d + n, 0, PAD_BYTES, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->comp_len = n;
+    return 0;
+}
+
+int dhts_open_path(dhts_ctx *c, const char *path) {
+    if (!c) return -1;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(c, "cannot open %s", path);
+    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
+    uint64_t n = (uint64_t)sb.st_size;
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_file_state(c);
+    if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc failed"); }
+    const size_t CH = 64u << 20;
+    void *pin[2] = {nullptr, nullptr};
+    if (hipHostMalloc(&pin[0], CH) != hipSuccess || hipHostMalloc(&pin[1], CH) != hipSuccess) { close(fd); return fail(c, "hipHostMalloc failed"); }
+    hipEvent_t done[2]; (void)hipEventCreate(&done[0]); (void)hipEventCreate(&done[1]);
+    uint64_t off = 0; int k = 0; bool used[2] = {false, false}; int rc = 0;
+    while (off < n) {
+        if (used[k]) (void)hipEventSynchronize(done[k]);
+        size_t want = (size_t)((n - off) < CH ? (n - off) : CH), got = 0;
+        while (got < want) { ssize_t r = pread(fd, (char *)pin[k] + got, want - got, (off_t)(off + got)); if (r <= 0) { rc = -1; break; } got += (size_t)r; }
+        if (rc) break;
+        if (hipMemcpyAsync((uint8_t *)c->comp.p + off, pin[k], want, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = -1; break; }
+        (void)hipEventRecord(done[k], c->stream); used[k] = true;
+        off += want; k ^= 1;
+    }
+    (void)hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]);
+    (void)hipHostFree(pin[0]); (void)hipHostFree(pin[1]); close(fd);
+    if (rc) return fail(c, "read error on %s", path);
+    c->comp_len = n;
+    return 0;
+}
+
+uint64_t dhts_resident_bytes(const dhts_ctx *c) { return c ? c->comp_len : 0; }
+
+// ---- scans --------------------------------------------------------------------------------
+static int run_scan(dhts_ctx *c, int narr, const uint32_t **in, uint32_t **out32, uint64_t **out64, int64_t n, uint64_t *totals_host) {
+    ScanArgs a; memset(&a, 0, sizeof(a));
+    int64_t nparts = (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS;      // +1: the apply pass also writes off[n]
+    if (nparts < 1) nparts = 1;
+    ENSURE(c, c->scan_partial, (size_t)narr * (size_t)nparts * 8);
+    ENSURE(c, c->scan_total, 8 * 8);
+    for (int k = 0; k < narr; k++) {
+        a.in[k] = in[k]; a.out32[k] = out32 ? out32[k] : nullptr; a.out64[k] = out64 ? out64[k] : nullptr;
+        a.partial[k] = (uint64_t *)c->scan_partial.p + (size_t)k * nparts; a.total[k] = (uint64_t *)c->scan_total.p + k;
+    }
+    a.n = n; a.narr = narr;
+    hipLaunchKernelGGL(scan_reduce, dim3((unsigned)nparts, narr), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(scan_partials, dim3(narr), dim3(1024), 0, c->stream, a, nparts);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nparts, narr), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    if (totals_host) {
+        HIPCHK(c, hipMemcpyAsync(totals_host, c->scan_total.p, 8 * narr, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// ---- BGZF index -------------------------------------------------------------------------------
+int64_t dhts_bgzf_index(dhts_ctx *c) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
+    const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
+    int64_t nspans = (int64_t)((n + 65535) / 65536);
+    DevBuf cnt, base, cand; uint64_t total = 0; int rc = 0;
+    auto cleanup = [&]() { cnt.release(); base.release(); cand.release(); };
+    if (cnt.ensure((size_t)nspans * 4 + 64) || base.ensure((size_t)(nspans + 1) * 4 + 64)) { cleanup(); return fail(c, "hipMalloc failed"); }
+    {
+        KTimer t(c, DHTS_K_SIGSCAN);
+        hipLaunchKernelGGL(bgzf_sig_count, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (uint32_t *)cnt.p);
+    }
+    const uint32_t *in[1] = {(const uint32_t *)cnt.p}; uint32_t *o32[1] = {(uint32_t *)base.p};
+    rc = run_scan(c, 1, in, o32, nullptr, nspans, &total);
+    if (rc) { cleanup(); return -1; }
+    int64_t ncand = (int64_t)total;
+    bool need_seq = (ncand == 0);
+    if (!need_seq) {
+        if (cand.ensure((size_t)ncand * 8) || c->coff.ensure((size_t)ncand * 8) || c->clen.ensure((size_t)ncand * 4) || c->isize.ensure((size_t)ncand * 4) ||
+            c->d_nfixed.ensure(64)) { cleanup(); return fail(c, "hipMalloc failed"); }
+        {
+            KTimer t(c, DHTS_K_SIGSCAN);
+            hipLaunchKernelGGL(bgzf_sig_write, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint32_t *)base.p, (uint64_t *)c->coff.p);
+        }
+        (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
+        hipLaunchKernelGGL(bgzf_chain_check, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint64_t *)c->coff.p, ncand,
+                           (uint32_t *)c->clen.p, (uint32_t *)c->isize.p, (uint32_t *)c->d_nfixed.p);
+        uint32_t bad = 0;
+        if (hipMemcpyAsync(&bad, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return fail(c, "bgzf index sync failed"); }
+        need_seq = bad != 0;
+        c->n_blocks = ncand; c->bgzf_status = 0;
+    }
+    if (need_seq) {
+        // unusual / corrupt container: restate htslib's sequential walk on the device
+        int64_t cap = (int64_t)(n / 26) + 2;
+        if (c->coff.ensure((size_t)cap * 8) || c->clen.ensure((size_t)cap * 4) || c->isize.ensure((size_t)cap * 4) || c->d_res.ensure(64)) { cleanup(); return fail(c, "hipMalloc failed"); }
+        hipLaunchKernelGGL(bgzf_chain_walk_seq, dim3(1), dim3(1), 0, c->stream, d, n, (uint64_t *)c->coff.p, (uint32_t *)c->clen.p, (uint32_t *)c->isize.p, cap, (int64_t *)c->d_res.p);
+        int64_t res[2] = {0, 0};
+        if (hipMemcpyAsync(res, c->d_res.p, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return fail(c, "bgzf index sync failed"); }
+        c->n_blocks = res[0]; c->bgzf_status = (int)res[1];
+    }
+    cleanup();
+    // uoff = exclusive prefix of min(isize, 65536)
+    const int64_t nb = c->n_blocks;
+    ENSURE(c, c->uoff, (size_t)(nb + 1) * 8 + 64);
+    ENSURE(c, c->blk_status, (size_t)(nb + 1) * 4);
+    if (nb > 0) {
+        const uint32_t *in2[1] = {(const uint32_t *)c->isize.p}; uint64_t *o64[1] = {(uint64_t *)c->uoff.p};
+        uint64_t tot2 = 0;
+        if (run_scan(c, 1, in2, nullptr, o64, nb, &tot2)) return -1;
+    } else { uint64_t z = 0; HIPCHK(c, hipMemcpy(c->uoff.p, &z, 8, hipMemcpyHostToDevice)); }
+    c->h_coff.resize(nb); c->h_clen.resize(nb); c->h_isize.resize(nb); c->h_uoff.resize(nb + 1);
+    if (nb) {
+        HIPCHK(c, hipMemcpy(c->h_coff.data(), c->coff.p, nb * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->h_clen.data(), c->clen.p, nb * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->h_isize.data(), c->isize.p, nb * 4, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(c, hipMemcpy(c->h_uoff.data(), c->uoff.p, (nb + 1) * 8, hipMemcpyDeviceToHost));
+    c->shard_b0 = 0; c->shard_b1 = nb; c->shard_rank = 0; c->shard_world = 1;
+    return nb;
+}
+
+int dhts_bgzf_table(const dhts_ctx *c, uint64_t *coff, uint32_t *clen, uint32_t *isize, int64_t cap) {
+    if (!c) return -1;
+    int64_t n = c->n_blocks < cap ? c->n_blocks : cap;
+    if (coff) memcpy(coff, c->h_coff.data(), n * 8);
+    if (clen) memcpy(clen, c->h_clen.data(), n * 4);
+    if (isize) memcpy(isize, c->h_isize.data(), n * 4);
+    return c->bgzf_status;
+}
+
+static BgzfTable dev_table(dhts_ctx *c) {
+    BgzfTable t; t.coff = (const uint64_t *)c->coff.p; t.clen = (const uint32_t *)c->clen.p; t.isize = (const uint32_t *)c->isize.p;
+    t.uoff = (const uint64_t *)c->uoff.p; t.n = c->n_blocks; return t;
+}
+
+// inflate blocks [b0, b0+nb) into `out` (device) so that block b lands at out + (uoff[b] - out_base)
+static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base) {
+    if (nb <= 0) return 0;
+    for (int64_t b = b0; b < b0 + nb; b++) if (c->h_isize[b] > 65536u) return fail(c, "BGZF block %lld claims ISIZE %u > 65536", (long long)b, c->h_isize[b]);
+    ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 64);
+    ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
+    ENSURE(c, c->meta, (size_t)nb * sizeof(InflateMeta));
+    BgzfTable t = dev_table(c);
+    {
+        KTimer tm(c, DHTS_K_HUFF);
+        hipLaunchKernelGGL(bgzf_huff_decode, dim3((unsigned)((nb + 63) / 64)), dim3(64), A_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p);
+    }
+    {
+        KTimer tm(c, DHTS_K_LZ);
+        hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)nb), dim3(64), B_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, out, out_base, (int32_t *)c->blk_status.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int64_t dhts_bgzf_inflate_to_host(dhts_ctx *c, int64_t blk0, int64_t nblk, uint8_t *out, uint64_t cap, int32_t *blk_status) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (blk0 < 0 || nblk < 0 || blk0 + nblk > c->n_blocks) return fail(c, "block range out of bounds");
+    if (nblk == 0) return 0;
+    uint64_t base = c->h_uoff[blk0], total = c->h_uoff[blk0 + nblk] - base;
+    if (total > cap) return fail(c, "output capacity too small (%llu needed)", (unsigned long long)total);
+    ENSURE(c, c->ubuf[0], total + PAD_BYTES);
+    HIPCHK(c, hipMemsetAsync(c->ubuf[0].p, 0, total + PAD_BYTES, c->stream));
+    if (inflate_blocks(c, blk0, nblk, (uint8_t *)c->ubuf[0].p, base)) return -1;
+    HIPCHK(c, hipMemcpyAsync(out, c->ubuf[0].p, total, hipMemcpyDeviceToHost, c->stream));
+    if (blk_status) HIPCHK(c, hipMemcpyAsync(blk_status, (int32_t *)c->blk_status.p + blk0, nblk * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return (int64_t)total;
+}
+
+// ---- BAM header (host mirror of bam_hdr_read + the @RG dictionary) ---------------------------
+static inline uint32_t hle32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static bool is_alpha(char ch) { return (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z'); }
+
+// htslib/header.c:995-1075 + 830-893 + 271-318: any malformed line voids the dictionary
+static void parse_rg_dict(dhts_ctx *c) {
+    c->rg_id.clear(); c->rg_sm.clear(); c->rg_has_sm.clear();
+    const char *text = c->text.data(); size_t len = c->text.size();
+    bool ok = true;
+    if (len < 3) { return; }
+    size_t i = 0;
+    while (ok && i < len - 3 && text[i] != '\0') {
+        const char *h = text + i; size_t rem = len - i;
+        if (h[0] != '@' || !is_alpha(h[1]) || !is_alpha(h[2]) || rem < 3 || h[3] == '\n') { ok = false; break; }
+        bool is_rg = h[1] == 'R' && h[2] == 'G', is_co = h[1] == 'C' && h[2] == 'O';
+        size_t j = 3; std::string id, sm; bool has_id = false, sm_seen = false;
+        if (is_co) {
+            if (rem == 3 || h[3] != '\t') { ok = false; break; }
+            for (j = 4; j < rem && h[j] != '\0' && h[j] != '\n'; j++) {}
+        } else {
+            do {
+                if (j == rem || h[j] != '\t') { ok = false; break; }
+                size_t k = ++j;
+                while (k < rem && h[k] != '\0' && h[k] != '\n' && h[k] != '\t') k++;
+                if (k - j < 3 || h[j + 2] != ':') { ok = false; break; }
+                if (is_rg && h[j] == 'I' && h[j + 1] == 'D' && !has_id) { id.assign(h + j + 3, k - j - 3); has_id = true; }
+                if (is_rg && h[j] == 'S' && h[j + 1] == 'M' && !sm_seen) { sm.assign(h + j + 3, k - j - 3); sm_seen = true; }
+                j = k;
+            } while (j < rem && h[j] != '\0' && h[j] != '\n');
+            if (!ok) break;
+        }
+        if (is_rg) {
+            if (!has_id) { ok = false; break; }
+            bool dup = false; for (auto &e : c->rg_id) if (e == id) dup = true;
+            if (!dup) { c->rg_id.push_back(id); c->rg_sm.push_back(sm); c->rg_has_sm.push_back(sm_seen && !sm.empty()); }
+        }
+        i += j + 1;
+    }
+    if (!ok) { c->rg_id.clear(); c->rg_sm.clear(); c->rg_has_sm.clear(); }
+}
+
+int dhts_bam_open(dhts_ctx *c) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_blocks <= 0) return fail(c, "Failed to read SAM/BAM/CRAM header");
+    // inflate leading blocks until the header is complete
+    int64_t k = c->n_blocks < 4 ? c->n_blocks : 4;
+    std::vector<uint8_t> h; std::vector<int32_t> bs;
+    for (;;) {
+        uint64_t total = c->h_uoff[k];
+        h.resize(total + 16); bs.resize(k);
+        if (dhts_bgzf_inflate_to_host(c, 0, k, h.data(), total, bs.data()) < 0) return -1;
+        uint64_t good = total;
+        for (int64_t b = 0; b < k; b++) if (bs[b] != 0) { good = c->h_uoff[b]; break; }
+        // try to parse
+        bool need_more = false, bad = false; uint64_t p = 0;
+        auto need = [&](uint64_t nbytes) { if (p + nbytes > good) { if (good == total && k < c->n_blocks) need_more = true; else bad = true; return false; } return true; };
+        c->ref_name.clear(); c->ref_len.clear();
+        do {
+            if (!need(8)) break;
+            if (memcmp(h.data(), "BAM\1", 4) != 0) { bad = true; break; }
+            uint32_t l_text = hle32(h.data() + 4); p = 8;
+            if (!need(l_text)) break;
+            c->text.assign((const char *)h.data() + p, l_text); p += l_text;
+            if (!need(4)) break;
+            int32_t n_ref = (int32_t)hle32(h.data() + p); p += 4;
+            if (n_ref < 0) { bad = true; break; }
+            for (int32_t i = 0; i < n_ref; i++) {
+                if (!need(4)) break;
+                int32_t l_name = (int32_t)hle32(h.data() + p); p += 4;
+                if (l_name <= 0) { bad = true; break; }
+                if (!need((uint64_t)l_name + 4)) break;
+                size_t nl = strnlen((const char *)h.data() + p, (size_t)l_name);
+                c->ref_name.emplace_back((const char *)h.data() + p, nl); p += (uint64_t)l_name;
+                c->ref_len.push_back(hle32(h.data() + p)); p += 4;
+            }
+        } while (0);
+        if (bad) return fail(c, "Failed to read SAM/BAM/CRAM header");
+        if (need_more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; }
+        c->first_rec_uoff = p;
+        break;
+    }
+    c->ref_name_p.clear(); for (auto &s : c->ref_name) c->ref_name_p.push_back(s.c_str());
+    parse_rg_dict(c);
+    c->rg_id_p.clear(); c->rg_sm_p.clear();
+    std::vector<uint32_t> off; std::string bytes; off.push_back(0);
+    for (size_t i = 0; i < c->rg_id.size(); i++) {
+        c->rg_id_p.push_back(c->rg_id[i].c_str()); c->rg_sm_p.push_back(c->rg_has_sm[i] ? c->rg_sm[i].c_str() : nullptr);
+        bytes += c->rg_id[i]; off.push_back((uint32_t)bytes.size());
+    }
+    ENSURE(c, c->d_rg_off, off.size() * 4 + 16); ENSURE(c, c->d_rg_bytes, bytes.size() + 16);
+    HIPCHK(c, hipMemcpy(c->d_rg_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    if (!bytes.empty()) HIPCHK(c, hipMemcpy(c->d_rg_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    c->bam_open = true;
+    return dhts_bam_rewind(c);
+}
+
+int dhts_bam_header_get(const dhts_ctx *c, dhts_bam_header *out) {
+    if (!c || !c->bam_open) return -1;
+    out->n_ref = (int32_t)c->ref_name.size(); out->ref_name = c->ref_name_p.data(); out->ref_len = c->ref_len.data();
+    out->text = c->text.data(); out->l_text = (uint32_t)c->text.size();
+    out->n_rg = (int32_t)c->rg_id.size(); out->rg_id = c->rg_id_p.data(); out->rg_sm = c->rg_sm_p.data();
+    out->first_rec_uoff = c->first_rec_uoff;
+    return 0;
+}
+
+int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return -1;
+    // contiguous block ranges balanced by compressed bytes
+    const int64_t nb = c->n_blocks;
+    auto cut = [&](int r) -> int64_t {
+        if (r <= 0) return 0; if (r >= world) return nb;
+        uint64_t target = (uint64_t)((__uint128_t)c->comp_len * (unsigned)r / (unsigned)world);
+        int64_t lo = 0, hi = nb;
+        while (lo < hi) { int64_t mid = (lo + hi) / 2; if (c->h_coff[mid] < target) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    c->shard_rank = rank; c->shard_world = world; c->shard_b0 = cut(rank); c->shard_b1 = cut(rank + 1);
+    return dhts_bam_rewind(c);
+}
+
+int dhts_bam_rewind(dhts_ctx *c) {
+    if (!c) return -1;
+    c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+    return 0;
+}
+
+int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out) {
+    if (!c || !out) return -1;
+    memset(out, 0, sizeof(*out));
+    if (!c->bam_open) return fail(c, "dhts_bam_open not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->stream_done) { out->status = 1; return 0; }
+    if (max_blocks <= 0) max_blocks = 16384;
+    if (max_blocks > 24576) max_blocks = 24576;               // keep every in-batch offset below 2^32
+    const bool sharded_tail = (c->shard_b1 < c->n_blocks);     // later shards exist: our last record may need halo blocks
+    int64_t b0 = c->next_block;
+    int64_t limit = c->shard_b1;
+    bool in_halo = b0 >= c->shard_b1;
+    if (in_halo) limit = c->n_blocks;
+    int64_t nb = limit - b0; if (nb > max_blocks) nb = max_blocks;
+    if (in_halo && nb > 4) nb = 4;
+    if (nb < 0) nb = 0;
+    const bool last_of_stream = (b0 + nb >= c->n_blocks);
+    const uint64_t carry = c->carry_len;
+    const uint64_t inflated = c->h_uoff[b0 + nb] - c->h_uoff[b0];
+    uint64_t ulen = carry + inflated;
+    if (ulen + PAD_BYTES >= (1ull << 32)) return fail(c, "batch too large");
+    DevBuf &ub = c->ubuf[c->ucur];
+    if (ub.cap < ulen + PAD_BYTES) {
+        // grow while preserving the carry bytes at the front
+        DevBuf nbuf; if (nbuf.ensure(ulen + PAD_BYTES)) return fail(c, "hipMalloc failed");
+        if (carry) HIPCHK(c, hipMemcpyAsync(nbuf.p, ub.p, carry, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ub.release(); ub = nbuf;
+    }
+    uint8_t *u = (uint8_t *)ub.p;
+    const uint64_t out_base = c->h_uoff[b0] - carry;          // absolute stream offset of u[0]
+    if (inflate_blocks(c, b0, nb, u, out_base)) return -1;
+    HIPCHK(c, hipMemsetAsync(u + ulen, 0, PAD_BYTES, c->stream));
+    // first bad block (if any) ends the byte stream there (bgzf.c:1241-1291: the read fails)
+    int blk_err = 0;
+    if (nb > 0) {
+        std::vector<int32_t> bs(nb);
+        HIPCHK(c, hipMemcpyAsync(bs.data(), (int32_t *)c->blk_status.p + b0, nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) { blk_err = bs[k]; ulen = carry + (c->h_uoff[b0 + k] - c->h_uoff[b0]); break; }
+    }
+    const bool final_batch = last_of_stream || blk_err != 0 || (last_of_stream && c->bgzf_status != 0);
+    BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0;
+
+    // ---- tiles ----
+    int64_t ntiles = (int64_t)((ulen + TILE_BYTES - 1) / TILE_BYTES); if (ntiles < 1) ntiles = 1;
+    ENSURE(c, c->t_first, ntiles * 8); ENSURE(c, c->t_end, ntiles * 8); ENSURE(c, c->t_count, ntiles * 4); ENSURE(c, c->t_err, ntiles * 4);
+    ENSURE(c, c->t_rowbase, ntiles * 4 + 16); ENSURE(c, c->d_res, 64); ENSURE(c, c->d_nfixed, 64);
+    TileOut to; to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
+    uint64_t start0;
+    if (c->first_batch) start0 = (c->shard_rank == 0) ? c->first_rec_uoff - out_base : NONE64;   // later shards speculate their first record
+    else start0 = 0;                                           // the carry begins on a record boundary
+    if (c->first_batch && c->shard_rank == 0 && c->first_rec_uoff < out_base) return fail(c, "internal: header beyond first batch");
+    uint64_t res[4] = {0, 0, 0, 0};
+    {
+        KTimer tm(c, DHTS_K_TILES);
+        hipLaunchKernelGGL(bam_tile_speculate, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, start0, TILE_BYTES, ntiles, to);
+        int rounds = 0;
+        for (;;) {
+            (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
+            hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (uint32_t *)c->d_nfixed.p);
+            uint32_t nfixed = 0;
+            HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (nfixed == 0) break;
+            if (++rounds > 64) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
+        }
+        hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
+    }
+    HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
+    uint64_t first0 = NONE64;
+    HIPCHK(c, hipMemcpyAsync(&first0, c->t_first.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t nrows = (int64_t)res[0]; uint64_t carry_start = res[1]; const bool rec_err = res[2] != 0;
+    if (carry_start == NONE64) carry_start = ulen;             // nothing recognisable in this batch
+
+    // sharding: rows belong to this shard iff their record STARTS before the shard's end in the inflated stream
+    uint64_t shard_end_u = sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
+    bool shard_finished = false;
+    (void)first0;
+
+    // ---- rows ----
+    if (nrows > 0) {
+        ENSURE(c, c->rec_off, nrows * 4 + 16);
+        {
+            KTimer tm(c, DHTS_K_TILES);
+            hipLaunchKernelGGL(bam_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to,
+                               (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p, (uint32_t *)c->rec_off.p);
+        }
+        if (sharded_tail && out_base + ulen > shard_end_u) {
+            // drop rows whose record starts at/after the shard end (they belong to the next shard): binary search on rec_off
+            std::vector<uint32_t> ro(nrows);
+            HIPCHK(c, hipMemcpyAsync(ro.data(), c->rec_off.p, nrows * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            uint64_t lim = shard_end_u - out_base;
+            int64_t lo = 0, hi = nrows;
+            while (lo < hi) { int64_t mid = (lo + hi) / 2; if (ro[mid] < lim) lo = mid + 1; else hi = mid; }
+            if (lo < nrows) { carry_start = ro[lo]; nrows = lo; shard_finished = true; }
+            else if (carry_start >= lim) shard_finished = true;
+        }
+    }
+    if (nrows > 0) {
+        size_t n = (size_t)nrows;
+        ENSURE(c, c->c_flag, n * 2 + 16); ENSURE(c, c->c_pos, n * 8); ENSURE(c, c->c_mapq, n * 4); ENSURE(c, c->c_pnext, n * 8); ENSURE(c, c->c_tlen, n * 8);
+        ENSURE(c, c->c_tid, n * 4); ENSURE(c, c->c_mtid, n * 4); ENSURE(c, c->c_rgidx, n * 4); ENSURE(c, c->c_rgvalid, (n / 64 + 2) * 8);
+        ENSURE(c, c->l_qname, n * 4 + 16); ENSURE(c, c->l_cigar, n * 4 + 16); ENSURE(c, c->l_seq, n * 4 + 16); ENSURE(c, c->l_qual, n * 4 + 16); ENSURE(c, c->l_rg, n * 4 + 16);
+        ENSURE(c, c->cig_rel, n * 4); ENSURE(c, c->ncig_eff, n * 4); ENSURE(c, c->rg_rel, n * 4); ENSURE(c, c->alen_qual, n * 4);
+        ENSURE(c, c->o_qname, (n + 1) * 4 + 16); ENSURE(c, c->o_cigar, (n + 1) * 4 + 16); ENSURE(c, c->o_seq, (n + 1) * 4 + 16); ENSURE(c, c->o_qual, (n + 1) * 4 + 16); ENSURE(c, c->o_rg, (n + 1) * 4 + 16);
+        BamDict dict; dict.n_rg = (int32_t)c->rg_id.size(); dict.rg_off = (const uint32_t *)c->d_rg_off.p; dict.rg_bytes = (const uint8_t *)c->d_rg_bytes.p;
+        BamCols bc; bc.flag = (uint16_t *)c->c_flag.p; bc.pos = (int64_t *)c->c_pos.p; bc.mapq = (int32_t *)c->c_mapq.p; bc.pnext = (int64_t *)c->c_pnext.p;
+        bc.tlen = (int64_t *)c->c_tlen.p; bc.tid = (int32_t *)c->c_tid.p; bc.mtid = (int32_t *)c->c_mtid.p; bc.rg_idx = (int32_t *)c->c_rgidx.p;
+        bc.rg_valid = (uint64_t *)c->c_rgvalid.p; bc.len_qname = (uint32_t *)c->l_qname.p; bc.len_cigar = (uint32_t *)c->l_cigar.p; bc.len_seq = (uint32_t *)c->l_seq.p;
+        bc.len_qual = (uint32_t *)c->l_qual.p; bc.len_rg = (uint32_t *)c->l_rg.p; bc.cig_rel = (uint32_t *)c->cig_rel.p; bc.ncig_eff = (uint32_t *)c->ncig_eff.p; bc.rg_rel = (uint32_t *)c->rg_rel.p;
+        {
+            KTimer tm(c, DHTS_K_CORE);
+            hipLaunchKernelGGL(bam_core_unpack, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, dict, (const uint32_t *)c->rec_off.p, nrows, colmask, bc);
+        }
+        const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
+        uint32_t *o32[5] = {(uint32_t *)c->o_qname.p, (uint32_t *)c->o_cigar.p, (uint32_t *)c->o_seq.p, (uint32_t *)c->o_qual.p, (uint32_t *)c->o_rg.p};
+        uint64_t tot[5] = {0, 0, 0, 0, 0};
+        {
+            KTimer tm(c, DHTS_K_SCAN);
+            if (run_scan(c, 5, in, o32, nullptr, nrows, nullptr)) return -1;
+        }
+        HIPCHK(c, hipMemcpyAsync(tot, c->scan_total.p, 40, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ENSURE(c, c->a_qname, tot[0] + PAD_BYTES); ENSURE(c, c->a_cigar, tot[1] + PAD_BYTES); ENSURE(c, c->a_seq, tot[2] + PAD_BYTES);
+        ENSURE(c, c->a_qual, tot[3] + PAD_BYTES); ENSURE(c, c->a_rg, tot[4] + PAD_BYTES);
+        BamStrOut so; so.off_qname = o32[0]; so.off_cigar = o32[1]; so.off_seq = o32[2]; so.off_qual = o32[3]; so.off_rg = o32[4];
+        so.qname = (uint8_t *)c->a_qname.p; so.cigar = (uint8_t *)c->a_cigar.p; so.seq = (uint8_t *)c->a_seq.p; so.qual = (uint8_t *)c->a_qual.p; so.rg = (uint8_t *)c->a_rg.p;
+        so.alen_qual = (uint32_t *)c->alen_qual.p;
+        {
+            KTimer tm(c, DHTS_K_STRINGS);
+            hipLaunchKernelGGL(bam_string_write, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, colmask, bc, so);
+        }
+        HIPCHK(c, hipGetLastError());
+        out->flag = bc.flag; out->pos = bc.pos; out->mapq = bc.mapq; out->pnext = bc.pnext; out->tlen = bc.tlen; out->tid = bc.tid; out->mtid = bc.mtid;
+        out->rg_idx = bc.rg_idx; out->rg_valid = bc.rg_valid;
+        out->qname = {o32[0], bc.len_qname, so.qname, tot[0]};
+        out->cigar = {o32[1], bc.len_cigar, so.cigar, tot[1]};
+        out->seq = {o32[2], bc.len_seq, so.seq, tot[2]};
+        out->qual = {o32[3], so.alen_qual, so.qual, tot[3]};
+        out->rg = {o32[4], bc.len_rg, so.rg, tot[4]};
+    }
+    out->n_rows = nrows;
+    out->end_uoff = out_base + carry_start;
+    {
+        uint64_t f = NONE64;
+        if (nrows > 0) { uint32_t r0 = 0; HIPCHK(c, hipMemcpyAsync(&r0, c->rec_off.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); f = out_base + r0; }
+        out->first_rec_uoff = f;
+    }
+    // ---- advance ----
+    c->first_batch = false;
+    c->next_block = b0 + nb;
+    if (rec_err || blk_err) { c->stream_done = true; out->status = blk_err ? blk_err * 100 : -4; }
+    else if (shard_finished) { c->stream_done = true; out->status = 1; }
+    else if (last_of_stream) { c->stream_done = true; out->status = (c->bgzf_status != 0) ? c->bgzf_status : 1; if (carry_start < ulen && out->status == 1) out->status = -4; }
+    else {
+        // move the incomplete tail to the front of the other buffer
+        uint64_t tail = ulen - carry_start;
+        DevBuf &nx = c->ubuf[c->ucur ^ 1];
+        ENSURE(c, nx, tail + PAD_BYTES);
+        if (tail) HIPCHK(c, hipMemcpyAsync(nx.p, u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream));
+        c->carry_len = tail; c->ucur ^= 1;
+        if (b0 + nb >= c->shard_b1 && !sharded_tail) { /* unreachable: last_of_stream handled above */ }
+        if (in_halo && tail == 0) { c->stream_done = true; out->status = 1; }
+        if (b0 + nb >= c->shard_b1 && sharded_tail && tail == 0) { c->stream_done = true; out->status = 1; }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+
+int dhts_memcpy_d2h(dhts_ctx *c, void *dst, const void *src_dev, uint64_t n) {
+    if (!c) return -1;
+    if (n == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src_dev, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dhts_sync(dhts_ctx *c) { if (!c) return -1; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); timing_collect(c); return 0; }
+
+double dhts_kernel_time_ms(const dhts_ctx *c, int id, int64_t *launches) {
+    if (!c || id < 0 || id >= DHTS_K_COUNT) return 0.0;
+    if (launches) *launches = c->k_n[id];
+    return c->k_ms[id];
+}
+void dhts_kernel_time_reset(dhts_ctx *c) { if (!c) return; for (int i = 0; i < DHTS_K_COUNT; i++) { c->k_ms[i] = 0; c->k_n[i] = 0; } }
+void dhts_set_timing(dhts_ctx *c, int enabled) { if (c) c->timing = enabled != 0; }
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+/*
+ * duckhts_amd.h -- thin C ABI between host code and the MI355X (gfx950) HIP scan path.
+ *
+ * This is the "inner" boundary named by the north star ("host C code calls hand-written HIP
+ * kernels through a thin C-ABI").  The reference has no such seam of its own: its scan
+ * callbacks call htslib directly.  Each entry point below names the reference interface whose
+ * work it takes over (paths relative to the reference tree; htslib/ = third_party/htslib/):
+ *
+ *   dhts_open_* / dhts_bgzf_index   <- hts_open/bgzf_open + the BSIZE chain walk inside
+ *                                      bgzf_read_block              htslib/bgzf.c:1155-1236
+ *   dhts_bgzf_inflate_to_host       <- inflate_block/bgzf_uncompress + CRC-32 compare
+ *                                                                    htslib/bgzf.c:762-824
+ *   dhts_bam_open / dhts_bam_header <- sam_hdr_read -> bam_hdr_read  htslib/sam.c:229-342
+ *                                      (+ @RG ID->SM dictionary: header.c:271-318, 2282-2312)
+ *   dhts_bam_next_batch             <- the loop body of bam_read_function
+ *                                      src/bam_reader.c:747-1035 over bam_read1 sam.c:779-855,
+ *                                      sam_read1_bam sam.c:4124-4134, bam_aux_get sam.c:4834-4855
+ *
+ * The "outer" drop-in boundary (DuckDB C-API extension entry point duckhts_init_c_api and the
+ * read_bam bind/init/local_init/scan callbacks, src/duckhts.c:48-93, src/bam_reader.c:1044-1068)
+ * is declared in duckhts_extension.h and implemented on top of this ABI.
+ *
+ * All pointers are plain; no torch / HIP types cross the boundary.  Every function fails
+ * loudly (non-zero return + dhts_error()) when no MI355X device / code object is available:
+ * there is no CPU fallback.
+ */
+#ifndef DUCKHTS_AMD_H
+#define DUCKHTS_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHTS_ABI_VERSION 1
+
+typedef struct dhts_ctx dhts_ctx;
+
+/* read_bam core column ids, same order as src/bam_reader.c:187-202 */
+enum {
+    DHTS_BAM_QNAME = 0, DHTS_BAM_FLAG, DHTS_BAM_RNAME, DHTS_BAM_POS, DHTS_BAM_MAPQ, DHTS_BAM_CIGAR, DHTS_BAM_RNEXT,
+    DHTS_BAM_PNEXT, DHTS_BAM_TLEN, DHTS_BAM_SEQ, DHTS_BAM_QUAL, DHTS_BAM_READ_GROUP_ID, DHTS_BAM_SAMPLE_ID,
+    DHTS_BAM_CORE_COUNT
+};
+#define DHTS_BAM_ALL_COLS ((1u << DHTS_BAM_CORE_COUNT) - 1u)
+
+/* variable-width column in device memory: row i = bytes[off[i] .. off[i]+len[i])            */
+typedef struct {
+    const uint32_t *off;     /* n+1 offsets (prefix sum of reserved widths)                    */
+    const uint32_t *len;     /* n actual lengths (<= reserved)                                 */
+    const uint8_t *bytes;
+    uint64_t nbytes;         /* off[n]                                                          */
+} dhts_strcol;
+
+/* One decoded batch.  All pointers are DEVICE pointers owned by the context and stay valid
+ * until the next dhts_bam_next_batch / dhts_bam_rewind / dhts_destroy on that context.        */
+typedef struct {
+    int64_t n_rows;
+    int32_t status;          /* 0 = more data may follow, 1 = end of stream reached cleanly,
+                                <0 = the stream ended on an error after these rows (the
+                                reference ends the scan silently: bam_reader.c:754-766)        */
+    int32_t reserved;
+    const uint16_t *flag;    /* FLAG  USMALLINT */
+    const int64_t *pos;      /* POS   BIGINT (1-based) */
+    const int32_t *mapq;     /* MAPQ  INTEGER */
+    const int64_t *pnext;    /* PNEXT BIGINT */
+    const int64_t *tlen;     /* TLEN  BIGINT */
+    const int32_t *tid;      /* dictionary id behind RNAME (-1 => "*") */
+    const int32_t *mtid;     /* dictionary id behind RNEXT (-1 => "*") */
+    const int32_t *rg_idx;   /* dictionary id behind SAMPLE_ID (index into header @RG table, -1 => NULL) */
+    const uint64_t *rg_valid;/* validity words of READ_GROUP_ID (bit = 1 valid) */
+    dhts_strcol qname, cigar, seq, qual, rg;
+    uint64_t first_rec_uoff; /* absolute inflated-stream offset of the first row's record        */
+    uint64_t end_uoff;       /* absolute inflated-stream offset just past the last row's record  */
+} dhts_bam_batch;
+
+/* Host copy of the BAM header dictionaries (pointers owned by the context).                   */
+typedef struct {
+    int32_t n_ref;
+    const char *const *ref_name;   /* NUL-terminated, as sam_hdr_tid2name would return          */
+    const uint32_t *ref_len;
+    const char *text; uint32_t l_text;
+    int32_t n_rg;                  /* distinct @RG IDs, header order                             */
+    const char *const *rg_id;
+    const char *const *rg_sm;      /* NULL when the @RG has no (non-empty) SM                    */
+    uint64_t first_rec_uoff;       /* inflated offset of the first alignment record              */
+} dhts_bam_header;
+
+/* kernel ids for dhts_kernel_time */
+enum { DHTS_K_SIGSCAN = 0, DHTS_K_HUFF, DHTS_K_LZ, DHTS_K_TILES, DHTS_K_CORE, DHTS_K_SCAN, DHTS_K_STRINGS, DHTS_K_COUNT };
+
+int dhts_abi_version(void);
+int dhts_device_count(void);                       /* number of visible HIP devices (0 => nothing will work) */
+dhts_ctx *dhts_create(int device_id);              /* NULL if the device / code object is unavailable */
+void dhts_destroy(dhts_ctx *);
+const char *dhts_error(const dhts_ctx *);          /* last error message ("" if none) */
+
+/* ---- input: compressed bytes become resident in HBM -------------------------------------- */
+int dhts_open_path(dhts_ctx *, const char *path);                  /* pread -> pinned -> HBM */
+int dhts_open_host(dhts_ctx *, const void *bytes, uint64_t n);     /* copy host bytes -> HBM */
+int dhts_open_tiled(dhts_ctx *, const void *head, uint64_t n_head, const void *body, uint64_t n_body, int reps,
+                    const void *tail, uint64_t n_tail);            /* HBM = head + body x reps + tail (benchmark helper) */
+uint64_t dhts_resident_bytes(const dhts_ctx *);
+
+/* ---- BGZF -------------------------------------------------------------------------------- */
+int64_t dhts_bgzf_index(dhts_ctx *);               /* block discovery on resident bytes; returns n_blocks or <0 */
+int dhts_bgzf_table(const dhts_ctx *, uint64_t *coff, uint32_t *clen, uint32_t *isize, int64_t cap);  /* host copies */
+/* inflate blocks [blk0, blk0+nblk) and copy the concatenated payload to host (parity tests) */
+int64_t dhts_bgzf_inflate_to_host(dhts_ctx *, int64_t blk0, int64_t nblk, uint8_t *out, uint64_t cap, int32_t *blk_status);
+
+/* ---- read_bam ------------------------------------------------------------------------------ */
+int dhts_bam_open(dhts_ctx *);                                     /* header + dictionaries; positions the scan at the first record */
+int dhts_bam_header_get(const dhts_ctx *, dhts_bam_header *out);
+int dhts_bam_set_shard(dhts_ctx *, int rank, int world);           /* scan only this rank's BGZF block range */
+int dhts_bam_rewind(dhts_ctx *);
+int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
+
+/* ---- utilities ------------------------------------------------------------------------------ */
+int dhts_memcpy_d2h(dhts_ctx *, void *dst, const void *src_dev, uint64_t n);
+int dhts_sync(dhts_ctx *);
+/* accumulated device time of one kernel family, measured with HIP events on the context's stream */
+double dhts_kernel_time_ms(const dhts_ctx *, int kernel_id, int64_t *launches);
+void dhts_kernel_time_reset(dhts_ctx *);
+void dhts_set_timing(dhts_ctx *, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

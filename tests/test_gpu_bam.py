@@ -1,0 +1,199 @@
+"""GPU parity tests proper: the HIP scan path (through the C ABI) vs the oracle, bit-exact."""
+import struct
+
+import numpy as np
+import pytest
+
+import cases
+import duckhts_amd
+import orc
+from conftest import read_golden
+
+pytestmark = pytest.mark.gpu
+
+COLS = duckhts_amd.BAM_COLUMNS
+
+
+def assert_same(got, exp, ctx=""):
+    assert got["n_rows"] == exp["n_rows"], f"{ctx}: rows {got['n_rows']} != {exp['n_rows']}"
+    assert (got["status"] < 0) == (exp["status"] < 0), f"{ctx}: status {got['status']} vs {exp['status']}"
+    for k in COLS:
+        a, b = got[k], exp[k]
+        if isinstance(b, np.ndarray):
+            assert np.array_equal(np.asarray(a), b), f"{ctx}: column {k} differs"
+        else:
+            if list(a) != list(b):
+                for i, (x, y) in enumerate(zip(a, b)):
+                    assert x == y, f"{ctx}: column {k} row {i}: {x!r} != {y!r}"
+                raise AssertionError(f"{ctx}: column {k} length differs")
+
+
+# ---- BGZF: block discovery + inflate + CRC ----
+
+@pytest.mark.parametrize("name", ["range.bam", "bgzf_boundaries1.bam", "bgzf_boundaries3.bam", "vcf_file.bcf", "colons.bam"])
+def test_bgzf_inflate_golden(name):
+    d = read_golden(name)
+    z = orc.bgzf_inflate_all(d)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(d)
+    nb = ctx.bgzf_index()
+    assert nb == z["n_blocks"]
+    coff, clen, isize, st = ctx.bgzf_table(nb)
+    assert st == 0
+    assert np.array_equal(coff.astype(np.int64), z["coff"]) and np.array_equal(clen.astype(np.int32), z["clen"])
+    assert np.array_equal(isize.astype(np.int32), z["ulen"])
+    out, bst = ctx.bgzf_inflate(0, nb, len(z["data"]))
+    assert np.all(bst == 0)
+    assert out.tobytes() == z["data"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["basic", "basic_small_blocks", "basic_tiny_blocks", "basic_stored", "basic_level1",
+                                  "basic_level9", "fixed_huffman", "long_record", "empty_blocks"])
+def test_bgzf_inflate_cases(case):
+    d = cases.ALL_CASES[case]()
+    z = orc.bgzf_inflate_all(d)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(d)
+    nb = ctx.bgzf_index()
+    assert nb == z["n_blocks"]
+    out, bst = ctx.bgzf_inflate(0, nb, len(z["data"]))
+    assert np.all(bst == 0) and out.tobytes() == z["data"]
+    # sub-ranges land at the right offsets too
+    if nb > 3:
+        lo = int(z["ulen"][:1].sum()); hi = int(z["ulen"][:3].sum())
+        out2, _ = ctx.bgzf_inflate(1, 2, hi - lo)
+        assert out2.tobytes() == z["data"][lo:hi]
+    ctx.close()
+
+
+def test_bgzf_errors_flagged_per_block():
+    for maker, code in ((cases.case_bad_crc, -4), (cases.case_bad_deflate, None)):
+        d = maker()
+        ctx = duckhts_amd.Context(0)
+        ctx.open(d)
+        nb = ctx.bgzf_index()
+        _, clen, isize, _ = ctx.bgzf_table(nb)
+        out, bst = ctx.bgzf_inflate(0, nb, int(isize.astype(np.int64).sum()))
+        bad = np.nonzero(bst)[0]
+        assert len(bad) == 1
+        if code is not None:
+            assert bst[bad[0]] == code
+        z = orc.bgzf_inflate_all(d)
+        assert z["n_blocks"] == bad[0]          # the oracle's stream ends exactly at that block
+        ctx.close()
+
+
+def test_bgzf_index_signature_inside_payload():
+    """a BGZF signature embedded in a stored payload must not be mistaken for a block start"""
+    import bamwriter as bw
+    inner = bw.bgzf_block(b"inner block")
+    raw = b"x" * 100 + inner + b"y" * 100
+    d = bw.bgzf_file(raw, level=0) 
+    z = orc.bgzf_inflate_all(d)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(d)
+    nb = ctx.bgzf_index()
+    assert nb == z["n_blocks"] == 2
+    out, bst = ctx.bgzf_inflate(0, nb, len(z["data"]))
+    assert out.tobytes() == z["data"] == raw
+    ctx.close()
+
+
+# ---- read_bam: golden fixtures ----
+
+@pytest.mark.parametrize("name", ["range.bam", "bgzf_boundaries1.bam", "bgzf_boundaries2.bam", "bgzf_boundaries3.bam",
+                                  "no_hdr_sq_1.bam", "colons.bam"])
+def test_read_bam_golden(name):
+    d = read_golden(name)
+    got = duckhts_amd.read_bam(d)
+    exp = orc.bam_read(d)
+    assert_same(got, exp, name)
+    assert got["header"]["ref_names"] == exp["ref_names"]
+    assert got["header"]["text"] == exp["text"]
+    assert got["header"]["first_rec_uoff"] == exp["first_rec_off"]
+
+
+def test_read_bam_range_sql_expectations():
+    """/root/reference/test/sql/duckhts.test:129-137, straight from the GPU path"""
+    got = duckhts_amd.read_bam(read_golden("range.bam"))
+    assert got["n_rows"] == 112
+    assert (got["QNAME"][0], int(got["FLAG"][0]), got["RNAME"][0], int(got["POS"][0]), int(got["MAPQ"][0])) == \
+        (b"HS18_09653:4:1315:19857:61712", 145, b"CHROMOSOME_I", 914, 23)
+    assert got["READ_GROUP_ID"][0] == b"1" and got["SAMPLE_ID"][0] == b"ERS225193"
+
+
+# ---- read_bam: edge cases ----
+
+@pytest.mark.parametrize("case", sorted(cases.ALL_CASES))
+def test_read_bam_cases(case):
+    d = cases.ALL_CASES[case]()
+    exp = orc.bam_read(d)
+    got = duckhts_amd.read_bam(d)
+    assert_same(got, exp, case)
+
+
+@pytest.mark.parametrize("max_blocks", [1, 2, 3, 7])
+def test_read_bam_small_batches_carry(max_blocks):
+    """records straddle batch boundaries: the carry logic must reproduce the single-pass result"""
+    for case in ["basic_small_blocks", "quirks", "long_record", "err_cigar_qlen", "truncated_record", "empty_blocks"]:
+        d = cases.ALL_CASES[case]()
+        exp = orc.bam_read(d)
+        got = duckhts_amd.read_bam(d, max_blocks=max_blocks)
+        assert_same(got, exp, f"{case}/mb{max_blocks}")
+
+
+def test_read_bam_synthetic_wgs_shape():
+    from duckhts_amd import synth
+    arr, st = synth.bam_segment(300000, seed=42)
+    d = arr.tobytes()
+    exp = orc.bam_read(d)
+    got = duckhts_amd.read_bam(d)
+    assert_same(got, exp, "synth300k")
+    got = duckhts_amd.read_bam(d, max_blocks=100)
+    assert_same(got, exp, "synth300k/mb100")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_read_bam_sharded_concat(world):
+    """BGZF block ranges shard across ranks; concatenating the shards gives the sequential scan, and the
+    hand-off offsets chain (end of shard r == first record of shard r+1)."""
+    from duckhts_amd import synth
+    arr, st = synth.bam_segment(120000, seed=9)
+    d = arr.tobytes()
+    exp = orc.bam_read(d)
+    parts = [duckhts_amd.read_bam(d, shard=(r, world), max_blocks=50) for r in range(world)]
+    assert sum(p["n_rows"] for p in parts) == exp["n_rows"]
+    for k in COLS:
+        cat = [x for p in parts for x in list(p[k])]
+        assert cat == list(exp[k]), k
+
+
+def test_full_size_properties():
+    """size-independent properties on a larger input (no oracle pass over the whole thing):
+    row count == records generated, coordinate-sortedness, mate symmetry, checksum of checksums of QUAL/SEQ lengths."""
+    from duckhts_amd import synth
+    n = 2_000_000
+    arr, st = synth.bam_segment(n, seed=123)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(arr)
+    ctx.bgzf_index()
+    hdr = ctx.bam_open()
+    rows = 0; last_key = -1; status = 0; seq_bytes = 0
+    while True:
+        b = ctx.next_batch(4096)
+        if b.n_rows:
+            tid = ctx.d2h(b.tid, b.n_rows, np.int32).astype(np.int64)
+            pos = ctx.d2h(b.pos, b.n_rows, np.int64)
+            key = tid * (1 << 32) + pos
+            assert key[0] >= last_key and np.all(np.diff(key) >= 0)
+            last_key = int(key[-1])
+            ls = ctx.d2h(b.seq.len, b.n_rows, np.uint32)
+            assert np.all(ls == 150)
+            seq_bytes += int(b.seq.nbytes)
+            rows += b.n_rows
+        status = b.status
+        if status != 0:
+            break
+    assert status == 1 and rows == n and seq_bytes == 150 * n
+    ctx.close()

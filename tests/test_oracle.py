@@ -1,0 +1,247 @@
+"""Pins the CPU restatement (oracle/) against the reference's own fixtures and against zlib.
+
+Runs without a GPU.  Expectations restate /root/reference/test/sql/duckhts.test (read_bam section,
+lines 127-149) and htslib's test.pl fixtures (ce#1.sam <-> bgzf_boundaries*.bam, test.pl:842-850;
+range.out / range.out2, test.pl:911-929; no_hdr_sq_1.expected.sam).
+"""
+import collections
+import random
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import bamwriter as bw
+import cases
+import orc
+from conftest import read_golden
+
+
+def parse_sam(text):
+    """SAM text -> list of dict of the 11 mandatory fields + tags (as written)."""
+    rows = []
+    for line in text.decode().splitlines():
+        if not line or line.startswith("@"):
+            continue
+        f = line.split("\t")
+        rows.append({"QNAME": f[0], "FLAG": int(f[1]), "RNAME": f[2], "POS": int(f[3]), "MAPQ": int(f[4]), "CIGAR": f[5],
+                     "RNEXT": f[6], "PNEXT": int(f[7]), "TLEN": int(f[8]), "SEQ": f[9], "QUAL": f[10], "tags": f[11:]})
+    return rows
+
+
+def check_against_sam(res, sam_rows, idx=None):
+    idx = range(len(sam_rows)) if idx is None else idx
+    for k, i in enumerate(idx):
+        s = sam_rows[k]
+        assert res["QNAME"][i].decode() == s["QNAME"]
+        assert int(res["FLAG"][i]) == s["FLAG"]
+        assert res["RNAME"][i].decode() == s["RNAME"]
+        assert int(res["POS"][i]) == s["POS"]
+        assert int(res["MAPQ"][i]) == s["MAPQ"]
+        assert res["CIGAR"][i].decode() == s["CIGAR"]
+        # the reference emits the contig NAME for RNEXT, never '=' (bam_reader.c:836-843)
+        want_rnext = s["RNAME"] if s["RNEXT"] == "=" else s["RNEXT"]
+        assert res["RNEXT"][i].decode() == want_rnext
+        assert int(res["PNEXT"][i]) == s["PNEXT"]
+        assert int(res["TLEN"][i]) == s["TLEN"]
+        assert res["SEQ"][i].decode() == s["SEQ"]
+        assert res["QUAL"][i].decode() == s["QUAL"]
+        rg = [t[5:] for t in s["tags"] if t.startswith("RG:Z:")]
+        assert (res["READ_GROUP_ID"][i].decode() if res["READ_GROUP_ID"][i] is not None else None) == (rg[0] if rg else None)
+
+
+# ---- DEFLATE / CRC-32 vs the reference's actual dependency (zlib) -----------------------------
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_inflate_matches_zlib(level):
+    rng = random.Random(level)
+    for trial in range(20):
+        n = rng.choice([0, 1, 2, 100, 1000, 20000, 65280])
+        kind = trial % 4
+        if kind == 0:
+            data = bytes(rng.randrange(256) for _ in range(n))
+        elif kind == 1:
+            data = bytes(rng.choice(b"ACGT") for _ in range(n))
+        elif kind == 2:
+            data = (b"FFFFFFFF,,,,::::" * (n // 16 + 1))[:n]
+        else:
+            data = bytes((i * 7 + (i >> 5)) & 0xff for i in range(n))
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        r, out = orc.inflate_raw(comp, 65536)
+        assert r == 0 and out == data
+        assert orc.crc32(data) == (zlib.crc32(data) & 0xffffffff)
+
+
+def test_inflate_fixed_and_multiblock():
+    data = b"hello hello hello hello " * 50
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    comp = co.compress(data) + co.flush()
+    assert orc.inflate_raw(comp)[1] == data
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data[:300]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(data[300:]) + co.flush()
+    assert orc.inflate_raw(comp)[1] == data
+
+
+def test_inflate_rejects_garbage():
+    assert orc.inflate_raw(b"\x07\xff\xff\xff")[0] < 0          # reserved block type 3
+    assert orc.inflate_raw(b"")[0] < 0
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(b"A" * 70000) + co.flush()
+    assert orc.inflate_raw(comp, 65536)[0] < 0                    # > 64 KiB output = error (bgzf.c:810)
+
+
+def test_bgzf_fixture_blocks_match_zlib():
+    for name in ["range.bam", "bgzf_boundaries3.bam", "vcf_file.bcf", "colons.bam"]:
+        d = read_golden(name)
+        z = orc.bgzf_inflate_all(d)
+        assert z["status"] == 0 and z["has_eof"] == 1
+        # independent walk with zlib
+        pos, parts = 0, []
+        while pos < len(d):
+            bl = struct.unpack_from("<H", d, pos + 16)[0] + 1
+            parts.append(zlib.decompress(d[pos + 18:pos + bl - 8], -15))
+            assert zlib.crc32(parts[-1]) & 0xffffffff == struct.unpack_from("<I", d, pos + bl - 8)[0]
+            pos += bl
+        assert z["data"] == b"".join(parts)
+        assert list(z["ulen"]) == [len(p) for p in parts]
+
+
+# ---- read_bam vs the reference's SQL expectations and SAM truth files --------------------------
+
+def test_range_bam_sql_expectations():
+    r = orc.bam_read(read_golden("range.bam"))
+    assert r["status"] == 0
+    assert r["n_rows"] == 112                                     # duckhts.test:129-131
+    assert (r["QNAME"][0], int(r["FLAG"][0]), r["RNAME"][0], int(r["POS"][0]), int(r["MAPQ"][0])) == \
+        (b"HS18_09653:4:1315:19857:61712", 145, b"CHROMOSOME_I", 914, 23)   # duckhts.test:135-137
+    c = collections.Counter(r["RNAME"])
+    assert c[b"CHROMOSOME_I"] == 18                                # duckhts.test:141-143 (region = whole contig)
+    # CHROMOSOME_I:1-1000 -> 2 rows (duckhts.test:147-149): overlap test end > beg && end_q > beg (hts.c:4584-4592)
+    n = 0
+    for i in range(r["n_rows"]):
+        if r["RNAME"][i] != b"CHROMOSOME_I":
+            continue
+        pos0 = int(r["POS"][i]) - 1
+        rlen, num = 0, ""
+        for ch in r["CIGAR"][i].decode():
+            if ch.isdigit():
+                num += ch
+            else:
+                if ch in "MDN=X":
+                    rlen += int(num)
+                num = ""
+        end = pos0 + max(rlen, 1)
+        if end > 0 and 1000 > pos0:
+            n += 1
+    assert n == 2
+    assert all(x == b"1" for x in r["READ_GROUP_ID"]) and all(x == b"ERS225193" for x in r["SAMPLE_ID"])
+    assert r["ref_names"][:2] == [b"CHROMOSOME_I", b"CHROMOSOME_II"] and r["n_ref"] == 7
+
+
+@pytest.mark.parametrize("name", ["range.out", "range.out2"])
+def test_range_bam_region_truth(name):
+    """htslib test.pl:911-929: SAM records expected from region queries on range.bam; every one must appear,
+    field-for-field, in the full scan."""
+    r = orc.bam_read(read_golden("range.bam"))
+    sam = parse_sam(read_golden(name))
+    key = {(r["QNAME"][i], int(r["FLAG"][i])): i for i in range(r["n_rows"])}
+    idx = [key[(s["QNAME"].encode(), s["FLAG"])] for s in sam]
+    check_against_sam(r, sam, idx)
+
+
+@pytest.mark.parametrize("name", ["bgzf_boundaries1.bam", "bgzf_boundaries2.bam", "bgzf_boundaries3.bam"])
+def test_bgzf_boundaries(name):
+    """records split across BGZF blocks (test.pl:842-850), truth = ce#1.sam"""
+    r = orc.bam_read(read_golden(name))
+    sam = parse_sam(read_golden("ce#1.sam"))
+    assert r["status"] == 0 and r["n_rows"] == len(sam) == 1
+    check_against_sam(r, sam)
+
+
+def test_no_hdr_sq():
+    r = orc.bam_read(read_golden("no_hdr_sq_1.bam"))
+    sam = parse_sam(read_golden("no_hdr_sq_1.expected.sam"))
+    assert r["n_rows"] == len(sam)
+    check_against_sam(r, sam)
+    assert all(x is None for x in r["SAMPLE_ID"])
+
+
+def test_colons():
+    r = orc.bam_read(read_golden("colons.bam"))
+    assert r["n_rows"] == 6 and r["ref_names"] == [b"chr1", b"chr1:100", b"chr1:100-200", b"chr2:100-200", b"chr3", b"chr1,chr3"]
+
+
+# ---- own edge cases: behaviours spelled out in SURVEY.md 8(a) ----------------------------------
+
+def test_quirks():
+    r = orc.bam_read(cases.case_quirks())
+    q = {r["QNAME"][i]: i for i in range(r["n_rows"])}
+    assert r["status"] == 0
+    assert r["QUAL"][q[b"q223"]] == bytes([43, 53])               # truncated where +33 wraps to NUL
+    assert r["QUAL"][q[b"q223first"]] == b""
+    assert r["QUAL"][q[b"qff"]] == b"*" and r["QUAL"][q[b"qff2"]][:1] == bytes([34])
+    assert b"nonul" in q and b"emb" in q and b"" in q
+    i = q[b"cgswap"]
+    assert r["CIGAR"][i] == b"2M1I3M" and r["READ_GROUP_ID"][i] == b"g1" and r["SAMPLE_ID"][i] == b"sampleA"
+    assert r["CIGAR"][q[b"cgswap_first"]] == b"2M1I3M" and r["SAMPLE_ID"][q[b"cgswap_first"]] is None
+    assert r["CIGAR"][q[b"cg_unplaced"]] == b"6S"                 # tid < 0: no swap (sam.c:686-687)
+    assert r["CIGAR"][q[b"ops"]] == b"3?1?4B"
+    assert r["CIGAR"][q[b"huge_oplen"]] == b"268435455M"
+    assert r["READ_GROUP_ID"][q[b"last"]] == b"1AE3"
+    assert len(r["CIGAR"][q[b"big"]]) == 12000
+
+
+def test_rg_dictionary():
+    r = orc.bam_read(cases.case_basic())
+    for rg, sm in zip(r["READ_GROUP_ID"], r["SAMPLE_ID"]):
+        want = {b"g1": b"sampleA", b"g2": None, b"g3": None, b"zz": None, b"": None, None: None}[rg]
+        assert sm == want
+    r = orc.bam_read(cases.case_bad_header_text())
+    assert r["READ_GROUP_ID"] == [b"g1"] and r["SAMPLE_ID"] == [None]
+
+
+@pytest.mark.parametrize("kind", ["blocklen_small", "inconsistent", "cigar_qlen", "tid_range", "mtid_range", "neg_lseq", "lq0"])
+def test_error_stops_scan_silently(kind):
+    """a record-level error ends the scan with the rows so far (bam_reader.c:754-766)"""
+    r = orc.bam_read(cases.case_error_midfile(kind))
+    assert r["n_rows"] == 77 and r["status"] < 0
+
+
+def test_truncation_and_container_errors():
+    full = orc.bam_read(cases.case_basic(payload=4000, n=150))
+    t = orc.bam_read(cases.case_truncated())
+    assert t["status"] < 0 and 0 < t["n_rows"] < full["n_rows"]
+    assert t["QNAME"] == full["QNAME"][: t["n_rows"]]
+    t = orc.bam_read(cases.case_truncated_record())
+    assert t["status"] < 0 and t["n_rows"] == 59
+    e = orc.bam_read(cases.case_empty_blocks())
+    assert e["status"] == 0 and e["n_rows"] == 80
+    for c in (cases.case_bad_crc(), cases.case_bad_deflate()):
+        b = orc.bam_read(c)
+        assert b["status"] < 0 and 0 < b["n_rows"] < 120
+    assert orc.bam_read(cases.case_header_only())["n_rows"] == 0
+    u = orc.bam_read(cases.case_no_refs_unmapped())
+    assert u["n_rows"] == 10 and set(u["RNAME"]) == {b"*"} and all(int(p) == 0 for p in u["POS"])
+
+
+def test_long_record_spanning_blocks():
+    r = orc.bam_read(cases.case_long_record())
+    assert r["n_rows"] == 3 and r["status"] == 0
+    assert r["CIGAR"][1] == b"1M1I" * 16000 and r["SEQ"][1] == b"A" * 32000 and r["QUAL"][1] == b"Q" * 32000
+
+
+def test_synthetic_generator_roundtrip():
+    from duckhts_amd import synth
+    arr, st = synth.bam_segment(20000, seed=7, threads=2)
+    r = orc.bam_read(arr.tobytes())
+    assert r["status"] == 0 and r["n_rows"] == 20000
+    key = r["tid"].astype(np.int64) * (1 << 32) + r["POS"]
+    assert np.all(np.diff(key) >= 0)
+    assert set(r["SAMPLE_ID"]) == {b"NA00001"}
+    # two half segments concatenate into the same stream of records
+    a, _ = synth.bam_segment(10000, seed=7, total_n=20000, rec0=0, with_eof=False, threads=2)
+    b, _ = synth.bam_segment(10000, seed=7, total_n=20000, rec0=10000, with_header=False, threads=2)
+    r2 = orc.bam_read(a.tobytes() + b.tobytes())
+    assert r2["n_rows"] == 20000 and r2["QNAME"] == r["QNAME"] and np.array_equal(r2["POS"], r["POS"])
