@@ -441,20 +441,20 @@ bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t 
         uint8_t *dseq = s.seq + s.off_seq[row];
         if (l_seq <= 0) { if (gl == 0) dseq[0] = '*'; }
         else {
-            const uint64_t NT_LO = ((uint64_t)'=') | ((uint64_t)'A' << 8) | ((uint64_t)'C' << 16) | ((uint64_t)'M' << 24) |
-                                   ((uint64_t)'G' << 32) | ((uint64_t)'R' << 40) | ((uint64_t)'S' << 48) | ((uint64_t)'V' << 56);
-            const uint64_t NT_HI = ((uint64_t)'T') | ((uint64_t)'W' << 8) | ((uint64_t)'Y' << 16) | ((uint64_t)'H' << 24) |
-                                   ((uint64_t)'K' << 32) | ((uint64_t)'D' << 40) | ((uint64_t)'B' << 48) | ((uint64_t)'N' << 56);
+            // 16-entry byte table held in four dwords; v_perm_b32 gathers 4 table bytes per instruction
+            const uint32_t T0 = 0x4d43413du, T1 = 0x56535247u, T2 = 0x48595754u, T3 = 0x4e42444bu;   // "=ACM" "GRSV" "TWYH" "KDBN"
             for (uint32_t b = gl * 16; b < (uint32_t)l_seq; b += 256) {
                 uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
-                uint64_t pk; __builtin_memcpy(&pk, seq + (b >> 1), 8);            // may read past the field; the buffer is padded
+                uint32_t p0 = ldu32(seq + (b >> 1)), p1 = ldu32(seq + (b >> 1) + 4);   // may read past the field; the buffer is padded
                 uint32_t w[4];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    uint32_t byte = (uint32_t)(pk >> (8 * (k >> 1))) & 0xff;
-                    uint32_t nib = (k & 1) ? (byte & 0xf) : (byte >> 4);
-                    uint32_t ch = (uint32_t)(((nib & 8) ? NT_HI : NT_LO) >> (8 * (nib & 7))) & 0xff;
-                    if ((k & 3) == 0) w[k >> 2] = ch; else w[k >> 2] |= ch << (8 * (k & 3));
+                for (int k = 0; k < 4; k++) {
+                    uint32_t x = ((k & 2) ? p1 : p0) >> ((k & 1) * 16);                   // two packed bytes = four bases
+                    uint32_t sel = ((x >> 4) & 0xfu) | ((x & 0xfu) << 8) | (((x >> 12) & 0xfu) << 16) | (((x >> 8) & 0xfu) << 24);
+                    uint32_t lo = __builtin_amdgcn_perm(T1, T0, sel & 0x07070707u);
+                    uint32_t hi = __builtin_amdgcn_perm(T3, T2, sel & 0x07070707u);
+                    uint32_t m = ((sel >> 3) & 0x01010101u) * 0xffu;
+                    w[k] = (hi & m) | (lo & ~m);
                 }
                 if (n == 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(dseq + b, &v, 16); }
                 else for (uint32_t k = 0; k < n; k++) dseq[b + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
@@ -511,11 +511,11 @@ bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t 
             if (has) {
                 uint32_t p = base + inc - w, nd = w - 1;
                 for (uint32_t q = 0; q < nd; q++) { dc[p + nd - 1 - q] = (uint8_t)('0' + ol % 10); ol /= 10; }
-                const uint64_t CG_LO = ((uint64_t)'M') | ((uint64_t)'I' << 8) | ((uint64_t)'D' << 16) | ((uint64_t)'N' << 24) |
-                                       ((uint64_t)'S' << 32) | ((uint64_t)'H' << 40) | ((uint64_t)'P' << 48) | ((uint64_t)'=' << 56);
-                const uint64_t CG_HI = ((uint64_t)'X') | ((uint64_t)'B' << 8) | 0x3f3f3f3f3f3f0000ull;       // sam.h:112 BAM_CIGAR_STR, '?' beyond
-                uint32_t oc = op & 0xf;
-                dc[p + nd] = (uint8_t)(((oc & 8) ? CG_HI : CG_LO) >> (8 * (oc & 7)));
+                // sam.h:112 BAM_CIGAR_STR "MIDNSHP=XB", '?' beyond; byte gather with v_perm_b32
+                const uint32_t C0 = 0x4e44494du, C1 = 0x3d504853u, C2 = 0x3f3f4258u, C3 = 0x3f3f3f3fu;
+                uint32_t oc = op & 0xf, selb = (oc & 7u) | 0x0c0c0c00u;
+                uint32_t chv = (oc & 8u) ? __builtin_amdgcn_perm(C3, C2, selb) : __builtin_amdgcn_perm(C1, C0, selb);
+                dc[p + nd] = (uint8_t)chv;
             }
             base += tot;
         }

@@ -159,9 +159,9 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         uint32_t nl, nd;
         if (type == 1) {
             // ---- fixed code lengths (RFC 1951 3.2.6) ----
-            nl = 288; nd = 30;
+            nl = 288; nd = 32;                               // 32 five-bit distance codes; 30/31 are rejected on use
             for (uint32_t i = 0; i < 288; i++) set_len(lens, lane, i, i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
-            for (uint32_t i = 0; i < 30; i++) set_len(lens, lane, 288 + i, 5);
+            for (uint32_t i = 0; i < 32; i++) set_len(lens, lane, 288 + i, 5);
         } else {
             // ---- dynamic: code-length code, then the two length vectors (3.2.7) ----
             br_refill(br);
@@ -295,7 +295,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                 uint32_t Ld = code_len(dl, wd);
                 if (Ld > 15) { status = DHTS_BLK_ERR_INFLATE; break; }
                 uint32_t od = (uint32_t)(uint16_t)(dbase[Ld * 64 + lane] + (uint16_t)(wd >> (15 - Ld)));
-                if (od >= 30) { status = DHTS_BLK_ERR_INFLATE; break; }
+                if (od >= 32) { status = DHTS_BLK_ERR_INFLATE; break; }
                 uint32_t ds = dsym[od * 64 + lane];
                 br_take(br, Ld);
                 if (ds >= 30) { status = DHTS_BLK_ERR_INFLATE; break; }
