@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libduckhts_amd.so")
+LIB_PATH = os.environ.get("DHTS_LIB") or os.path.join(_HERE, "libduckhts_amd.so")   # DHTS_LIB: kernel-variant experiments
 _LIB = None
 
 BAM_COLUMNS = ["QNAME", "FLAG", "RNAME", "POS", "MAPQ", "CIGAR", "RNEXT", "PNEXT", "TLEN", "SEQ", "QUAL",

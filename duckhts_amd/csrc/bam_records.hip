@@ -117,6 +117,10 @@ __device__ int rec_check(const BamStream &st, uint64_t o, RecInfo &r, bool full)
     if (!full) {
         // speculation filter only: cheap header-range sanity (not part of exactness)
         if (r.tid < -1 || r.tid >= st.n_ref || r.mtid < -1 || r.mtid >= st.n_ref) return REC_INVALID;
+        // heuristics (a wrong rejection only costs a repair round): NUL-terminated name, aux area of sane size
+        uint64_t core = ((uint64_t)r.n_cigar << 2) + r.l_qname + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq;
+        if (body - core > 8 * core + 65536) return REC_INVALID;
+        if (u[o + 36 + r.l_qname - 1] != 0) return REC_INVALID;
         return REC_OK;
     }
     uint64_t end = o + 4 + r.block_len;

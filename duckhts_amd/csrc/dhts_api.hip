@@ -43,6 +43,8 @@ struct dhts_ctx {
     std::vector<uint64_t> h_coff, h_uoff; std::vector<uint32_t> h_clen, h_isize;
     // inflate scratch
     DevBuf lit, tok, meta;
+    int64_t huff_b0 = 0, huff_nb = 0;     // block range whose tokens are in the scratch
+    int64_t super_blocks = 65536;        // phase A runs ahead over this many blocks so that 4 waves/CU are resident
     // inflated stream double buffer (carry moves between them)
     DevBuf ubuf[2]; int ucur = 0; uint64_t carry_len = 0;
     // tiles
@@ -139,6 +141,7 @@ void dhts_destroy(dhts_ctx *c) {
 const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no context (no MI355X device or code object)"; }
 
 static void reset_file_state(dhts_ctx *c) {
+    c->huff_b0 = c->huff_nb = 0;
     c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
     c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
 }
@@ -235,6 +238,7 @@ static int run_scan(dhts_ctx *c, int narr, const uint32_t **in, uint32_t **out32
 int64_t dhts_bgzf_index(dhts_ctx *c) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    c->huff_b0 = c->huff_nb = 0;
     if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
     const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
     int64_t nspans = (int64_t)((n + 65535) / 65536);
@@ -309,23 +313,37 @@ static BgzfTable dev_table(dhts_ctx *c) {
     t.uoff = (const uint64_t *)c->uoff.p; t.n = c->n_blocks; return t;
 }
 
-// inflate blocks [b0, b0+nb) into `out` (device) so that block b lands at out + (uoff[b] - out_base)
-static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base) {
-    if (nb <= 0) return 0;
-    for (int64_t b = b0; b < b0 + nb; b++) if (c->h_isize[b] > 65536u) return fail(c, "BGZF block %lld claims ISIZE %u > 65536", (long long)b, c->h_isize[b]);
-    ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 64);
+// phase A over [b0, b0+nb): tokens + literals into the scratch
+static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb) {
+    ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 8192);
     ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
     ENSURE(c, c->meta, (size_t)nb * sizeof(InflateMeta));
     BgzfTable t = dev_table(c);
     {
         KTimer tm(c, DHTS_K_HUFF);
-        hipLaunchKernelGGL(bgzf_huff_decode, dim3((unsigned)((nb + 63) / 64)), dim3(64), A_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+        hipLaunchKernelGGL(bgzf_huff_decode, dim3((unsigned)((nb + A_SL - 1) / A_SL)), dim3(64), A_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
                            (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p);
     }
+    HIPCHK(c, hipGetLastError());
+    c->huff_b0 = b0; c->huff_nb = nb;
+    return 0;
+}
+
+// inflate blocks [b0, b0+nb) into `out` (device) so that block b lands at out + (uoff[b] - out_base)
+static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
+    if (nb <= 0) return 0;
+    for (int64_t b = b0; b < b0 + nb; b++) if (c->h_isize[b] > 65536u) return fail(c, "BGZF block %lld claims ISIZE %u > 65536", (long long)b, c->h_isize[b]);
+    if (!(b0 >= c->huff_b0 && b0 + nb <= c->huff_b0 + c->huff_nb)) {
+        int64_t want = c->super_blocks > nb ? c->super_blocks : nb;
+        if (b0 + want > ahead_limit) want = ahead_limit - b0;
+        if (want < nb) want = nb;
+        if (huff_blocks(c, b0, want)) return -1;
+    }
+    BgzfTable t = dev_table(c);
     {
         KTimer tm(c, DHTS_K_LZ);
         hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)nb), dim3(64), B_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
-                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, out, out_base, (int32_t *)c->blk_status.p);
+                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, c->huff_b0, out, out_base, (int32_t *)c->blk_status.p);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -340,7 +358,7 @@ int64_t dhts_bgzf_inflate_to_host(dhts_ctx *c, int64_t blk0, int64_t nblk, uint8
     if (total > cap) return fail(c, "output capacity too small (%llu needed)", (unsigned long long)total);
     ENSURE(c, c->ubuf[0], total + PAD_BYTES);
     HIPCHK(c, hipMemsetAsync(c->ubuf[0].p, 0, total + PAD_BYTES, c->stream));
-    if (inflate_blocks(c, blk0, nblk, (uint8_t *)c->ubuf[0].p, base)) return -1;
+    if (inflate_blocks(c, blk0, nblk, (uint8_t *)c->ubuf[0].p, base, blk0 + nblk)) return -1;
     HIPCHK(c, hipMemcpyAsync(out, c->ubuf[0].p, total, hipMemcpyDeviceToHost, c->stream));
     if (blk_status) HIPCHK(c, hipMemcpyAsync(blk_status, (int32_t *)c->blk_status.p + blk0, nblk * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -472,6 +490,7 @@ int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
 int dhts_bam_rewind(dhts_ctx *c) {
     if (!c) return -1;
     c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+    c->huff_b0 = c->huff_nb = 0;            // a new pass redoes phase A (nothing is cached across scans)
     return 0;
 }
 
@@ -506,7 +525,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     }
     uint8_t *u = (uint8_t *)ub.p;
     const uint64_t out_base = c->h_uoff[b0] - carry;          // absolute stream offset of u[0]
-    if (inflate_blocks(c, b0, nb, u, out_base)) return -1;
+    if (inflate_blocks(c, b0, nb, u, out_base, c->n_blocks)) return -1;
     HIPCHK(c, hipMemsetAsync(u + ulen, 0, PAD_BYTES, c->stream));
     // first bad block (if any) ends the byte stream there (bgzf.c:1241-1291: the read fails)
     int blk_err = 0;
@@ -539,6 +558,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
             uint32_t nfixed = 0;
             HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
             if (nfixed == 0) break;
             if (++rounds > 64) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
         }
@@ -645,6 +665,13 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_collect(c);
+    return 0;
+}
+
+// debugging aid (not part of the public header): phase-A metadata of scratch slot s
+int dhts_debug_meta(dhts_ctx *c, int64_t s, uint32_t *out4) {
+    if (!c || s < 0 || s >= c->huff_nb) return -1;
+    HIPCHK(c, hipMemcpy(out4, (InflateMeta *)c->meta.p + s, 16, hipMemcpyDeviceToHost));
     return 0;
 }
 

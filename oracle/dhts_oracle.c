@@ -12,6 +12,7 @@
  * source, and pinned in tests against CPython's zlib module.
  */
 #include "dhts_oracle.h"
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -186,6 +187,42 @@ int orc_inflate_raw(const uint8_t *src, size_t slen, uint8_t *dst, size_t dcap, 
     return 0;
 }
 
+/* ---- optional system-zlib inflate for the cpu_baseline timing leg -------------------------
+ * The reference inflates through system zlib (htslib/bgzf.c:775-793).  For an honest host
+ * baseline the timing path may use the same library (dlopen libz.so.1) instead of the
+ * readable-but-slow RFC restatement above; parity tests never use this path.            */
+typedef struct { const unsigned char *next_in; unsigned avail_in; unsigned long total_in; unsigned char *next_out; unsigned avail_out;
+                 unsigned long total_out; const char *msg; void *state; void *zalloc; void *zfree; void *opaque; int data_type;
+                 unsigned long adler; unsigned long reserved; } orc_zstream;
+static int (*z_inflateInit2_)(orc_zstream *, int, const char *, int);
+static int (*z_inflate)(orc_zstream *, int);
+static int (*z_inflateEnd)(orc_zstream *);
+static unsigned long (*z_crc32)(unsigned long, const unsigned char *, unsigned);
+static int z_ready = 0;
+static int zlib_load(void) {
+    if (z_ready) return z_ready > 0;
+    void *h = dlopen("libz.so.1", RTLD_NOW);
+    if (!h) { z_ready = -1; return 0; }
+    z_inflateInit2_ = (int (*)(orc_zstream *, int, const char *, int))dlsym(h, "inflateInit2_");
+    z_inflate = (int (*)(orc_zstream *, int))dlsym(h, "inflate");
+    z_inflateEnd = (int (*)(orc_zstream *))dlsym(h, "inflateEnd");
+    z_crc32 = (unsigned long (*)(unsigned long, const unsigned char *, unsigned))dlsym(h, "crc32");
+    z_ready = (z_inflateInit2_ && z_inflate && z_inflateEnd && z_crc32) ? 1 : -1;
+    return z_ready > 0;
+}
+static int use_zlib = 0;
+int orc_use_system_zlib(int on) { use_zlib = on && zlib_load(); return use_zlib; }
+static int zlib_inflate_raw(const uint8_t *src, size_t slen, uint8_t *dst, size_t dcap, size_t *dlen) {
+    orc_zstream zs; memset(&zs, 0, sizeof(zs));
+    zs.next_in = src; zs.avail_in = (unsigned)slen; zs.next_out = dst; zs.avail_out = (unsigned)dcap;
+    if (z_inflateInit2_(&zs, -15, "1.2.11", (int)sizeof(zs)) != 0) return -1;
+    int r = z_inflate(&zs, 4 /* Z_FINISH */);
+    z_inflateEnd(&zs);
+    if (r != 1 /* Z_STREAM_END */) return -1;
+    *dlen = dcap - zs.avail_out;
+    return 0;
+}
+
 /* ========================================================================
  * BGZF framing
  * ======================================================================== */
@@ -221,11 +258,13 @@ int orc_bgzf_inflate_all(const uint8_t *file, size_t flen, orc_bgzf_t *out) {
         if (block_length < 26) { out->status = -3; break; }           /* no room for trailer: inflate fails */
         if (out->len + 65536 > cap) { cap = cap * 2 + 65536; out->data = (uint8_t *)realloc(out->data, cap); }
         size_t dlen = 0;
-        int r = orc_inflate_raw(file + pos + 18, (size_t)block_length - 18, out->data + out->len, 65536, &dlen);
+        int r = use_zlib ? zlib_inflate_raw(file + pos + 18, (size_t)block_length - 18, out->data + out->len, 65536, &dlen)
+                         : orc_inflate_raw(file + pos + 18, (size_t)block_length - 18, out->data + out->len, 65536, &dlen);
         if (r < 0) { out->status = -3; break; }                       /* BGZF_ERR_ZLIB */
         const uint8_t *t = file + pos + block_length - 8;
         uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
-        if (orc_crc32(0, out->data + out->len, dlen) != crc) { out->status = -4; break; } /* BGZF_ERR_CRC */
+        uint32_t have = use_zlib ? (uint32_t)z_crc32(z_crc32(0, NULL, 0), out->data + out->len, (unsigned)dlen) : orc_crc32(0, out->data + out->len, dlen);
+        if (have != crc) { out->status = -4; break; }                 /* BGZF_ERR_CRC */
         if ((size_t)out->n_blocks == nb_cap) {
             nb_cap *= 2;
             out->coff = (int64_t *)realloc(out->coff, nb_cap * sizeof(int64_t));

@@ -80,6 +80,8 @@ void orc_bam_free(orc_bam_t *b);
 /* timing helper for bench.py's cpu_baseline ("port"): decodes the whole file
  * (inflate + crc + record decode + 13-column materialisation), returns rows. */
 int64_t orc_bam_scan_count(const uint8_t *file, size_t flen, int *status);
+/* timing leg only: inflate + crc32 through system zlib (the reference's own dependency) instead of the RFC restatement */
+int orc_use_system_zlib(int on);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,8 @@ def lib():
         L.orc_bam_free.argtypes = [C.POINTER(Bam)]
         L.orc_bam_scan_count.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
         L.orc_bam_scan_count.restype = C.c_int64
+        L.orc_use_system_zlib.argtypes = [C.c_int]
+        L.orc_use_system_zlib.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -123,3 +125,8 @@ def bam_scan_count(file_bytes: bytes):
     st = C.c_int(0)
     n = lib().orc_bam_scan_count(file_bytes, len(file_bytes), C.byref(st))
     return n, st.value
+
+
+def use_system_zlib(on: bool) -> bool:
+    """timing leg only (bench.py cpu_baseline): route inflate/crc32 through libz.so.1 like the reference does"""
+    return bool(lib().orc_use_system_zlib(int(on)))
