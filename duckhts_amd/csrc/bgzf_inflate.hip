@@ -369,6 +369,21 @@ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
 #define B_RING (B_CRCT + 4096)           /* u8 [4096] literal staging ring */
 #define B_LDS_BYTES (B_RING + 4096)
 #define B_NULLTOK 0xffffffffu
+#ifdef DHTS_DIAG
+__device__ unsigned long long g_diag[8];   // batches, rounds, easy, hard, lit_iters, long_lit
+#define DIAG_ADD(i, v) do { unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_diag[i], v_); } while (0)
+#define DIAG_T(var) unsigned long long var = clock64()
+__device__ unsigned long long g_diagt[8];
+#define DIAG_TADD(i, a, b) do { dacc[i] += (b) - (a); } while (0)
+#define DIAG_DECL unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DIAG_FLUSH do { if (lane == 0) for (int q_ = 0; q_ < 8; q_++) atomicAdd(&g_diagt[q_], dacc[q_]); } while (0)
+#else
+#define DIAG_DECL do {} while (0)
+#define DIAG_FLUSH do {} while (0)
+#define DIAG_T(var) do {} while (0)
+#define DIAG_TADD(i, a, b) do {} while (0)
+#define DIAG_ADD(i, v) do {} while (0)
+#endif
 
 extern "C" __global__ void __launch_bounds__(64)
 bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
@@ -387,6 +402,8 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     const uint32_t isize = tab.isize[bi];
     const uint32_t clen = tab.clen[bi];
 
+    DIAG_DECL;
+    DIAG_T(t_begin);
     // slice-by-4 tables (built per workgroup: 4 entries per lane per table)
     for (int k = lane; k < 256; k += 64) {
         uint32_t c = (uint32_t)k;
@@ -402,6 +419,8 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         c = crct[c & 0xff] ^ (c >> 8); crct[768 + k] = c;
     }
     __syncthreads();
+    DIAG_T(t_tab);
+    DIAG_TADD(0, t_begin, t_tab);
 
     int st = m.status;
     if (st == 0 && m.outlen != isize) st = DHTS_BLK_ERR_ISIZE;   // htslib does not test ISIZE; we flag it
@@ -431,6 +450,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         const uint32_t tot_adv = RDLANE(adv_i, 63), tot_lit = RDLANE(lit_i, 63);
         const uint32_t dst = outpos + adv_i - (lrun + mlen);       // where this token's literals start
         const uint32_t lsrc = litpos + lit_i - lrun;               // absolute index of its first literal byte
+        DIAG_T(t_a);
         // ---- literals ----
         if (tot_lit <= 2048u) {
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
@@ -448,6 +468,8 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             pend = false; stage_hi = (litpos + tot_lit) & ~1023u;
         }
         __syncthreads();
+        DIAG_T(t_b);
+        DIAG_TADD(1, t_a, t_b);
         // ---- matches ----
         // A pending match is ready when its source overlaps no destination of an EARLIER pending match (all literals of
         // the batch are already placed).  Destinations/sources are rasterised into 64 cells covering the batch's output
@@ -487,6 +509,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             }
             // (b) the rest of the ready set, one at a time, replayed by the whole wave
             uint64_t H = __ballot(ready && !easy);
+
             while (H) {
                 const int i = __ffsll((unsigned long long)H) - 1; H &= H - 1;
                 const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
@@ -498,9 +521,13 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             __syncthreads();
             P &= ~__ballot(ready);
         }
+        DIAG_T(t_c);
+        DIAG_TADD(2, t_b, t_c);
         outpos += tot_adv; litpos += tot_lit;
         STAGE_COMMIT();
     }
+    DIAG_T(t_loop);
+    DIAG_TADD(3, t_tab, t_loop);
     // trailing literals
     {
         uint32_t rem = m.nlit - litpos;
@@ -510,6 +537,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     __syncthreads();
     if (outpos != m.outlen) { if (lane == 0) blk_status[bi] = DHTS_BLK_ERR_INFLATE; return; }
 
+    DIAG_T(t_crc0);
     // ---- CRC-32 of win[0..outlen): per-lane chunk, then combine ----
     const uint32_t n = m.outlen;
     const uint32_t chunk = ((n + 63) / 64 + 3) & ~3u;          // multiple of 4
@@ -542,6 +570,8 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     if (lane == 0) blk_status[bi] = st;
     if (st != 0) return;
 
+    DIAG_T(t_crc1);
+    DIAG_TADD(4, t_crc0, t_crc1);
     // ---- flush to the inflated stream: 16-byte coalesced stores over the aligned interior ----
     uint8_t *dstp = out + (tab.uoff[bi] - out_base);
     uint32_t head = (uint32_t)((16 - ((uintptr_t)dstp & 15)) & 15); if (head > n) head = n;
@@ -552,4 +582,8 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         *(uint4 *)(dstp + head + k) = v;
     }
     for (uint32_t k = head + body + lane; k < n; k += 64) dstp[k] = win[k];
+    DIAG_T(t_end);
+    DIAG_TADD(5, t_crc1, t_end);
+    DIAG_TADD(6, t_begin, t_end);
+    DIAG_FLUSH;
 }

@@ -668,6 +668,14 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     return 0;
 }
 
+#ifdef DHTS_DIAG
+int dhts_debug_diag(dhts_ctx *c, unsigned long long *out8) {
+    if (!c) return -1;
+    HIPCHK(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), 64));
+    HIPCHK(c, hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(g_diagt), 64));
+    return 0;
+}
+#endif
 // debugging aid (not part of the public header): phase-A metadata of scratch slot s
 int dhts_debug_meta(dhts_ctx *c, int64_t s, uint32_t *out4) {
     if (!c || s < 0 || s >= c->huff_nb) return -1;

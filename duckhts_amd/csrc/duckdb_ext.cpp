@@ -1,0 +1,273 @@
+// duckdb_ext.cpp -- DuckDB C-API extension surface (outer drop-in boundary) over the MI355X scan path.
+//
+// Mirrors, callback for callback, the reference's read_bam table function:
+//   register_read_bam_function   src/bam_reader.c:1044-1068
+//   bam_read_bind                src/bam_reader.c:410-557   (parameters, schema, error strings)
+//   bam_read_global_init         src/bam_reader.c:563-588
+//   bam_read_local_init          src/bam_reader.c:594-682   (projection ids)
+//   bam_read_function            src/bam_reader.c:722-1038  (<= vector_size rows per call, size 0 = done)
+// The htslib calls underneath are replaced by include/duckhts_amd.h (HIP kernels); DuckDB is reached only
+// through the function-pointer table returned by access->get_api(info, "v1.2.0").
+//
+// Scan mode: the reference's sequential mode (i): one scan thread, all records in file
+// order including unplaced reads, full 2048-row chunks except the last.  region / tag columns / CRAM / SAM are
+// not on the GPU path yet and are rejected at bind time with an explicit message.
+#include "../../include/duckhts_amd.h"
+#include "../../include/duckhts_extension.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static const void *const *g_api = nullptr;   // duckdb_ext_api_v1 viewed as an array of function pointers
+
+#define API(ret, name, ...) ((ret(*)(__VA_ARGS__))g_api[SLOT_##name])
+
+static inline void set_null(duckdb_vector vec, idx_t row) {           // src/bam_reader.c:38-42
+    API(void, duckdb_vector_ensure_validity_writable, duckdb_vector)(vec);
+    uint64_t *v = API(uint64_t *, duckdb_vector_get_validity, duckdb_vector)(vec);
+    v[row / 64] &= ~((uint64_t)1 << (row % 64));
+}
+
+struct BamBind {
+    std::string path;
+    dhts_ctx *ctx = nullptr;          // resident file + header, reused by the scan (one GPU)
+    dhts_bam_header hdr;
+    int has_index = 0;
+};
+
+struct HostStr { std::vector<uint32_t> off, len; std::vector<uint8_t> bytes; };
+struct BamLocal {
+    std::vector<idx_t> column_ids;
+    uint32_t colmask = 0;
+    bool done = false;
+    // current batch, host side
+    int64_t n = 0, cur = 0;
+    int status = 0;
+    std::vector<uint16_t> flag; std::vector<int64_t> pos, pnext, tlen; std::vector<int32_t> mapq, tid, mtid, rgidx; std::vector<uint64_t> rgvalid;
+    HostStr qname, cigar, seq, qual, rg;
+};
+
+static void destroy_bind(void *p) { BamBind *b = (BamBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
+static void destroy_local(void *p) { delete (BamLocal *)p; }
+static void destroy_global(void *p) { free(p); }
+
+static char *get_named_varchar(duckdb_bind_info info, const char *name) {
+    duckdb_value v = API(duckdb_value, duckdb_bind_get_named_parameter, duckdb_bind_info, const char *)(info, name);
+    char *s = nullptr;
+    if (v && !API(bool, duckdb_is_null_value, duckdb_value)(v)) s = API(char *, duckdb_get_varchar, duckdb_value)(v);
+    if (v) API(void, duckdb_destroy_value, duckdb_value *)(&v);
+    return s;
+}
+static int get_named_bool(duckdb_bind_info info, const char *name) {
+    duckdb_value v = API(duckdb_value, duckdb_bind_get_named_parameter, duckdb_bind_info, const char *)(info, name);
+    int r = 0;
+    if (v && !API(bool, duckdb_is_null_value, duckdb_value)(v)) r = API(bool, duckdb_get_bool, duckdb_value)(v) ? 1 : 0;
+    if (v) API(void, duckdb_destroy_value, duckdb_value *)(&v);
+    return r;
+}
+static bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+
+static void bam_read_bind(duckdb_bind_info info) {
+    auto set_error = API(void, duckdb_bind_set_error, duckdb_bind_info, const char *);
+    auto dfree = API(void, duckdb_free, void *);
+    duckdb_value pv = API(duckdb_value, duckdb_bind_get_parameter, duckdb_bind_info, idx_t)(info, 0);
+    char *file_path = API(char *, duckdb_get_varchar, duckdb_value)(pv);
+    API(void, duckdb_destroy_value, duckdb_value *)(&pv);
+    if (!file_path || strlen(file_path) == 0) {
+        set_error(info, "read_bam requires a file path");                         // bam_reader.c:416
+        if (file_path) dfree(file_path);
+        return;
+    }
+    char *region = get_named_varchar(info, "region");
+    char *index_path = get_named_varchar(info, "index_path");
+    char *reference = get_named_varchar(info, "reference");
+    int standard_tags = get_named_bool(info, "standard_tags"), auxiliary_tags = get_named_bool(info, "auxiliary_tags");
+    BamBind *b = new BamBind();
+    b->path = file_path;
+    std::string idx = index_path ? index_path : "";
+    bool has_region = region && strlen(region) > 0;
+    dfree(file_path); if (region) dfree(region); if (index_path) dfree(index_path); if (reference) dfree(reference);
+
+    char err[768];
+    if (!file_exists(b->path)) {
+        snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());   // bam_reader.c:446
+        set_error(info, err); delete b; return;
+    }
+    int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
+    b->ctx = dhts_create(dev);
+    if (!b->ctx) { set_error(info, "read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); delete b; return; }
+    if (dhts_open_path(b->ctx, b->path.c_str()) != 0) {
+        snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());
+        set_error(info, err); delete b; return;
+    }
+    if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bam_open(b->ctx) != 0 || dhts_bam_header_get(b->ctx, &b->hdr) != 0) {
+        set_error(info, "Failed to read SAM/BAM/CRAM header");                    // bam_reader.c:461 (also what SAM/CRAM input gets here)
+        delete b; return;
+    }
+    b->has_index = (!idx.empty() && file_exists(idx)) || file_exists(b->path + ".bai") || file_exists(b->path + ".csi");   // bam_reader.c:499-503
+    if (has_region) {
+        if (!b->has_index) set_error(info, "Region query requires an index (.bai/.csi/.crai)");                           // bam_reader.c:647-648
+        else set_error(info, "read_bam: region queries are not on the MI355X scan path yet");
+        delete b; return;
+    }
+    if (standard_tags || auxiliary_tags) { set_error(info, "read_bam: standard_tags / auxiliary_tags are not on the MI355X scan path yet"); delete b; return; }
+
+    auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
+    auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);
+    auto rm = API(void, duckdb_destroy_logical_type, duckdb_logical_type *);
+    duckdb_logical_type t_varchar = mk(DUCKDB_TYPE_VARCHAR), t_int = mk(DUCKDB_TYPE_INTEGER), t_big = mk(DUCKDB_TYPE_BIGINT), t_us = mk(DUCKDB_TYPE_USMALLINT);
+    add(info, "QNAME", t_varchar); add(info, "FLAG", t_us); add(info, "RNAME", t_varchar); add(info, "POS", t_big); add(info, "MAPQ", t_int);   // bam_reader.c:514-526
+    add(info, "CIGAR", t_varchar); add(info, "RNEXT", t_varchar); add(info, "PNEXT", t_big); add(info, "TLEN", t_big); add(info, "SEQ", t_varchar);
+    add(info, "QUAL", t_varchar); add(info, "READ_GROUP_ID", t_varchar); add(info, "SAMPLE_ID", t_varchar);
+    rm(&t_varchar); rm(&t_int); rm(&t_big); rm(&t_us);
+    API(void, duckdb_bind_set_bind_data, duckdb_bind_info, void *, duckdb_delete_callback_t)(info, b, destroy_bind);
+}
+
+static void bam_read_global_init(duckdb_init_info info) {
+    // sequential mode: one scan thread (bam_reader.c:582-585).  The GPU supplies the parallelism.
+    API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, 1);
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, calloc(1, 16), destroy_global);
+}
+
+static void bam_read_local_init(duckdb_init_info info) {
+    BamBind *bind = (BamBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
+    BamLocal *l = new BamLocal();
+    idx_t n = API(idx_t, duckdb_init_get_column_count, duckdb_init_info)(info);               // bam_reader.c:676-679
+    for (idx_t i = 0; i < n; i++) {
+        idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
+        l->column_ids.push_back(id);
+        if (id < DHTS_BAM_CORE_COUNT) l->colmask |= 1u << id;
+    }
+    if (dhts_bam_rewind(bind->ctx) != 0) { API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, l, destroy_local);
+}
+
+static int fetch_str(dhts_ctx *c, const dhts_strcol &d, int64_t n, HostStr &h, bool want) {
+    if (!want) return 0;
+    h.off.resize(n + 1); h.len.resize(n); h.bytes.resize(d.nbytes + 1);
+    if (dhts_memcpy_d2h(c, h.off.data(), d.off, (n + 1) * 4) || dhts_memcpy_d2h(c, h.len.data(), d.len, n * 4) || dhts_memcpy_d2h(c, h.bytes.data(), d.bytes, d.nbytes)) return -1;
+    return 0;
+}
+
+// pulls the next GPU batch and copies only the projected columns to the host
+static int next_host_batch(BamBind *bind, BamLocal *l) {
+    dhts_bam_batch b;
+    for (;;) {
+        if (dhts_bam_next_batch(bind->ctx, 0, l->colmask, &b) != 0) return -1;
+        l->status = b.status;
+        if (b.n_rows > 0 || b.status != 0) break;
+    }
+    int64_t n = b.n_rows; l->n = n; l->cur = 0;
+    if (n == 0) return 0;
+    dhts_ctx *c = bind->ctx; uint32_t m = l->colmask;
+#define FETCH(vec, ptr, bit) do { if (m & (1u << (bit))) { (vec).resize(n); if (dhts_memcpy_d2h(c, (vec).data(), ptr, n * sizeof((vec)[0]))) return -1; } } while (0)
+    FETCH(l->flag, b.flag, DHTS_BAM_FLAG); FETCH(l->pos, b.pos, DHTS_BAM_POS); FETCH(l->mapq, b.mapq, DHTS_BAM_MAPQ);
+    FETCH(l->pnext, b.pnext, DHTS_BAM_PNEXT); FETCH(l->tlen, b.tlen, DHTS_BAM_TLEN); FETCH(l->tid, b.tid, DHTS_BAM_RNAME); FETCH(l->mtid, b.mtid, DHTS_BAM_RNEXT);
+    FETCH(l->rgidx, b.rg_idx, DHTS_BAM_SAMPLE_ID);
+    if (m & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) { l->rgvalid.resize((n + 63) / 64); if (dhts_memcpy_d2h(c, l->rgvalid.data(), b.rg_valid, l->rgvalid.size() * 8)) return -1; }
+    if (fetch_str(c, b.qname, n, l->qname, m & (1u << DHTS_BAM_QNAME)) || fetch_str(c, b.cigar, n, l->cigar, m & (1u << DHTS_BAM_CIGAR)) ||
+        fetch_str(c, b.seq, n, l->seq, m & (1u << DHTS_BAM_SEQ)) || fetch_str(c, b.qual, n, l->qual, m & (1u << DHTS_BAM_QUAL)) ||
+        fetch_str(c, b.rg, n, l->rg, m & (1u << DHTS_BAM_READ_GROUP_ID))) return -1;
+    return 0;
+}
+
+static void bam_read_function(duckdb_function_info info, duckdb_data_chunk output) {
+    BamBind *bind = (BamBind *)API(void *, duckdb_function_get_bind_data, duckdb_function_info)(info);
+    BamLocal *l = (BamLocal *)API(void *, duckdb_function_get_local_init_data, duckdb_function_info)(info);
+    auto set_size = API(void, duckdb_data_chunk_set_size, duckdb_data_chunk, idx_t);
+    if (!l || l->done) { set_size(output, 0); return; }                                      // bam_reader.c:730-733
+    const idx_t vector_size = API(idx_t, duckdb_vector_size, void)();
+    auto get_vec = API(duckdb_vector, duckdb_data_chunk_get_vector, duckdb_data_chunk, idx_t);
+    auto get_data = API(void *, duckdb_vector_get_data, duckdb_vector);
+    auto assign_len = API(void, duckdb_vector_assign_string_element_len, duckdb_vector, idx_t, const char *, idx_t);
+    idx_t row_count = 0;
+    while (row_count < vector_size) {
+        if (l->cur >= l->n) {
+            if (l->status != 0) { l->done = true; break; }          // end of stream or silent stop on error (bam_reader.c:754-766)
+            if (next_host_batch(bind, l) != 0) {
+                API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, dhts_error(bind->ctx));
+                l->done = true; set_size(output, 0); return;
+            }
+            if (l->n == 0) { l->done = true; break; }
+        }
+        idx_t take = (idx_t)(l->n - l->cur); if (take > vector_size - row_count) take = vector_size - row_count;
+        const int64_t s = l->cur;
+        for (size_t ci = 0; ci < l->column_ids.size(); ci++) {
+            duckdb_vector vec = get_vec(output, ci);
+            auto put_str = [&](const HostStr &h) { for (idx_t r = 0; r < take; r++) assign_len(vec, row_count + r, (const char *)h.bytes.data() + h.off[s + r], h.len[s + r]); };
+            auto put_name = [&](const std::vector<int32_t> &ids) {
+                for (idx_t r = 0; r < take; r++) { int32_t t = ids[s + r]; const char *nm = t >= 0 ? bind->hdr.ref_name[t] : "*"; assign_len(vec, row_count + r, nm, strlen(nm)); } };
+            switch (l->column_ids[ci]) {
+            case DHTS_BAM_QNAME: put_str(l->qname); break;
+            case DHTS_BAM_FLAG: memcpy((uint16_t *)get_data(vec) + row_count, l->flag.data() + s, take * 2); break;
+            case DHTS_BAM_RNAME: put_name(l->tid); break;
+            case DHTS_BAM_POS: memcpy((int64_t *)get_data(vec) + row_count, l->pos.data() + s, take * 8); break;
+            case DHTS_BAM_MAPQ: memcpy((int32_t *)get_data(vec) + row_count, l->mapq.data() + s, take * 4); break;
+            case DHTS_BAM_CIGAR: put_str(l->cigar); break;
+            case DHTS_BAM_RNEXT: put_name(l->mtid); break;
+            case DHTS_BAM_PNEXT: memcpy((int64_t *)get_data(vec) + row_count, l->pnext.data() + s, take * 8); break;
+            case DHTS_BAM_TLEN: memcpy((int64_t *)get_data(vec) + row_count, l->tlen.data() + s, take * 8); break;
+            case DHTS_BAM_SEQ: put_str(l->seq); break;
+            case DHTS_BAM_QUAL: put_str(l->qual); break;
+            case DHTS_BAM_READ_GROUP_ID:
+                for (idx_t r = 0; r < take; r++) {
+                    int64_t g = s + (int64_t)r;
+                    if ((l->rgvalid[g >> 6] >> (g & 63)) & 1) assign_len(vec, row_count + r, (const char *)l->rg.bytes.data() + l->rg.off[g], l->rg.len[g]);
+                    else set_null(vec, row_count + r);
+                }
+                break;
+            case DHTS_BAM_SAMPLE_ID:
+                for (idx_t r = 0; r < take; r++) {
+                    int64_t g = s + (int64_t)r; int32_t k = l->rgidx[g];
+                    const char *sm = (((l->rgvalid[g >> 6] >> (g & 63)) & 1) && k >= 0) ? bind->hdr.rg_sm[k] : nullptr;
+                    if (sm) assign_len(vec, row_count + r, sm, strlen(sm)); else set_null(vec, row_count + r);
+                }
+                break;
+            default: break;                                        // unknown ids (e.g. a row-id pseudo column) write nothing, like the reference's default arm
+            }
+        }
+        row_count += take; l->cur += (int64_t)take;
+    }
+    set_size(output, row_count);
+}
+
+static void register_read_bam_function(duckdb_connection connection) {                      // bam_reader.c:1044-1068
+    duckdb_table_function tf = API(duckdb_table_function, duckdb_create_table_function, void)();
+    API(void, duckdb_table_function_set_name, duckdb_table_function, const char *)(tf, "read_bam");
+    auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
+    auto rm = API(void, duckdb_destroy_logical_type, duckdb_logical_type *);
+    auto named = API(void, duckdb_table_function_add_named_parameter, duckdb_table_function, const char *, duckdb_logical_type);
+    duckdb_logical_type t_varchar = mk(DUCKDB_TYPE_VARCHAR);
+    API(void, duckdb_table_function_add_parameter, duckdb_table_function, duckdb_logical_type)(tf, t_varchar);
+    named(tf, "region", t_varchar); named(tf, "index_path", t_varchar); named(tf, "reference", t_varchar);
+    rm(&t_varchar);
+    duckdb_logical_type t_bool = mk(DUCKDB_TYPE_BOOLEAN);
+    named(tf, "standard_tags", t_bool); named(tf, "auxiliary_tags", t_bool);
+    rm(&t_bool);
+    API(void, duckdb_table_function_set_bind, duckdb_table_function, duckdb_table_function_bind_t)(tf, bam_read_bind);
+    API(void, duckdb_table_function_set_init, duckdb_table_function, duckdb_table_function_init_t)(tf, bam_read_global_init);
+    API(void, duckdb_table_function_set_local_init, duckdb_table_function, duckdb_table_function_init_t)(tf, bam_read_local_init);
+    API(void, duckdb_table_function_set_function, duckdb_table_function, duckdb_table_function_t)(tf, bam_read_function);
+    API(void, duckdb_table_function_supports_projection_pushdown, duckdb_table_function, bool)(tf, true);
+    API(duckdb_state, duckdb_register_table_function, duckdb_connection, duckdb_table_function)(connection, tf);
+    API(void, duckdb_destroy_table_function, duckdb_table_function *)(&tf);
+}
+
+extern "C" __attribute__((visibility("default"))) bool duckhts_init_c_api(duckdb_extension_info info, struct duckdb_extension_access *access) {
+    // duckdb_extension.h:1151-1158,1182-1194: fetch the API table, connect, register, disconnect
+    const void *api = access->get_api(info, DUCKHTS_API_VERSION);
+    if (!api) return false;
+    g_api = (const void *const *)api;
+    duckdb_database *db = access->get_database(info);
+    duckdb_connection conn = nullptr;
+    if (API(duckdb_state, duckdb_connect, duckdb_database, duckdb_connection *)(*db, &conn) == DuckDBError) {
+        access->set_error(info, "Failed to open connection to database");
+        return false;
+    }
+    register_read_bam_function(conn);
+    API(void, duckdb_disconnect, duckdb_connection *)(&conn);
+    return true;
+}
