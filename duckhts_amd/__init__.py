@@ -43,7 +43,7 @@ class BamHeader(C.Structure):
 
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
-           "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard",
+           "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
            "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing"]
 
@@ -74,6 +74,8 @@ def lib():
         L.dhts_bam_open.argtypes = [C.c_void_p]
         L.dhts_bam_header_get.argtypes = [C.c_void_p, C.POINTER(BamHeader)]
         L.dhts_bam_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.dhts_bam_set_block_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+        L.dhts_shard_cut.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.dhts_bam_rewind.argtypes = [C.c_void_p]
         L.dhts_bam_next_batch.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(BamBatch)]
         L.dhts_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -170,6 +172,9 @@ class Context:
 
     def set_shard(self, rank, world):
         self._chk(self.L.dhts_bam_set_shard(self.h, rank, world))
+
+    def set_block_range(self, b0, b1, speculative):
+        self._chk(self.L.dhts_bam_set_block_range(self.h, b0, b1, int(speculative)))
 
     def rewind(self):
         self._chk(self.L.dhts_bam_rewind(self.h))
@@ -270,3 +275,21 @@ def read_bam(src, device=0, max_blocks=0, shard=None):
         return out
     finally:
         ctx.close()
+
+
+def shard_cut(coff, comp_len, rank, world):
+    """Block range [b0, b1) of `rank` (same arithmetic as dhts_bam_set_shard; host only, no device needed)."""
+    coff = np.ascontiguousarray(coff, dtype=np.uint64)
+    b0, b1 = C.c_int64(0), C.c_int64(0)
+    if lib().dhts_shard_cut(coff.ctypes.data, len(coff), int(comp_len), rank, world, C.byref(b0), C.byref(b1)) != 0:
+        raise ValueError("bad shard arguments")
+    return b0.value, b1.value
+
+
+def check_handoff(spans):
+    """spans: per-rank (first_rec_uoff, end_uoff, n_rows) in rank order, absolute inflated-stream offsets.
+    Adjacent shards must chain exactly: the record after rank r's last one is rank r+1's first one."""
+    for r in range(len(spans) - 1):
+        if spans[r][1] != spans[r + 1][0]:
+            raise RuntimeError(f"shard hand-off broken between rank {r} and {r + 1}: {spans[r][1]} != {spans[r + 1][0]}")
+    return sum(s[2] for s in spans)

@@ -472,19 +472,32 @@ int dhts_bam_header_get(const dhts_ctx *c, dhts_bam_header *out) {
     return 0;
 }
 
-int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
-    if (!c || world < 1 || rank < 0 || rank >= world) return -1;
-    // contiguous block ranges balanced by compressed bytes
-    const int64_t nb = c->n_blocks;
+// contiguous block ranges balanced by compressed bytes; pure host arithmetic, no device needed
+int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, int rank, int world, int64_t *b0, int64_t *b1) {
+    if (!coff || world < 1 || rank < 0 || rank >= world || !b0 || !b1) return -1;
     auto cut = [&](int r) -> int64_t {
-        if (r <= 0) return 0; if (r >= world) return nb;
-        uint64_t target = (uint64_t)((__uint128_t)c->comp_len * (unsigned)r / (unsigned)world);
-        int64_t lo = 0, hi = nb;
-        while (lo < hi) { int64_t mid = (lo + hi) / 2; if (c->h_coff[mid] < target) lo = mid + 1; else hi = mid; }
+        if (r <= 0) return 0;
+        if (r >= world) return n_blocks;
+        uint64_t target = (uint64_t)((__uint128_t)comp_len * (unsigned)r / (unsigned)world);
+        int64_t lo = 0, hi = n_blocks;
+        while (lo < hi) { int64_t mid = (lo + hi) / 2; if (coff[mid] < target) lo = mid + 1; else hi = mid; }
         return lo;
     };
-    c->shard_rank = rank; c->shard_world = world; c->shard_b0 = cut(rank); c->shard_b1 = cut(rank + 1);
+    *b0 = cut(rank); *b1 = cut(rank + 1);
+    return 0;
+}
+
+int dhts_bam_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculative_start) {
+    if (!c || b0 < 0 || b1 < b0 || b1 > c->n_blocks) return -1;
+    c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = speculative_start ? 1 : 0; c->shard_world = (b1 < c->n_blocks || speculative_start) ? 2 : 1;
     return dhts_bam_rewind(c);
+}
+
+int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
+    if (!c) return -1;
+    int64_t b0, b1;
+    if (dhts_shard_cut(c->h_coff.data(), c->n_blocks, c->comp_len, rank, world, &b0, &b1)) return -1;
+    return dhts_bam_set_block_range(c, b0, b1, rank > 0);
 }
 
 int dhts_bam_rewind(dhts_ctx *c) {

@@ -113,6 +113,9 @@ int64_t dhts_bgzf_inflate_to_host(dhts_ctx *, int64_t blk0, int64_t nblk, uint8_
 int dhts_bam_open(dhts_ctx *);                                     /* header + dictionaries; positions the scan at the first record */
 int dhts_bam_header_get(const dhts_ctx *, dhts_bam_header *out);
 int dhts_bam_set_shard(dhts_ctx *, int rank, int world);           /* scan only this rank's BGZF block range */
+int dhts_bam_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);   /* explicit shard: blocks [b0,b1) */
+/* the shard cut itself (host arithmetic only): blocks [*b0,*b1) of rank, balanced by compressed bytes */
+int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, int rank, int world, int64_t *b0, int64_t *b1);
 int dhts_bam_rewind(dhts_ctx *);
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 
