@@ -146,10 +146,11 @@ def main():
         assert spans["end"] - spans["first"] == raw_bytes - 0, (spans, raw_bytes)
     if dist is not None:
         import torch
-        sp = torch.tensor([spans["first"], spans["end"], rows], dtype=torch.int64, device=tdev)
+        # every rank's shard must span exactly its own `reps` segments and yield its own record count (seeds differ per rank)
+        sp = torch.tensor([spans["end"] - spans["first"], raw_bytes, rows, n_records], dtype=torch.int64, device=tdev)
         allsp = [torch.zeros_like(sp) for _ in range(world)]
         dist.all_gather(allsp, sp)
-        assert all(int(a[1] - a[0]) == int(allsp[0][1] - allsp[0][0]) and int(a[2]) == n_records for a in allsp)
+        assert all(int(a[0]) == int(a[1]) and int(a[2]) == int(a[3]) for a in allsp), [a.tolist() for a in allsp]
         tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
