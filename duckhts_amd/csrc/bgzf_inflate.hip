@@ -364,10 +364,20 @@ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
     return p;
 }
 
+// Unaligned 2/4/8-byte LDS accesses are legal on gfx950 in the HSA alignment mode (verified on hardware:
+// tools/dbg/lds_unaligned.hip); the build passes +unaligned-ds-access so these memcpys become single DS ops.
+__device__ __forceinline__ uint64_t lds_ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {   // stores exactly min(n, 8) bytes
+    if (n >= 8) { __builtin_memcpy(p, &v, 8); return; }
+    if (n & 4) { uint32_t x = (uint32_t)v; __builtin_memcpy(p, &x, 4); p += 4; v >>= 32; }
+    if (n & 2) { uint16_t x = (uint16_t)v; __builtin_memcpy(p, &x, 2); p += 2; v >>= 16; }
+    if (n & 1) *p = (uint8_t)v;
+}
+
 #define B_WIN 0                          /* u8 [65536 + 64] */
 #define B_CRCT (65536 + 64)              /* u32 [4][256] slice-by-4 tables */
-#define B_RING (B_CRCT + 4096)           /* u8 [4096] literal staging ring */
-#define B_LDS_BYTES (B_RING + 4096)
+#define B_RING (B_CRCT + 4096)           /* u8 [4096 + 16] literal staging ring (first 16 bytes mirrored past the end) */
+#define B_LDS_BYTES (B_RING + 4096 + 16)
 #define B_NULLTOK 0xffffffffu
 #ifdef DHTS_DIAG
 __device__ unsigned long long g_diag[8];   // batches, rounds, easy, hard, lit_iters, long_lit
@@ -433,7 +443,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     // literal staging ring: literal bytes [.., stage_hi) are in LDS at (abs & 4095); filled 1 KiB at a time, one piece in flight
     uint32_t stage_hi = 0; bool pend = false; uint4 pv = make_uint4(0, 0, 0, 0);
 #define STAGE_ISSUE() do { if (!pend && stage_hi < m.nlit && (int32_t)(stage_hi - litpos) <= 3072) { __builtin_memcpy(&pv, lit + stage_hi + lane * 16, 16); pend = true; } } while (0)
-#define STAGE_COMMIT() do { if (pend) { *(uint4 *)(ring + ((stage_hi + lane * 16) & 4095u)) = pv; stage_hi += 1024u; pend = false; } } while (0)
+#define STAGE_COMMIT() do { if (pend) { const uint32_t ro_ = (stage_hi + lane * 16) & 4095u; *(uint4 *)(ring + ro_) = pv; if (ro_ == 0) *(uint4 *)(ring + 4096) = pv; stage_hi += 1024u; pend = false; } } while (0)
     STAGE_ISSUE(); STAGE_COMMIT(); STAGE_ISSUE(); STAGE_COMMIT();
     uint32_t tnext = (lane < (int)m.ntok) ? tok[lane] : B_NULLTOK;
 
@@ -455,12 +465,9 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         if (tot_lit <= 2048u) {
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
             __syncthreads();
-            for (uint32_t q0 = 0; q0 < lrun; q0 += 8) {
-                uint8_t b[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) b[k] = (q0 + k < lrun) ? ring[(lsrc + q0 + k) & 4095u] : (uint8_t)0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (q0 + k < lrun) win[dst + q0 + k] = b[k];
+            // 8 bytes per lane per step: one unaligned 64-bit ring read, then an exact-length store
+            for (uint32_t q0 = 0; __ballot(q0 < lrun) != 0ull; q0 += 8) {
+                if (q0 < lrun) lds_st_n(win + dst + q0, lds_ld64(ring + ((lsrc + q0) & 4095u)), lrun - q0);
             }
         } else {
             // very long literal runs: place straight from global memory, then restart the ring behind them
@@ -493,23 +500,21 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             const uint32_t el = wave_shr1(wave_incl_scan_or((uint32_t)e)), eh = wave_shr1(wave_incl_scan_or((uint32_t)(e >> 32)));
             const uint64_t owed = ((uint64_t)eh << 32) | el;                   // exclusive prefix-OR over earlier lanes
             const bool ready = pending && ((smask & owed) == 0ull);
-            // (a) lane-parallel: short non-overlapping copies and byte runs
-            const bool easy = ready && (mlen <= 16u) && (mdist >= mlen || mdist == 1u);
+            // (a) lane-parallel, 8 bytes per step with unaligned 64-bit LDS accesses: byte runs (dist 1), non-overlapping
+            //     copies, and overlapping copies with dist >= 8 (a chunk never reads what it writes; chunks go in order)
+            const bool easy = ready && (mlen <= 32u) && (mdist >= 8u || mdist >= mlen || mdist == 1u);
             if (easy) {
-                uint8_t b[16];
-                if (mdist == 1u) { uint8_t v = win[ms];
+                const uint64_t rep = (uint64_t)win[ms] * 0x0101010101010101ull;
 #pragma unroll
-                    for (int k = 0; k < 16; k++) b[k] = v; }
-                else {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) b[k] = ((uint32_t)k < mlen) ? win[ms + k] : (uint8_t)0;
+                for (uint32_t k0 = 0; k0 < 32; k0 += 8) {
+                    if (k0 < mlen) {
+                        const uint64_t v = (mdist == 1u) ? rep : lds_ld64(win + ms + k0);
+                        lds_st_n(win + md + k0, v, mlen - k0);
+                    }
                 }
-#pragma unroll
-                for (int k = 0; k < 16; k++) if ((uint32_t)k < mlen) win[md + k] = b[k];
             }
             // (b) the rest of the ready set, one at a time, replayed by the whole wave
             uint64_t H = __ballot(ready && !easy);
-
             while (H) {
                 const int i = __ffsll((unsigned long long)H) - 1; H &= H - 1;
                 const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
