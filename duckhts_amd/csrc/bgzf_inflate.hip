@@ -106,6 +106,9 @@ __device__ __forceinline__ void set_len(uint8_t *lens, int lane, uint32_t i, uin
     lens[idx] = (uint8_t)((i & 1) ? ((b & 0x0f) | (v << 4)) : ((b & 0xf0) | v));
 }
 
+#ifdef DHTS_DIAG
+__device__ unsigned long long g_diagA[8];
+#endif
 extern "C" __global__ void __launch_bounds__(64)
 bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                  uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta) {
@@ -134,6 +137,9 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
     const uint32_t payload_bits = clen >= 26 ? (clen - 26) * 8 : 0;
 
     uint32_t nlit = 0, ntok = 0, outpos = 0, run = 0, litbuf = 0;
+#ifdef DHTS_DIAG
+    unsigned long long dA_t0 = clock64(), dA_sym = 0, dA_it = 0, dA_build = 0;
+#endif
     int status = clen >= 26 ? 0 : DHTS_BLK_ERR_INFLATE;
     bool last = (status != 0);
     Limits ll, dl;
@@ -284,8 +290,14 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
             if (l) { uint32_t o = cnt[l * A_ST + lane]; cnt[l * A_ST + lane] = (uint16_t)(o + 1); dsym[(o & 31) * A_ST + lane] = (uint8_t)i; }
         }
 
+#ifdef DHTS_DIAG
+        unsigned long long dA_s0 = clock64();
+#endif
         // ---- symbol loop ----
         for (;;) {
+#ifdef DHTS_DIAG
+            dA_it++;
+#endif
             br_refill(br);
             uint32_t w = __brev((uint32_t)br.buf) >> 17;
             uint32_t L = code_len(ll, w);
@@ -323,8 +335,14 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
             }
             if (br.pos * 8 - br.cnt > payload_bits + 64) { status = DHTS_BLK_ERR_INFLATE; break; }   // ran off the payload
         }
+#ifdef DHTS_DIAG
+        dA_sym += clock64() - dA_s0;
+#endif
         if (status == 0 && br.pos * 8 - br.cnt > payload_bits) status = DHTS_BLK_ERR_INFLATE;
     }
+#ifdef DHTS_DIAG
+    if (lane == 0) { atomicAdd(&g_diagA[0], dA_sym); atomicAdd(&g_diagA[1], dA_it); atomicAdd(&g_diagA[3], clock64() - dA_t0); atomicAdd(&g_diagA[4], 1ull); }
+#endif
     if (nlit & 3) *(uint32_t *)(lit + (nlit & ~3u)) = litbuf;
     InflateMeta m; m.ntok = ntok; m.nlit = nlit; m.outlen = outpos; m.status = status;
     meta[s] = m;
@@ -374,10 +392,16 @@ __device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {  
     if (n & 1) *p = (uint8_t)v;
 }
 
-#define B_WIN 0                          /* u8 [65536 + 64] */
-#define B_CRCT (65536 + 64)              /* u32 [4][256] slice-by-4 tables */
-#define B_RING (B_CRCT + 4096)           /* u8 [4096 + 16] literal staging ring (first 16 bytes mirrored past the end) */
-#define B_LDS_BYTES (B_RING + 4096 + 16)
+// Window ring: 32 KiB of DEFLATE history + 2 KiB of batch span (a batch places its literals before its matches, so a
+// batch may run at most BR_SPAN bytes ahead of the oldest byte a match of the same batch can still need).
+// 34,816 + 4,096 (CRC tables) + 2,048 (literal ring) = 40,960 B: four workgroups per CU.
+#define BR_R 34560u
+#define BR_SPAN 1792u
+#define BR_FLUSH 8192u
+#define B_WIN 0
+#define B_CRCT (BR_R)                    /* u32 [4][256] slice-by-4 tables */
+#define B_RING (B_CRCT + 4096)           /* u8 [2048] literal staging ring */
+#define B_LDS_BYTES (B_RING + 2048)
 #define B_NULLTOK 0xffffffffu
 #ifdef DHTS_DIAG
 __device__ unsigned long long g_diag[8];   // batches, rounds, easy, hard, lit_iters, long_lit
@@ -395,6 +419,27 @@ __device__ unsigned long long g_diagt[8];
 #define DIAG_ADD(i, v) do {} while (0)
 #endif
 
+
+__device__ __forceinline__ uint32_t ridx(uint32_t p) { return p >= BR_R ? p - BR_R : p; }      // p < 2*BR_R
+__device__ __forceinline__ uint64_t win_ld64(const uint8_t *win, uint32_t p) {
+    const uint32_t i = ridx(p);
+    if (i + 8 <= BR_R) return lds_ld64(win + i);
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < 8; k++) v |= (uint64_t)win[ridx(p + k)] << (8 * k);
+    return v;
+}
+__device__ __forceinline__ void win_st_n(uint8_t *win, uint32_t p, uint64_t v, uint32_t n) {
+    const uint32_t i = ridx(p), m = n < 8 ? n : 8;
+    if (i + m <= BR_R) lds_st_n(win + i, v, n);
+    else for (uint32_t k = 0; k < m; k++) win[ridx(p + k)] = (uint8_t)(v >> (8 * k));
+}
+// x^(8*nbytes) mod P (reflected)
+__device__ __forceinline__ uint32_t crc_xpow8(uint32_t nbytes) {
+    uint32_t pw = 0x80000000u, sq = 0x00800000u;
+    while (nbytes) { if (nbytes & 1) pw = crc_mulmod(pw, sq); sq = crc_mulmod(sq, sq); nbytes >>= 1; }
+    return pw;
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                 const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
@@ -411,9 +456,9 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     const InflateMeta m = meta[s];
     const uint32_t isize = tab.isize[bi];
     const uint32_t clen = tab.clen[bi];
-
     DIAG_DECL;
     DIAG_T(t_begin);
+
     // slice-by-4 tables (built per workgroup: 4 entries per lane per table)
     for (int k = lane; k < 256; k += 64) {
         uint32_t c = (uint32_t)k;
@@ -438,12 +483,36 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
 
     const uint32_t *tok = tok_all + (size_t)s * DHTS_TOK_STRIDE;
     const uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
-    uint32_t outpos = 0, litpos = 0;
+    uint8_t *dstp = out + (tab.uoff[bi] - out_base);
+    uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
+    // constants of the 8 KiB flush-chunk CRC: lane's 128-byte piece is followed by 128*(63-lane) bytes of the chunk
+    const uint32_t K_lane = crc_xpow8(128u * (63u - (uint32_t)lane));
+    const uint32_t X_F = crc_xpow8(BR_FLUSH);
 
-    // literal staging ring: literal bytes [.., stage_hi) are in LDS at (abs & 4095); filled 1 KiB at a time, one piece in flight
+    // Flush the 8 KiB chunk [flushed, flushed + 8192): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
+    // BR_R is a multiple of 128, so neither a lane's 128-byte CRC piece nor a 16-byte store unit wraps in the ring.
+#define FLUSH_CHUNK() do {                                                                                              \
+        const uint32_t pi_ = ridx(flushed + (uint32_t)lane * 128u);                                                     \
+        uint32_t c_ = (flushed == 0 && lane == 0) ? 0xffffffffu : 0u;                                                   \
+        for (uint32_t q_ = 0; q_ < 128; q_ += 4) {                                                                      \
+            uint32_t v_ = *(const uint32_t *)(win + pi_ + q_) ^ c_;                                                     \
+            c_ = crct[768 + (v_ & 0xff)] ^ crct[512 + ((v_ >> 8) & 0xff)] ^ crct[256 + ((v_ >> 16) & 0xff)] ^ crct[v_ >> 24]; \
+        }                                                                                                               \
+        c_ = crc_mulmod(c_, K_lane);                                                                                    \
+        _Pragma("unroll") for (int d_ = 32; d_ >= 1; d_ >>= 1) c_ ^= __shfl_xor(c_, d_, 64);                           \
+        crc_run = crc_mulmod(crc_run, X_F) ^ c_;                                                                        \
+        for (uint32_t k_ = 0; k_ < BR_FLUSH; k_ += 1024) {                                                              \
+            const uint32_t p_ = flushed + k_ + (uint32_t)lane * 16u;                                                    \
+            uint4 v4_ = *(const uint4 *)(win + ridx(p_));                                                               \
+            __builtin_memcpy(dstp + p_, &v4_, 16);                                                                      \
+        }                                                                                                               \
+        flushed += BR_FLUSH;                                                                                            \
+    } while (0)
+
+    // literal staging ring: literal bytes [.., stage_hi) are in LDS at (abs & 2047); filled 1 KiB at a time, one piece in flight
     uint32_t stage_hi = 0; bool pend = false; uint4 pv = make_uint4(0, 0, 0, 0);
-#define STAGE_ISSUE() do { if (!pend && stage_hi < m.nlit && (int32_t)(stage_hi - litpos) <= 3072) { __builtin_memcpy(&pv, lit + stage_hi + lane * 16, 16); pend = true; } } while (0)
-#define STAGE_COMMIT() do { if (pend) { const uint32_t ro_ = (stage_hi + lane * 16) & 4095u; *(uint4 *)(ring + ro_) = pv; if (ro_ == 0) *(uint4 *)(ring + 4096) = pv; stage_hi += 1024u; pend = false; } } while (0)
+#define STAGE_ISSUE() do { if (!pend && stage_hi < m.nlit && (int32_t)(stage_hi - litpos) <= 1024) { __builtin_memcpy(&pv, lit + stage_hi + lane * 16, 16); pend = true; } } while (0)
+#define STAGE_COMMIT() do { if (pend) { *(uint4 *)(ring + ((stage_hi + lane * 16) & 2047u)) = pv; stage_hi += 1024u; pend = false; } } while (0)
     STAGE_ISSUE(); STAGE_COMMIT(); STAGE_ISSUE(); STAGE_COMMIT();
     uint32_t tnext = (lane < (int)m.ntok) ? tok[lane] : B_NULLTOK;
 
@@ -461,74 +530,100 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         const uint32_t dst = outpos + adv_i - (lrun + mlen);       // where this token's literals start
         const uint32_t lsrc = litpos + lit_i - lrun;               // absolute index of its first literal byte
         DIAG_T(t_a);
-        // ---- literals ----
-        if (tot_lit <= 2048u) {
+        if (tot_adv <= BR_SPAN && tot_lit <= 1024u) {
+            // ---- literals ----
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
             __syncthreads();
-            // 8 bytes per lane per step: one unaligned 64-bit ring read, then an exact-length store
+            // 8 bytes per lane per step: one (usually unaligned) 64-bit ring read, then an exact-length store
             for (uint32_t q0 = 0; __ballot(q0 < lrun) != 0ull; q0 += 8) {
-                if (q0 < lrun) lds_st_n(win + dst + q0, lds_ld64(ring + ((lsrc + q0) & 4095u)), lrun - q0);
-            }
-        } else {
-            // very long literal runs: place straight from global memory, then restart the ring behind them
-            for (uint32_t q = 0; q < lrun; q++) win[dst + q] = lit[lsrc + q];
-            pend = false; stage_hi = (litpos + tot_lit) & ~1023u;
-        }
-        __syncthreads();
-        DIAG_T(t_b);
-        DIAG_TADD(1, t_a, t_b);
-        // ---- matches ----
-        // A pending match is ready when its source overlaps no destination of an EARLIER pending match (all literals of
-        // the batch are already placed).  Destinations/sources are rasterised into 64 cells covering the batch's output
-        // span; an exclusive prefix-OR over lanes gives each lane the cells still owed by earlier matches.  The earliest
-        // pending match always sees an empty set, so every round makes progress; cell granularity only delays.
-        const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
-        uint32_t sh = 4; while ((tot_adv >> sh) > 63u) sh++;
-        uint64_t dmask = 0, smask = 0;
-        if (mlen > 0) {
-            const uint32_t lo = (md - outpos) >> sh, hi = (md - outpos + mlen - 1) >> sh;
-            dmask = ((~0ull) >> (63u - hi)) & ((~0ull) << lo);
-            if (ms + mspan > outpos) {
-                const uint32_t slo = (ms > outpos ? ms - outpos : 0u) >> sh, shi = (ms + mspan - 1 - outpos) >> sh;
-                smask = ((~0ull) >> (63u - shi)) & ((~0ull) << slo);
-            }
-        }
-        uint64_t P = __ballot(mlen > 0);
-        while (P) {
-            const bool pending = (P >> lane) & 1ull;
-            const uint64_t e = pending ? dmask : 0ull;
-            const uint32_t el = wave_shr1(wave_incl_scan_or((uint32_t)e)), eh = wave_shr1(wave_incl_scan_or((uint32_t)(e >> 32)));
-            const uint64_t owed = ((uint64_t)eh << 32) | el;                   // exclusive prefix-OR over earlier lanes
-            const bool ready = pending && ((smask & owed) == 0ull);
-            // (a) lane-parallel, 8 bytes per step with unaligned 64-bit LDS accesses: byte runs (dist 1), non-overlapping
-            //     copies, and overlapping copies with dist >= 8 (a chunk never reads what it writes; chunks go in order)
-            const bool easy = ready && (mlen <= 32u) && (mdist >= 8u || mdist >= mlen || mdist == 1u);
-            if (easy) {
-                const uint64_t rep = (uint64_t)win[ms] * 0x0101010101010101ull;
-#pragma unroll
-                for (uint32_t k0 = 0; k0 < 32; k0 += 8) {
-                    if (k0 < mlen) {
-                        const uint64_t v = (mdist == 1u) ? rep : lds_ld64(win + ms + k0);
-                        lds_st_n(win + md + k0, v, mlen - k0);
-                    }
+                if (q0 < lrun) {
+                    const uint32_t ri = (lsrc + q0) & 2047u;
+                    uint64_t v;
+                    if (ri <= 2040u) v = lds_ld64(ring + ri);
+                    else { v = 0; for (uint32_t k = 0; k < 8; k++) v |= (uint64_t)ring[(ri + k) & 2047u] << (8 * k); }
+                    win_st_n(win, dst + q0, v, lrun - q0);
                 }
             }
-            // (b) the rest of the ready set, one at a time, replayed by the whole wave
-            uint64_t H = __ballot(ready && !easy);
-            while (H) {
-                const int i = __ffsll((unsigned long long)H) - 1; H &= H - 1;
-                const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
-                const uint32_t src0 = d0 - di;
-                if (l0 <= di) { for (uint32_t k = lane; k < l0; k += 64) win[d0 + k] = win[src0 + k]; }
-                else if (di == 1u) { const uint8_t v = win[src0]; for (uint32_t k = lane; k < l0; k += 64) win[d0 + k] = v; }
-                else { for (uint32_t k = lane; k < l0; k += 64) win[d0 + k] = win[src0 + (k % di)]; }
-            }
             __syncthreads();
-            P &= ~__ballot(ready);
+            DIAG_T(t_b);
+            DIAG_TADD(1, t_a, t_b);
+            // ---- matches ----
+            // A pending match is ready when its source overlaps no destination of an EARLIER pending match (all literals of
+            // the batch are already placed).  Destinations/sources are rasterised into 64 cells covering the batch's output
+            // span; an exclusive prefix-OR over lanes gives each lane the cells still owed by earlier matches.  The earliest
+            // pending match always sees an empty set, so every round makes progress; cell granularity only delays.
+            const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
+            uint32_t sh = 4; while ((tot_adv >> sh) > 63u) sh++;
+            uint64_t dmask = 0, smask = 0;
+            if (mlen > 0) {
+                const uint32_t lo = (md - outpos) >> sh, hi = (md - outpos + mlen - 1) >> sh;
+                dmask = ((~0ull) >> (63u - hi)) & ((~0ull) << lo);
+                if (ms + mspan > outpos) {
+                    const uint32_t slo = (ms > outpos ? ms - outpos : 0u) >> sh, shi = (ms + mspan - 1 - outpos) >> sh;
+                    smask = ((~0ull) >> (63u - shi)) & ((~0ull) << slo);
+                }
+            }
+            uint64_t P = __ballot(mlen > 0);
+            while (P) {
+                const bool pending = (P >> lane) & 1ull;
+                const uint64_t e = pending ? dmask : 0ull;
+                const uint32_t el = wave_shr1(wave_incl_scan_or((uint32_t)e)), eh = wave_shr1(wave_incl_scan_or((uint32_t)(e >> 32)));
+                const uint64_t owed = ((uint64_t)eh << 32) | el;                   // exclusive prefix-OR over earlier lanes
+                const bool ready = pending && ((smask & owed) == 0ull);
+                // (a) lane-parallel, 8 bytes per step with unaligned 64-bit LDS accesses: byte runs (dist 1), non-overlapping
+                //     copies, and overlapping copies with dist >= 8 (a chunk never reads what it writes; chunks go in order).
+                //     Matches whose source or destination would wrap in the ring go to (b).
+                const uint32_t rs = ridx(ms), rd = ridx(md);
+                const bool easy = ready && (mlen <= 32u) && (mdist >= 8u || mdist >= mlen || mdist == 1u) && (rs + 40u <= BR_R) && (rd + 40u <= BR_R);
+                if (easy) {
+                    const uint8_t *sp = win + rs; uint8_t *dp = win + rd;
+                    const uint32_t full = mlen >> 3, tail = mlen & 7u;
+                    if (mdist == 1u) {
+                        const uint64_t rep = (uint64_t)sp[0] * 0x0101010101010101ull;
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; c++) if (c < full) __builtin_memcpy(dp + 8 * c, &rep, 8);
+                        if (tail) lds_st_n(dp + 8 * full, rep, tail);
+                    } else {
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; c++) if (c < full) { const uint64_t v = lds_ld64(sp + 8 * c); __builtin_memcpy(dp + 8 * c, &v, 8); }
+                        if (tail) lds_st_n(dp + 8 * full, lds_ld64(sp + 8 * full), tail);
+                    }
+                }
+                // (b) the rest of the ready set, one at a time, replayed by the whole wave
+                uint64_t H = __ballot(ready && !easy);
+                while (H) {
+                    const int i = __ffsll((unsigned long long)H) - 1; H &= H - 1;
+                    const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
+                    const uint32_t src0 = d0 - di;
+                    if (l0 <= di) { for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = win[ridx(src0 + k)]; }
+                    else if (di == 1u) { const uint8_t v = win[ridx(src0)]; for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = v; }
+                    else { for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = win[ridx(src0 + (k % di))]; }
+                }
+                __syncthreads();
+                P &= ~__ballot(ready);
+            }
+            DIAG_T(t_c);
+            DIAG_TADD(2, t_b, t_c);
+            outpos += tot_adv; litpos += tot_lit;
+            while (outpos - flushed >= BR_FLUSH) FLUSH_CHUNK();
+        } else {
+            // ---- oversized batch (long literal runs / long matches): strict stream order, one token at a time ----
+            for (int i = 0; i < 64; i++) {
+                const uint32_t lr = RDLANE(lrun, i), ml = RDLANE(mlen, i), di = RDLANE(mdist, i);
+                for (uint32_t k = lane; k < lr; k += 64) win[ridx(outpos + k)] = lit[litpos + k];
+                outpos += lr; litpos += lr;
+                __syncthreads();
+                if (ml) {
+                    const uint32_t src0 = outpos - di;
+                    if (ml <= di) { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + k)]; }
+                    else { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + (k % di))]; }
+                    outpos += ml;
+                    __syncthreads();
+                }
+                while (outpos - flushed >= BR_FLUSH) FLUSH_CHUNK();
+            }
+            pend = false; stage_hi = litpos & ~1023u;          // restart the literal ring behind the literals consumed here
         }
-        DIAG_T(t_c);
-        DIAG_TADD(2, t_b, t_c);
-        outpos += tot_adv; litpos += tot_lit;
         STAGE_COMMIT();
     }
     DIAG_T(t_loop);
@@ -536,57 +631,46 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     // trailing literals
     {
         uint32_t rem = m.nlit - litpos;
-        for (uint32_t k = lane; k < rem; k += 64) win[outpos + k] = lit[litpos + k];
-        outpos += rem;
+        while (rem) {
+            const uint32_t n = rem < 4096u ? rem : 4096u;
+            for (uint32_t k = lane; k < n; k += 64) win[ridx(outpos + k)] = lit[litpos + k];
+            outpos += n; litpos += n; rem -= n;
+            __syncthreads();
+            while (outpos - flushed >= BR_FLUSH) FLUSH_CHUNK();
+        }
     }
     __syncthreads();
     if (outpos != m.outlen) { if (lane == 0) blk_status[bi] = DHTS_BLK_ERR_INFLATE; return; }
 
     DIAG_T(t_crc0);
-    // ---- CRC-32 of win[0..outlen): per-lane chunk, then combine ----
-    const uint32_t n = m.outlen;
-    const uint32_t chunk = ((n + 63) / 64 + 3) & ~3u;          // multiple of 4
+    // ---- tail [flushed, outlen): CRC per lane + combine, then fold into crc_run ----
+    const uint32_t n = m.outlen - flushed;                     // < BR_FLUSH
+    const uint32_t chunk = ((n + 63) / 64 + 3) & ~3u;          // multiple of 4; flushed is a multiple of 4, so dwords never wrap
     uint32_t beg = lane * chunk; if (beg > n) beg = n;
     uint32_t end = beg + chunk; if (end > n) end = n;
-    uint32_t c = (lane == 0) ? 0xffffffffu : 0u;
+    uint32_t c = (flushed == 0 && lane == 0) ? 0xffffffffu : 0u;
     uint32_t q = beg;
     for (; q + 4 <= end; q += 4) {
-        uint32_t v = *(const uint32_t *)(win + q) ^ c;
+        uint32_t v = *(const uint32_t *)(win + ridx(flushed + q)) ^ c;
         c = crct[768 + (v & 0xff)] ^ crct[512 + ((v >> 8) & 0xff)] ^ crct[256 + ((v >> 16) & 0xff)] ^ crct[v >> 24];
     }
-    for (; q < end; q++) c = crct[(c ^ win[q]) & 0xff] ^ (c >> 8);
-    // advance lane's register by the bytes that follow its chunk: multiply by x^(8*after) mod P
-    {
-        uint32_t after = n - end;
-        uint32_t pw = 0x80000000u;                               // x^0
-        uint32_t sq = 0x00800000u;                               // x^8 (reflected: bit 31-8)
-        while (after) {
-            if (after & 1) pw = crc_mulmod(pw, sq);
-            sq = crc_mulmod(sq, sq);
-            after >>= 1;
-        }
-        c = crc_mulmod(c, pw);
-    }
+    for (; q < end; q++) c = crct[(c ^ win[ridx(flushed + q)]) & 0xff] ^ (c >> 8);
+    c = crc_mulmod(c, crc_xpow8(n - end));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
+    c ^= crc_mulmod(crc_run, crc_xpow8(n));
     c ^= 0xffffffffu;
     uint32_t want; __builtin_memcpy(&want, comp + tab.coff[bi] + clen - 8, 4);
     if (c != want) st = DHTS_BLK_ERR_CRC;
     if (lane == 0) blk_status[bi] = st;
-    if (st != 0) return;
-
     DIAG_T(t_crc1);
     DIAG_TADD(4, t_crc0, t_crc1);
-    // ---- flush to the inflated stream: 16-byte coalesced stores over the aligned interior ----
-    uint8_t *dstp = out + (tab.uoff[bi] - out_base);
-    uint32_t head = (uint32_t)((16 - ((uintptr_t)dstp & 15)) & 15); if (head > n) head = n;
-    for (uint32_t k = lane; k < head; k += 64) dstp[k] = win[k];
-    uint32_t body = (n - head) & ~15u;
-    for (uint32_t k = lane * 16; k < body; k += 64 * 16) {
-        uint4 v; __builtin_memcpy(&v, win + head + k, 16);
-        *(uint4 *)(dstp + head + k) = v;
+    // a CRC mismatch ends the stream at this block: the host cuts the inflated stream here, the bytes already stored are ignored
+    for (uint32_t k = lane * 16; k < n; k += 1024) {
+        const uint32_t p = flushed + k;
+        if (k + 16 <= n) { uint4 v4 = *(const uint4 *)(win + ridx(p)); __builtin_memcpy(dstp + p, &v4, 16); }
+        else for (uint32_t j = k; j < n; j++) dstp[flushed + j] = win[ridx(flushed + j)];
     }
-    for (uint32_t k = head + body + lane; k < n; k += 64) dstp[k] = win[k];
     DIAG_T(t_end);
     DIAG_TADD(5, t_crc1, t_end);
     DIAG_TADD(6, t_begin, t_end);

@@ -686,6 +686,7 @@ int dhts_debug_diag(dhts_ctx *c, unsigned long long *out8) {
     if (!c) return -1;
     HIPCHK(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), 64));
     HIPCHK(c, hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(g_diagt), 64));
+    HIPCHK(c, hipMemcpyFromSymbol(out8 + 16, HIP_SYMBOL(g_diagA), 64));
     return 0;
 }
 #endif
