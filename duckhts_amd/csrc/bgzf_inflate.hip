@@ -294,46 +294,81 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         unsigned long long dA_s0 = clock64();
 #endif
         // ---- symbol loop ----
-        for (;;) {
+        // Input comes through an LDS window: every 4 iterations (wave-uniform) each lane fetches the 64 bytes at its own
+        // stream position into registers, and the fetch of the previous period is parked in LDS ([dword][lane], aliasing
+        // the code-length scratch, idle now).  Refills read that window, so the only vmcnt wait of the loop sits at the
+        // period boundary, one whole period after the loads (and the scattered literal/token stores) were issued.
+        {
+            uint32_t *winA = (uint32_t *)lens;
+            const uint8_t *sp = br.p;
+            uint32_t wbase = br.pos, rbase = br.pos;
+            uint4 R0, R1, R2, R3;
+            __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
+            __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
+            bool live = true;
+#define WIN_PARK() do {                                                                                         \
+                winA[0 * A_ST + lane] = R0.x; winA[1 * A_ST + lane] = R0.y; winA[2 * A_ST + lane] = R0.z; winA[3 * A_ST + lane] = R0.w;       \
+                winA[4 * A_ST + lane] = R1.x; winA[5 * A_ST + lane] = R1.y; winA[6 * A_ST + lane] = R1.z; winA[7 * A_ST + lane] = R1.w;       \
+                winA[8 * A_ST + lane] = R2.x; winA[9 * A_ST + lane] = R2.y; winA[10 * A_ST + lane] = R2.z; winA[11 * A_ST + lane] = R2.w;     \
+                winA[12 * A_ST + lane] = R3.x; winA[13 * A_ST + lane] = R3.y; winA[14 * A_ST + lane] = R3.z; winA[15 * A_ST + lane] = R3.w;   \
+                wbase = rbase; } while (0)
+#define WIN_REFILL() do { if (br.cnt <= 32) {                                                                   \
+                const uint32_t off_ = br.pos - wbase;                                                            \
+                const uint32_t word_ = (off_ < 64u) ? winA[(off_ >> 2) * A_ST + lane] : ld32_guard(sp, br.pos, br.lim);  \
+                br.buf |= (uint64_t)word_ << br.cnt; br.pos += 4; br.cnt += 32; } } while (0)
+            WIN_PARK();
+            for (uint32_t it = 0; __ballot(live) != 0ull; it++) {
 #ifdef DHTS_DIAG
-            dA_it++;
+                dA_it++;
 #endif
-            br_refill(br);
-            uint32_t w = __brev((uint32_t)br.buf) >> 17;
-            uint32_t L = code_len(ll, w);
-            if (L > 15) { status = DHTS_BLK_ERR_INFLATE; break; }
-            uint32_t o = (uint32_t)(uint16_t)(lbase[L * A_ST + lane] + (uint16_t)(w >> (15 - L)));
-            if (o >= 288) { status = DHTS_BLK_ERR_INFLATE; break; }
-            uint32_t sym = lsym_lo[o * A_ST + lane] | (((lsym_hi[(o >> 5) * A_ST + lane] >> (o & 31)) & 1u) << 8);
-            br_take(br, L);
-            if (sym < 256) {
-                EMIT_LIT(sym);
-                if (status != 0) break;
-            } else if (sym == 256) {
-                break;
-            } else {
-                uint32_t i = sym - 257;
-                if (i >= 29) { status = DHTS_BLK_ERR_INFLATE; break; }
-                uint32_t eb = (i < 8 || i == 28) ? 0 : (i >> 2) - 1;
-                uint32_t len = (i < 8) ? 3 + i : (i == 28) ? 258 : 3 + ((4 + (i & 3)) << eb);
-                len += br_take(br, eb);
-                br_refill(br);
-                uint32_t wd = __brev((uint32_t)br.buf) >> 17;
-                uint32_t Ld = code_len(dl, wd);
-                if (Ld > 15) { status = DHTS_BLK_ERR_INFLATE; break; }
-                uint32_t od = (uint32_t)(uint16_t)(dbase[Ld * A_ST + lane] + (uint16_t)(wd >> (15 - Ld)));
-                if (od >= 32) { status = DHTS_BLK_ERR_INFLATE; break; }
-                uint32_t ds = dsym[od * A_ST + lane];
-                br_take(br, Ld);
-                if (ds >= 30) { status = DHTS_BLK_ERR_INFLATE; break; }
-                uint32_t deb = (ds < 4) ? 0 : (ds >> 1) - 1;
-                uint32_t dist = (ds < 4) ? 1 + ds : 1 + ((2 + (ds & 1)) << deb);
-                dist += br_take(br, deb);
-                if (dist > outpos || outpos + len > 65536u) { status = DHTS_BLK_ERR_INFLATE; break; }
-                tok[ntok++] = (run << 23) | ((len - 3) << 15) | (dist - 1);
-                run = 0; outpos += len;
+                if ((it & 3u) == 0u) {
+                    if (it) WIN_PARK();
+                    rbase = br.pos;
+                    __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
+                    __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
+                }
+                if (!live) continue;
+                WIN_REFILL();
+                uint32_t w = __brev((uint32_t)br.buf) >> 17;
+                uint32_t L = code_len(ll, w);
+                if (L > 15) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                uint32_t o = (uint32_t)(uint16_t)(lbase[L * A_ST + lane] + (uint16_t)(w >> (15 - L)));
+                if (o >= 288) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                uint32_t sym = lsym_lo[o * A_ST + lane] | (((lsym_hi[(o >> 5) * A_ST + lane] >> (o & 31)) & 1u) << 8);
+                br_take(br, L);
+                if (sym < 256) {
+                    EMIT_LIT(sym);
+                    if (status != 0) { live = false; continue; }
+                } else if (sym == 256) {
+                    live = false; continue;
+                } else {
+                    uint32_t i = sym - 257;
+                    if (i >= 29) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                    uint32_t eb = (i < 8 || i == 28) ? 0 : (i >> 2) - 1;
+                    uint32_t len = (i < 8) ? 3 + i : (i == 28) ? 258 : 3 + ((4 + (i & 3)) << eb);
+                    len += br_take(br, eb);
+                    WIN_REFILL();
+                    uint32_t wd = __brev((uint32_t)br.buf) >> 17;
+                    uint32_t Ld = code_len(dl, wd);
+                    if (Ld > 15) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                    uint32_t od = (uint32_t)(uint16_t)(dbase[Ld * A_ST + lane] + (uint16_t)(wd >> (15 - Ld)));
+                    if (od >= 32) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                    uint32_t ds = dsym[od * A_ST + lane];
+                    br_take(br, Ld);
+                    if (ds >= 30) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                    uint32_t deb = (ds < 4) ? 0 : (ds >> 1) - 1;
+                    uint32_t dist = (ds < 4) ? 1 + ds : 1 + ((2 + (ds & 1)) << deb);
+                    dist += br_take(br, deb);
+                    if (dist > outpos || outpos + len > 65536u) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
+                    tok[ntok++] = (run << 23) | ((len - 3) << 15) | (dist - 1);
+                    run = 0; outpos += len;
+                }
+                if (br.pos * 8 - br.cnt > payload_bits + 64) { status = DHTS_BLK_ERR_INFLATE; live = false; }   // ran off the payload
             }
-            if (br.pos * 8 - br.cnt > payload_bits + 64) { status = DHTS_BLK_ERR_INFLATE; break; }   // ran off the payload
+#undef WIN_PARK
+#undef WIN_REFILL
+            // back to the plain reader for the next block header: re-prime its two look-ahead words
+            br.w0 = ld32_guard(br.p, br.pos, br.lim); br.w1 = ld32_guard(br.p, br.pos + 4, br.lim);
         }
 #ifdef DHTS_DIAG
         dA_sym += clock64() - dA_s0;

@@ -16,6 +16,8 @@ struct dim3s { unsigned x, y, z; };
 static thread_local dim3s threadIdx, blockIdx;
 static inline uint32_t __brev(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 #define HOSTSIM 1
+struct uint4 { uint32_t x, y, z, w; };
+static inline unsigned long long __ballot(bool b) { return b ? 1ull : 0ull; }
 static uint8_t *g_smem;
 #define HIP_RUNTIME_STUB
 #include <stdint.h>
