@@ -21,6 +21,9 @@
 // ------------------------------------------------------------------------------------
 // phase A
 // ------------------------------------------------------------------------------------
+#ifndef A_LDS_ROUND
+#define A_LDS_ROUND 64
+#endif
 #ifndef A_SL
 #define A_SL 64                          /* streams (active lanes) per wave */
 #endif
@@ -35,7 +38,8 @@
 #define A_CNT (A_DBASE + 16 * A_ST * 2)    /* u16 [16][SL]  */
 #define A_LENS (A_CNT + 16 * A_ST * 2)     /* u8  [160][SL] nibble-packed code lengths */
 #define A_CLSYM (A_LENS + 160 * A_ST)      /* u8  [19][SL]  */
-#define A_LDS_BYTES (A_CLSYM + 19 * A_ST)  /* 40,384 B at SL=64: four waves per CU */
+#define A_LDS_RAW (A_CLSYM + 19 * A_ST)
+#define A_LDS_BYTES ((A_LDS_RAW + A_LDS_ROUND - 1) / A_LDS_ROUND * A_LDS_ROUND)  /* 40,384 B at SL=64: four waves per CU */
 
 struct BitR {
     const uint8_t *p;   // stream base (deflate payload start)
@@ -313,9 +317,11 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                 winA[12 * A_ST + lane] = R3.x; winA[13 * A_ST + lane] = R3.y; winA[14 * A_ST + lane] = R3.z; winA[15 * A_ST + lane] = R3.w;   \
                 wbase = rbase; } while (0)
 #define WIN_REFILL() do { if (br.cnt <= 32) {                                                                   \
-                const uint32_t off_ = br.pos - wbase;                                                            \
-                const uint32_t word_ = (off_ < 64u) ? winA[(off_ >> 2) * A_ST + lane] : ld32_guard(sp, br.pos, br.lim);  \
+                const uint32_t word_ = winA[(((br.pos - wbase) >> 2) & 15u) * A_ST + lane];                       \
                 br.buf |= (uint64_t)word_ << br.cnt; br.pos += 4; br.cnt += 32; } } while (0)
+#define WIN_FETCH() do { rbase = br.pos;                                                                        \
+                __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);                 \
+                __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16); } while (0)
             WIN_PARK();
             for (uint32_t it = 0; __ballot(live) != 0ull; it++) {
 #ifdef DHTS_DIAG
@@ -323,9 +329,11 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
 #endif
                 if ((it & 3u) == 0u) {
                     if (it) WIN_PARK();
-                    rbase = br.pos;
-                    __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
-                    __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
+                    WIN_FETCH();
+                } else if (__ballot(live && (br.pos - wbase) > 48u) != 0ull) {
+                    // rare (streams of very long codes): a lane could outrun its window within this iteration (<= 8 bytes):
+                    // refetch for the whole wave, synchronously
+                    WIN_FETCH(); WIN_PARK(); WIN_FETCH();
                 }
                 if (!live) continue;
                 WIN_REFILL();
@@ -367,6 +375,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
             }
 #undef WIN_PARK
 #undef WIN_REFILL
+#undef WIN_FETCH
             // back to the plain reader for the next block header: re-prime its two look-ahead words
             br.w0 = ld32_guard(br.p, br.pos, br.lim); br.w1 = ld32_guard(br.p, br.pos + 4, br.lim);
         }
