@@ -152,13 +152,32 @@ struct TileOut {
     int32_t *err;        // 0, or 1 = chain stopped on an invalid record at end_next
 };
 
+// chain walk used by the repair kernels: same core-only tests as rec_hop in bam_tiles_lds.hip (the CIGAR/qlen test and the
+// CG swap are checked per row by bam_tile_unpack)
 __device__ void tile_walk(const BamStream &st, uint64_t start, uint64_t tile_end, uint64_t &end_next, uint32_t &count, int &err) {
     uint64_t o = start; uint32_t c = 0; err = 0;
+    const uint8_t *u = st.u;
     while (o < tile_end) {
-        RecInfo r; int rc = rec_check(st, o, r, true);
+        int rc = REC_OK; uint32_t bl = 0;
+        if (st.ulen - o < 4) rc = REC_INCOMPLETE;
+        else {
+            const int32_t b = (int32_t)ldu32(u + o);
+            if (b < 32) rc = REC_INVALID;
+            else if (st.ulen - o - 4 < 32) rc = REC_INCOMPLETE;
+            else {
+                const int32_t tid = (int32_t)ldu32(u + o + 4), mtid = (int32_t)ldu32(u + o + 24), l_seq = (int32_t)ldu32(u + o + 20);
+                const uint32_t l_qname = ldu32(u + o + 12) & 0xff, n_cigar = ldu32(u + o + 16) & 0xffff;
+                const uint64_t body = (uint64_t)(uint32_t)b - 32;
+                if (l_seq < 0 || l_qname < 1) rc = REC_INVALID;
+                else if (((uint64_t)n_cigar << 2) + l_qname + (((uint64_t)l_seq + 1) >> 1) + (uint64_t)l_seq > body) rc = REC_INVALID;
+                else if (st.ulen - o - 36 < body) rc = REC_INCOMPLETE;
+                else if (tid >= st.n_ref || tid < -1 || mtid >= st.n_ref || mtid < -1) rc = REC_INVALID;
+                bl = (uint32_t)b;
+            }
+        }
         if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }   // truncated tail = read error (sam.c:790-791,833-835)
         if (rc == REC_INVALID) { err = 1; break; }
-        c++; o += 4ull + r.block_len;
+        c++; o += 4ull + bl;
     }
     end_next = o; count = c;
 }
@@ -194,33 +213,34 @@ bam_tile_speculate(BamStream st, uint64_t start0, uint32_t tile_bytes, int64_t n
     out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
 }
 
-// One round of continuity proof + repair.  nfixed counts the tiles changed this round.
+// One round of continuity proof + repair, OUT OF PLACE (reads `in`, writes `out` for every tile; the host swaps), so a round
+// never observes half-updated neighbours.  A tile is re-walked only when its predecessor is itself consistent with ITS
+// predecessor: a mis-speculated tile is repaired first and its (correctly speculated) successors simply wait one round,
+// instead of being re-walked from a wrong position.  nfixed counts the tiles changed this round.
+__device__ __forceinline__ bool tile_consistent(const TileOut &in, int64_t t, uint64_t te_t) {
+    // is tile t consistent with the chain exit of tile t-1?   (t >= 1)
+    const uint64_t p = in.end_next[t - 1];
+    if (p == NONE64 || in.err[t - 1]) return false;
+    if (p >= te_t) return in.first[t] == NONE64 && in.end_next[t] == p && in.count[t] == 0;
+    return in.first[t] == p;
+}
 extern "C" __global__ void __launch_bounds__(256)
-bam_tile_fix(BamStream st, uint32_t tile_bytes, int64_t ntiles, TileOut out, uint32_t *nfixed) {
+bam_tile_fix(BamStream st, uint32_t tile_bytes, int64_t ntiles, TileOut in, TileOut out, uint32_t *nfixed) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles || t == 0) return;
-    uint64_t p = *(volatile uint64_t *)&out.end_next[t - 1];
-    if (p == NONE64) return;                             // predecessor unresolved: it is repaired first
-    if (*(volatile int32_t *)&out.err[t - 1]) return;    // chain already stopped before this tile
-    uint64_t tb = (uint64_t)t * tile_bytes, te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
-    if (p >= te && t + 1 < ntiles) {
-        // tile lies inside a record that started earlier
-        if (out.first[t] == NONE64 && out.end_next[t] == p && out.count[t] == 0 && out.err[t] == 0) return;
-        out.first[t] = NONE64; out.count[t] = 0; out.err[t] = 0; out.end_next[t] = p;
-        atomicAdd(nfixed, 1u);
-        return;
+    if (t >= ntiles) return;
+    uint64_t f = in.first[t], en = in.end_next[t]; uint32_t cnt = in.count[t]; int32_t err = in.err[t];
+    if (t >= 1) {
+        const uint64_t tb = (uint64_t)t * tile_bytes; uint64_t te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
+        const uint64_t p = in.end_next[t - 1];
+        bool pred_ok = (p != NONE64) && !in.err[t - 1];
+        if (pred_ok && t >= 2) pred_ok = tile_consistent(in, t - 1, tb);      // tile_end(t-1) == tile_begin(t)
+        if (pred_ok && !tile_consistent(in, t, te)) {
+            if (p >= te) { f = NONE64; cnt = 0; err = 0; en = p; }          // tile lies inside a record that started earlier
+            else { int e; tile_walk(st, p, te, en, cnt, e); f = p; err = e; }
+            atomicAdd(nfixed, 1u);
+        }
     }
-    if (p >= te) {                                       // last tile, chain already past it
-        if (out.first[t] == NONE64 && out.end_next[t] == p && out.count[t] == 0) return;
-        out.first[t] = NONE64; out.count[t] = 0; out.err[t] = 0; out.end_next[t] = p;
-        atomicAdd(nfixed, 1u);
-        return;
-    }
-    if (out.first[t] == p) return;
-    uint64_t en; uint32_t cnt; int err;
-    tile_walk(st, p, te, en, cnt, err);
-    out.first[t] = p; out.count[t] = cnt; out.err[t] = err; out.end_next[t] = en;
-    atomicAdd(nfixed, 1u);
+    out.first[t] = f; out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
 }
 
 // Sequential fallback (pathological inputs only): one thread proves/repairs every tile in order.

@@ -1,0 +1,302 @@
+// bam_tiles_lds.hip -- LDS-staged tile kernels for the BAM record stage (gfx950).
+//
+// Same exact algorithm as bam_records.hip (speculate the first record of every 8 KiB tile with bam_read1's predicates,
+// walk the chain, prove continuity tile-to-tile, unpack the 13 core columns), but one WAVE owns one tile: the tile (+1 KiB
+// halo) is staged into LDS with 16-byte coalesced loads, the 64 lanes test 64 candidate offsets at once, the chain walk and
+// every per-record byte access (QNAME NUL scan, CIGAR ops, aux tag walk) run out of LDS instead of issuing one global load
+// per field per lane.  Bytes beyond the staged window (long records) fall back to global memory through the accessor.
+//   replaces: htslib sam.c:779-855 bam_read1, 675-730 bam_tag2cigar, 4124-4134 sam_read1_bam, 4785-4855 aux walk;
+//             src/bam_reader.c:785-918 fixed-width writers and string-length bookkeeping.
+#pragma once
+
+#define TL_TILE 8192u
+#define TL_HALO 1024u
+
+// global-memory accessor (records that do not fit the staged window)
+struct GSrc {
+    const uint8_t *g;
+    __device__ __forceinline__ uint8_t u8(uint64_t o) const { return g[o]; }
+    __device__ __forceinline__ uint32_t u32(uint64_t o) const { return ldu32(g + o); }
+};
+struct LSrc { const uint8_t *g; const uint8_t *l; uint64_t base; uint32_t len; };   // staged-window descriptor
+
+// direct accessor into the staged window: every offset touched must lie inside it (checked by the caller once per record).
+// Kept as (LDS pointer, 32-bit index) so the compiler emits ds_read, not flat loads.
+struct PSrc {
+    const uint8_t *l; uint64_t base;
+    __device__ __forceinline__ uint8_t u8(uint64_t o) const { return l[(uint32_t)(o - base)]; }
+    __device__ __forceinline__ uint32_t u32(uint64_t o) const { uint32_t v; __builtin_memcpy(&v, l + (uint32_t)(o - base), 4); return v; }
+};
+
+template <class S> __device__ __forceinline__ uint64_t aux_skip_t(const S &s, uint64_t p, uint64_t end) {
+    if (p >= end) return end;
+    uint8_t t = s.u8(p); ++p;
+    if (t == 'Z' || t == 'H') {
+        while (p < end && s.u8(p) != 0) p++;
+        return p < end ? p + 1 : end;
+    }
+    if (t == 'B') {
+        if (end - p < 5) return NONE64;
+        uint8_t sub = s.u8(p);
+        int sz = aux_size(sub); if (sub == 'Z' || sub == 'H' || sub == 'B') sz = sub;
+        ++p;
+        uint64_t n = s.u32(p); p += 4;
+        if (sz == 0 || end - p < (uint64_t)sz * n) return NONE64;
+        return p + (uint64_t)sz * n;
+    }
+    int sz = aux_size(t);
+    if (sz == 0) return NONE64;
+    if (end - p < (uint64_t)sz) return NONE64;
+    return p + sz;
+}
+
+template <class S> __device__ __forceinline__ uint64_t aux_find_t(const S &s, uint64_t aux, uint64_t end, uint8_t t0, uint8_t t1, bool *bad, uint64_t skip_beg, uint64_t skip_end) {
+    *bad = false;
+    uint64_t eff_len = (end - aux) - (skip_end - skip_beg);
+    if (eff_len <= 2) return NONE64;
+    uint64_t p = aux;
+    if (p == skip_beg) p = skip_end;
+    p += 2;
+    for (;;) {
+        if (s.u8(p - 2) == t0 && s.u8(p - 1) == t1) {
+            uint64_t e = aux_skip_t(s, p, end);
+            if (e == NONE64) { *bad = true; return NONE64; }
+            uint8_t ty = s.u8(p);
+            if ((ty == 'Z' || ty == 'H') && s.u8(e - 1) != 0) { *bad = true; return NONE64; }
+            return p;
+        }
+        uint64_t nx = aux_skip_t(s, p, end);
+        if (nx == NONE64) { *bad = true; return NONE64; }
+        if (nx == skip_beg) nx = skip_end;
+        if (end - nx <= 2) return NONE64;
+        p = nx + 2;
+    }
+}
+
+// same predicates as rec_check (bam_records.hip), reading through the accessor
+template <class S> __device__ __forceinline__ int rec_check_t(const BamStream &st, const S &s, uint64_t o, RecInfo &r, bool full) {
+    if (st.ulen - o < 4) return REC_INCOMPLETE;
+    int32_t block_len = (int32_t)s.u32(o);
+    if (block_len < 32) return REC_INVALID;
+    if (st.ulen - o - 4 < 32) return REC_INCOMPLETE;
+    r.block_len = (uint32_t)block_len;
+    r.tid = (int32_t)s.u32(o + 4); r.pos = (int32_t)s.u32(o + 8);
+    uint32_t x2 = s.u32(o + 12), x3 = s.u32(o + 16);
+    r.mapq = (x2 >> 8) & 0xff; r.l_qname = x2 & 0xff;
+    r.flag = x3 >> 16; r.n_cigar = x3 & 0xffff;
+    r.l_seq = (int32_t)s.u32(o + 20); r.mtid = (int32_t)s.u32(o + 24); r.mpos = (int32_t)s.u32(o + 28); r.tlen = (int32_t)s.u32(o + 32);
+    uint64_t body = (uint64_t)r.block_len - 32;
+    if (r.l_seq < 0 || r.l_qname < 1) return REC_INVALID;
+    if (((uint64_t)r.n_cigar << 2) + r.l_qname + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq > body) return REC_INVALID;
+    if (!full) {
+        // speculation filter (not part of exactness; a wrong rejection only costs a repair round).  The header-range and
+        // aux-size tests come BEFORE the "body runs past the buffer" exit, so a hop that lands on garbage with a huge
+        // block_len is rejected instead of being mistaken for the incomplete last record of the batch.
+        if (r.tid < -1 || r.tid >= st.n_ref || r.mtid < -1 || r.mtid >= st.n_ref) return REC_INVALID;
+        uint64_t core = ((uint64_t)r.n_cigar << 2) + r.l_qname + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq;
+        if (body - core > 8 * core + 65536) return REC_INVALID;
+        if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
+        if (s.u8(o + 36 + r.l_qname - 1) != 0) return REC_INVALID;
+        return REC_OK;
+    }
+    if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
+    r.cig_off = o + 36 + r.l_qname; r.n_cigar_eff = r.n_cigar; r.cg_beg = r.cg_end = 0;
+    uint64_t end = o + 4 + r.block_len;
+    uint64_t aux = r.cig_off + 4ull * r.n_cigar + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq;
+    if (r.n_cigar > 0 && s.u32(r.cig_off) == (4u | ((uint32_t)r.l_seq << 4)) && r.tid >= 0 && r.pos >= 0) {
+        bool bad; uint64_t cg = aux_find_t(s, aux, end, 'C', 'G', &bad, 0, 0);
+        if (cg == NONE64 && bad) return REC_INVALID;
+        if (cg != NONE64 && s.u8(cg) == 'B' && (s.u8(cg + 1) == 'I' || s.u8(cg + 1) == 'i')) {
+            uint32_t cgl = s.u32(cg + 2);
+            if (cgl >= r.n_cigar && cgl < (1u << 29)) { r.cig_off = cg + 6; r.n_cigar_eff = cgl; r.cg_beg = cg - 2; r.cg_end = cg + 6 + 4ull * cgl; }
+        }
+    }
+    if (r.n_cigar_eff > 0) {
+        int64_t qlen = 0;
+        for (uint32_t k = 0; k < r.n_cigar_eff; k++) { uint32_t c = s.u32(r.cig_off + 4ull * k); if (CIG_QUERY(c & 0xf)) qlen += c >> 4; }
+        if (r.l_seq > 0 && !(r.flag & 4) && qlen != r.l_seq) return REC_INVALID;
+    }
+    if (r.tid >= st.n_ref || r.tid < -1 || r.mtid >= st.n_ref || r.mtid < -1) return REC_INVALID;
+    return REC_OK;
+}
+
+// One hop of the record chain: the exact bam_read1 tests that need only the 36-byte core (sam.c:794, 820-823) plus the
+// header range test (sam.c:4127-4131).  A walk that starts on garbage fails these almost immediately, which is what keeps
+// a wrong speculation from propagating.  The CIGAR/qlen test and the CG swap run lane-parallel in bam_tile_unpack,
+// which reports the first invalid row.
+template <class S> __device__ __forceinline__ int rec_hop(const BamStream &st, const S &s, uint64_t o, uint32_t &bl) {
+    if (st.ulen - o < 4) return REC_INCOMPLETE;
+    const int32_t b = (int32_t)s.u32(o);
+    if (b < 32) return REC_INVALID;
+    if (st.ulen - o - 4 < 32) return REC_INCOMPLETE;
+    const int32_t tid = (int32_t)s.u32(o + 4), mtid = (int32_t)s.u32(o + 24), l_seq = (int32_t)s.u32(o + 20);
+    const uint32_t l_qname = s.u32(o + 12) & 0xff, n_cigar = s.u32(o + 16) & 0xffff;
+    const uint64_t body = (uint64_t)(uint32_t)b - 32;
+    if (l_seq < 0 || l_qname < 1) return REC_INVALID;
+    if (((uint64_t)n_cigar << 2) + l_qname + (((uint64_t)l_seq + 1) >> 1) + (uint64_t)l_seq > body) return REC_INVALID;
+    if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
+    if (tid >= st.n_ref || tid < -1 || mtid >= st.n_ref || mtid < -1) return REC_INVALID;
+    bl = (uint32_t)b;
+    return REC_OK;
+}
+
+__device__ __forceinline__ void tile_stage(const BamStream &st, uint64_t tb, uint8_t *buf, LSrc &s, int lane) {
+    uint64_t left = st.ulen - tb;
+    uint32_t avail = left < (uint64_t)(TL_TILE + TL_HALO) ? (uint32_t)left : (TL_TILE + TL_HALO);
+    uint32_t pad = (avail + 15u) & ~15u;                      // the inflated buffer carries >= 256 bytes of padding
+    for (uint32_t k = (uint32_t)lane * 16u; k < pad; k += 1024u) { uint4 v = *(const uint4 *)(st.u + tb + k); *(uint4 *)(buf + k) = v; }
+    s.g = st.u; s.l = buf; s.base = tb; s.len = avail;
+    __syncthreads();
+}
+
+// One wave per tile: speculate the first record start (64 candidates per step), walk the chain.
+extern "C" __global__ void __launch_bounds__(64)
+bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
+    __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const uint64_t tb = (uint64_t)t * TL_TILE;
+    uint64_t te = tb + TL_TILE; if (te > st.ulen) te = st.ulen;
+    LSrc s; tile_stage(st, tb, buf, s, lane);
+    PSrc ls; ls.l = buf; ls.base = tb;                        // valid for offsets inside the staged window only
+    GSrc gs; gs.g = st.u;
+    uint64_t first = NONE64;
+    if (t == 0 && start0 != NONE64) first = start0;
+    else {
+        const uint64_t lim = (t == 0) ? st.ulen : te;         // a shard that begins mid-stream keeps looking past its first tile
+        for (uint64_t base = tb; base < lim; base += 64) {
+            const uint64_t o = base + (uint64_t)lane;
+            bool ok = false;
+            if (o < lim) {
+                RecInfo r;
+                // the cheap test touches <= 36 + 255 bytes: straight LDS when that lies inside the staged window
+                const bool inw = (o - tb) + 300u <= (uint64_t)s.len;
+                const int rc0 = inw ? rec_check_t(st, ls, o, r, false) : rec_check_t(st, gs, o, r, false);
+                if (rc0 == REC_OK) {
+                    ok = true;
+                    uint64_t o2 = o + 4ull + r.block_len;
+                    for (int k = 0; k < 2 && ok; k++) {
+                        RecInfo r2;
+                        const bool inw2 = (o2 >= tb) && (o2 - tb) + 300u <= (uint64_t)s.len;
+                        const int rc = inw2 ? rec_check_t(st, ls, o2, r2, false) : rec_check_t(st, gs, o2, r2, false);
+                        if (rc == REC_INVALID) ok = false;
+                        else if (rc == REC_INCOMPLETE) break;
+                        else o2 += 4ull + r2.block_len;
+                    }
+                }
+            }
+            const uint64_t m = __ballot(ok);
+            if (m) { first = base + (uint64_t)(__ffsll((unsigned long long)m) - 1); break; }
+        }
+    }
+    // chain walk: wave-uniform (every lane computes the same values; LDS reads broadcast)
+    uint64_t en = NONE64; uint32_t cnt = 0; int err = 0;
+    if (first != NONE64 && first < te) {
+        uint64_t o = first;
+        while (o < te) {
+            uint32_t bl = 0;
+            const int rc = ((o - tb) + 36 <= (uint64_t)s.len) ? rec_hop(st, ls, o, bl) : rec_hop(st, gs, o, bl);
+            if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }
+            if (rc == REC_INVALID) { err = 1; break; }
+            cnt++; o += 4ull + bl;
+        }
+        en = o;
+    } else if (first != NONE64) en = first;
+    if (lane == 0) {
+        out.first[t] = (first != NONE64 && first < te) ? first : NONE64;
+        out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
+    }
+}
+
+template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &st, const S &s, const BamDict &dict, uint64_t o, int64_t row,
+                                                         uint32_t *rec_off, uint8_t *rg_flag, const BamCols &c) {
+    RecInfo r; const int rcv = rec_check_t(st, s, o, r, true);
+    rec_off[row] = (uint32_t)o;
+    if (rcv != REC_OK) {          // first such row ends the scan (bam_reader.c:754-766); keep the column slots defined
+        c.len_qname[row] = 0; c.len_cigar[row] = 0; c.len_seq[row] = 0; c.len_qual[row] = 0; c.len_rg[row] = 0;
+        c.cig_rel[row] = 0; c.ncig_eff[row] = 0; c.rg_rel[row] = 0; c.rg_idx[row] = -1; rg_flag[row] = 0;
+        return false;
+    }
+    c.flag[row] = (uint16_t)r.flag;
+    c.pos[row] = (int64_t)r.pos + 1;
+    c.mapq[row] = (int32_t)r.mapq;
+    c.pnext[row] = (int64_t)r.mpos + 1;
+    c.tlen[row] = (int64_t)r.tlen;
+    c.tid[row] = r.tid; c.mtid[row] = r.mtid;
+    uint32_t ql = 0;
+    while (ql < r.l_qname && s.u8(o + 36 + ql) != 0) ql++;
+    c.len_qname[row] = ql;
+    uint32_t cl = 0;
+    for (uint32_t j = 0; j < r.n_cigar_eff; j++) cl += ndigits(s.u32(r.cig_off + 4ull * j) >> 4) + 1;
+    c.len_cigar[row] = r.n_cigar_eff ? cl : 1;
+    c.cig_rel[row] = (uint32_t)(r.cig_off - o); c.ncig_eff[row] = r.n_cigar_eff;
+    const uint64_t seq = o + 36 + r.l_qname + 4ull * r.n_cigar;
+    const uint64_t qual = seq + (((uint64_t)r.l_seq + 1) >> 1);
+    c.len_seq[row] = r.l_seq > 0 ? (uint32_t)r.l_seq : 1;
+    c.len_qual[row] = (r.l_seq > 0 && s.u8(qual) != 255) ? (uint32_t)r.l_seq : 1;
+    const uint64_t aux = qual + (uint64_t)r.l_seq, end = o + 4ull + r.block_len;
+    bool bad; const uint64_t rg = aux_find_t(s, aux, end, 'R', 'G', &bad, r.cg_beg, r.cg_end);
+    uint32_t rl = 0; int32_t rgi = -1; uint8_t rgv = 0;
+    if (rg != NONE64 && (s.u8(rg) == 'Z' || s.u8(rg) == 'H')) {
+        rgv = 1;
+        while (s.u8(rg + 1 + rl) != 0) rl++;
+        for (int32_t q = 0; q < dict.n_rg; q++) {
+            const uint32_t a = dict.rg_off[q], b = dict.rg_off[q + 1];
+            if (b - a != rl) continue;
+            bool eq = true;
+            for (uint32_t j = 0; j < rl; j++) if (dict.rg_bytes[a + j] != s.u8(rg + 1 + j)) { eq = false; break; }
+            if (eq) { rgi = q; break; }
+        }
+        c.rg_rel[row] = (uint32_t)(rg + 1 - o);
+    } else c.rg_rel[row] = 0;
+    c.len_rg[row] = rl; c.rg_idx[row] = rgi; rg_flag[row] = rgv;
+    return true;
+}
+
+// One wave per tile: rebuild the record list in LDS, then one lane per record writes the fixed-width columns, the
+// string lengths and the per-row scratch of the string pass.  rg_flag is one byte per row (packed to validity words later).
+extern "C" __global__ void __launch_bounds__(64)
+bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res,
+                int64_t nrows, uint32_t *rec_off, uint8_t *rg_flag, BamCols c, unsigned long long *bad_row) {
+    __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
+    __shared__ uint32_t recs[256];
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    if (t >= ntiles || (uint64_t)t > res[3]) return;
+    const uint64_t first = out.first[t];
+    const uint32_t n = out.count[t];
+    if (first == NONE64 || n == 0) return;
+    const uint32_t row0 = rowbase[t];
+    if ((int64_t)row0 >= nrows) return;
+    const uint64_t tb = (uint64_t)t * TL_TILE;
+    LSrc s; tile_stage(st, tb, buf, s, lane);
+    PSrc ls; ls.l = buf; ls.base = tb;
+    GSrc gs; gs.g = st.u;
+    {   // record starts (the chain was validated by the scan / fix kernels)
+        uint64_t o = first;
+        for (uint32_t k = 0; k < n; k++) { if (lane == 0 && k < 256) recs[k] = (uint32_t)o; o += 4ull + (((o - tb) + 4 <= (uint64_t)s.len) ? ls.u32(o) : gs.u32(o)); }
+    }
+    __syncthreads();
+    for (uint32_t k = lane; k < n; k += 64) {
+        const int64_t row = (int64_t)row0 + k;
+        if (row >= nrows) break;
+        uint64_t o;
+        if (k < 256) o = recs[k];
+        else { o = first; for (uint32_t j = 0; j < k; j++) o += 4ull + gs.u32(o); }    // > 256 records per tile cannot happen (36-byte minimum)
+        const uint64_t rel = o - tb;
+        bool fast = false;
+        if (rel + 4 <= (uint64_t)s.len) { const uint32_t bl = ls.u32(o); fast = (bl >= 32u) && (rel + 4ull + bl <= (uint64_t)s.len); }
+        const bool good = fast ? unpack_one(st, ls, dict, o, row, rec_off, rg_flag, c) : unpack_one(st, gs, dict, o, row, rec_off, rg_flag, c);
+        if (!good) atomicMin(bad_row, (unsigned long long)row);
+    }
+}
+
+// validity words from the per-row flags
+extern "C" __global__ void __launch_bounds__(256)
+bam_pack_validity(const uint8_t *flag, int64_t nrows, uint64_t *words) {
+    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool v = row < nrows && flag[row] != 0;
+    uint64_t m = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && row < nrows) words[row >> 6] = m;
+}

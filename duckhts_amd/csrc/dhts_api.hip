@@ -4,6 +4,7 @@
 #include "../../include/duckhts_amd.h"
 #include "bgzf_inflate.hip"
 #include "bam_records.hip"
+#include "bam_tiles_lds.hip"
 
 #include <fcntl.h>
 #include <stdarg.h>
@@ -49,7 +50,9 @@ struct dhts_ctx {
     DevBuf ubuf[2]; int ucur = 0; uint64_t carry_len = 0;
     // tiles
     DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed;
+    DevBuf t2_first, t2_end, t2_count, t2_err;      // second tile table: repair rounds are out of place
     // rows
+    DevBuf c_rgflag;
     DevBuf rec_off, c_flag, c_pos, c_mapq, c_pnext, c_tlen, c_tid, c_mtid, c_rgidx, c_rgvalid;
     DevBuf l_qname, l_cigar, l_seq, l_qual, l_rg, cig_rel, ncig_eff, rg_rel, alen_qual;
     DevBuf o_qname, o_cigar, o_seq, o_qual, o_rg, scan_partial, scan_total;
@@ -132,7 +135,7 @@ void dhts_destroy(dhts_ctx *c) {
                      &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
                      &c->c_mapq, &c->c_pnext, &c->c_tlen, &c->c_tid, &c->c_mtid, &c->c_rgidx, &c->c_rgvalid, &c->l_qname, &c->l_cigar, &c->l_seq,
                      &c->l_qual, &c->l_rg, &c->cig_rel, &c->ncig_eff, &c->rg_rel, &c->alen_qual, &c->o_qname, &c->o_cigar, &c->o_seq, &c->o_qual,
-                     &c->o_rg, &c->scan_partial, &c->scan_total, &c->a_qname, &c->a_cigar, &c->a_seq, &c->a_qual, &c->a_rg, &c->d_rg_off, &c->d_rg_bytes};
+                     &c->o_rg, &c->scan_partial, &c->scan_total, &c->a_qname, &c->a_cigar, &c->a_seq, &c->a_qual, &c->a_rg, &c->d_rg_off, &c->d_rg_bytes, &c->c_rgflag, &c->t2_first, &c->t2_end, &c->t2_count, &c->t2_err};
     for (auto b : all) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -555,7 +558,9 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     int64_t ntiles = (int64_t)((ulen + TILE_BYTES - 1) / TILE_BYTES); if (ntiles < 1) ntiles = 1;
     ENSURE(c, c->t_first, ntiles * 8); ENSURE(c, c->t_end, ntiles * 8); ENSURE(c, c->t_count, ntiles * 4); ENSURE(c, c->t_err, ntiles * 4);
     ENSURE(c, c->t_rowbase, ntiles * 4 + 16); ENSURE(c, c->d_res, 64); ENSURE(c, c->d_nfixed, 64);
+    ENSURE(c, c->t2_first, ntiles * 8); ENSURE(c, c->t2_end, ntiles * 8); ENSURE(c, c->t2_count, ntiles * 4); ENSURE(c, c->t2_err, ntiles * 4);
     TileOut to; to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
+    TileOut to2; to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
     uint64_t start0;
     if (c->first_batch) start0 = (c->shard_rank == 0) ? c->first_rec_uoff - out_base : NONE64;   // later shards speculate their first record
     else start0 = 0;                                           // the carry begins on a record boundary
@@ -563,17 +568,18 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     uint64_t res[4] = {0, 0, 0, 0};
     {
         KTimer tm(c, DHTS_K_TILES);
-        hipLaunchKernelGGL(bam_tile_speculate, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, start0, TILE_BYTES, ntiles, to);
+        hipLaunchKernelGGL(bam_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to);
         int rounds = 0;
         for (;;) {
             (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
-            hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (uint32_t *)c->d_nfixed.p);
+            hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
+            { TileOut tmp = to; to = to2; to2 = tmp; }         // the round's output is the current table
             uint32_t nfixed = 0;
             HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
             if (nfixed == 0) break;
-            if (++rounds > 64) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
+            if (++rounds > 256) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
         }
         hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
     }
@@ -581,7 +587,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     uint64_t first0 = NONE64;
     HIPCHK(c, hipMemcpyAsync(&first0, c->t_first.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int64_t nrows = (int64_t)res[0]; uint64_t carry_start = res[1]; const bool rec_err = res[2] != 0;
+    int64_t nrows = (int64_t)res[0]; uint64_t carry_start = res[1]; bool rec_err = res[2] != 0;
     if (carry_start == NONE64) carry_start = ulen;             // nothing recognisable in this batch
 
     // sharding: rows belong to this shard iff their record STARTS before the shard's end in the inflated stream
@@ -590,14 +596,33 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     (void)first0;
 
     // ---- rows ----
+    BamCols bc; memset(&bc, 0, sizeof(bc));
     if (nrows > 0) {
-        ENSURE(c, c->rec_off, nrows * 4 + 16);
+        size_t n = (size_t)nrows;
+        ENSURE(c, c->rec_off, n * 4 + 16); ENSURE(c, c->c_rgflag, n + 64);
+        ENSURE(c, c->c_flag, n * 2 + 16); ENSURE(c, c->c_pos, n * 8); ENSURE(c, c->c_mapq, n * 4); ENSURE(c, c->c_pnext, n * 8); ENSURE(c, c->c_tlen, n * 8);
+        ENSURE(c, c->c_tid, n * 4); ENSURE(c, c->c_mtid, n * 4); ENSURE(c, c->c_rgidx, n * 4); ENSURE(c, c->c_rgvalid, (n / 64 + 2) * 8);
+        ENSURE(c, c->l_qname, n * 4 + 16); ENSURE(c, c->l_cigar, n * 4 + 16); ENSURE(c, c->l_seq, n * 4 + 16); ENSURE(c, c->l_qual, n * 4 + 16); ENSURE(c, c->l_rg, n * 4 + 16);
+        ENSURE(c, c->cig_rel, n * 4); ENSURE(c, c->ncig_eff, n * 4); ENSURE(c, c->rg_rel, n * 4); ENSURE(c, c->alen_qual, n * 4);
+        ENSURE(c, c->o_qname, (n + 1) * 4 + 16); ENSURE(c, c->o_cigar, (n + 1) * 4 + 16); ENSURE(c, c->o_seq, (n + 1) * 4 + 16); ENSURE(c, c->o_qual, (n + 1) * 4 + 16); ENSURE(c, c->o_rg, (n + 1) * 4 + 16);
+        BamDict dict; dict.n_rg = (int32_t)c->rg_id.size(); dict.rg_off = (const uint32_t *)c->d_rg_off.p; dict.rg_bytes = (const uint8_t *)c->d_rg_bytes.p;
+        bc.flag = (uint16_t *)c->c_flag.p; bc.pos = (int64_t *)c->c_pos.p; bc.mapq = (int32_t *)c->c_mapq.p; bc.pnext = (int64_t *)c->c_pnext.p;
+        bc.tlen = (int64_t *)c->c_tlen.p; bc.tid = (int32_t *)c->c_tid.p; bc.mtid = (int32_t *)c->c_mtid.p; bc.rg_idx = (int32_t *)c->c_rgidx.p;
+        bc.rg_valid = (uint64_t *)c->c_rgvalid.p; bc.len_qname = (uint32_t *)c->l_qname.p; bc.len_cigar = (uint32_t *)c->l_cigar.p; bc.len_seq = (uint32_t *)c->l_seq.p;
+        bc.len_qual = (uint32_t *)c->l_qual.p; bc.len_rg = (uint32_t *)c->l_rg.p; bc.cig_rel = (uint32_t *)c->cig_rel.p; bc.ncig_eff = (uint32_t *)c->ncig_eff.p; bc.rg_rel = (uint32_t *)c->rg_rel.p;
+        HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));     // first invalid row (none)
         {
-            KTimer tm(c, DHTS_K_TILES);
-            hipLaunchKernelGGL(bam_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to,
-                               (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p, (uint32_t *)c->rec_off.p);
+            KTimer tm(c, DHTS_K_CORE);
+            hipLaunchKernelGGL(bam_tile_unpack, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, dict, ntiles, to, (const uint32_t *)c->t_rowbase.p,
+                               (const uint64_t *)c->d_res.p, nrows, (uint32_t *)c->rec_off.p, (uint8_t *)c->c_rgflag.p, bc, (unsigned long long *)((uint64_t *)c->d_res.p + 4));
         }
-        if (sharded_tail && out_base + ulen > shard_end_u) {
+        {   // the first row that fails bam_read1's validation ends the scan there (rows before it are kept)
+            unsigned long long bad = ~0ull;
+            HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (bad < (unsigned long long)nrows) { nrows = (int64_t)bad; rec_err = true; }
+        }
+        if (nrows > 0 && sharded_tail && out_base + ulen > shard_end_u) {
             // drop rows whose record starts at/after the shard end (they belong to the next shard): binary search on rec_off
             std::vector<uint32_t> ro(nrows);
             HIPCHK(c, hipMemcpyAsync(ro.data(), c->rec_off.p, nrows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -610,20 +635,9 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         }
     }
     if (nrows > 0) {
-        size_t n = (size_t)nrows;
-        ENSURE(c, c->c_flag, n * 2 + 16); ENSURE(c, c->c_pos, n * 8); ENSURE(c, c->c_mapq, n * 4); ENSURE(c, c->c_pnext, n * 8); ENSURE(c, c->c_tlen, n * 8);
-        ENSURE(c, c->c_tid, n * 4); ENSURE(c, c->c_mtid, n * 4); ENSURE(c, c->c_rgidx, n * 4); ENSURE(c, c->c_rgvalid, (n / 64 + 2) * 8);
-        ENSURE(c, c->l_qname, n * 4 + 16); ENSURE(c, c->l_cigar, n * 4 + 16); ENSURE(c, c->l_seq, n * 4 + 16); ENSURE(c, c->l_qual, n * 4 + 16); ENSURE(c, c->l_rg, n * 4 + 16);
-        ENSURE(c, c->cig_rel, n * 4); ENSURE(c, c->ncig_eff, n * 4); ENSURE(c, c->rg_rel, n * 4); ENSURE(c, c->alen_qual, n * 4);
-        ENSURE(c, c->o_qname, (n + 1) * 4 + 16); ENSURE(c, c->o_cigar, (n + 1) * 4 + 16); ENSURE(c, c->o_seq, (n + 1) * 4 + 16); ENSURE(c, c->o_qual, (n + 1) * 4 + 16); ENSURE(c, c->o_rg, (n + 1) * 4 + 16);
-        BamDict dict; dict.n_rg = (int32_t)c->rg_id.size(); dict.rg_off = (const uint32_t *)c->d_rg_off.p; dict.rg_bytes = (const uint8_t *)c->d_rg_bytes.p;
-        BamCols bc; bc.flag = (uint16_t *)c->c_flag.p; bc.pos = (int64_t *)c->c_pos.p; bc.mapq = (int32_t *)c->c_mapq.p; bc.pnext = (int64_t *)c->c_pnext.p;
-        bc.tlen = (int64_t *)c->c_tlen.p; bc.tid = (int32_t *)c->c_tid.p; bc.mtid = (int32_t *)c->c_mtid.p; bc.rg_idx = (int32_t *)c->c_rgidx.p;
-        bc.rg_valid = (uint64_t *)c->c_rgvalid.p; bc.len_qname = (uint32_t *)c->l_qname.p; bc.len_cigar = (uint32_t *)c->l_cigar.p; bc.len_seq = (uint32_t *)c->l_seq.p;
-        bc.len_qual = (uint32_t *)c->l_qual.p; bc.len_rg = (uint32_t *)c->l_rg.p; bc.cig_rel = (uint32_t *)c->cig_rel.p; bc.ncig_eff = (uint32_t *)c->ncig_eff.p; bc.rg_rel = (uint32_t *)c->rg_rel.p;
         {
             KTimer tm(c, DHTS_K_CORE);
-            hipLaunchKernelGGL(bam_core_unpack, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, dict, (const uint32_t *)c->rec_off.p, nrows, colmask, bc);
+            hipLaunchKernelGGL(bam_pack_validity, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->c_rgflag.p, nrows, (uint64_t *)c->c_rgvalid.p);
         }
         const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
         uint32_t *o32[5] = {(uint32_t *)c->o_qname.p, (uint32_t *)c->o_cigar.p, (uint32_t *)c->o_seq.p, (uint32_t *)c->o_qual.p, (uint32_t *)c->o_rg.p};

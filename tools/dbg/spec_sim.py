@@ -16,6 +16,9 @@ def chk(o):
     if (nc<<2) + lq + ((lseq+1)>>1) + lseq > bl-32: return 1, 0
     if ulen - o - 36 < bl-32: return 2, 0
     if tid < -1 or tid >= n_ref or mtid < -1 or mtid >= n_ref: return 1, 0
+    core=(nc<<2)+lq+((lseq+1)>>1)+lseq
+    if (bl-32)-core > 8*core+65536: return 1,0
+    if u[o+36+lq-1] != 0: return 1,0
     return 0, bl
 T=8192; bad=0; tot=0
 import bisect
