@@ -83,6 +83,14 @@ int64_t orc_bam_scan_count(const uint8_t *file, size_t flen, int *status);
 /* timing leg only: inflate + crc32 through system zlib (the reference's own dependency) instead of the RFC restatement */
 int orc_use_system_zlib(int on);
 
+/* ---- read_bcf (bcf_oracle.c) ---------------------------------------------- */
+/* Sequential read_bcf scan of a whole BCF file; `blob` receives the canonical serialisation of every schema column
+ * (layout documented above orc_bcf_read in bcf_oracle.c; free with orc_free).  materialise = 0 only frames and
+ * validates records (row count).  Returns 0 clean EOF, -2 stream ended at a bad record (rows before it kept),
+ * -100 not a BGZF/BCF file, -101 header unreadable, -102 VEP columns would be required (out of scope). */
+int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, uint8_t **blob, size_t *blob_len, int64_t *n_rows);
+void orc_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

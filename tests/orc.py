@@ -130,3 +130,128 @@ def bam_scan_count(file_bytes: bytes):
 def use_system_zlib(on: bool) -> bool:
     """timing leg only (bench.py cpu_baseline): route inflate/crc32 through libz.so.1 like the reference does"""
     return bool(lib().orc_use_system_zlib(int(on)))
+
+
+# ---- read_bcf ---------------------------------------------------------------------------------------------------
+BCF_TYPES = {1: "VARCHAR", 2: "BIGINT", 3: "DOUBLE", 4: "BOOLEAN", 5: "INTEGER", 6: "FLOAT"}
+
+
+def decode_bcf_blob(blob: bytes):
+    """Canonical column blob (oracle/bcf_oracle.c, also produced by duckhts_amd.read_bcf) -> dict."""
+    mv = memoryview(blob)
+    ncol, = np.frombuffer(mv[0:4], np.uint32)
+    nrows, = np.frombuffer(mv[4:12], np.uint64)
+    status, = np.frombuffer(mv[12:16], np.int32)
+    first, = np.frombuffer(mv[16:24], np.uint64)
+    nsmp, = np.frombuffer(mv[24:28], np.uint32)
+    n = int(nrows)
+    pos = 28
+    cols = []
+
+    def take(cnt, dtype):
+        nonlocal pos
+        sz = cnt * np.dtype(dtype).itemsize
+        a = np.frombuffer(mv[pos:pos + sz], dtype)
+        pos += sz
+        return a
+
+    def payload(c, cnt, pre):
+        if c["type"] == 1:
+            c[pre + "soff"] = take(cnt + 1, np.uint64)
+            c[pre + "sbytes"] = take(int(c[pre + "soff"][-1]), np.uint8)
+        else:
+            c[pre + "fixed"] = take(cnt, np.uint64)
+
+    for _ in range(int(ncol)):
+        nl = int(take(1, np.uint16)[0])
+        name = bytes(take(nl, np.uint8)).decode()
+        t, il = (int(x) for x in take(2, np.uint8))
+        c = {"name": name, "type": t, "is_list": il, "valid": take(n, np.uint8)}
+        if not il:
+            payload(c, n, "")
+        else:
+            le = take(2 * n, np.uint64).reshape(n, 2)
+            c["loff"], c["llen"] = le[:, 0].copy(), le[:, 1].copy()
+            c["child_n"] = int(take(1, np.uint64)[0])
+            payload(c, c["child_n"], "c")
+        cols.append(c)
+    assert pos == len(blob), (pos, len(blob))
+    return {"n_rows": n, "status": int(status), "first_rec_off": int(first), "n_samples": int(nsmp), "cols": cols,
+            "by_name": {c["name"]: c for c in cols}}
+
+
+def bcf_read(file_bytes: bytes, tidy: bool = False):
+    L = lib()
+    L.orc_bcf_read.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
+    L.orc_bcf_read.restype = C.c_int
+    L.orc_free.argtypes = [C.c_void_p]
+    blob = C.c_void_p()
+    n = C.c_size_t(0)
+    rows = C.c_int64(0)
+    st = L.orc_bcf_read(file_bytes, len(file_bytes), int(tidy), 1, C.byref(blob), C.byref(n), C.byref(rows))
+    if st <= -100:
+        return {"status": st, "n_rows": 0, "cols": [], "by_name": {}}
+    data = C.string_at(blob, n.value)
+    L.orc_free(blob)
+    res = decode_bcf_blob(data)
+    assert res["status"] == st
+    return res
+
+
+def bcf_scan_count(file_bytes: bytes, tidy: bool = False):
+    L = lib()
+    L.orc_bcf_read.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
+    L.orc_bcf_read.restype = C.c_int
+    rows = C.c_int64(0)
+    st = L.orc_bcf_read(file_bytes, len(file_bytes), int(tidy), 0, None, None, C.byref(rows))
+    return rows.value, st
+
+
+def _scalar_py(c, i, pre=""):
+    t = c["type"]
+    if t == 1:
+        return bytes(c[pre + "sbytes"][int(c[pre + "soff"][i]):int(c[pre + "soff"][i + 1])])
+    b = int(c[pre + "fixed"][i])
+    if t == 2:
+        return b - (1 << 64) if b >> 63 else b
+    if t == 3:
+        return float(np.array([b], np.uint64).view(np.float64)[0])
+    if t == 4:
+        return bool(b)
+    if t == 5:
+        b &= 0xFFFFFFFF
+        return b - (1 << 32) if b >> 31 else b
+    return float(np.array([b & 0xFFFFFFFF], np.uint32).view(np.float32)[0])
+
+
+def bcf_col_py(c):
+    """Column -> list of python values (None = NULL, lists for LIST columns); for small fixtures."""
+    out = []
+    for i in range(len(c["valid"])):
+        if not c["valid"][i]:
+            out.append(None)
+        elif c["is_list"]:
+            o, l = int(c["loff"][i]), int(c["llen"][i])
+            out.append([_scalar_py(c, j, "c") for j in range(o, o + l)])
+        else:
+            out.append(_scalar_py(c, i))
+    return out
+
+
+def bcf_cols_diff(a, b):
+    """First difference between two decoded tables (None if identical)."""
+    if a["n_rows"] != b["n_rows"]:
+        return f"n_rows {a['n_rows']} != {b['n_rows']}"
+    if len(a["cols"]) != len(b["cols"]):
+        return f"ncol {len(a['cols'])} != {len(b['cols'])}"
+    for ca, cb in zip(a["cols"], b["cols"]):
+        for k in ("name", "type", "is_list"):
+            if ca[k] != cb[k]:
+                return f"{ca['name']}: {k} {ca[k]} != {cb[k]}"
+        for k in ("valid", "fixed", "soff", "sbytes", "loff", "llen", "cfixed", "csoff", "csbytes"):
+            if (k in ca) != (k in cb):
+                return f"{ca['name']}: field {k} presence"
+            if k in ca and not np.array_equal(ca[k], cb[k]):
+                bad = np.nonzero(ca[k][:min(len(ca[k]), len(cb[k]))] != cb[k][:min(len(ca[k]), len(cb[k]))])[0]
+                return f"{ca['name']}: {k} differs (len {len(ca[k])} vs {len(cb[k])}, first at {bad[0] if len(bad) else 'tail'})"
+    return None
