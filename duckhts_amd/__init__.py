@@ -19,7 +19,7 @@ _LIB = None
 
 BAM_COLUMNS = ["QNAME", "FLAG", "RNAME", "POS", "MAPQ", "CIGAR", "RNEXT", "PNEXT", "TLEN", "SEQ", "QUAL",
                "READ_GROUP_ID", "SAMPLE_ID"]
-K_NAMES = ["sigscan", "huff_decode", "lz_resolve", "tiles", "core_unpack", "scan", "string_write"]
+K_NAMES = ["sigscan", "huff_decode", "lz_resolve", "tiles", "core_unpack", "scan", "string_write", "bcf_check", "bcf_measure", "bcf_write"]
 
 
 class StrCol(C.Structure):
@@ -41,11 +41,36 @@ class BamHeader(C.Structure):
                 ("rg_id", C.POINTER(C.c_char_p)), ("rg_sm", C.POINTER(C.c_char_p)), ("first_rec_uoff", C.c_uint64)]
 
 
+class BcfColInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("is_list", C.c_int32), ("encoding", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BcfInfo(C.Structure):
+    _fields_ = [("n_cols", C.c_int32), ("cols", C.POINTER(BcfColInfo)), ("n_contigs", C.c_int32), ("contig_name", C.POINTER(C.c_char_p)),
+                ("n_dict", C.c_int32), ("dict_name", C.POINTER(C.c_char_p)), ("n_samples", C.c_int32), ("sample_name", C.POINTER(C.c_char_p)),
+                ("tidy", C.c_int32), ("first_rec_uoff", C.c_uint64)]
+
+
+class BcfCol(C.Structure):
+    _fields_ = [("col", C.c_int32), ("reserved", C.c_int32), ("valid", C.c_void_p), ("fixed", C.c_void_p), ("off", C.c_void_p),
+                ("bytes", C.c_void_p), ("nbytes", C.c_uint64), ("child_fixed", C.c_void_p), ("child_off", C.c_void_p), ("child_n", C.c_uint64)]
+
+
+class BcfBatch(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("status", C.c_int32), ("n_cols", C.c_int32), ("cols", C.POINTER(BcfCol)),
+                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64)]
+
+
+# DUCKDB_TYPE_* element codes -> the canonical type tags of the test oracle's column blob
+_CANON_TYPE = {17: 1, 5: 2, 11: 3, 1: 4, 4: 5, 10: 6}
+ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
+
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
            "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
-           "dhts_kernel_time_reset", "dhts_set_timing"]
+           "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range",
+           "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
 
 def lib():
@@ -84,6 +109,12 @@ def lib():
         L.dhts_kernel_time_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.dhts_kernel_time_reset.argtypes = [C.c_void_p]
         L.dhts_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.dhts_bcf_open.argtypes = [C.c_void_p, C.c_int]
+        L.dhts_bcf_info_get.argtypes = [C.c_void_p, C.POINTER(BcfInfo)]
+        L.dhts_bcf_set_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.dhts_bcf_set_block_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+        L.dhts_bcf_rewind.argtypes = [C.c_void_p]
+        L.dhts_bcf_next_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(BcfBatch)]
         _LIB = L
     return _LIB
 
@@ -243,6 +274,174 @@ class Context:
         sm = hdr["rg_sm"]
         res["SAMPLE_ID"] = [sm[k] if (valid[i] and k >= 0 and sm[k] is not None) else None for i, k in enumerate(rgi)]
         return res
+
+
+def _gather_strings(ids, names):
+    """ids (int array, -1 allowed only when names has a trailing default) -> (offsets u64[n+1], bytes u8) by dictionary lookup."""
+    lens = np.array([len(x) for x in names], np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)])[:-1]
+    flat = np.frombuffer(b"".join(names), np.uint8)
+    l = lens[ids]
+    off = np.concatenate([[0], np.cumsum(l)]).astype(np.uint64)
+    total = int(off[-1])
+    if total == 0:
+        return off, np.zeros(0, np.uint8)
+    idx = np.repeat(starts[ids] - off[:-1].astype(np.int64), l) + np.arange(total)
+    return off, flat[idx]
+
+
+class BcfScan:
+    """read_bcf over one context: schema + batches as canonical column tables (same layout tests/orc.py decodes)."""
+
+    def __init__(self, ctx, tidy=False):
+        self.ctx = ctx
+        ctx._chk(ctx.L.dhts_bcf_open(ctx.h, int(tidy)))
+        inf = BcfInfo()
+        ctx._chk(ctx.L.dhts_bcf_info_get(ctx.h, C.byref(inf)))
+        self.schema = [{"name": inf.cols[i].name.decode(), "type": inf.cols[i].type, "is_list": inf.cols[i].is_list, "encoding": inf.cols[i].encoding}
+                       for i in range(inf.n_cols)]
+        self.contigs = [inf.contig_name[i] if inf.contig_name[i] is not None else b"" for i in range(inf.n_contigs)]
+        self.dict_names = [inf.dict_name[i] if inf.dict_name[i] is not None else b"." for i in range(inf.n_dict)] + [b"PASS"]   # id -1 -> literal PASS
+        self.samples = [inf.sample_name[i] for i in range(inf.n_samples)]
+        self.tidy = bool(inf.tidy)
+        self.first_rec_uoff = inf.first_rec_uoff
+        self.projection = list(range(len(self.schema)))
+
+    def set_projection(self, cols):
+        ids = [c if isinstance(c, int) else [s["name"] for s in self.schema].index(c) for c in cols]
+        arr = np.array(ids, np.int32)
+        self.ctx._chk(self.ctx.L.dhts_bcf_set_projection(self.ctx.h, arr.ctypes.data, len(ids)))
+        self.projection = ids
+
+    def set_block_range(self, b0, b1, speculative):
+        self.ctx._chk(self.ctx.L.dhts_bcf_set_block_range(self.ctx.h, b0, b1, int(speculative)))
+
+    def rewind(self):
+        self.ctx._chk(self.ctx.L.dhts_bcf_rewind(self.ctx.h))
+
+    def next_batch(self, max_blocks=0):
+        b = BcfBatch()
+        self.ctx._chk(self.ctx.L.dhts_bcf_next_batch(self.ctx.h, max_blocks, C.byref(b)))
+        return b
+
+    def batch_table(self, b):
+        """device columns of one batch -> canonical table (dictionary-coded columns expanded to strings)"""
+        n = int(b.n_rows)
+        d2h = self.ctx.d2h
+        cols = []
+        for i in range(b.n_cols):
+            dc = b.cols[i]
+            sc = self.schema[dc.col]
+            c = {"name": sc["name"], "type": _CANON_TYPE[sc["type"]], "is_list": sc["is_list"]}
+            c["valid"] = d2h(dc.valid, n, np.uint8) if n else np.zeros(0, np.uint8)
+            enc = sc["encoding"]
+            names = {ENC_CONTIG: self.contigs, ENC_DICT: self.dict_names, ENC_SAMPLE: self.samples}.get(enc)
+            if not sc["is_list"]:
+                if enc != ENC_PLAIN:
+                    ids = d2h(dc.fixed, n, np.int32).astype(np.int64)
+                    c["soff"], c["sbytes"] = _gather_strings(ids, names)
+                elif sc["type"] == 17:
+                    c["soff"] = d2h(dc.off, n + 1, np.uint32).astype(np.uint64) if n else np.zeros(1, np.uint64)
+                    c["sbytes"] = d2h(dc.bytes, int(dc.nbytes), np.uint8)
+                else:
+                    w = {1: np.uint8, 4: np.uint32, 10: np.uint32, 5: np.uint64, 11: np.uint64}[sc["type"]]
+                    c["fixed"] = d2h(dc.fixed, n, w).astype(np.uint64)
+            else:
+                off = d2h(dc.off, n + 1, np.uint32).astype(np.uint64) if n else np.zeros(1, np.uint64)
+                c["loff"], c["llen"] = off[:-1].copy(), off[1:] - off[:-1]
+                cn = int(dc.child_n)
+                c["child_n"] = cn
+                if enc != ENC_PLAIN:
+                    ids = d2h(dc.child_fixed, cn, np.int32).astype(np.int64)
+                    c["csoff"], c["csbytes"] = _gather_strings(ids, names)
+                elif sc["type"] == 17:
+                    c["csoff"] = d2h(dc.child_off, cn + 1, np.uint32).astype(np.uint64) if n else np.zeros(1, np.uint64)
+                    c["csbytes"] = d2h(dc.bytes, int(dc.nbytes), np.uint8)
+                else:
+                    c["cfixed"] = d2h(dc.child_fixed, cn, np.uint32).astype(np.uint64)
+            cols.append(c)
+        return {"n_rows": n, "status": int(b.status), "cols": cols}
+
+
+def _concat_tables(parts, schema_cols):
+    if not parts:
+        return None
+    out = []
+    for k in range(len(parts[0]["cols"])):
+        cs = [p["cols"][k] for p in parts]
+        c = {"name": cs[0]["name"], "type": cs[0]["type"], "is_list": cs[0]["is_list"], "valid": np.concatenate([x["valid"] for x in cs])}
+
+        def cat_off(key, bkey):
+            base, offs = 0, []
+            for x in cs:
+                offs.append(x[key][:-1] + np.uint64(base))
+                base += int(x[key][-1])
+            return np.concatenate(offs + [np.array([base], np.uint64)]), np.concatenate([x[bkey] for x in cs])
+
+        if not c["is_list"]:
+            if "fixed" in cs[0]:
+                c["fixed"] = np.concatenate([x["fixed"] for x in cs])
+            else:
+                c["soff"], c["sbytes"] = cat_off("soff", "sbytes")
+        else:
+            base, lo = 0, []
+            for x in cs:
+                lo.append(x["loff"] + np.uint64(base))
+                base += x["child_n"]
+            c["loff"], c["llen"], c["child_n"] = np.concatenate(lo), np.concatenate([x["llen"] for x in cs]), base
+            if "cfixed" in cs[0]:
+                c["cfixed"] = np.concatenate([x["cfixed"] for x in cs])
+            else:
+                c["csoff"], c["csbytes"] = cat_off("csoff", "csbytes")
+        out.append(c)
+    return out
+
+
+def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=None):
+    """Full sequential read_bcf scan (every record in file order); returns the canonical column table.
+    columns: optional projection (names or schema ids), like DuckDB's projection pushdown."""
+    ctx = Context(device)
+    try:
+        ctx.open(src)
+        ctx.bgzf_index()
+        sc = BcfScan(ctx, tidy)
+        if columns is not None:
+            sc.set_projection(columns)
+        if block_range is not None:
+            sc.set_block_range(*block_range)
+        parts, status, first, end = [], 0, None, None
+        while True:
+            b = sc.next_batch(max_blocks)
+            if b.n_rows:
+                parts.append(sc.batch_table(b))
+                first = b.first_rec_uoff if first is None else first
+            end = b.end_uoff
+            status = b.status
+            if b.status != 0:
+                break
+        proj = [sc.schema[i] for i in sc.projection]
+        cols = _concat_tables(parts, proj)
+        if cols is None:
+            cols = []
+            for s_ in proj:
+                c = {"name": s_["name"], "type": _CANON_TYPE[s_["type"]], "is_list": s_["is_list"], "valid": np.zeros(0, np.uint8)}
+                varchar = s_["type"] == 17
+                if not s_["is_list"]:
+                    if varchar:
+                        c["soff"], c["sbytes"] = np.zeros(1, np.uint64), np.zeros(0, np.uint8)
+                    else:
+                        c["fixed"] = np.zeros(0, np.uint64)
+                else:
+                    c["loff"], c["llen"], c["child_n"] = np.zeros(0, np.uint64), np.zeros(0, np.uint64), 0
+                    if varchar:
+                        c["csoff"], c["csbytes"] = np.zeros(1, np.uint64), np.zeros(0, np.uint8)
+                    else:
+                        c["cfixed"] = np.zeros(0, np.uint64)
+                cols.append(c)
+        return {"n_rows": sum(p["n_rows"] for p in parts), "status": status, "cols": cols, "by_name": {c["name"]: c for c in cols},
+                "schema": sc.schema, "samples": sc.samples, "first_rec_uoff": first, "end_uoff": end, "header_first_rec_uoff": sc.first_rec_uoff}
+    finally:
+        ctx.close()
 
 
 def read_bam(src, device=0, max_blocks=0, shard=None):

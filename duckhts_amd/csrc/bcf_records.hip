@@ -1,0 +1,540 @@
+// bcf_records.hip -- BCF record boundary discovery, validation and typed INFO/FORMAT column unpack for MI355X (gfx950).
+//
+// Replaces, for the read_bcf scan (src/bcf_reader.c:1155-2049):
+//   htslib vcf.c:1874-1911 bcf_read1_core (framing), 2040-2212 bcf_record_check (+ updatephasing 1985-2029),
+//   4234-4302 bcf_unpack, 3036-3079 bcf_fmt_array (ID / allele text), 6056-6138 bcf_get_info_values,
+//   6140-6177 bcf_get_format_string, 6179-6248 bcf_get_format_values, and the column writers
+//   src/bcf_reader.c:1381-1462 (core), 1542-1733 (INFO), 1738-1982 (FORMAT wide/tidy, GT text), 996-1061 (comma lists).
+//
+// Stages (all integer/byte work, HBM-bound):
+//   1. bcf_tile_scan / bcf_tile_fix: the record chain (next = cur + 8 + l_shared + l_indiv) is cut into 8 KiB tiles; one
+//      wave per tile speculates the first record inside its tile, walks to the tile end, and continuity is proven
+//      tile-to-tile exactly as for BAM (bam_records.hip) -- a wrong guess only costs a repair round.
+//   2. bcf_rec_check: one lane per record runs every bcf_record_check predicate and leaves a small directory
+//      (offsets of the allele / FILTER vectors and of each schema INFO / FORMAT field inside the record).
+//   3. bcf_cells<false>: one lane per (row, projected column) evaluates the cell through the directory: validity,
+//      fixed-width payloads, and the child / byte counts of variable-width cells.
+//   4. matrix prefix sums over those counts, then bcf_cells<true> writes list children and string bytes in place.
+#pragma once
+#include "dhts_common.h"
+
+struct BcfStream {
+    const uint8_t *u; uint64_t ulen;
+    int32_t n_ctg, n_ids, n_smp, final_batch;
+    int32_t n_info_f, n_fmt_f;
+    const uint8_t *ctg_ok;        // n_ctg: contig id present in the header dictionary
+    const uint8_t *id_ok;         // n_ids: dictionary id present
+    const int16_t *info_slot;     // n_ids: schema INFO field index of a dictionary id, -1 if none
+    const int16_t *fmt_slot;      // n_ids: schema FORMAT field index, -1 if none
+};
+
+__device__ __constant__ uint8_t BCF_SHIFT[16] = {0, 0, 1, 2, 3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // vcf.c:91
+
+__device__ __forceinline__ uint32_t b_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ int32_t b_i16(const uint8_t *p) { return (int32_t)(int16_t)b_u16(p); }
+
+// one hop of the chain: the tests bcf_read1_core / bcf_record_check make on the 32-byte core alone
+template <class S> __device__ __forceinline__ int bcf_hop(const BcfStream &st, const S &s, uint64_t o, uint64_t &sz, bool spec) {
+    if (st.ulen - o < 32) return REC_INCOMPLETE;
+    const uint32_t l_shared = s.u32(o), l_indiv = s.u32(o + 4);
+    if (l_shared < 24) return REC_INVALID;                                   // vcf.c:1885
+    const int32_t rid = (int32_t)s.u32(o + 8);
+    if (rid < 0 || rid >= st.n_ctg) return REC_INVALID;                      // vcf.c:2069-2073 (dictionary holes are tested in bcf_rec_check)
+    if ((s.u32(o + 24) >> 16) < 1) return REC_INVALID;                       // n_allele >= 1, vcf.c:2088-2092
+    if (spec) {                                                              // speculation filter only: never decides validity
+        if (l_shared > (1u << 28) || l_indiv > (1u << 30)) return REC_INVALID;
+        const uint32_t x = s.u32(o + 28);
+        if ((x >> 24) != 0 && (x & 0xffffff) != 0 && (x & 0xffffff) != (uint32_t)st.n_smp) return REC_INVALID;
+    }
+    sz = 8ull + l_shared + l_indiv;
+    if (st.ulen - o < sz) return REC_INCOMPLETE;
+    return REC_OK;
+}
+
+__device__ void bcf_tile_walk(const BcfStream &st, uint64_t start, uint64_t tile_end, uint64_t &end_next, uint32_t &count, int &err) {
+    GSrc gs; gs.g = st.u;
+    uint64_t o = start; uint32_t c = 0; err = 0;
+    while (o < tile_end) {
+        uint64_t sz = 0;
+        const int rc = bcf_hop(st, gs, o, sz, false);
+        if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }   // short read = error (vcf.c:1879-1882, 1908-1909)
+        if (rc == REC_INVALID) { err = 1; break; }
+        c++; o += sz;
+    }
+    end_next = o; count = c;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+bcf_tile_scan(BcfStream st, uint64_t start0, int64_t ntiles, TileOut out) {
+    __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const uint64_t tb = (uint64_t)t * TL_TILE;
+    uint64_t te = tb + TL_TILE; if (te > st.ulen) te = st.ulen;
+    BamStream bs; bs.u = st.u; bs.ulen = st.ulen; bs.n_ref = 0; bs.final_batch = st.final_batch;
+    LSrc s; tile_stage(bs, tb, buf, s, lane);
+    PSrc ls; ls.l = buf; ls.base = tb;
+    GSrc gs; gs.g = st.u;
+    uint64_t first = NONE64;
+    if (t == 0 && start0 != NONE64) first = start0;
+    else {
+        const uint64_t lim = (t == 0) ? st.ulen : te;
+        for (uint64_t base = tb; base < lim; base += 64) {
+            const uint64_t o = base + (uint64_t)lane;
+            bool ok = false;
+            if (o < lim) {
+                uint64_t sz = 0;
+                const bool inw = (o - tb) + 32u <= (uint64_t)s.len;
+                const int rc0 = inw ? bcf_hop(st, ls, o, sz, true) : bcf_hop(st, gs, o, sz, true);
+                if (rc0 == REC_OK) {
+                    ok = true;
+                    uint64_t o2 = o + sz;
+                    for (int k = 0; k < 2 && ok; k++) {
+                        uint64_t s2 = 0;
+                        const bool inw2 = (o2 >= tb) && (o2 - tb) + 32u <= (uint64_t)s.len;
+                        const int rc = inw2 ? bcf_hop(st, ls, o2, s2, true) : bcf_hop(st, gs, o2, s2, true);
+                        if (rc == REC_INVALID) ok = false;
+                        else if (rc == REC_INCOMPLETE) break;
+                        else o2 += s2;
+                    }
+                }
+            }
+            const uint64_t m = __ballot(ok);
+            if (m) { first = base + (uint64_t)(__ffsll((unsigned long long)m) - 1); break; }
+        }
+    }
+    uint64_t en = NONE64; uint32_t cnt = 0; int err = 0;
+    if (first != NONE64 && first < te) {
+        uint64_t o = first;
+        while (o < te) {
+            uint64_t sz = 0;
+            const int rc = ((o - tb) + 32 <= (uint64_t)s.len) ? bcf_hop(st, ls, o, sz, false) : bcf_hop(st, gs, o, sz, false);
+            if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }
+            if (rc == REC_INVALID) { err = 1; break; }
+            cnt++; o += sz;
+        }
+        en = o;
+    } else if (first != NONE64) en = first;
+    if (lane == 0) {
+        out.first[t] = (first != NONE64 && first < te) ? first : NONE64;
+        out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
+    }
+}
+
+// out-of-place continuity proof + repair round (same protocol as bam_tile_fix)
+extern "C" __global__ void __launch_bounds__(256)
+bcf_tile_fix(BcfStream st, uint32_t tile_bytes, int64_t ntiles, TileOut in, TileOut out, uint32_t *nfixed) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    uint64_t f = in.first[t], en = in.end_next[t]; uint32_t cnt = in.count[t]; int32_t err = in.err[t];
+    if (t >= 1) {
+        const uint64_t tb = (uint64_t)t * tile_bytes; uint64_t te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
+        const uint64_t p = in.end_next[t - 1];
+        bool pred_ok = (p != NONE64) && !in.err[t - 1];
+        if (pred_ok && t >= 2) pred_ok = tile_consistent(in, t - 1, tb);
+        if (pred_ok && !tile_consistent(in, t, te)) {
+            if (p >= te) { f = NONE64; cnt = 0; err = 0; en = p; }
+            else { int e; bcf_tile_walk(st, p, te, en, cnt, e); f = p; err = e; }
+            atomicAdd(nfixed, 1u);
+        }
+    }
+    out.first[t] = f; out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
+}
+
+extern "C" __global__ void bcf_tile_fix_seq(BcfStream st, uint32_t tile_bytes, int64_t ntiles, TileOut out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int64_t t = 1; t < ntiles; t++) {
+        if (out.err[t - 1]) return;
+        uint64_t p = out.end_next[t - 1];
+        uint64_t tb = (uint64_t)t * tile_bytes, te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
+        if (p >= te) { out.first[t] = NONE64; out.count[t] = 0; out.err[t] = 0; out.end_next[t] = p; continue; }
+        if (out.first[t] == p) continue;
+        uint64_t en; uint32_t cnt; int err;
+        bcf_tile_walk(st, p, te, en, cnt, err);
+        out.first[t] = p; out.count[t] = cnt; out.err[t] = err; out.end_next[t] = en;
+    }
+}
+
+// record offsets by record id (one lane per tile; <= 256 records per 8 KiB tile)
+extern "C" __global__ void __launch_bounds__(256)
+bcf_tile_offsets(BcfStream st, uint32_t tile_bytes, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res, int64_t nrec, uint32_t *rec_off) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles || (uint64_t)t > res[3]) return;
+    uint64_t o = out.first[t]; if (o == NONE64) return;
+    uint32_t n = out.count[t], row = rowbase[t];
+    for (uint32_t k = 0; k < n && (int64_t)(row + k) < nrec; k++) { rec_off[row + k] = (uint32_t)o; o += 8ull + ldu32(st.u + o) + ldu32(st.u + o + 4); }
+}
+
+// ---- typed values (BCF2 typed-value codec, htslib/vcf.h:1586-1690) ------------------------------------------------------
+__device__ __forceinline__ bool bcf_dec_int1_safe(const uint8_t *u, uint64_t &p, uint64_t end, int32_t &val) {   // vcf.c:1918-1949
+    if (end - p < 2) return false;
+    const int t = u[p] & 0xf; uint64_t q = p + 1;
+    if (t == 1) { val = (int8_t)u[q]; q += 1; }
+    else {
+        if (end - q < (1ull << BCF_SHIFT[t])) return false;
+        if (t == 2) { val = b_i16(u + q); q += 2; }
+        else if (t == 3) { val = (int32_t)ldu32(u + q); q += 4; }
+        else return false;
+    }
+    p = q; return true;
+}
+__device__ __forceinline__ bool bcf_dec_size_safe(const uint8_t *u, uint64_t &p, uint64_t end, int &num, int &type) {   // vcf.c:1951-1963
+    if (p >= end) return false;
+    type = u[p] & 0xf;
+    if ((u[p] >> 4) != 15) { num = u[p] >> 4; p += 1; return true; }
+    uint64_t q = p + 1; int32_t v;
+    if (!bcf_dec_int1_safe(u, q, end, v)) return false;
+    if (v < 0) return false;
+    num = v; p = q; return true;
+}
+// unchecked variant for vectors bcf_rec_check has already validated
+__device__ __forceinline__ void bcf_dec_size(const uint8_t *u, uint64_t &p, int &num, int &type) {
+    type = u[p] & 0xf;
+    if ((u[p] >> 4) != 15) { num = u[p] >> 4; p += 1; return; }
+    const int t = u[p + 1] & 0xf;
+    if (t == 1) { num = (int8_t)u[p + 2]; p += 3; }
+    else if (t == 2) { num = b_i16(u + p + 2); p += 4; }
+    else { num = (int32_t)ldu32(u + p + 2); p += 6; }
+}
+
+// One lane per record: bcf_record_check (vcf.c:2040-2212) + the per-record directory.
+// dir is slot-major: dir[slot * stride + rec]; slot 0 = first allele descriptor, 1 = FILTER descriptor, then one slot per
+// schema INFO field and per schema FORMAT field (offset of the value descriptor relative to the record start, 0 = absent;
+// the first occurrence of a key wins, vcf.c:6064-6066 / 6192-6194).
+extern "C" __global__ void __launch_bounds__(256)
+bcf_rec_check(BcfStream st, const uint32_t *rec_off, int64_t nrec, uint32_t *dir, uint32_t stride, unsigned long long *bad_rec) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint8_t *u = st.u;
+    const uint64_t o = rec_off[r];
+    const int D = 2 + st.n_info_f + st.n_fmt_f;
+    for (int k = 0; k < D; k++) dir[(size_t)k * stride + r] = 0;
+    const uint32_t l_shared = ldu32(u + o) - 24, l_indiv = ldu32(u + o + 4);
+    const int32_t rid = (int32_t)ldu32(u + o + 8);
+    const uint32_t n_info = b_u16(u + o + 24), n_allele = b_u16(u + o + 26);
+    const uint32_t n_sample = ldu32(u + o + 28) & 0xffffff; uint32_t n_fmt = u[o + 31];
+    if ((!l_indiv || !n_sample) && n_fmt) n_fmt = 0;                          // vcf.c:1906
+    const uint64_t she = o + 32 + l_shared, ine = she + l_indiv;
+    bool err = false, bad = false;
+    if (rid < 0 || rid >= st.n_ctg || !st.ctg_ok[rid]) err = true;
+    uint64_t p = o + 32; int num = 0, type = 0;
+    do {
+        if (!bcf_dec_size_safe(u, p, she, num, type)) { bad = true; break; }            // ID
+        if (type != 7) err = true;
+        uint64_t bytes = (uint64_t)num << BCF_SHIFT[type];
+        if (she - p < bytes) { bad = true; break; }
+        p += bytes;
+        if (n_allele < 1) err = true;
+        for (uint32_t i = 0; i < n_allele; i++) {
+            if (i == 0) dir[r] = (uint32_t)(p - o);
+            if (!bcf_dec_size_safe(u, p, she, num, type)) { bad = true; break; }
+            if (type != 7) err = true;
+            bytes = (uint64_t)num << BCF_SHIFT[type];
+            if (she - p < bytes) { bad = true; break; }
+            p += bytes;
+        }
+        if (bad) break;
+        dir[(size_t)stride + r] = (uint32_t)(p - o);
+        if (!bcf_dec_size_safe(u, p, she, num, type)) { bad = true; break; }            // FILTER
+        if (num > 0) {
+            bytes = (uint64_t)num << BCF_SHIFT[type];
+            if (she - p < bytes) { bad = true; break; }
+            if (!(type == 1 || type == 2 || type == 3)) { err = true; p += bytes; }
+            else for (int i = 0; i < num; i++) {
+                int32_t key = type == 1 ? (int32_t)(int8_t)u[p] : type == 2 ? b_i16(u + p) : (int32_t)ldu32(u + p);
+                p += 1ull << BCF_SHIFT[type];
+                if (key < 0 || key >= st.n_ids || !st.id_ok[key]) err = true;
+            }
+        }
+        for (uint32_t i = 0; i < n_info; i++) {
+            int32_t key = -1;
+            if (!bcf_dec_int1_safe(u, p, she, key)) { bad = true; break; }
+            const bool kok = !(key < 0 || key >= st.n_ids || !st.id_ok[key]);
+            if (!kok) err = true;
+            const uint32_t d = (uint32_t)(p - o);
+            if (!bcf_dec_size_safe(u, p, she, num, type)) { bad = true; break; }
+            if (!(type == 0 || type == 1 || type == 2 || type == 3 || type == 5 || type == 7) || (type == 0 && num > 0)) err = true;
+            bytes = (uint64_t)num << BCF_SHIFT[type];
+            if (she - p < bytes) { bad = true; break; }
+            if (kok) { const int sl = st.info_slot[key]; if (sl >= 0 && dir[(size_t)(2 + sl) * stride + r] == 0) dir[(size_t)(2 + sl) * stride + r] = d; }
+            p += bytes;
+        }
+        if (bad) break;
+        p = she;
+        for (uint32_t i = 0; i < n_fmt; i++) {
+            int32_t key = -1;
+            if (!bcf_dec_int1_safe(u, p, ine, key)) { bad = true; break; }
+            const bool kok = !(key < 0 || key >= st.n_ids || !st.id_ok[key]);
+            if (!kok) err = true;
+            const uint32_t d = (uint32_t)(p - o);
+            if (!bcf_dec_size_safe(u, p, ine, num, type)) { bad = true; break; }
+            if (!(type == 0 || type == 1 || type == 2 || type == 3 || type == 5 || type == 7) || (type == 0 && num > 0)) err = true;
+            bytes = ((uint64_t)num << BCF_SHIFT[type]) * n_sample;               // also updatephasing's own bounds test (vcf.c:1989-1991)
+            if (ine - p < bytes) { bad = true; break; }
+            if (kok) { const int sl = st.fmt_slot[key]; if (sl >= 0) { const size_t q = (size_t)(2 + st.n_info_f + sl) * stride + r; if (dir[q] == 0) dir[q] = d; } }
+            p += bytes;
+        }
+    } while (0);
+    if (bad || err) atomicMin(bad_rec, (unsigned long long)r);
+}
+
+// ---- cells -------------------------------------------------------------------------------------------------------------------
+enum { BK_CHROM = 0, BK_POS, BK_ID, BK_REF, BK_ALT, BK_QUAL, BK_FILTER, BK_INFO, BK_SAMPLE_ID, BK_FORMAT };
+enum { BF_NULL_ALWAYS = 1, BF_GT = 2, BF_GT_FIX = 4 };
+
+struct BcfColDev {
+    int32_t kind, htype, is_list, slot, sample, flags;
+    int32_t sa_cnt, sa_bytes;     // rows of the count matrix (children / bytes) or -1
+    uint8_t *valid;               // nrows bytes
+    void *fixed;                  // nrows x native width (scalar fixed-width columns, dictionary-coded columns)
+    uint8_t *bytes;               // VARCHAR bytes (scalar) or child bytes (list of VARCHAR)
+    uint32_t *child_off;          // list of VARCHAR: child_n + 1 byte offsets
+    uint32_t *child_fixed;        // list of 4-byte words (INTEGER, FLOAT bits, dictionary ids)
+};
+
+struct BcfCellArgs {
+    const uint32_t *rec_off; const uint32_t *dir; uint32_t stride;
+    int64_t nrows; int32_t tidy, n_smp;
+    uint32_t *lens; const uint32_t *offs; uint32_t ostride;
+    const BcfColDev *cols;
+};
+
+__device__ __forceinline__ uint32_t cstr_len(const uint8_t *p, uint32_t n) { uint32_t l = 0; while (l < n && p[l]) l++; return l; }
+
+// widen one stored element (getter BRANCH macros, vcf.c:6096-6131 / 6221-6244)
+__device__ __forceinline__ void bcf_elem(const uint8_t *p, int type, int j, uint32_t &w, bool &is_end, bool &is_miss) {
+    if (type == 1) { const int32_t v = (int8_t)p[j]; is_end = v == -127; is_miss = v == -128; w = (uint32_t)v; }
+    else if (type == 2) { const int32_t v = b_i16(p + 2 * j); is_end = v == -32767; is_miss = v == -32768; w = (uint32_t)v; }
+    else if (type == 3) { const uint32_t v = ldu32(p + 4 * j); is_end = v == 0x80000001u; is_miss = v == 0x80000000u; w = v; }
+    else { const uint32_t v = ldu32(p + 4 * j); is_end = v == 0x7F800002u; is_miss = v == 0x7F800001u; w = v; }
+}
+__device__ __forceinline__ bool bcf_numeric_type(int t) { return t == 1 || t == 2 || t == 3 || t == 5; }
+
+__device__ __forceinline__ uint64_t f32_bits_to_f64_bits(uint32_t b) {      // exact widening, NaN payload kept and quieted like cvtss2sd
+    const uint64_t sign = (uint64_t)(b >> 31) << 63; const uint32_t e = (b >> 23) & 0xff; uint32_t m = b & 0x7fffff;
+    if (e == 0xff) return sign | (0x7ffull << 52) | ((uint64_t)m << 29) | (m ? (1ull << 51) : 0);
+    if (e == 0) {
+        if (!m) return sign;
+        const int sh = __clz(m) - 8;                                          // normalise the denormal
+        m = (m << sh) & 0x7fffff;
+        return sign | ((uint64_t)(1 - sh - 127 + 1023) << 52) | ((uint64_t)m << 29);
+    }
+    return sign | ((uint64_t)(e - 127 + 1023) << 52) | ((uint64_t)m << 29);
+}
+
+__device__ __forceinline__ uint32_t ndigits10(uint32_t a) { return ndigits(a) + (a >= 1000000000u); }
+__device__ __forceinline__ uint32_t dec_len_i32(int32_t v) {
+    uint32_t a = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
+    return ndigits10(a) + (v < 0);
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nrows) return;
+    const BcfColDev cd = a.cols[blockIdx.y];
+    if (WRITE && cd.sa_cnt < 0 && cd.sa_bytes < 0) return;
+    const uint8_t *u = st.u;
+    const int64_t rec = a.tidy ? row / a.n_smp : row;
+    const int smp = cd.sample >= 0 ? cd.sample : (a.tidy ? (int)(row % a.n_smp) : 0);
+    const uint64_t o = a.rec_off[rec];
+    uint32_t cnt = 0, nbytes = 0; bool valid = true;
+    uint32_t cbase = 0, bbase = 0;
+    if (WRITE) {
+        if (cd.sa_cnt >= 0) cbase = a.offs[(size_t)cd.sa_cnt * a.ostride + row];
+        if (cd.sa_bytes >= 0) bbase = a.offs[(size_t)cd.sa_bytes * a.ostride + row];
+    }
+    auto put_str = [&](const uint8_t *p, uint32_t l) {                        // scalar VARCHAR payload
+        if (WRITE) for (uint32_t k = 0; k < l; k++) cd.bytes[bbase + k] = p[k];
+        nbytes = l;
+    };
+    auto put_child_str = [&](const uint8_t *p, uint32_t l) {
+        if (WRITE) { cd.child_off[cbase + cnt] = bbase + nbytes; for (uint32_t k = 0; k < l; k++) cd.bytes[bbase + nbytes + k] = p[k]; }
+        cnt++; nbytes += l;
+    };
+    auto put_child_w = [&](uint32_t w) { if (WRITE) cd.child_fixed[cbase + cnt] = w; cnt++; };
+    const uint8_t dot = '.';
+
+    switch (cd.kind) {
+    case BK_CHROM: if (!WRITE) ((int32_t *)cd.fixed)[row] = (int32_t)ldu32(u + o + 8); break;
+    case BK_POS: if (!WRITE) { const uint32_t p32 = ldu32(u + o + 12); ((int64_t *)cd.fixed)[row] = p32 == 0xffffffffu ? 0 : (int64_t)p32 + 1; } break;   // vcf.c:1895-1896
+    case BK_QUAL: if (!WRITE) {
+            const uint32_t b = ldu32(u + o + 20);
+            if (b == 0x7F800001u) { valid = false; ((uint64_t *)cd.fixed)[row] = 0; }           // NULL, payload 0.0 (bcf_reader.c:1427-1434)
+            else ((uint64_t *)cd.fixed)[row] = f32_bits_to_f64_bits(b);
+        } break;
+    case BK_SAMPLE_ID: if (!WRITE) ((int32_t *)cd.fixed)[row] = smp; break;
+    case BK_ID: {
+            uint64_t p = o + 32; int n, t; bcf_dec_size(u, p, n, t);
+            const uint32_t l = n > 0 ? cstr_len(u + p, (uint32_t)n) : 0;
+            if (n <= 0 || (l == 1 && u[p] == '.')) valid = false;               // "." (bcf_reader.c:1393-1401)
+            else put_str(u + p, l);
+        } break;
+    case BK_REF: {
+            uint64_t p = o + a.dir[rec]; int n, t; bcf_dec_size(u, p, n, t);
+            if (n > 0) put_str(u + p, cstr_len(u + p, (uint32_t)n)); else put_str(&dot, 1);     // vcf.c:3040-3042
+        } break;
+    case BK_ALT: {
+            const uint32_t n_allele = b_u16(u + o + 26);
+            uint64_t p = o + a.dir[rec];
+            for (uint32_t i = 0; i < n_allele; i++) {
+                int n, t; bcf_dec_size(u, p, n, t);
+                if (i > 0) { if (n > 0) put_child_str(u + p, cstr_len(u + p, (uint32_t)n)); else put_child_str(&dot, 1); }
+                p += (uint64_t)n;
+            }
+        } break;
+    case BK_FILTER: {
+            uint64_t p = o + a.dir[(size_t)a.stride + rec]; int n, t; bcf_dec_size(u, p, n, t);
+            if (n <= 0) put_child_w(0xffffffffu);                              // no filters => literal "PASS" (bcf_reader.c:1443-1447)
+            else for (int i = 0; i < n; i++) put_child_w((uint32_t)(t == 1 ? (int32_t)(int8_t)u[p + i] : t == 2 ? b_i16(u + p + 2 * i) : (int32_t)ldu32(u + p + 4 * i)));
+        } break;
+    case BK_INFO: {
+            const uint32_t d = a.dir[(size_t)(2 + cd.slot) * a.stride + rec];
+            if (cd.htype == 0) { if (!WRITE) ((uint8_t *)cd.fixed)[row] = d != 0; break; }      // Flag: present or not, never NULL
+            if (!d) { valid = false; break; }
+            uint64_t p = o + d; int n, t; bcf_dec_size(u, p, n, t);
+            if (cd.htype == 3) {                                               // String: info->len BYTES, C-string semantics (vcf.c:6071-6081)
+                if (n <= 0) { valid = false; break; }
+                const uint32_t l = cstr_len(u + p, (uint32_t)n);
+                if (l == 1 && u[p] == '.') { valid = false; break; }
+                if (!cd.is_list) { put_str(u + p, l); break; }
+                uint32_t stt = 0;                                              // comma split; the last token only if non-empty (bcf_reader.c:1018-1057)
+                for (uint32_t i = 0; i < l; i++) if (u[p + i] == ',') { put_child_str(u + p + stt, i - stt); stt = i + 1; }
+                if (l > stt) put_child_str(u + p + stt, l - stt);
+                break;
+            }
+            if (!bcf_numeric_type(t)) { valid = false; break; }
+            const uint32_t miss_h = cd.htype == 1 ? 0x80000000u : 0x7F800001u, vend_h = cd.htype == 1 ? 0x80000001u : 0x7F800002u;
+            const uint32_t miss_s = t == 5 ? 0x7F800001u : 0x80000000u;
+            int j = 0; uint32_t w0 = 0;
+            for (; j < n; j++) {                                               // the getter stops at the first vector_end (vcf.c:6105)
+                uint32_t w; bool ie, im; bcf_elem(u + p, t, j, w, ie, im);
+                if (ie) break;
+                if (im) w = miss_s;
+                if (j == 0) w0 = w;
+                if (cd.is_list && w != miss_h && w != vend_h) put_child_w(w);
+            }
+            if (j == 0) { valid = false; cnt = 0; break; }
+            if (!cd.is_list) { if (w0 == miss_h) valid = false; else if (!WRITE) ((uint32_t *)cd.fixed)[row] = w0; }
+        } break;
+    case BK_FORMAT: {
+            const uint32_t d = (cd.flags & BF_NULL_ALWAYS) ? 0 : a.dir[(size_t)(2 + st.n_info_f + cd.slot) * a.stride + rec];
+            const uint32_t n_sample = ldu32(u + o + 28) & 0xffffff;
+            if (!d || (uint32_t)smp >= n_sample) { valid = false; break; }
+            uint64_t p = o + d; int n, t; bcf_dec_size(u, p, n, t);
+            if (cd.htype == 3 && !(cd.flags & BF_GT)) {                        // plain string: n BYTES per sample at stride n (vcf.c:6166-6174)
+                const uint8_t *q = u + p + (uint64_t)smp * (uint32_t)(n > 0 ? n : 0);
+                put_str(q, n > 0 ? cstr_len(q, (uint32_t)n) : 0);
+                break;
+            }
+            if (n <= 0 || !bcf_numeric_type(t)) { valid = false; break; }
+            const uint8_t *q = u + p + (uint64_t)smp * ((uint64_t)n << BCF_SHIFT[t]);
+            const uint32_t miss_s = t == 5 ? 0x7F800001u : 0x80000000u, vend_s = t == 5 ? 0x7F800002u : 0x80000001u;
+            if (cd.flags & BF_GT) {                                            // GT text (bcf_reader.c:1904-1957)
+                uint8_t tmp[12];
+                for (int j = 0; j < n; j++) {
+                    uint32_t w; bool ie, im; bcf_elem(q, t, j, w, ie, im);
+                    if (j == 0 && (cd.flags & BF_GT_FIX)) {                    // updatephasing on pre-4.4 files (vcf.c:1985-2029): low byte of the first allele
+                        const int inc = 1 << BCF_SHIFT[t];
+                        uint8_t lo = q[0];
+                        if (n == 1) { if (lo) lo |= 1; }
+                        else if (n == 2) lo |= (q[inc] & 1);
+                        else { uint8_t all = 1; for (int k = 1; k < n; k++) all &= q[inc * k]; lo |= all; }
+                        uint8_t e4[4] = {lo, 0, 0, 0};
+                        for (int k = 1; k < inc; k++) e4[k] = q[k];
+                        bcf_elem(e4, t, 0, w, ie, im);
+                    }
+                    if (im) w = miss_s; else if (ie) break;
+                    const int32_t v = (int32_t)w;
+                    if (v == (int32_t)0x80000001u) break;
+                    if (j > 0) { const uint8_t sep = (v & 1) ? '|' : '/'; if (WRITE) cd.bytes[bbase + nbytes] = sep; nbytes++; }
+                    if ((v >> 1) == 0) { if (WRITE) cd.bytes[bbase + nbytes] = '.'; nbytes++; }
+                    else {
+                        const int32_t al = (v >> 1) - 1;
+                        const uint32_t l = dec_len_i32(al);
+                        if (WRITE) {
+                            uint32_t mag = al < 0 ? (uint32_t)(-(int64_t)al) : (uint32_t)al;
+                            for (uint32_t k = 0; k < l; k++) { tmp[l - 1 - k] = (uint8_t)('0' + mag % 10); mag /= 10; }
+                            if (al < 0) tmp[0] = '-';
+                            for (uint32_t k = 0; k < l; k++) cd.bytes[bbase + nbytes + k] = tmp[k];
+                        }
+                        nbytes += l;
+                    }
+                }
+                if (nbytes == 0) valid = false;
+                break;
+            }
+            const uint32_t miss_h = cd.htype == 1 ? 0x80000000u : 0x7F800001u, vend_h = cd.htype == 1 ? 0x80000001u : 0x7F800002u;
+            bool ended = false; uint32_t w0 = 0;
+            for (int j = 0; j < n; j++) {                                      // per-sample widen + vector_end padding (vcf.c:6221-6236)
+                uint32_t w = vend_s;
+                if (!ended) { bool ie, im; bcf_elem(q, t, j, w, ie, im); if (im) w = miss_s; else if (ie) { ended = true; w = vend_s; } }
+                if (j == 0) w0 = w;
+                if (cd.is_list) { if (w != miss_h && w != vend_h) put_child_w(w); }
+                else break;
+            }
+            if (!cd.is_list) { if (w0 == miss_h) valid = false; else if (!WRITE) ((uint32_t *)cd.fixed)[row] = w0; }
+        } break;
+    }
+    if (!WRITE) {
+        cd.valid[row] = valid ? 1 : 0;
+        if (!valid) {
+            cnt = 0; nbytes = 0;
+            if (cd.fixed && cd.kind != BK_QUAL) {
+                if (cd.kind == BK_POS) ((int64_t *)cd.fixed)[row] = 0;
+                else if (cd.htype == 0 && cd.kind == BK_INFO) ((uint8_t *)cd.fixed)[row] = 0;
+                else ((uint32_t *)cd.fixed)[row] = 0;
+            }
+        }
+        if (cd.sa_cnt >= 0) a.lens[(size_t)cd.sa_cnt * a.ostride + row] = cnt;
+        if (cd.sa_bytes >= 0) a.lens[(size_t)cd.sa_bytes * a.ostride + row] = nbytes;
+    } else if (row == a.nrows - 1 && cd.child_off && cd.sa_cnt >= 0 && cd.sa_bytes >= 0) {
+        // closing offset of the child string table
+        cd.child_off[a.offs[(size_t)cd.sa_cnt * a.ostride + a.nrows]] = a.offs[(size_t)cd.sa_bytes * a.ostride + a.nrows];
+    }
+}
+
+// ---- matrix exclusive scan: rows of `lens` (narr x stride) -> rows of `offs`, off[n] = total -------------------------------
+struct MScanArgs { const uint32_t *in; uint32_t *out; uint64_t *partial; uint64_t *total; uint32_t stride; int64_t n; int64_t nparts; };
+
+extern "C" __global__ void __launch_bounds__(256) mscan_reduce(MScanArgs a) {
+    __shared__ uint32_t sh[256];
+    const uint32_t *in = a.in + (size_t)blockIdx.y * a.stride;
+    int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (int k = 0; k < 16; k++) { int64_t i = base + k * 256 + threadIdx.x; if (i < a.n) s += in[i]; }
+    sh[threadIdx.x] = s; __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) a.partial[(size_t)blockIdx.y * a.nparts + blockIdx.x] = sh[0];
+}
+extern "C" __global__ void __launch_bounds__(1024) mscan_partials(MScanArgs a) {
+    __shared__ uint64_t sh[1024]; __shared__ uint64_t carry;
+    uint64_t *p = a.partial + (size_t)blockIdx.x * a.nparts;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < a.nparts; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        uint64_t v = i < a.nparts ? p[i] : 0;
+        sh[threadIdx.x] = v; __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) { uint64_t t = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+        if (i < a.nparts) p[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.total[blockIdx.x] = carry;
+}
+extern "C" __global__ void __launch_bounds__(256) mscan_apply(MScanArgs a) {
+    __shared__ uint32_t sh[256];
+    const uint32_t *in = a.in + (size_t)blockIdx.y * a.stride; uint32_t *out = a.out + (size_t)blockIdx.y * a.stride;
+    int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS + (int64_t)threadIdx.x * 16;
+    uint32_t v[16]; uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { int64_t i = base + k; v[k] = i < a.n ? in[i] : 0; s += v[k]; }
+    sh[threadIdx.x] = s; __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { uint32_t t = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+    uint64_t run = a.partial[(size_t)blockIdx.y * a.nparts + blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { int64_t i = base + k; if (i <= a.n) out[i] = (uint32_t)run; run += v[k]; }
+}

@@ -5,6 +5,8 @@
 #include "bgzf_inflate.hip"
 #include "bam_records.hip"
 #include "bam_tiles_lds.hip"
+#include "bcf_records.hip"
+#include "bcf_header.h"
 
 #include <fcntl.h>
 #include <stdarg.h>
@@ -64,6 +66,12 @@ struct dhts_ctx {
     std::vector<std::string> rg_id, rg_sm; std::vector<char> rg_has_sm; std::vector<const char *> rg_id_p, rg_sm_p;
     uint64_t first_rec_uoff = 0;
     DevBuf d_rg_off, d_rg_bytes;
+    // read_bcf
+    bool bcf_open = false; bool bcf_tidy_req = false;
+    dhts::BcfHeader bh; dhts::BcfSchema bsch;
+    std::vector<dhts_bcf_colinfo> bcf_colinfo; std::vector<const char *> bcf_ctg_p, bcf_dict_p, bcf_smp_p;
+    std::vector<int32_t> bcf_proj; std::vector<dhts_bcf_col> bcf_out;
+    DevBuf d_ctg_ok, d_id_ok, d_info_slot, d_fmt_slot, b_rec_off, b_dir, b_lens, b_offs, b_partial, b_total, b_coldev, b_fixed, b_valid, b_var;
     // scan position
     int64_t shard_b0 = 0, shard_b1 = 0;   // block range of this shard
     int shard_rank = 0, shard_world = 1;
@@ -503,22 +511,31 @@ int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
     return dhts_bam_set_block_range(c, b0, b1, rank > 0);
 }
 
+// a scan that starts at the top of the file begins with the block that holds the first record (headers may span many blocks)
+static void skip_header_blocks(dhts_ctx *c) {
+    if (c->shard_rank != 0 || c->shard_b0 != 0 || c->n_blocks <= 0) return;
+    int64_t lo = 0, hi = c->n_blocks;                       // last block b with uoff[b] <= first_rec_uoff
+    while (hi - lo > 1) { int64_t mid = (lo + hi) / 2; if (c->h_uoff[mid] <= c->first_rec_uoff) lo = mid; else hi = mid; }
+    if (lo < c->shard_b1) c->next_block = lo;
+}
+
 int dhts_bam_rewind(dhts_ctx *c) {
     if (!c) return -1;
     c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;            // a new pass redoes phase A (nothing is cached across scans)
+    skip_header_blocks(c);
     return 0;
 }
 
-int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out) {
-    if (!c || !out) return -1;
-    memset(out, 0, sizeof(*out));
-    if (!c->bam_open) return fail(c, "dhts_bam_open not called");
-    HIPCHK(c, hipSetDevice(c->device));
-    if (c->stream_done) { out->status = 1; return 0; }
+// ---- one batch of inflated bytes: carry + blocks [b0, b0+nb), shared by the read_bam and read_bcf drivers ---------------
+struct Batch {
+    int64_t b0 = 0, nb = 0; bool in_halo = false, last_of_stream = false, sharded_tail = false, final_batch = false;
+    uint64_t carry = 0, ulen = 0, out_base = 0; uint8_t *u = nullptr; int blk_err = 0;
+};
+static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     if (max_blocks <= 0) max_blocks = 16384;
     if (max_blocks > 24576) max_blocks = 24576;               // keep every in-batch offset below 2^32
-    const bool sharded_tail = (c->shard_b1 < c->n_blocks);     // later shards exist: our last record may need halo blocks
+    B.sharded_tail = (c->shard_b1 < c->n_blocks);              // later shards exist: our last record may need halo blocks
     int64_t b0 = c->next_block;
     int64_t limit = c->shard_b1;
     bool in_halo = b0 >= c->shard_b1;
@@ -526,7 +543,8 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     int64_t nb = limit - b0; if (nb > max_blocks) nb = max_blocks;
     if (in_halo && nb > 4) nb = 4;
     if (nb < 0) nb = 0;
-    const bool last_of_stream = (b0 + nb >= c->n_blocks);
+    B.b0 = b0; B.nb = nb; B.in_halo = in_halo;
+    B.last_of_stream = (b0 + nb >= c->n_blocks);
     const uint64_t carry = c->carry_len;
     const uint64_t inflated = c->h_uoff[b0 + nb] - c->h_uoff[b0];
     uint64_t ulen = carry + inflated;
@@ -551,7 +569,42 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) { blk_err = bs[k]; ulen = carry + (c->h_uoff[b0 + k] - c->h_uoff[b0]); break; }
     }
-    const bool final_batch = last_of_stream || blk_err != 0 || (last_of_stream && c->bgzf_status != 0);
+    B.final_batch = B.last_of_stream || blk_err != 0;
+    B.carry = carry; B.ulen = ulen; B.out_base = out_base; B.u = u; B.blk_err = blk_err;
+    return 0;
+}
+// advance the scan position; *status as documented for dhts_bam_batch.status
+static int batch_end(dhts_ctx *c, const Batch &B, uint64_t carry_start, bool rec_err, bool shard_finished, int32_t *status) {
+    c->first_batch = false;
+    c->next_block = B.b0 + B.nb;
+    if (rec_err || B.blk_err) { c->stream_done = true; *status = B.blk_err ? B.blk_err * 100 : -4; }
+    else if (shard_finished) { c->stream_done = true; *status = 1; }
+    else if (B.last_of_stream) { c->stream_done = true; *status = (c->bgzf_status != 0) ? c->bgzf_status : 1; if (carry_start < B.ulen && *status == 1) *status = -4; }
+    else {
+        // move the incomplete tail to the front of the other buffer
+        uint64_t tail = B.ulen - carry_start;
+        DevBuf &nx = c->ubuf[c->ucur ^ 1];
+        ENSURE(c, nx, tail + PAD_BYTES);
+        if (tail) HIPCHK(c, hipMemcpyAsync(nx.p, B.u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream));
+        c->carry_len = tail; c->ucur ^= 1;
+        if (B.in_halo && tail == 0) { c->stream_done = true; *status = 1; }
+        if (B.b0 + B.nb >= c->shard_b1 && B.sharded_tail && tail == 0) { c->stream_done = true; *status = 1; }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    return 0;
+}
+
+int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out) {
+    if (!c || !out) return -1;
+    memset(out, 0, sizeof(*out));
+    if (!c->bam_open) return fail(c, "dhts_bam_open not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->stream_done) { out->status = 1; return 0; }
+    Batch B;
+    if (batch_begin(c, max_blocks, B)) return -1;
+    const bool sharded_tail = B.sharded_tail, final_batch = B.final_batch;
+    uint8_t *u = B.u; uint64_t ulen = B.ulen; const uint64_t out_base = B.out_base;
     BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0;
 
     // ---- tiles ----
@@ -674,25 +727,289 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         out->first_rec_uoff = f;
     }
     // ---- advance ----
-    c->first_batch = false;
-    c->next_block = b0 + nb;
-    if (rec_err || blk_err) { c->stream_done = true; out->status = blk_err ? blk_err * 100 : -4; }
-    else if (shard_finished) { c->stream_done = true; out->status = 1; }
-    else if (last_of_stream) { c->stream_done = true; out->status = (c->bgzf_status != 0) ? c->bgzf_status : 1; if (carry_start < ulen && out->status == 1) out->status = -4; }
-    else {
-        // move the incomplete tail to the front of the other buffer
-        uint64_t tail = ulen - carry_start;
-        DevBuf &nx = c->ubuf[c->ucur ^ 1];
-        ENSURE(c, nx, tail + PAD_BYTES);
-        if (tail) HIPCHK(c, hipMemcpyAsync(nx.p, u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream));
-        c->carry_len = tail; c->ucur ^= 1;
-        if (b0 + nb >= c->shard_b1 && !sharded_tail) { /* unreachable: last_of_stream handled above */ }
-        if (in_halo && tail == 0) { c->stream_done = true; out->status = 1; }
-        if (b0 + nb >= c->shard_b1 && sharded_tail && tail == 0) { c->stream_done = true; out->status = 1; }
+    return batch_end(c, B, carry_start, rec_err, shard_finished, &out->status);
+}
+
+// ---- read_bcf ---------------------------------------------------------------------------------------
+int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->bcf_open = false;
+    if (c->n_blocks <= 0) return fail(c, "Failed to read BCF/VCF header");
+    int64_t k = c->n_blocks < 4 ? c->n_blocks : 4;
+    std::vector<uint8_t> h; std::vector<int32_t> bs;
+    uint64_t text_end = 0;
+    for (;;) {
+        uint64_t total = c->h_uoff[k];
+        h.assign(total + 16, 0); bs.resize(k);
+        if (dhts_bgzf_inflate_to_host(c, 0, k, h.data(), total, bs.data()) < 0) return -1;
+        uint64_t good = total;
+        for (int64_t b = 0; b < k; b++) if (bs[b] != 0) { good = c->h_uoff[b]; break; }
+        const bool more = (good == total && k < c->n_blocks);
+        if (good < 9) { if (more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; } return fail(c, "Failed to read BCF/VCF header"); }
+        if (memcmp(h.data(), "BCF\2\2", 5) != 0) return fail(c, "Failed to read BCF/VCF header");       // vcf.c:1733-1740
+        const uint64_t l_text = hle32(h.data() + 5);
+        if (9 + l_text > good) { if (more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; } return fail(c, "Failed to read BCF/VCF header"); }
+        text_end = 9 + l_text;
+        std::string text((const char *)h.data() + 9, l_text);      // bcf_hdr_parse works on the NUL-terminated text (vcf.c:1752-1753)
+        std::string perr;
+        if (!dhts::bcf_parse_header(text.c_str(), c->bh, &perr)) return fail(c, "Failed to read BCF/VCF header");
+        break;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    timing_collect(c);
+    if (c->bh.has_vep_tag) return fail(c, "read_bcf: VEP/CSQ annotation columns are not supported by this build");
+    dhts::bcf_build_schema(c->bh, tidy_format != 0, c->bsch);
+    c->bcf_tidy_req = tidy_format != 0;
+    c->first_rec_uoff = text_end;
+    // host-visible dictionaries
+    c->bcf_colinfo.clear(); c->bcf_ctg_p.clear(); c->bcf_dict_p.clear(); c->bcf_smp_p.clear();
+    for (auto &col : c->bsch.cols) {
+        dhts_bcf_colinfo ci; ci.name = col.name.c_str(); ci.type = col.duck_type; ci.is_list = col.is_list ? 1 : 0; ci.reserved = 0;
+        ci.encoding = col.kind == dhts::BK_CHROM ? DHTS_ENC_CONTIG : col.kind == dhts::BK_FILTER ? DHTS_ENC_DICT : col.kind == dhts::BK_SAMPLE_ID ? DHTS_ENC_SAMPLE : DHTS_ENC_PLAIN;
+        c->bcf_colinfo.push_back(ci);
+    }
+    for (size_t i = 0; i < c->bh.ctg.size(); i++) c->bcf_ctg_p.push_back(c->bh.ctg_present[i] ? c->bh.ctg[i].c_str() : nullptr);
+    for (auto &e : c->bh.ids) c->bcf_dict_p.push_back(e.present ? e.key.c_str() : nullptr);
+    for (auto &sm : c->bh.samples) c->bcf_smp_p.push_back(sm.c_str());
+    // device tables
+    const size_t nc = c->bh.ctg.size(), ni = c->bh.ids.size();
+    std::vector<uint8_t> ctg_ok(nc + 1, 0), id_ok(ni + 1, 0); std::vector<int16_t> islot(ni + 1, -1), fslot(ni + 1, -1);
+    if (c->bsch.info_fields.size() > 30000 || c->bsch.format_fields.size() > 30000) return fail(c, "read_bcf: too many INFO/FORMAT fields");
+    for (size_t i = 0; i < nc; i++) ctg_ok[i] = c->bh.ctg_present[i] ? 1 : 0;
+    for (size_t i = 0; i < ni; i++) id_ok[i] = c->bh.ids[i].present ? 1 : 0;
+    for (size_t f = 0; f < c->bsch.info_fields.size(); f++) islot[c->bsch.info_fields[f].id] = (int16_t)f;
+    for (size_t f = 0; f < c->bsch.format_fields.size(); f++) if (c->bsch.format_fields[f].id >= 0) fslot[c->bsch.format_fields[f].id] = (int16_t)f;
+    ENSURE(c, c->d_ctg_ok, nc + 16); ENSURE(c, c->d_id_ok, ni + 16); ENSURE(c, c->d_info_slot, ni * 2 + 16); ENSURE(c, c->d_fmt_slot, ni * 2 + 16);
+    HIPCHK(c, hipMemcpy(c->d_ctg_ok.p, ctg_ok.data(), nc + 1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_id_ok.p, id_ok.data(), ni + 1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_info_slot.p, islot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_fmt_slot.p, fslot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
+    c->bcf_proj.clear();
+    for (size_t i = 0; i < c->bsch.cols.size(); i++) c->bcf_proj.push_back((int32_t)i);
+    c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1;
+    c->bcf_open = true;
+    return dhts_bcf_rewind(c);
+}
+
+int dhts_bcf_info_get(const dhts_ctx *c, dhts_bcf_info *out) {
+    if (!c || !c->bcf_open || !out) return -1;
+    out->n_cols = (int32_t)c->bcf_colinfo.size(); out->cols = c->bcf_colinfo.data();
+    out->n_contigs = (int32_t)c->bcf_ctg_p.size(); out->contig_name = c->bcf_ctg_p.data();
+    out->n_dict = (int32_t)c->bcf_dict_p.size(); out->dict_name = c->bcf_dict_p.data();
+    out->n_samples = (int32_t)c->bcf_smp_p.size(); out->sample_name = c->bcf_smp_p.data();
+    out->tidy = c->bsch.tidy ? 1 : 0; out->first_rec_uoff = c->first_rec_uoff;
     return 0;
+}
+
+int dhts_bcf_set_projection(dhts_ctx *c, const int32_t *col_ids, int32_t n) {
+    if (!c || !c->bcf_open) return -1;
+    std::vector<int32_t> pr;
+    for (int32_t i = 0; i < n; i++) { if (col_ids[i] < 0 || col_ids[i] >= (int32_t)c->bsch.cols.size()) return fail(c, "projection column %d out of range", col_ids[i]); pr.push_back(col_ids[i]); }
+    c->bcf_proj = pr;
+    return 0;
+}
+
+int dhts_bcf_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculative_start) {
+    if (!c || !c->bcf_open) return -1;
+    if (b0 < 0 || b1 > c->n_blocks || b0 > b1) return fail(c, "bad block range");
+    c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = speculative_start ? 1 : 0; c->shard_world = 2;
+    return dhts_bcf_rewind(c);
+}
+
+int dhts_bcf_rewind(dhts_ctx *c) {
+    if (!c) return -1;
+    c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+    c->huff_b0 = c->huff_nb = 0;
+    skip_header_blocks(c);
+    return 0;
+}
+
+static size_t fixed_width(const dhts::BcfColumn &col) {
+    if (col.is_list) return 0;
+    switch (col.kind) {
+    case dhts::BK_CHROM: case dhts::BK_SAMPLE_ID: return 4;
+    case dhts::BK_POS: case dhts::BK_QUAL: return 8;
+    case dhts::BK_ID: case dhts::BK_REF: return 0;
+    default: break;
+    }
+    return col.duck_type == dhts::DT_BOOLEAN ? 1 : col.duck_type == dhts::DT_VARCHAR ? 0 : 4;
+}
+
+int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
+    if (!c || !out) return -1;
+    memset(out, 0, sizeof(*out));
+    if (!c->bcf_open) return fail(c, "dhts_bcf_open not called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ncols = (int)c->bcf_proj.size();
+    c->bcf_out.assign(ncols, dhts_bcf_col());
+    for (int i = 0; i < ncols; i++) { memset(&c->bcf_out[i], 0, sizeof(dhts_bcf_col)); c->bcf_out[i].col = c->bcf_proj[i]; }
+    out->n_cols = ncols; out->cols = c->bcf_out.data();
+    if (c->stream_done) { out->status = 1; return 0; }
+    Batch B;
+    if (batch_begin(c, max_blocks, B)) return -1;
+    uint8_t *u = B.u; uint64_t ulen = B.ulen; const uint64_t out_base = B.out_base;
+    BcfStream st; memset(&st, 0, sizeof(st));
+    st.u = u; st.ulen = ulen; st.n_ctg = (int32_t)c->bh.ctg.size(); st.n_ids = (int32_t)c->bh.ids.size(); st.n_smp = c->bsch.n_samples;
+    st.final_batch = B.final_batch ? 1 : 0; st.n_info_f = (int32_t)c->bsch.info_fields.size(); st.n_fmt_f = (int32_t)c->bsch.format_fields.size();
+    st.ctg_ok = (const uint8_t *)c->d_ctg_ok.p; st.id_ok = (const uint8_t *)c->d_id_ok.p;
+    st.info_slot = (const int16_t *)c->d_info_slot.p; st.fmt_slot = (const int16_t *)c->d_fmt_slot.p;
+
+    // ---- tiles: record chain ----
+    int64_t ntiles = (int64_t)((ulen + TILE_BYTES - 1) / TILE_BYTES); if (ntiles < 1) ntiles = 1;
+    ENSURE(c, c->t_first, ntiles * 8); ENSURE(c, c->t_end, ntiles * 8); ENSURE(c, c->t_count, ntiles * 4); ENSURE(c, c->t_err, ntiles * 4);
+    ENSURE(c, c->t_rowbase, ntiles * 4 + 16); ENSURE(c, c->d_res, 64); ENSURE(c, c->d_nfixed, 64);
+    ENSURE(c, c->t2_first, ntiles * 8); ENSURE(c, c->t2_end, ntiles * 8); ENSURE(c, c->t2_count, ntiles * 4); ENSURE(c, c->t2_err, ntiles * 4);
+    TileOut to; to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
+    TileOut to2; to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
+    uint64_t start0;
+    if (c->first_batch) start0 = (c->shard_rank == 0) ? c->first_rec_uoff - out_base : NONE64;
+    else start0 = 0;
+    if (c->first_batch && c->shard_rank == 0 && c->first_rec_uoff < out_base) return fail(c, "internal: header beyond first batch");
+    uint64_t res[4] = {0, 0, 0, 0};
+    {
+        KTimer tm(c, DHTS_K_TILES);
+        hipLaunchKernelGGL(bcf_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to);
+        int rounds = 0;
+        for (;;) {
+            (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
+            hipLaunchKernelGGL(bcf_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
+            { TileOut tmp = to; to = to2; to2 = tmp; }
+            uint32_t nfixed = 0;
+            HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] bcf tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
+            if (nfixed == 0) break;
+            if (++rounds > 256) { hipLaunchKernelGGL(bcf_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
+        }
+        hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
+    }
+    HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t nrec = (int64_t)res[0]; uint64_t carry_start = res[1]; bool rec_err = res[2] != 0;
+    if (carry_start == NONE64) carry_start = ulen;
+    const uint64_t shard_end_u = B.sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
+    bool shard_finished = false;
+    const int reps = c->bsch.tidy ? c->bsch.n_samples : 1;
+    const int D = 2 + st.n_info_f + st.n_fmt_f;
+    uint32_t rec0_off = 0;
+
+    if (nrec > 0) {
+        const size_t n = (size_t)nrec;
+        const uint32_t stride = (uint32_t)((n + 63) & ~(size_t)63);
+        ENSURE(c, c->b_rec_off, n * 4 + 16); ENSURE(c, c->b_dir, (size_t)D * stride * 4 + 16);
+        hipLaunchKernelGGL(bcf_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (const uint32_t *)c->t_rowbase.p,
+                           (const uint64_t *)c->d_res.p, nrec, (uint32_t *)c->b_rec_off.p);
+        HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));
+        {
+            KTimer tm(c, DHTS_K_BCF_CHECK);
+            hipLaunchKernelGGL(bcf_rec_check, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->b_rec_off.p, nrec, (uint32_t *)c->b_dir.p, stride,
+                               (unsigned long long *)((uint64_t *)c->d_res.p + 4));
+        }
+        unsigned long long bad = ~0ull;
+        HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&rec0_off, c->b_rec_off.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (bad < (unsigned long long)nrec) { nrec = (int64_t)bad; rec_err = true; }    // the first bad record ends the scan (bcf_reader.c:1319-1349)
+        if (nrec > 0 && B.sharded_tail && out_base + ulen > shard_end_u) {
+            std::vector<uint32_t> ro(nrec);
+            HIPCHK(c, hipMemcpyAsync(ro.data(), c->b_rec_off.p, nrec * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const uint64_t lim = shard_end_u - out_base;
+            int64_t lo = 0, hi = nrec;
+            while (lo < hi) { int64_t mid = (lo + hi) / 2; if (ro[mid] < lim) lo = mid + 1; else hi = mid; }
+            if (lo < nrec) { carry_start = ro[lo]; nrec = lo; shard_finished = true; }
+            else if (carry_start >= lim) shard_finished = true;
+        }
+        if (nrec > 0 && ncols > 0) {
+            const int64_t nrows = nrec * reps;
+            const uint32_t ostride = (uint32_t)(((size_t)nrows + 1 + 63) & ~(size_t)63);
+            // column program for this projection
+            std::vector<BcfColDev> cd(ncols);
+            int nsa = 0; size_t fixed_bytes = 0;
+            std::vector<size_t> fixed_at(ncols, 0);
+            for (int i = 0; i < ncols; i++) {
+                const dhts::BcfColumn &col = c->bsch.cols[c->bcf_proj[i]];
+                BcfColDev &d = cd[i]; memset(&d, 0, sizeof(d));
+                d.kind = col.kind; d.is_list = col.is_list ? 1 : 0; d.sample = col.sample; d.slot = col.field < 0 ? 0 : col.field; d.flags = 0; d.sa_cnt = d.sa_bytes = -1;
+                if (col.kind == dhts::BK_INFO) d.htype = c->bsch.info_fields[col.field].htype;
+                if (col.kind == dhts::BK_FORMAT) {
+                    const dhts::BcfField &f = c->bsch.format_fields[col.field];
+                    d.htype = f.htype;
+                    if (f.htype == dhts::BCF_HT_FLAG || f.id < 0) d.flags |= BF_NULL_ALWAYS;          // no getter yields a value for a FORMAT Flag; default GT column (bcf_reader.c:683-692)
+                    if (f.htype == dhts::BCF_HT_STR && f.name == "GT") { d.flags |= BF_GT; if (!c->bsch.gt_string_ok) d.flags |= BF_NULL_ALWAYS; if (c->bh.version < 4004000 && f.id == c->bsch.gt_id) d.flags |= BF_GT_FIX; }
+                    else if (f.htype == dhts::BCF_HT_STR && f.is_list) d.flags |= BF_NULL_ALWAYS;       // LIST(VARCHAR) FORMAT strings: undefined in the reference, NULL here
+                    if (f.name == "GT" && f.htype != dhts::BCF_HT_STR) d.flags |= BF_NULL_ALWAYS;      // getter type check vcf.c:6183-6187
+                }
+                const bool varchar = col.duck_type == dhts::DT_VARCHAR && col.kind != dhts::BK_CHROM && col.kind != dhts::BK_SAMPLE_ID && col.kind != dhts::BK_FILTER;
+                if (col.is_list) { d.sa_cnt = nsa++; if (varchar) d.sa_bytes = nsa++; }
+                else if (varchar) d.sa_bytes = nsa++;
+                const size_t w = fixed_width(col);
+                fixed_at[i] = fixed_bytes; fixed_bytes += (w * (size_t)nrows + 63) & ~(size_t)63;
+            }
+            ENSURE(c, c->b_valid, (size_t)ncols * nrows + 64); ENSURE(c, c->b_fixed, fixed_bytes + 64);
+            ENSURE(c, c->b_lens, (size_t)(nsa ? nsa : 1) * ostride * 4 + 64); ENSURE(c, c->b_offs, (size_t)(nsa ? nsa : 1) * ostride * 4 + 64);
+            ENSURE(c, c->b_coldev, sizeof(BcfColDev) * ncols);
+            for (int i = 0; i < ncols; i++) {
+                cd[i].valid = (uint8_t *)c->b_valid.p + (size_t)i * nrows;
+                cd[i].fixed = fixed_width(c->bsch.cols[c->bcf_proj[i]]) ? (void *)((uint8_t *)c->b_fixed.p + fixed_at[i]) : nullptr;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->b_coldev.p, cd.data(), sizeof(BcfColDev) * ncols, hipMemcpyHostToDevice, c->stream));
+            BcfCellArgs ca; memset(&ca, 0, sizeof(ca));
+            ca.rec_off = (const uint32_t *)c->b_rec_off.p; ca.dir = (const uint32_t *)c->b_dir.p; ca.stride = stride; ca.nrows = nrows; ca.tidy = c->bsch.tidy ? 1 : 0;
+            ca.n_smp = c->bsch.n_samples > 0 ? c->bsch.n_samples : 1; ca.lens = (uint32_t *)c->b_lens.p; ca.offs = (const uint32_t *)c->b_offs.p; ca.ostride = ostride;
+            ca.cols = (const BcfColDev *)c->b_coldev.p;
+            {
+                KTimer tm(c, DHTS_K_BCF_MEASURE);
+                hipLaunchKernelGGL(bcf_cells<false>, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream, st, ca);
+            }
+            std::vector<uint64_t> tot(nsa ? nsa : 1, 0);
+            if (nsa > 0) {
+                MScanArgs ma; ma.in = (const uint32_t *)c->b_lens.p; ma.out = (uint32_t *)c->b_offs.p; ma.stride = ostride; ma.n = nrows;
+                ma.nparts = (nrows + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS; if (ma.nparts < 1) ma.nparts = 1;
+                ENSURE(c, c->b_partial, (size_t)nsa * ma.nparts * 8 + 64); ENSURE(c, c->b_total, (size_t)nsa * 8 + 64);
+                ma.partial = (uint64_t *)c->b_partial.p; ma.total = (uint64_t *)c->b_total.p;
+                {
+                    KTimer tm(c, DHTS_K_SCAN);
+                    hipLaunchKernelGGL(mscan_reduce, dim3((unsigned)ma.nparts, (unsigned)nsa), dim3(256), 0, c->stream, ma);
+                    hipLaunchKernelGGL(mscan_partials, dim3((unsigned)nsa), dim3(1024), 0, c->stream, ma);
+                    hipLaunchKernelGGL(mscan_apply, dim3((unsigned)ma.nparts, (unsigned)nsa), dim3(256), 0, c->stream, ma);
+                }
+                HIPCHK(c, hipMemcpyAsync(tot.data(), c->b_total.p, (size_t)nsa * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                for (int k = 0; k < nsa; k++) if (tot[k] >= (1ull << 32)) return fail(c, "read_bcf: a column exceeds 4 GiB in one batch; use a smaller max_blocks");
+                // arena for children / bytes
+                size_t var_bytes = 0; std::vector<size_t> at_child(ncols, 0), at_coff(ncols, 0), at_bytes(ncols, 0);
+                for (int i = 0; i < ncols; i++) {
+                    if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes < 0) { at_child[i] = var_bytes; var_bytes += (tot[cd[i].sa_cnt] * 4 + 63) & ~(size_t)63; }
+                    if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes >= 0) { at_coff[i] = var_bytes; var_bytes += ((tot[cd[i].sa_cnt] + 1) * 4 + 63) & ~(size_t)63; }
+                    if (cd[i].sa_bytes >= 0) { at_bytes[i] = var_bytes; var_bytes += (tot[cd[i].sa_bytes] + 63) & ~(size_t)63; }
+                }
+                ENSURE(c, c->b_var, var_bytes + 64);
+                for (int i = 0; i < ncols; i++) {
+                    uint8_t *base = (uint8_t *)c->b_var.p;
+                    if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes < 0) cd[i].child_fixed = (uint32_t *)(base + at_child[i]);
+                    if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes >= 0) cd[i].child_off = (uint32_t *)(base + at_coff[i]);
+                    if (cd[i].sa_bytes >= 0) cd[i].bytes = base + at_bytes[i];
+                }
+                HIPCHK(c, hipMemcpyAsync(c->b_coldev.p, cd.data(), sizeof(BcfColDev) * ncols, hipMemcpyHostToDevice, c->stream));
+                {
+                    KTimer tm(c, DHTS_K_BCF_WRITE);
+                    hipLaunchKernelGGL(bcf_cells<true>, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream, st, ca);
+                }
+            }
+            HIPCHK(c, hipGetLastError());
+            for (int i = 0; i < ncols; i++) {
+                dhts_bcf_col &o = c->bcf_out[i];
+                o.valid = cd[i].valid; o.fixed = cd[i].fixed;
+                if (cd[i].sa_cnt >= 0) { o.off = (const uint32_t *)c->b_offs.p + (size_t)cd[i].sa_cnt * ostride; o.child_n = tot[cd[i].sa_cnt]; o.child_fixed = cd[i].child_fixed; o.child_off = cd[i].child_off; }
+                else if (cd[i].sa_bytes >= 0) o.off = (const uint32_t *)c->b_offs.p + (size_t)cd[i].sa_bytes * ostride;
+                if (cd[i].sa_bytes >= 0) { o.bytes = cd[i].bytes; o.nbytes = tot[cd[i].sa_bytes]; }
+            }
+        }
+    }
+    out->n_rows = nrec * reps;
+    out->end_uoff = out_base + carry_start;
+    out->first_rec_uoff = nrec > 0 ? out_base + rec0_off : NONE64;
+    return batch_end(c, B, carry_start, rec_err, shard_finished, &out->status);
 }
 
 #ifdef DHTS_DIAG

@@ -88,7 +88,8 @@ typedef struct {
 } dhts_bam_header;
 
 /* kernel ids for dhts_kernel_time */
-enum { DHTS_K_SIGSCAN = 0, DHTS_K_HUFF, DHTS_K_LZ, DHTS_K_TILES, DHTS_K_CORE, DHTS_K_SCAN, DHTS_K_STRINGS, DHTS_K_COUNT };
+enum { DHTS_K_SIGSCAN = 0, DHTS_K_HUFF, DHTS_K_LZ, DHTS_K_TILES, DHTS_K_CORE, DHTS_K_SCAN, DHTS_K_STRINGS,
+       DHTS_K_BCF_CHECK, DHTS_K_BCF_MEASURE, DHTS_K_BCF_WRITE, DHTS_K_COUNT };
 
 int dhts_abi_version(void);
 int dhts_device_count(void);                       /* number of visible HIP devices (0 => nothing will work) */
@@ -118,6 +119,69 @@ int dhts_bam_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative
 int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, int rank, int world, int64_t *b0, int64_t *b1);
 int dhts_bam_rewind(dhts_ctx *);
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
+
+/* ---- read_bcf ------------------------------------------------------------------------------
+ *   dhts_bcf_open                   <- bcf_hdr_read -> bcf_hdr_parse      htslib/vcf.c:1710-1769, 1410-1489, 831-1024
+ *                                      + schema construction              src/bcf_reader.c:540-760, src/include/vcf_types.h
+ *   dhts_bcf_next_batch             <- the loop body of bcf_read_function src/bcf_reader.c:1155-2049 over bcf_read
+ *                                      vcf.c:2255-2265 (bcf_read1_core 1874-1911, bcf_record_check 2040-2212),
+ *                                      bcf_unpack 4234-4302 and the bcf_get_info_* / bcf_get_format_* getters 6056-6248
+ * Sequential (no index) mode; VEP_* columns are not produced: dhts_bcf_open fails on headers that would add them. */
+
+/* element types of a read_bcf column (values of DUCKDB_TYPE_* in duckdb.h) */
+enum { DHTS_T_BOOLEAN = 1, DHTS_T_INTEGER = 4, DHTS_T_BIGINT = 5, DHTS_T_FLOAT = 10, DHTS_T_DOUBLE = 11, DHTS_T_VARCHAR = 17 };
+/* how a column's payload is coded on the device */
+enum { DHTS_ENC_PLAIN = 0,      /* payload is the value itself                                              */
+       DHTS_ENC_CONTIG = 1,     /* int32 contig id   -> dhts_bcf_info.contig_name[id]   (CHROM)               */
+       DHTS_ENC_DICT = 2,       /* int32 dictionary id -> dhts_bcf_info.dict_name[id], -1 = "PASS" (FILTER)    */
+       DHTS_ENC_SAMPLE = 3 };   /* int32 sample index -> dhts_bcf_info.sample_name[i]   (SAMPLE_ID)           */
+
+typedef struct {
+    const char *name;        /* result column name, as duckdb_bind_add_result_column receives it           */
+    int32_t type;            /* DHTS_T_* of the element                                                     */
+    int32_t is_list;         /* LIST(type)                                                                  */
+    int32_t encoding;        /* DHTS_ENC_*                                                                  */
+    int32_t reserved;
+} dhts_bcf_colinfo;
+
+typedef struct {
+    int32_t n_cols; const dhts_bcf_colinfo *cols;
+    int32_t n_contigs; const char *const *contig_name;      /* NULL entries = holes left by IDX= numbering    */
+    int32_t n_dict; const char *const *dict_name;           /* FILTER/INFO/FORMAT dictionary (BCF_DT_ID)      */
+    int32_t n_samples; const char *const *sample_name;
+    int32_t tidy;                                           /* rows are (record, sample) pairs                 */
+    uint64_t first_rec_uoff;                                /* inflated offset of the first record             */
+} dhts_bcf_info;
+
+/* One projected column of a batch; DEVICE pointers, valid until the next call on the context.
+ * scalar fixed-width : fixed[n_rows] in the native width of `type` (BOOLEAN 1 byte, INTEGER/FLOAT/ids 4, BIGINT/DOUBLE 8)
+ * scalar VARCHAR     : off[n_rows+1] byte offsets into bytes
+ * LIST               : off[n_rows+1] child offsets; children in child_fixed[child_n] (4-byte words) or, for
+ *                      LIST(VARCHAR) in plain encoding, child_off[child_n+1] byte offsets into bytes                   */
+typedef struct {
+    int32_t col;             /* schema column id                                                            */
+    int32_t reserved;
+    const uint8_t *valid;    /* n_rows bytes, 1 = valid                                                     */
+    const void *fixed;
+    const uint32_t *off;
+    const uint8_t *bytes; uint64_t nbytes;
+    const uint32_t *child_fixed; const uint32_t *child_off; uint64_t child_n;
+} dhts_bcf_col;
+
+typedef struct {
+    int64_t n_rows;
+    int32_t status;          /* same convention as dhts_bam_batch.status                                    */
+    int32_t n_cols;          /* projected columns, in projection order                                      */
+    const dhts_bcf_col *cols;/* host array of n_cols descriptors (device pointers inside)                   */
+    uint64_t first_rec_uoff, end_uoff;
+} dhts_bcf_batch;
+
+int dhts_bcf_open(dhts_ctx *, int tidy_format);                      /* header + dictionaries + schema; positions the scan at the first record */
+int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
+int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /* default: every schema column */
+int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);
+int dhts_bcf_rewind(dhts_ctx *);
+int dhts_bcf_next_batch(dhts_ctx *, int64_t max_blocks, dhts_bcf_batch *out);
 
 /* ---- utilities ------------------------------------------------------------------------------ */
 int dhts_memcpy_d2h(dhts_ctx *, void *dst, const void *src_dev, uint64_t n);

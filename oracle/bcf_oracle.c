@@ -535,6 +535,7 @@ static void emit_format(scan_t *s, col_t *c, const field_t *f, const ent_t *e, i
     /* Parity domain: a record whose n_sample is smaller than the header's makes the reference read past the vector
      * (the getters iterate bcf_hdr_nsamples, vcf.c:6215); here such cells are NULL. */
     if (e && smp >= e->ns) e = NULL;
+    if ((f->htype == HT_INT || f->htype == HT_REAL) && !strcmp(f->name, "GT")) { col_null(c); return; }   /* tag "GT" must be declared String: vcf.c:6183-6187 returns -2 */
     if (f->htype == HT_INT || f->htype == HT_REAL) {
         /* bcf_get_format_values: >0 values only when present with n > 0; stored CHAR/NULL make htslib exit(1): out of domain */
         if (!e || e->n <= 0 || !(e->type == 1 || e->type == 2 || e->type == 3 || e->type == 5)) { col_null(c); return; }

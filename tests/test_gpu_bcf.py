@@ -1,0 +1,95 @@
+"""GPU parity tests for read_bcf: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import bcf_cases
+import orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gold(name):
+    with open(os.path.join(GOLD, name), "rb") as f:
+        return f.read()
+
+
+def _check(data, tidy=False, **kw):
+    import duckhts_amd
+    exp = orc.bcf_read(data, tidy)
+    got = duckhts_amd.read_bcf(data, tidy=tidy, **kw)
+    d = orc.bcf_cols_diff(exp, got)
+    assert d is None, d
+    assert (got["status"] == 1) == (exp["status"] == 0), (got["status"], exp["status"])
+    return exp, got
+
+
+def test_golden_vcf_file_bcf():
+    exp, got = _check(_gold("vcf_file.bcf"))
+    assert got["n_rows"] == 15 and len(got["cols"]) == 23
+    col = {c["name"]: orc.bcf_col_py(c) for c in got["cols"]}
+    assert (col["CHROM"][0], col["POS"][0], col["FORMAT_GT_A"][0], col["FORMAT_GQ_A"][0]) == (b"1", 3000150, b"0/1", 245)   # duckhts.test:28-62
+    assert col["INFO_TEST"][3] == 5 and col["FILTER"][2] == [b"q10"]
+
+
+def test_golden_tidy():
+    exp, got = _check(_gold("vcf_file.bcf"), tidy=True)
+    assert got["n_rows"] == 30
+
+
+@pytest.mark.parametrize("name,data,tidy", bcf_cases.all_cases(), ids=[c[0] for c in bcf_cases.all_cases()])
+def test_cases(name, data, tidy):
+    _check(data, tidy)
+
+
+@pytest.mark.parametrize("mb", [1, 2, 3])
+def test_small_batches_carry(mb):
+    cases = {n: (d, t) for n, d, t in bcf_cases.all_cases()}
+    for name in ("fuzz_small_blocks", "fuzz_tidy", "long_record", "bad_info_key", "truncated_mid_record", "basic"):
+        d, t = cases[name]
+        _check(d, t, max_blocks=mb)
+
+
+def test_header_errors():
+    import duckhts_amd
+    for name, data in bcf_cases.header_error_cases():
+        with pytest.raises(duckhts_amd.DhtsError) as e:
+            duckhts_amd.read_bcf(data)
+        if name != "not_bgzf":
+            assert "Failed to read BCF/VCF header" in str(e.value), (name, str(e.value))
+
+
+def test_projection_subsets():
+    import duckhts_amd
+    data = dict((n, d) for n, d, _ in bcf_cases.all_cases())["fuzz_small_blocks"]
+    exp = orc.bcf_read(data)
+    for proj in (["CHROM"], ["POS", "QUAL"], ["FORMAT_GT_S2", "INFO_TAGS", "ALT"], ["FILTER", "ID", "FORMAT_PL_S3", "INFO_DB", "REF"]):
+        got = duckhts_amd.read_bcf(data, columns=proj)
+        sub = {"n_rows": exp["n_rows"], "cols": [exp["by_name"][p] for p in proj]}
+        d = orc.bcf_cols_diff(sub, got)
+        assert d is None, (proj, d)
+
+
+def test_sharded_block_ranges_concatenate():
+    """BGZF block-range shards (speculative first record, halo for the last) reproduce the sequential scan."""
+    import duckhts_amd
+    data = dict((n, d) for n, d, _ in bcf_cases.all_cases())["fuzz_small_blocks"]
+    exp = orc.bcf_read(data)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(data)
+    nb = ctx.bgzf_index()
+    ctx.close()
+    cuts = [0, nb // 3, (2 * nb) // 3, nb]
+    spans, rows = [], 0
+    parts = []
+    for r in range(3):
+        got = duckhts_amd.read_bcf(data, block_range=(cuts[r], cuts[r + 1], r > 0))
+        spans.append((got["first_rec_uoff"], got["end_uoff"], got["n_rows"]))
+        parts.append(got)
+    assert duckhts_amd.check_handoff(spans) == exp["n_rows"]
+    pos = np.concatenate([p["by_name"]["POS"]["fixed"] for p in parts])
+    assert np.array_equal(pos, exp["by_name"]["POS"]["fixed"])
+    gq = np.concatenate([p["by_name"]["FORMAT_GQ_S1"]["fixed"] for p in parts])
+    assert np.array_equal(gq, exp["by_name"]["FORMAT_GQ_S1"]["fixed"])
