@@ -256,6 +256,240 @@ static void register_read_bam_function(duckdb_connection connection) {          
     API(void, duckdb_destroy_table_function, duckdb_table_function *)(&tf);
 }
 
+
+// =====================================================================================================================
+// read_bcf -- mirrors register_read_bcf_function src/bcf_reader.c:2055-2080, bcf_read_bind 452-880 (schema 540-760),
+// global/local init 886-1150 (projection ids, region error), bcf_read_function 1155-2049 (<= vector_size rows per call).
+// Sequential mode; tidy_format supported; region / VCF text / VEP columns are rejected with explicit messages.
+// =====================================================================================================================
+struct BcfBind {
+    std::string path, region;
+    dhts_ctx *ctx = nullptr;
+    dhts_bcf_info inf;
+    int has_index = 0;
+};
+struct HostCol {
+    int col = 0;
+    std::vector<uint8_t> valid, fixed, bytes;
+    std::vector<uint32_t> off, child_off, child_fixed;
+    uint64_t child_n = 0;
+};
+struct BcfLocal {
+    std::vector<idx_t> column_ids;       // schema ids per output vector
+    std::vector<int> slot;               // output vector -> index into `cols` (or -1 for unknown ids)
+    std::vector<HostCol> cols;           // projected (deduplicated) columns of the current batch
+    bool done = false; int64_t n = 0, cur = 0; int status = 0;
+};
+static void destroy_bcf_bind(void *p) { BcfBind *b = (BcfBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
+static void destroy_bcf_local(void *p) { delete (BcfLocal *)p; }
+
+static void bcf_read_bind(duckdb_bind_info info) {
+    auto set_error = API(void, duckdb_bind_set_error, duckdb_bind_info, const char *);
+    auto dfree = API(void, duckdb_free, void *);
+    duckdb_value pv = API(duckdb_value, duckdb_bind_get_parameter, duckdb_bind_info, idx_t)(info, 0);
+    char *file_path = API(char *, duckdb_get_varchar, duckdb_value)(pv);
+    API(void, duckdb_destroy_value, duckdb_value *)(&pv);
+    if (!file_path || strlen(file_path) == 0) {
+        set_error(info, "read_bcf requires a file path");                          // bcf_reader.c:461
+        if (file_path) dfree(file_path);
+        return;
+    }
+    char *region = get_named_varchar(info, "region");
+    char *index_path = get_named_varchar(info, "index_path");
+    const int tidy = get_named_bool(info, "tidy_format");
+    BcfBind *b = new BcfBind();
+    b->path = file_path; if (region) b->region = region;
+    std::string idx = index_path ? index_path : "";
+    dfree(file_path); if (region) dfree(region); if (index_path) dfree(index_path);
+    char err[768];
+    if (!file_exists(b->path)) {
+        snprintf(err, sizeof(err), "Failed to open BCF/VCF file: %s", b->path.c_str());       // bcf_reader.c:494
+        set_error(info, err); delete b; return;
+    }
+    int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
+    b->ctx = dhts_create(dev);
+    if (!b->ctx) { set_error(info, "read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); delete b; return; }
+    if (dhts_open_path(b->ctx, b->path.c_str()) != 0) {
+        snprintf(err, sizeof(err), "Failed to open BCF/VCF file: %s", b->path.c_str());
+        set_error(info, err); delete b; return;
+    }
+    if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bcf_open(b->ctx, tidy) != 0 || dhts_bcf_info_get(b->ctx, &b->inf) != 0) {
+        const char *m = dhts_error(b->ctx);
+        set_error(info, (m && strstr(m, "VEP")) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505
+        delete b; return;
+    }
+    b->has_index = (!idx.empty() && file_exists(idx)) || file_exists(b->path + ".csi") || file_exists(b->path + ".tbi");
+    auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
+    auto mklist = API(duckdb_logical_type, duckdb_create_list_type, duckdb_logical_type);
+    auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);
+    auto rm = API(void, duckdb_destroy_logical_type, duckdb_logical_type *);
+    for (int i = 0; i < b->inf.n_cols; i++) {                                               // create_bcf_field_type bcf_reader.c:388-418
+        const dhts_bcf_colinfo &ci = b->inf.cols[i];
+        duckdb_logical_type el = mk(ci.type);
+        if (ci.is_list) { duckdb_logical_type lt = mklist(el); add(info, ci.name, lt); rm(&lt); }
+        else add(info, ci.name, el);
+        rm(&el);
+    }
+    API(void, duckdb_bind_set_bind_data, duckdb_bind_info, void *, duckdb_delete_callback_t)(info, b, destroy_bcf_bind);
+}
+
+static void bcf_read_global_init(duckdb_init_info info) {
+    BcfBind *bind = (BcfBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
+    if (!bind->region.empty()) {
+        char err[900];
+        if (!bind->has_index) snprintf(err, sizeof(err), "Region query requires an index file (.tbi or .csi). Region: %s", bind->region.c_str());   // bcf_reader.c:922-923
+        else snprintf(err, sizeof(err), "read_bcf: region queries are not on the MI355X scan path yet. Region: %s", bind->region.c_str());
+        API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, err);
+        return;
+    }
+    API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, 1);
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, calloc(1, 16), destroy_global);
+}
+
+static void bcf_read_local_init(duckdb_init_info info) {
+    BcfBind *bind = (BcfBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
+    BcfLocal *l = new BcfLocal();
+    idx_t n = API(idx_t, duckdb_init_get_column_count, duckdb_init_info)(info);
+    std::vector<int32_t> proj;
+    for (idx_t i = 0; i < n; i++) {
+        idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
+        l->column_ids.push_back(id);
+        int sl = -1;
+        if (id < (idx_t)bind->inf.n_cols) {
+            for (size_t k = 0; k < proj.size(); k++) if (proj[k] == (int32_t)id) sl = (int)k;
+            if (sl < 0) { sl = (int)proj.size(); proj.push_back((int32_t)id); }
+        }
+        l->slot.push_back(sl);
+    }
+    l->cols.resize(proj.size());
+    if (dhts_bcf_set_projection(bind->ctx, proj.data(), (int32_t)proj.size()) != 0 || dhts_bcf_rewind(bind->ctx) != 0) {
+        API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, "Failed to open BCF/VCF file"); delete l; return;
+    }
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, l, destroy_bcf_local);
+}
+
+static size_t bcf_fixed_width(const dhts_bcf_colinfo &ci) {
+    if (ci.is_list) return 0;
+    if (ci.encoding != DHTS_ENC_PLAIN) return 4;
+    switch (ci.type) { case DHTS_T_BOOLEAN: return 1; case DHTS_T_INTEGER: case DHTS_T_FLOAT: return 4; case DHTS_T_BIGINT: case DHTS_T_DOUBLE: return 8; default: return 0; }
+}
+
+static int bcf_next_host_batch(BcfBind *bind, BcfLocal *l) {
+    dhts_bcf_batch b;
+    for (;;) {
+        if (dhts_bcf_next_batch(bind->ctx, 0, &b) != 0) return -1;
+        l->status = b.status;
+        if (b.n_rows > 0 || b.status != 0) break;
+    }
+    const int64_t n = b.n_rows; l->n = n; l->cur = 0;
+    if (n == 0) return 0;
+    dhts_ctx *c = bind->ctx;
+    for (int i = 0; i < b.n_cols; i++) {
+        const dhts_bcf_col &d = b.cols[i]; HostCol &h = l->cols[i]; h.col = d.col;
+        const dhts_bcf_colinfo &ci = bind->inf.cols[d.col];
+        h.valid.resize(n); if (dhts_memcpy_d2h(c, h.valid.data(), d.valid, n)) return -1;
+        const size_t w = bcf_fixed_width(ci);
+        if (w) { h.fixed.resize(w * n); if (dhts_memcpy_d2h(c, h.fixed.data(), d.fixed, w * n)) return -1; }
+        if (d.off) { h.off.resize(n + 1); if (dhts_memcpy_d2h(c, h.off.data(), d.off, (n + 1) * 4)) return -1; }
+        if (d.bytes) { h.bytes.resize(d.nbytes + 1); if (dhts_memcpy_d2h(c, h.bytes.data(), d.bytes, d.nbytes)) return -1; }
+        h.child_n = d.child_n;
+        if (d.child_fixed) { h.child_fixed.resize(d.child_n + 1); if (dhts_memcpy_d2h(c, h.child_fixed.data(), d.child_fixed, d.child_n * 4)) return -1; }
+        if (d.child_off) { h.child_off.resize(d.child_n + 1); if (dhts_memcpy_d2h(c, h.child_off.data(), d.child_off, (d.child_n + 1) * 4)) return -1; }
+    }
+    return 0;
+}
+
+static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk output) {
+    BcfBind *bind = (BcfBind *)API(void *, duckdb_function_get_bind_data, duckdb_function_info)(info);
+    BcfLocal *l = (BcfLocal *)API(void *, duckdb_function_get_local_init_data, duckdb_function_info)(info);
+    auto set_size = API(void, duckdb_data_chunk_set_size, duckdb_data_chunk, idx_t);
+    if (!l || l->done) { set_size(output, 0); return; }                                       // bcf_reader.c:1166-1169
+    const idx_t vector_size = API(idx_t, duckdb_vector_size, void)();
+    auto get_vec = API(duckdb_vector, duckdb_data_chunk_get_vector, duckdb_data_chunk, idx_t);
+    auto get_data = API(void *, duckdb_vector_get_data, duckdb_vector);
+    auto assign_len = API(void, duckdb_vector_assign_string_element_len, duckdb_vector, idx_t, const char *, idx_t);
+    auto list_size = API(idx_t, duckdb_list_vector_get_size, duckdb_vector);
+    auto list_reserve = API(duckdb_state, duckdb_list_vector_reserve, duckdb_vector, idx_t);
+    auto list_set_size = API(duckdb_state, duckdb_list_vector_set_size, duckdb_vector, idx_t);
+    auto list_child = API(duckdb_vector, duckdb_list_vector_get_child, duckdb_vector);
+    idx_t row_count = 0;
+    while (row_count < vector_size) {
+        if (l->cur >= l->n) {
+            if (l->status != 0) { l->done = true; break; }           // EOF, or silent stop at the first bad record (bcf_reader.c:1319-1349)
+            if (bcf_next_host_batch(bind, l) != 0) {
+                API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, dhts_error(bind->ctx));
+                l->done = true; set_size(output, 0); return;
+            }
+            if (l->n == 0) { l->done = true; break; }
+        }
+        idx_t take = (idx_t)(l->n - l->cur); if (take > vector_size - row_count) take = vector_size - row_count;
+        const int64_t s = l->cur;
+        for (size_t ci = 0; ci < l->column_ids.size(); ci++) {
+            if (l->slot[ci] < 0) continue;                          // ids outside the schema write nothing
+            const HostCol &h = l->cols[l->slot[ci]];
+            const dhts_bcf_colinfo &inf = bind->inf.cols[h.col];
+            duckdb_vector vec = get_vec(output, ci);
+            const char *const *names = inf.encoding == DHTS_ENC_CONTIG ? bind->inf.contig_name : inf.encoding == DHTS_ENC_DICT ? bind->inf.dict_name :
+                                       inf.encoding == DHTS_ENC_SAMPLE ? bind->inf.sample_name : nullptr;
+            auto name_of = [&](int32_t id) -> const char * { if (id < 0) return "PASS"; const char *nm = names[id]; return nm ? nm : "."; };
+            if (!inf.is_list) {
+                const size_t w = bcf_fixed_width(inf);
+                if (names) {
+                    for (idx_t r = 0; r < take; r++) { const char *nm = name_of(((const int32_t *)h.fixed.data())[s + r]); assign_len(vec, row_count + r, nm, strlen(nm)); }
+                } else if (w) {
+                    memcpy((uint8_t *)get_data(vec) + row_count * w, h.fixed.data() + (size_t)s * w, take * w);
+                    for (idx_t r = 0; r < take; r++) if (!h.valid[s + r]) set_null(vec, row_count + r);
+                } else {
+                    for (idx_t r = 0; r < take; r++) {
+                        if (h.valid[s + r]) assign_len(vec, row_count + r, (const char *)h.bytes.data() + h.off[s + r], h.off[s + r + 1] - h.off[s + r]);
+                        else set_null(vec, row_count + r);
+                    }
+                }
+                continue;
+            }
+            // LIST: entries {offset = current child size, length}; children appended in row order (bcf_reader.c:1403-1424, 1436-1461, 1584-1610)
+            duckdb_list_entry *le = (duckdb_list_entry *)get_data(vec);
+            idx_t base = list_size(vec);
+            const uint32_t c0 = h.off[s], c1 = h.off[s + take];
+            if (c1 > c0) { list_reserve(vec, base + (c1 - c0)); list_set_size(vec, base + (c1 - c0)); }
+            duckdb_vector child = list_child(vec);
+            for (idx_t r = 0; r < take; r++) {
+                le[row_count + r].offset = base + (h.off[s + r] - c0); le[row_count + r].length = h.off[s + r + 1] - h.off[s + r];
+                if (!h.valid[s + r]) set_null(vec, row_count + r);
+            }
+            if (c1 > c0) {
+                if (names) for (uint32_t k = c0; k < c1; k++) { const char *nm = name_of((int32_t)h.child_fixed[k]); assign_len(child, base + (k - c0), nm, strlen(nm)); }
+                else if (inf.type == DHTS_T_VARCHAR) for (uint32_t k = c0; k < c1; k++) assign_len(child, base + (k - c0), (const char *)h.bytes.data() + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
+                else memcpy((uint32_t *)get_data(child) + base, h.child_fixed.data() + c0, (size_t)(c1 - c0) * 4);
+            }
+        }
+        row_count += take; l->cur += (int64_t)take;
+    }
+    set_size(output, row_count);
+}
+
+static void register_read_bcf_function(duckdb_connection connection) {                       // bcf_reader.c:2055-2080
+    duckdb_table_function tf = API(duckdb_table_function, duckdb_create_table_function, void)();
+    API(void, duckdb_table_function_set_name, duckdb_table_function, const char *)(tf, "read_bcf");
+    auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
+    auto rm = API(void, duckdb_destroy_logical_type, duckdb_logical_type *);
+    auto named = API(void, duckdb_table_function_add_named_parameter, duckdb_table_function, const char *, duckdb_logical_type);
+    duckdb_logical_type t_varchar = mk(DUCKDB_TYPE_VARCHAR);
+    API(void, duckdb_table_function_add_parameter, duckdb_table_function, duckdb_logical_type)(tf, t_varchar);
+    named(tf, "region", t_varchar); named(tf, "index_path", t_varchar);
+    rm(&t_varchar);
+    duckdb_logical_type t_bool = mk(DUCKDB_TYPE_BOOLEAN);
+    named(tf, "tidy_format", t_bool);
+    rm(&t_bool);
+    API(void, duckdb_table_function_set_bind, duckdb_table_function, duckdb_table_function_bind_t)(tf, bcf_read_bind);
+    API(void, duckdb_table_function_set_init, duckdb_table_function, duckdb_table_function_init_t)(tf, bcf_read_global_init);
+    API(void, duckdb_table_function_set_local_init, duckdb_table_function, duckdb_table_function_init_t)(tf, bcf_read_local_init);
+    API(void, duckdb_table_function_set_function, duckdb_table_function, duckdb_table_function_t)(tf, bcf_read_function);
+    API(void, duckdb_table_function_supports_projection_pushdown, duckdb_table_function, bool)(tf, true);
+    API(duckdb_state, duckdb_register_table_function, duckdb_connection, duckdb_table_function)(connection, tf);
+    API(void, duckdb_destroy_table_function, duckdb_table_function *)(&tf);
+}
+
 extern "C" __attribute__((visibility("default"))) bool duckhts_init_c_api(duckdb_extension_info info, struct duckdb_extension_access *access) {
     // duckdb_extension.h:1151-1158,1182-1194: fetch the API table, connect, register, disconnect
     const void *api = access->get_api(info, DUCKHTS_API_VERSION);
@@ -267,6 +501,7 @@ extern "C" __attribute__((visibility("default"))) bool duckhts_init_c_api(duckdb
         access->set_error(info, "Failed to open connection to database");
         return false;
     }
+    register_read_bcf_function(conn);                     // registration order of src/duckhts.c:54-71
     register_read_bam_function(conn);
     API(void, duckdb_disconnect, duckdb_connection *)(&conn);
     return true;

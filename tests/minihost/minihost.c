@@ -6,7 +6,8 @@
  * chunk) for one call and serialises every DataChunk canonically (SURVEY.md 8(c) "Parity definition"):
  *   per chunk: u64 n_rows; per projected column: u32 type id, validity words (NULL pointer = all ones, tail bits
  *   masked), then the payload: fixed width = n x width bytes (invalid rows zeroed); VARCHAR = per row u32 len
- *   (0xFFFFFFFF for NULL) + bytes.
+ *   (0xFFFFFFFF for NULL) + bytes; LIST = n x (u64 offset, u64 length) exactly as written, u64 child size, u32 child type,
+ *   then the child payload in the scalar encoding (child validity is not used by the readers: children are always valid).
  * usage: minihost <ext.so> <function> <path> [-n name=value]... [-p 0,3,5] [-o out.bin]
  */
 #include <dlfcn.h>
@@ -22,15 +23,15 @@
 
 typedef struct LType { int id; struct LType *child; } LType;
 typedef struct Value { int is_null; int is_bool; int b; char *s; } Value;
-typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap; } Vec;
+typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap; int child_type; struct Vec *child; idx_t list_size, list_cap; } Vec;
 typedef struct Chunk { Vec *vecs; size_t ncol; idx_t size; } Chunk;
 typedef struct TF {
     char name[64]; duckdb_table_function_bind_t bind; duckdb_table_function_init_t init, local_init; duckdb_table_function_t func;
     char named[16][32]; int named_type[16]; int n_named; int pushdown;
 } TF;
-typedef struct Bind { TF *tf; const char *path; char names[16][32]; char vals[16][512]; int n_named; char colname[256][64]; int coltype[256]; int ncol;
+typedef struct Bind { TF *tf; const char *path; char names[16][32]; char vals[16][512]; int n_named; char colname[1024][256]; int coltype[1024]; int colchild[1024]; int ncol;
                       void *bind_data; duckdb_delete_callback_t bind_del; char err[1024]; int has_err; } Bind;
-typedef struct Init { Bind *b; idx_t proj[256]; idx_t nproj; void *data; duckdb_delete_callback_t del; idx_t max_threads; char err[1024]; int has_err; } Init;
+typedef struct Init { Bind *b; idx_t proj[1024]; idx_t nproj; void *data; duckdb_delete_callback_t del; idx_t max_threads; char err[1024]; int has_err; } Init;
 typedef struct Func { Bind *b; Init *g, *l; char err[1024]; int has_err; } Func;
 
 static TF g_tfs[8]; static int g_ntf = 0;
@@ -42,9 +43,9 @@ static idx_t h_vector_size(void) { return VSIZE; }
 static duckdb_state h_connect(duckdb_database db, duckdb_connection *out) { (void)db; *out = (void *)0x1; return DuckDBSuccess; }
 static void h_disconnect(duckdb_connection *c) { *c = NULL; }
 static duckdb_logical_type h_create_logical_type(int id) { LType *t = calloc(1, sizeof(LType)); t->id = id; return t; }
-static duckdb_logical_type h_create_list_type(duckdb_logical_type c) { LType *t = calloc(1, sizeof(LType)); t->id = DUCKDB_TYPE_LIST; t->child = c; return t; }
+static duckdb_logical_type h_create_list_type(duckdb_logical_type c) { LType *t = calloc(1, sizeof(LType)); t->id = DUCKDB_TYPE_LIST; t->child = calloc(1, sizeof(LType)); t->child->id = ((LType *)c)->id; return t; }
 static duckdb_logical_type h_create_map_type(duckdb_logical_type k, duckdb_logical_type v) { (void)k; (void)v; LType *t = calloc(1, sizeof(LType)); t->id = DUCKDB_TYPE_MAP; return t; }
-static void h_destroy_logical_type(duckdb_logical_type *t) { if (t && *t) { free(*t); *t = NULL; } }
+static void h_destroy_logical_type(duckdb_logical_type *t) { if (t && *t) { free(((LType *)*t)->child); free(*t); *t = NULL; } }
 static char *h_get_varchar(duckdb_value v) { Value *x = v; if (!x || !x->s) return NULL; char *r = malloc(strlen(x->s) + 1); strcpy(r, x->s); return r; }
 static bool h_get_bool(duckdb_value v) { Value *x = v; return x && x->b; }
 static bool h_is_null_value(duckdb_value v) { Value *x = v; return !x || x->is_null; }
@@ -70,7 +71,8 @@ static duckdb_value h_bind_get_named(duckdb_bind_info i, const char *name) {
         Value *v = calloc(1, sizeof(Value)); v->s = strdup(b->vals[k]); v->b = (!strcmp(b->vals[k], "true") || !strcmp(b->vals[k], "1")); return v; }
     return NULL;                                   /* unset named parameter */
 }
-static void h_bind_add_result_column(duckdb_bind_info i, const char *n, duckdb_logical_type t) { Bind *b = i; snprintf(b->colname[b->ncol], 64, "%s", n); b->coltype[b->ncol++] = ((LType *)t)->id; }
+static void h_bind_add_result_column(duckdb_bind_info i, const char *n, duckdb_logical_type t) {
+    Bind *b = i; LType *lt = t; snprintf(b->colname[b->ncol], 256, "%s", n); b->colchild[b->ncol] = lt->child ? lt->child->id : 0; b->coltype[b->ncol++] = lt->id; }
 static void h_bind_set_bind_data(duckdb_bind_info i, void *d, duckdb_delete_callback_t del) { Bind *b = i; b->bind_data = d; b->bind_del = del; }
 static void h_bind_set_error(duckdb_bind_info i, const char *e) { Bind *b = i; snprintf(b->err, sizeof(b->err), "%s", e); b->has_err = 1; }
 static void *h_init_get_bind_data(duckdb_init_info i) { return ((Init *)i)->b->bind_data; }
@@ -105,6 +107,19 @@ static int type_width(int t) {
     case DUCKDB_TYPE_BIGINT: case DUCKDB_TYPE_DOUBLE: return 8; case DUCKDB_TYPE_VARCHAR: return 16; default: return 16; }
 }
 
+/* LIST vectors: the child grows on reserve / set_size (the readers call set_size without reserve on one path, bcf_reader.c:1446) */
+static void list_grow(Vec *x, idx_t need) {
+    if (need <= x->list_cap) return;
+    idx_t nc = x->list_cap ? x->list_cap : VSIZE; while (nc < need) nc *= 2;
+    size_t w = (size_t)type_width(x->child->type);
+    x->child->data = realloc(x->child->data, nc * w); memset((char *)x->child->data + x->list_cap * w, 0, (nc - x->list_cap) * w);
+    x->list_cap = nc;
+}
+static idx_t h_list_get_size(duckdb_vector v) { return ((Vec *)v)->list_size; }
+static duckdb_state h_list_reserve(duckdb_vector v, idx_t cap) { list_grow(v, cap); return DuckDBSuccess; }
+static duckdb_state h_list_set_size(duckdb_vector v, idx_t n) { list_grow(v, n); ((Vec *)v)->list_size = n; return DuckDBSuccess; }
+static duckdb_vector h_list_get_child(duckdb_vector v) { return ((Vec *)v)->child; }
+
 static const void *get_api(duckdb_extension_info info, const char *version) { (void)info; return strcmp(version, "v1.2.0") == 0 ? g_api : NULL; }
 static duckdb_database g_db = (void *)0x2;
 static duckdb_database *get_database(duckdb_extension_info info) { (void)info; return &g_db; }
@@ -129,6 +144,8 @@ int main(int argc, char **argv) {
     SET(duckdb_data_chunk_get_size, h_chunk_get_size); SET(duckdb_vector_get_data, h_vector_get_data); SET(duckdb_vector_get_validity, h_vector_get_validity);
     SET(duckdb_vector_ensure_validity_writable, h_vector_ensure_validity_writable); SET(duckdb_validity_set_row_invalid, h_validity_set_row_invalid);
     SET(duckdb_vector_assign_string_element, h_assign); SET(duckdb_vector_assign_string_element_len, h_assign_len);
+    SET(duckdb_list_vector_get_size, h_list_get_size); SET(duckdb_list_vector_reserve, h_list_reserve); SET(duckdb_list_vector_set_size, h_list_set_size);
+    SET(duckdb_list_vector_get_child, h_list_get_child);
 
     void *so = dlopen(argv[1], RTLD_NOW);
     if (!so) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
@@ -165,12 +182,13 @@ int main(int argc, char **argv) {
 
     FILE *fo = out ? fopen(out, "wb") : NULL;
     /* schema record */
-    if (fo) { uint32_t nc = (uint32_t)b.ncol; fwrite(&nc, 4, 1, fo); for (int i = 0; i < b.ncol; i++) { uint32_t t = (uint32_t)b.coltype[i]; fwrite(&t, 4, 1, fo); fwrite(b.colname[i], 1, 64, fo); } uint32_t np = (uint32_t)g.nproj; fwrite(&np, 4, 1, fo); }
+    if (fo) { uint32_t nc = (uint32_t)b.ncol; fwrite(&nc, 4, 1, fo); for (int i = 0; i < b.ncol; i++) { uint32_t t = (uint32_t)b.coltype[i]; fwrite(&t, 4, 1, fo); uint32_t ct = (uint32_t)b.colchild[i]; fwrite(&ct, 4, 1, fo); fwrite(b.colname[i], 1, 256, fo); } uint32_t np = (uint32_t)g.nproj; fwrite(&np, 4, 1, fo); }
     Func fi = { &b, &g, &l, {0}, 0 };
     uint64_t total = 0, chunks = 0;
     for (;;) {
         Chunk c; c.ncol = g.nproj; c.size = 0; c.vecs = calloc(c.ncol, sizeof(Vec));
-        for (size_t k = 0; k < c.ncol; k++) { int t = g.proj[k] < (idx_t)b.ncol ? b.coltype[g.proj[k]] : DUCKDB_TYPE_BIGINT; c.vecs[k].type = t; c.vecs[k].data = calloc(VSIZE, (size_t)type_width(t)); }
+        for (size_t k = 0; k < c.ncol; k++) { int t = g.proj[k] < (idx_t)b.ncol ? b.coltype[g.proj[k]] : DUCKDB_TYPE_BIGINT; c.vecs[k].type = t; c.vecs[k].data = calloc(VSIZE, (size_t)type_width(t));
+            if (t == DUCKDB_TYPE_LIST) { Vec *ch = calloc(1, sizeof(Vec)); ch->type = b.colchild[g.proj[k]]; c.vecs[k].child = ch; c.vecs[k].child_type = ch->type; list_grow(&c.vecs[k], VSIZE); } }
         tf->func(&fi, &c);
         if (fi.has_err) { printf("ERROR scan: %s\n", fi.err); return 3; }
         uint64_t n = c.size;
@@ -180,6 +198,15 @@ int main(int argc, char **argv) {
                 Vec *v = &c.vecs[k]; uint32_t t = (uint32_t)v->type; fwrite(&t, 4, 1, fo);
                 uint64_t words = (n + 63) / 64;
                 for (uint64_t w = 0; w < words; w++) { uint64_t m = v->validity ? v->validity[w] : ~0ull; if (w == words - 1 && (n % 64)) m &= (1ull << (n % 64)) - 1; fwrite(&m, 8, 1, fo); }
+                if (v->type == DUCKDB_TYPE_LIST) {
+                    fwrite(v->data, 16, n, fo);
+                    uint64_t cn = v->list_size; uint32_t ct = (uint32_t)v->child->type; fwrite(&cn, 8, 1, fo); fwrite(&ct, 4, 1, fo);
+                    for (uint64_t r = 0; r < cn; r++) {
+                        if (ct == DUCKDB_TYPE_VARCHAR) { duckdb_string_t *d = (duckdb_string_t *)v->child->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo); fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo); }
+                        else fwrite((char *)v->child->data + r * type_width((int)ct), 1, (size_t)type_width((int)ct), fo);
+                    }
+                    continue;
+                }
                 for (uint64_t r = 0; r < n; r++) {
                     int valid = v->validity ? (int)((v->validity[r / 64] >> (r % 64)) & 1) : 1;
                     if (v->type == DUCKDB_TYPE_VARCHAR) {
@@ -189,7 +216,10 @@ int main(int argc, char **argv) {
                 }
             }
         }
-        for (size_t k = 0; k < c.ncol; k++) { for (size_t h = 0; h < c.vecs[k].nheap; h++) free(c.vecs[k].heap[h]); free(c.vecs[k].heap); free(c.vecs[k].data); free(c.vecs[k].validity); }
+        for (size_t k = 0; k < c.ncol; k++) {
+            Vec *ch = c.vecs[k].child;
+            if (ch) { for (size_t h = 0; h < ch->nheap; h++) free(ch->heap[h]); free(ch->heap); free(ch->data); free(ch); }
+            for (size_t h = 0; h < c.vecs[k].nheap; h++) free(c.vecs[k].heap[h]); free(c.vecs[k].heap); free(c.vecs[k].data); free(c.vecs[k].validity); }
         free(c.vecs);
         if (n == 0) break;
         total += n; chunks++;

@@ -17,6 +17,7 @@ from conftest import GOLDEN, ROOT
 HOST = os.path.join(ROOT, "tests", "minihost", "minihost")
 TYPE_W = {1: 1, 7: 2, 4: 4, 10: 4, 5: 8, 11: 8}
 VARCHAR = 17
+LIST = 24
 
 
 def run_host(path, named=(), proj=None, fn="read_bam"):
@@ -37,10 +38,27 @@ def parse_chunks(fn):
     (nc,) = struct.unpack_from("<I", d, p); p += 4
     schema = []
     for _ in range(nc):
-        (t,) = struct.unpack_from("<I", d, p); p += 4
-        schema.append((d[p:p + 64].split(b"\0")[0].decode(), t)); p += 64
+        t, ct = struct.unpack_from("<II", d, p); p += 8
+        name = d[p:p + 256].split(b"\0")[0].decode(); p += 256
+        schema.append((name, t) if t != LIST else (name, t, ct))
     (nproj,) = struct.unpack_from("<I", d, p); p += 4
     chunks = []
+
+    def payload(t, n):
+        nonlocal p
+        if t == VARCHAR:
+            vals = []
+            for _r in range(n):
+                (ln,) = struct.unpack_from("<I", d, p); p += 4
+                if ln == 0xFFFFFFFF:
+                    vals.append(None)
+                else:
+                    vals.append(d[p:p + ln]); p += ln
+            return vals
+        w = TYPE_W[t]
+        vals = np.frombuffer(d, {1: np.uint8, 2: np.uint16, 4: np.int32, 8: np.int64}[w], n, p).copy(); p += w * n
+        return vals
+
     while p < len(d):
         (n,) = struct.unpack_from("<Q", d, p); p += 8
         cols = []
@@ -48,17 +66,12 @@ def parse_chunks(fn):
             (t,) = struct.unpack_from("<I", d, p); p += 4
             words = (n + 63) // 64
             val = np.frombuffer(d, np.uint64, words, p); p += 8 * words
-            if t == VARCHAR:
-                vals = []
-                for _r in range(n):
-                    (ln,) = struct.unpack_from("<I", d, p); p += 4
-                    if ln == 0xFFFFFFFF:
-                        vals.append(None)
-                    else:
-                        vals.append(d[p:p + ln]); p += ln
+            if t == LIST:
+                ent = np.frombuffer(d, np.uint64, 2 * n, p).reshape(n, 2).copy(); p += 16 * n
+                cn, ct = struct.unpack_from("<QI", d, p); p += 12
+                vals = (ent, ct, payload(ct, cn))
             else:
-                w = TYPE_W[t]
-                vals = np.frombuffer(d, {1: np.uint8, 2: np.uint16, 4: np.int32, 8: np.int64}[w], n, p).copy(); p += w * n
+                vals = payload(t, n)
             cols.append((t, val, vals))
         chunks.append((n, cols))
     return schema, chunks
@@ -144,3 +157,98 @@ def test_read_bam_bind_errors_on_gpu(tmp_path):
     open(good, "wb").write(cases.case_basic(n=50))
     rc, out, _ = run_host(good, named=[("region", "chr1:1-100")])
     assert rc == 3 and out == "ERROR bind: Region query requires an index (.bai/.csi/.crai)"   # bam_reader.c:647-648
+
+
+# ---- read_bcf ---------------------------------------------------------------------------------------------------------
+import bcf_cases  # noqa: E402
+
+CANON2DUCK = {1: 17, 2: 5, 3: 11, 4: 1, 5: 4, 6: 10}
+
+
+def test_read_bcf_bind_errors_without_gpu_dependency():
+    rc, out, _ = run_host("", fn="read_bcf")
+    assert rc == 3 and out == "ERROR bind: read_bcf requires a file path"                      # bcf_reader.c:461
+    rc, out, _ = run_host("/no/such/file.bcf", fn="read_bcf")
+    assert rc == 3 and out == "ERROR bind: Failed to open BCF/VCF file: /no/such/file.bcf"     # bcf_reader.c:494
+    rc, out, _ = run_host("x.bcf", named=[("standard_tags", "1")], fn="read_bcf")
+    assert rc == 3 and "unknown named parameter" in out
+    for k in ("region", "index_path", "tidy_format"):
+        rc, out, _ = run_host("/no/such/file.bcf", named=[(k, "x")], fn="read_bcf")
+        assert "unknown named parameter" not in out
+
+
+def compare_bcf(data, tmp_path, tidy=False, proj=None):
+    fn = os.path.join(str(tmp_path), "in.bcf")
+    open(fn, "wb").write(data)
+    exp = orc.bcf_read(data, tidy)
+    rc, out, dump = run_host(fn, named=[("tidy_format", "true")] if tidy else (), proj=proj, fn="read_bcf")
+    assert rc == 0, out
+    schema, chunks = parse_chunks(dump)
+    want_schema = [(c["name"], CANON2DUCK[c["type"]]) if not c["is_list"] else (c["name"], LIST, CANON2DUCK[c["type"]]) for c in exp["cols"]]
+    assert schema == want_schema
+    proj = list(range(len(exp["cols"]))) if proj is None else proj
+    n = exp["n_rows"]
+    assert [c[0] for c in chunks] == [min(2048, n - c0) for c0 in range(0, n, 2048)]          # full chunks except the last
+    c0 = 0
+    for nrows, cols in chunks:
+        for (t, val, vals), j in zip(cols, proj):
+            c = exp["cols"][j]
+            name = c["name"]
+            bits = np.array([(int(val[i >> 6]) >> (i & 63)) & 1 for i in range(nrows)], np.uint8)
+            assert np.array_equal(bits, c["valid"][c0:c0 + nrows]), name
+            if not c["is_list"]:
+                if c["type"] == 1:
+                    want = [bytes(c["sbytes"][int(c["soff"][i]):int(c["soff"][i + 1])]) if c["valid"][i] else None for i in range(c0, c0 + nrows)]
+                    assert list(vals) == want, name
+                else:
+                    w = TYPE_W[t]
+                    got = vals.astype({1: np.uint8, 4: np.uint32, 8: np.uint64}[w]).astype(np.uint64)
+                    assert np.array_equal(got, c["fixed"][c0:c0 + nrows]), name
+            else:
+                ent, ct, child = vals
+                k0 = int(c["loff"][c0]) if nrows else 0
+                assert np.array_equal(ent[:, 0], c["loff"][c0:c0 + nrows] - np.uint64(k0)), name     # each chunk's child vector starts at 0
+                assert np.array_equal(ent[:, 1], c["llen"][c0:c0 + nrows]), name
+                k1 = k0 + int(c["llen"][c0:c0 + nrows].sum())
+                if c["type"] == 1:
+                    want = [bytes(c["csbytes"][int(c["csoff"][i]):int(c["csoff"][i + 1])]) for i in range(k0, k1)]
+                    assert list(child) == want, name
+                else:
+                    assert np.array_equal(child.astype(np.uint32).astype(np.uint64), c["cfixed"][k0:k1]), name
+        c0 += nrows
+    assert f"rows={n} " in out and "max_threads=1" in out
+    return exp
+
+
+@pytest.mark.gpu
+def test_read_bcf_golden_all_columns(tmp_path):
+    data = open(os.path.join(GOLDEN, "vcf_file.bcf"), "rb").read()
+    exp = compare_bcf(data, tmp_path)
+    assert exp["n_rows"] == 15                                                     # duckhts.test:74-76
+    compare_bcf(data, tmp_path, tidy=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proj", [[0, 1, 5], [3, 4], [6], [7, 9, 12], [14, 15], [22, 0, 22]])
+def test_read_bcf_projection_pushdown(tmp_path, proj):
+    """duckhts.test:28-62: rid/pos/qual only, strings only, filter only, info only, format only"""
+    compare_bcf(open(os.path.join(GOLDEN, "vcf_file.bcf"), "rb").read(), tmp_path, proj=proj)
+
+
+@pytest.mark.gpu
+def test_read_bcf_cases_multichunk_and_error_stop(tmp_path):
+    cases_ = {n: (d, t) for n, d, t in bcf_cases.all_cases()}
+    for name in ("fuzz_small_blocks", "fuzz_tidy", "basic", "mismatch", "bad_info_key", "idx_header", "no_format_defs", "empty_no_records", "qual_bits"):
+        d, t = cases_[name]
+        compare_bcf(d, tmp_path, tidy=t)
+
+
+@pytest.mark.gpu
+def test_read_bcf_errors_on_gpu(tmp_path):
+    fn = os.path.join(str(tmp_path), "x.bcf")
+    open(fn, "wb").write(dict(bcf_cases.header_error_cases())["bad_magic"])
+    rc, out, _ = run_host(fn, fn="read_bcf")
+    assert rc == 3 and out == "ERROR bind: Failed to read BCF/VCF header"                      # bcf_reader.c:505
+    open(fn, "wb").write(open(os.path.join(GOLDEN, "vcf_file.bcf"), "rb").read())
+    rc, out, _ = run_host(fn, named=[("region", "1:3000150-3000151")], fn="read_bcf")
+    assert rc == 3 and out == "ERROR init: Region query requires an index file (.tbi or .csi). Region: 1:3000150-3000151"   # bcf_reader.c:922-923
