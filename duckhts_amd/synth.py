@@ -31,6 +31,8 @@ def _lib():
         L.synth_bam_segment.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.synth_bam_segment.restype = C.c_size_t
+        L.synth_bcf_segment.argtypes = L.synth_bam_segment.argtypes
+        L.synth_bcf_segment.restype = C.c_size_t
         _LIB = L
     return _LIB
 
@@ -56,4 +58,23 @@ def bam_segment(n, seed=42, total_n=None, rec0=0, with_header=True, with_eof=Tru
 
 def bam_file(n, seed=42, **kw) -> bytes:
     arr, _ = bam_segment(n, seed=seed, **kw)
+    return arr.tobytes()
+
+
+def bcf_segment(n, seed=43, total_n=None, rec0=0, with_header=True, with_eof=True, level=6, payload=65280, threads=None, out=None):
+    """Synthetic 16-sample BCF records [rec0, rec0+n) -> (uint8 array, stats dict)."""
+    total_n = n if total_n is None else total_n
+    threads = threads or min(os.cpu_count() or 1, 32)
+    cap = int(n) * 700 + (1 << 20)
+    if out is None:
+        out = np.empty(cap, dtype=np.uint8)
+    stats = (C.c_uint64 * 2)()
+    got = _lib().synth_bcf_segment(seed, total_n, rec0, n, int(with_header), int(with_eof), level, payload, threads, out.ctypes.data, out.nbytes, stats)
+    if got == 0:
+        raise RuntimeError("synth_bcf_segment: output capacity too small")
+    return out[:got], {"raw_bytes": int(stats[0]), "n_blocks": int(stats[1]), "n_records": int(n)}
+
+
+def bcf_file(n, seed=43, **kw) -> bytes:
+    arr, _ = bcf_segment(n, seed=seed, **kw)
     return arr.tobytes()

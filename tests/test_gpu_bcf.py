@@ -93,3 +93,13 @@ def test_sharded_block_ranges_concatenate():
     assert np.array_equal(pos, exp["by_name"]["POS"]["fixed"])
     gq = np.concatenate([p["by_name"]["FORMAT_GQ_S1"]["fixed"] for p in parts])
     assert np.array_equal(gq, exp["by_name"]["FORMAT_GQ_S1"]["fixed"])
+
+
+@pytest.mark.parametrize("tidy", [False, True])
+def test_synthetic_config3_shape(tidy):
+    """SURVEY.md 8(d) config 3 shape: 16 samples, typed INFO/FORMAT, int8/16/32 widths, missing values; multi-batch."""
+    from duckhts_amd import synth
+    data = synth.bcf_file(30000 if tidy else 60000, seed=43)
+    exp, got = _check(data, tidy, max_blocks=64)
+    assert len(got["cols"]) == (7 + 8 + 1 + 6 if tidy else 7 + 8 + 96)
+    assert got["n_rows"] == (30000 * 16 if tidy else 60000)

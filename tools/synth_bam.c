@@ -223,14 +223,15 @@ static size_t bgzf_block(const uint8_t *src, size_t slen, uint8_t *dst, int leve
     return total;
 }
 
+typedef size_t (*gen_fn)(const model_t *, uint64_t, uint8_t *);
 typedef struct {
-    const model_t *m; uint64_t i0, i1; uint8_t *buf; size_t len;
+    const model_t *m; uint64_t i0, i1; uint8_t *buf; size_t len; gen_fn gen; size_t rec_cap;
 } gen_job_t;
 static void *gen_thread(void *a) {
     gen_job_t *j = (gen_job_t *)a;
-    size_t cap = (size_t)(j->i1 - j->i0) * 420 + 1024;
+    size_t cap = (size_t)(j->i1 - j->i0) * j->rec_cap + 1024;
     j->buf = (uint8_t *)malloc(cap); j->len = 0;
-    for (uint64_t i = j->i0; i < j->i1; i++) j->len += gen_record(j->m, i, j->buf + j->len);
+    for (uint64_t i = j->i0; i < j->i1; i++) j->len += j->gen(j->m, i, j->buf + j->len);
     return NULL;
 }
 typedef struct {
@@ -260,18 +261,18 @@ static void *cmp_thread(void *a) {
  * Returns bytes written to out (0 on error / insufficient capacity).
  * stats[0] = uncompressed bytes, stats[1] = number of BGZF blocks.
  */
-size_t synth_bam_segment(uint64_t seed, uint64_t total_n, uint64_t rec0, uint64_t n, int with_header, int with_eof,
-                         int level, int payload, int threads, uint8_t *out, size_t out_cap, uint64_t *stats) {
+static size_t segment_impl(gen_fn gen, size_t rec_cap, const uint8_t *hdr, size_t hl, uint64_t seed, uint64_t total_n, uint64_t rec0, uint64_t n, int with_eof,
+                           int level, int payload, int threads, uint8_t *out, size_t out_cap, uint64_t *stats) {
     static const uint8_t EOFB[28] = {0x1f,0x8b,0x08,0x04,0,0,0,0,0,0xff,0x06,0,0x42,0x43,0x02,0,0x1b,0,0x03,0,0,0,0,0,0,0,0,0};
     model_t m; model_init(&m, total_n, seed);
     if (threads < 1) threads = 1; if (threads > 256) threads = 256;
     if (payload <= 0 || payload > 65280) payload = 65280;
     gen_job_t gj[256]; pthread_t th[256];
     for (int t = 0; t < threads; t++) {
-        gj[t].m = &m; gj[t].i0 = rec0 + n * (uint64_t)t / (uint64_t)threads; gj[t].i1 = rec0 + n * (uint64_t)(t + 1) / (uint64_t)threads;
+        gj[t].m = &m; gj[t].gen = gen; gj[t].rec_cap = rec_cap; gj[t].i0 = rec0 + n * (uint64_t)t / (uint64_t)threads; gj[t].i1 = rec0 + n * (uint64_t)(t + 1) / (uint64_t)threads;
         pthread_create(&th[t], NULL, gen_thread, &gj[t]);
     }
-    size_t raw_len = 0; uint8_t hdr[8192]; size_t hl = with_header ? gen_header(hdr) : 0;
+    size_t raw_len = 0;
     for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); raw_len += gj[t].len; }
     raw_len += hl;
     uint8_t *raw = (uint8_t *)malloc(raw_len + 16); size_t o = 0;
@@ -298,4 +299,140 @@ size_t synth_bam_segment(uint64_t seed, uint64_t total_n, uint64_t rec0, uint64_
     if (stats) { stats[0] = raw_len; stats[1] = n_chunks + (with_eof ? 1 : 0); }
     free(raw); free(cbuf); free(clen);
     return o;
+}
+
+size_t synth_bam_segment(uint64_t seed, uint64_t total_n, uint64_t rec0, uint64_t n, int with_header, int with_eof,
+                         int level, int payload, int threads, uint8_t *out, size_t out_cap, uint64_t *stats) {
+    uint8_t hdr[8192]; size_t hl = with_header ? gen_header(hdr) : 0;
+    return segment_impl(gen_record, 420, hdr, hl, seed, total_n, rec0, n, with_eof, level, payload, threads, out, out_cap, stats);
+}
+
+/* =====================================================================================================================
+ * Synthetic BCF: VCFv4.2 header, 25 contigs, FILTER q10/s50, INFO DP:1:Integer AF:A:Float
+ * AC:A:Integer AN:1:Integer MQ:1:Float DB:0:Flag SB:4:Integer ANN_S:1:String, FORMAT GT GQ:1 DP:1 AD:R PL:G (Integer)
+ * GL:G (Float) for 16 samples; 90 % biallelic SNV, 8 % indel, 2 % tri-allelic; ~3 % missing values, 1 % missing QUAL;
+ * FILTER PASS / q10 / q10+s50; integer vectors use the narrowest of int8/int16/int32 that fits the record's values.
+ * ===================================================================================================================== */
+#define BCF_NS 16
+static const char *BCF_SAMPLES[BCF_NS] = {"NA00001","NA00002","NA00003","NA00004","NA00005","NA00006","NA00007","NA00008",
+    "NA00009","NA00010","NA00011","NA00012","NA00013","NA00014","NA00015","NA00016"};
+enum { K_PASS = 0, K_Q10, K_S50, K_DP, K_AF, K_AC, K_AN, K_MQ, K_DB, K_SB, K_ANN, K_GT, K_GQ, K_AD, K_PL, K_GL };
+
+static size_t gen_bcf_header(uint8_t *dst) {
+    char *p = (char *)dst + 9; char *q = p;
+    q += sprintf(q, "##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n");
+    for (int i = 0; i < NREF; i++) q += sprintf(q, "##contig=<ID=%s,length=%u>\n", REF_NAME[i], REF_LEN[i]);
+    q += sprintf(q, "##FILTER=<ID=q10,Description=\"Quality below 10\">\n##FILTER=<ID=s50,Description=\"Less than 50%% of samples have data\">\n");
+    q += sprintf(q, "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Total Depth\">\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n");
+    q += sprintf(q, "##INFO=<ID=AC,Number=A,Type=Integer,Description=\"Allele count\">\n##INFO=<ID=AN,Number=1,Type=Integer,Description=\"Allele number\">\n");
+    q += sprintf(q, "##INFO=<ID=MQ,Number=1,Type=Float,Description=\"RMS mapping quality\">\n##INFO=<ID=DB,Number=0,Type=Flag,Description=\"dbSNP membership\">\n");
+    q += sprintf(q, "##INFO=<ID=SB,Number=4,Type=Integer,Description=\"Strand counts\">\n##INFO=<ID=ANN_S,Number=1,Type=String,Description=\"Short annotation\">\n");
+    q += sprintf(q, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">\n");
+    q += sprintf(q, "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Read Depth\">\n##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths\">\n");
+    q += sprintf(q, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scaled likelihoods\">\n##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"Genotype likelihoods\">\n");
+    q += sprintf(q, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");
+    for (int i = 0; i < BCF_NS; i++) q += sprintf(q, "\t%s", BCF_SAMPLES[i]);
+    *q++ = '\n'; *q++ = 0;
+    size_t l_text = (size_t)(q - p);
+    memcpy(dst, "BCF\2\2", 5); put32(dst + 5, (uint32_t)l_text);
+    return 9 + l_text;
+}
+
+static inline uint8_t *put_desc(uint8_t *p, int n, int t) {
+    if (n < 15) { *p++ = (uint8_t)((n << 4) | t); return p; }
+    *p++ = (uint8_t)(0xF0 | t);
+    if (n < 128) { *p++ = 0x11; *p++ = (uint8_t)n; } else { *p++ = 0x12; *p++ = (uint8_t)n; *p++ = (uint8_t)(n >> 8); }
+    return p;
+}
+/* integer vector with the narrowest width; v == INT32_MIN encodes "missing" */
+static uint8_t *put_ints(uint8_t *p, const int32_t *v, int n, int per_desc) {
+    int w = 1;
+    for (int i = 0; i < n; i++) { if (v[i] == INT32_MIN) continue; if (v[i] < -120 || v[i] > 127) w = w < 2 ? 2 : w; if (v[i] < -32000 || v[i] > 32767) w = 4; }
+    p = put_desc(p, per_desc, w == 1 ? 1 : w == 2 ? 2 : 3);
+    for (int i = 0; i < n; i++) {
+        int miss = v[i] == INT32_MIN;
+        if (w == 1) *p++ = miss ? 0x80 : (uint8_t)v[i];
+        else if (w == 2) { uint16_t x = miss ? 0x8000 : (uint16_t)v[i]; *p++ = (uint8_t)x; *p++ = (uint8_t)(x >> 8); }
+        else { put32(p, miss ? 0x80000000u : (uint32_t)v[i]); p += 4; }
+    }
+    return p;
+}
+static inline uint8_t *put_key(uint8_t *p, int k) { *p++ = 0x11; *p++ = (uint8_t)k; return p; }
+static inline uint8_t *put_f32(uint8_t *p, float f) { uint32_t b; memcpy(&b, &f, 4); put32(p, b); return p + 4; }
+
+static size_t gen_bcf_record(const model_t *m, uint64_t idx, uint8_t *dst) {
+    rng_t r; r.s = mix64(m->seed * 0x2545F4914F6CDD1Dull + idx);
+    int tid; int64_t pos; model_pos(m, idx, &tid, &pos);
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    uint64_t kind = rnext(&r) % 100;
+    int n_allele = kind < 98 ? 2 : 3;
+    char al[3][16]; int all[3];
+    if (kind < 90) { int a = (int)(rnext(&r) & 3), b = (a + 1 + (int)(rnext(&r) % 3)) & 3; al[0][0] = B[a]; all[0] = 1; al[1][0] = B[b]; all[1] = 1; }
+    else if (kind < 98) {
+        int L = 2 + (int)(rnext(&r) % 9); for (int i = 0; i < L; i++) al[0][i] = B[rnext(&r) & 3]; all[0] = L; al[1][0] = al[0][0]; all[1] = 1;
+        if (rnext(&r) & 1) { char t[16]; memcpy(t, al[0], 16); memcpy(al[0], al[1], 16); memcpy(al[1], t, 16); int x = all[0]; all[0] = all[1]; all[1] = x; }
+    } else { int a = (int)(rnext(&r) & 3); al[0][0] = B[a]; all[0] = 1; al[1][0] = B[(a + 1) & 3]; all[1] = 1; al[2][0] = B[a]; al[2][1] = B[(a + 2) & 3]; all[2] = 2; }
+    int G = n_allele * (n_allele + 1) / 2;
+    uint8_t *sh = dst + 32, *p = sh;
+    if (rnext(&r) % 10 < 3) { char id[16]; int l = 2 + fmt_u(id + 2, 1000 + rnext(&r) % 900000000ull); id[0] = 'r'; id[1] = 's'; p = put_desc(p, l, 7); memcpy(p, id, (size_t)l); p += l; }
+    else *p++ = 0x07;
+    for (int a = 0; a < n_allele; a++) { p = put_desc(p, all[a], 7); memcpy(p, al[a], (size_t)all[a]); p += all[a]; }
+    uint64_t fl = rnext(&r) % 100;
+    if (fl < 80) { *p++ = 0x11; *p++ = K_PASS; } else if (fl < 92) { *p++ = 0x11; *p++ = K_Q10; } else { *p++ = 0x21; *p++ = K_Q10; *p++ = K_S50; }
+    int n_info = 0; int32_t iv[8];
+    const int miss3 = 3;
+    int32_t dp_tot = (int32_t)(50 + rnext(&r) % 900); if (rnext(&r) % 64 == 0) dp_tot += 40000;
+    iv[0] = (rnext(&r) % 100 < (uint64_t)miss3) ? INT32_MIN : dp_tot;
+    p = put_key(p, K_DP); p = put_ints(p, iv, 1, 1); n_info++;
+    p = put_key(p, K_AF); p = put_desc(p, n_allele - 1, 5);
+    for (int a = 1; a < n_allele; a++) { if (rnext(&r) % 100 < (uint64_t)miss3) { put32(p, 0x7F800001u); p += 4; } else p = put_f32(p, (float)(rnext(&r) % 10000) / 10000.0f); }
+    n_info++;
+    for (int a = 1; a < n_allele; a++) iv[a - 1] = (int32_t)(1 + rnext(&r) % 31);
+    p = put_key(p, K_AC); p = put_ints(p, iv, n_allele - 1, n_allele - 1); n_info++;
+    iv[0] = 2 * BCF_NS; p = put_key(p, K_AN); p = put_ints(p, iv, 1, 1); n_info++;
+    p = put_key(p, K_MQ); p = put_desc(p, 1, 5); p = put_f32(p, 20.0f + (float)(rnext(&r) % 4000) / 100.0f); n_info++;
+    if (rnext(&r) % 10 < 3) { p = put_key(p, K_DB); *p++ = 0x00; n_info++; }
+    for (int k = 0; k < 4; k++) iv[k] = (int32_t)(rnext(&r) % 300);
+    p = put_key(p, K_SB); p = put_ints(p, iv, 4, 4); n_info++;
+    { static const char *ANN[6] = {"missense_variant", "synonymous_variant", "intron_variant", "intergenic_region", "stop_gained", "splice_region_variant&intron_variant"};
+      const char *a = ANN[rnext(&r) % 6]; int l = (int)strlen(a); p = put_key(p, K_ANN); p = put_desc(p, l, 7); memcpy(p, a, (size_t)l); p += l; n_info++; }
+    size_t l_shared = (size_t)(p - sh);
+    /* ---- individual data ---- */
+    uint8_t *in = p;
+    int32_t gq[BCF_NS], dp[BCF_NS], ad[BCF_NS * 3], pl[BCF_NS * 6]; float gl[BCF_NS * 6]; uint8_t gt[BCF_NS * 2];
+    for (int s = 0; s < BCF_NS; s++) {
+        uint64_t x = rnext(&r);
+        int a0 = (int)(x % (uint64_t)n_allele), a1 = (int)((x >> 8) % (uint64_t)n_allele); if (a0 > a1) { int t = a0; a0 = a1; a1 = t; }
+        int ph = (int)((x >> 16) & 1);
+        int missing = ((x >> 20) % 100) < 2;
+        gt[2 * s] = missing ? 0 : (uint8_t)(((a0 + 1) << 1));
+        gt[2 * s + 1] = missing ? 0 : (uint8_t)(((a1 + 1) << 1) | ph);
+        gq[s] = ((x >> 28) % 100 < (uint64_t)miss3) ? INT32_MIN : (int32_t)((x >> 36) % 100);
+        int d = (int)(5 + (x >> 44) % 60); if ((x >> 52) % 97 == 0) d += 200;
+        dp[s] = ((x >> 56) % 100 < (uint64_t)miss3) ? INT32_MIN : d;
+        uint64_t y = rnext(&r);
+        int rem = d;
+        for (int a = 0; a < n_allele; a++) { int v = a == n_allele - 1 ? rem : (int)(y % (uint64_t)(rem + 1)); y >>= 8; ad[s * n_allele + a] = v; rem -= v; }
+        int best = (int)(rnext(&r) % (uint64_t)G);
+        for (int g = 0; g < G; g++) { int v = g == best ? 0 : (int)(10 + rnext(&r) % 1500); pl[s * G + g] = v; gl[s * G + g] = -(float)v / 10.0f; }
+    }
+    p = put_key(p, K_GT); p = put_desc(p, 2, 1); memcpy(p, gt, BCF_NS * 2); p += BCF_NS * 2;
+    p = put_key(p, K_GQ); p = put_ints(p, gq, BCF_NS, 1);
+    p = put_key(p, K_DP); p = put_ints(p, dp, BCF_NS, 1);
+    p = put_key(p, K_AD); p = put_ints(p, ad, BCF_NS * n_allele, n_allele);
+    p = put_key(p, K_PL); p = put_ints(p, pl, BCF_NS * G, G);
+    p = put_key(p, K_GL); p = put_desc(p, G, 5); for (int i = 0; i < BCF_NS * G; i++) p = put_f32(p, gl[i]);
+    size_t l_indiv = (size_t)(p - in);
+    put32(dst, (uint32_t)(24 + l_shared)); put32(dst + 4, (uint32_t)l_indiv);
+    put32(dst + 8, (uint32_t)tid); put32(dst + 12, (uint32_t)pos); put32(dst + 16, (uint32_t)all[0]);
+    if (rnext(&r) % 100 == 0) put32(dst + 20, 0x7F800001u); else { float qf = (float)(rnext(&r) % 50000) / 10.0f; uint32_t b; memcpy(&b, &qf, 4); put32(dst + 20, b); }
+    dst[24] = (uint8_t)n_info; dst[25] = 0; dst[26] = (uint8_t)n_allele; dst[27] = 0;
+    put32(dst + 28, (uint32_t)BCF_NS | (6u << 24));
+    return 32 + l_shared + l_indiv;
+}
+
+size_t synth_bcf_segment(uint64_t seed, uint64_t total_n, uint64_t rec0, uint64_t n, int with_header, int with_eof,
+                         int level, int payload, int threads, uint8_t *out, size_t out_cap, uint64_t *stats) {
+    uint8_t hdr[16384]; size_t hl = with_header ? gen_bcf_header(hdr) : 0;
+    return segment_impl(gen_bcf_record, 1400, hdr, hl, seed, total_n, rec0, n, with_eof, level, payload, threads, out, out_cap, stats);
 }
