@@ -176,8 +176,21 @@ def main():
     bytes_per_step = file_bytes + raw_bytes
     achieved = bytes_per_step / (inflate_ms_step * 1e-3) / 1e9 if inflate_ms_step > 0 else 0.0
     lz_n = max(ktimes["lz_resolve"][1], 1)
+    # HBM traffic of the inflate stage from the committed PMC passes (rocprofv3 cannot wrap itself): bytes per BGZF block
+    # measured on full-size launches of this same workload (profiles/<round>/pmc_traffic_*.json), times the blocks of one step
+    traffic, traffic_src = None, None
+    try:
+        cand = sorted(f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
+                      [os.path.join(ROOT, "profiles", r_, x) for x in sorted(os.listdir(os.path.join(ROOT, "profiles", r_))) if x.startswith("pmc_traffic_")])
+        if cand:
+            pj = json.load(open(cand[-1]))["per_block"]
+            per_blk = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in pj.values())
+            traffic = int(per_blk * nb)
+            traffic_src = os.path.relpath(cand[-1], ROOT)
+    except Exception:
+        traffic = None
     roof = {"bound": "hbm", "kernel": "bgzf_huff_decode+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src,
             "ms_per_step": round(inflate_ms_step, 3), "bytes_per_step": int(bytes_per_step),
             "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
             "path_frac": round(value * (C + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5)}
