@@ -68,7 +68,7 @@ ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
-           "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
+           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
@@ -102,6 +102,8 @@ def lib():
         L.dhts_bam_set_block_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
         L.dhts_shard_cut.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.dhts_bam_rewind.argtypes = [C.c_void_p]
+        L.dhts_bam_set_regions.argtypes = [C.c_void_p, C.c_char_p]
+        L.dhts_bam_load_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bam_next_batch.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(BamBatch)]
         L.dhts_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_sync.argtypes = [C.c_void_p]
@@ -209,6 +211,14 @@ class Context:
 
     def rewind(self):
         self._chk(self.L.dhts_bam_rewind(self.h))
+
+    def set_regions(self, regions):
+        """region := 'chr:beg-end,...'; returns False when no region names a known reference"""
+        return self._chk(self.L.dhts_bam_set_regions(self.h, regions.encode() if isinstance(regions, str) else regions)) == 0
+
+    def load_index(self, bai_bytes):
+        buf = np.frombuffer(bai_bytes, dtype=np.uint8)
+        self._chk(self.L.dhts_bam_load_index(self.h, buf.ctypes.data, buf.nbytes))
 
     def next_batch(self, max_blocks=0, colmask=0x1FFF):
         b = BamBatch()
@@ -444,8 +454,9 @@ def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=
         ctx.close()
 
 
-def read_bam(src, device=0, max_blocks=0, shard=None):
-    """Full sequential scan (reference mode (i)): all rows in file order."""
+def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None):
+    """Full sequential scan (reference mode (i)): all rows in file order.
+    region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window."""
     ctx = Context(device)
     try:
         ctx.open(src)
@@ -453,6 +464,11 @@ def read_bam(src, device=0, max_blocks=0, shard=None):
         hdr = ctx.bam_open()
         if shard is not None:
             ctx.set_shard(*shard)
+        if region is not None:
+            if not ctx.set_regions(region):
+                raise DhtsError(f"No reads found for region(s): {region}")
+            if index is not None:
+                ctx.load_index(index)
         parts = []
         status = 0
         while True:

@@ -212,6 +212,7 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
 template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &st, const S &s, const BamDict &dict, uint64_t o, int64_t row,
                                                          uint32_t *rec_off, uint8_t *rg_flag, const BamCols &c) {
     RecInfo r; const int rcv = rec_check_t(st, s, o, r, true);
+    if (row < 0) return rcv == REC_OK;                      // filtered out by the region predicate: still validated (the iterator reads it)
     rec_off[row] = (uint32_t)o;
     if (rcv != REC_OK) {          // first such row ends the scan (bam_reader.c:754-766); keep the column slots defined
         c.len_qname[row] = 0; c.len_cigar[row] = 0; c.len_seq[row] = 0; c.len_qual[row] = 0; c.len_rg[row] = 0;
@@ -258,7 +259,7 @@ template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &s
 // string lengths and the per-row scratch of the string pass.  rg_flag is one byte per row (packed to validity words later).
 extern "C" __global__ void __launch_bounds__(64)
 bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res,
-                int64_t nrows, uint32_t *rec_off, uint8_t *rg_flag, BamCols c, unsigned long long *bad_row) {
+                int64_t nrows, uint32_t *rec_off, uint8_t *rg_flag, BamCols c, unsigned long long *bad_row, const uint32_t *row_map) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
     __shared__ uint32_t recs[256];
     const int lane = threadIdx.x;
@@ -287,7 +288,10 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
         const uint64_t rel = o - tb;
         bool fast = false;
         if (rel + 4 <= (uint64_t)s.len) { const uint32_t bl = ls.u32(o); fast = (bl >= 32u) && (rel + 4ull + bl <= (uint64_t)s.len); }
-        const bool good = fast ? unpack_one(st, ls, dict, o, row, rec_off, rg_flag, c) : unpack_one(st, gs, dict, o, row, rec_off, rg_flag, c);
+        // with a region filter: row_map[row] = compacted row if kept (map[row+1] > map[row]), rows are validated either way
+        int64_t dst = row;
+        if (row_map) dst = (row_map[row + 1] > row_map[row]) ? (int64_t)row_map[row] : -1;
+        const bool good = fast ? unpack_one(st, ls, dict, o, dst, rec_off, rg_flag, c) : unpack_one(st, gs, dict, o, dst, rec_off, rg_flag, c);
         if (!good) atomicMin(bad_row, (unsigned long long)row);
     }
 }
@@ -299,4 +303,37 @@ bam_pack_validity(const uint8_t *flag, int64_t nrows, uint64_t *words) {
     bool v = row < nrows && flag[row] != 0;
     uint64_t m = __ballot(v);
     if ((threadIdx.x & 63) == 0 && row < nrows) words[row >> 6] = m;
+}
+
+
+// ---- region predicate -----------------------------------------------------------------------------------
+// keep[row] = 1 iff the record overlaps one of the merged query intervals of its reference:
+//   end > iv.beg && iv.end > beg, beg = pos, end = bam_endpos (htslib sam.c:668-673: pos + reference length of the effective
+//   CIGAR, 1 if that is 0 or the read is unmapped)          -- hts_itr_multi_next hts.c:4575-4592, sam_readrec sam.c:1596-1612
+// Unplaced reads (tid < 0) are kept only by the "*" region.  Intervals are sorted and merged per tid (region.c:100-120).
+struct RegionDev { const int64_t *beg, *end; const uint32_t *tid_first; int32_t n_ref, all, nocoor, pad; };
+
+extern "C" __global__ void __launch_bounds__(256)
+bam_region_keep(BamStream st, RegionDev rg, const uint32_t *rec_off, int64_t nrows, uint32_t *keep) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    GSrc gs; gs.g = st.u;
+    const uint64_t o = rec_off[row];
+    RecInfo r;
+    uint32_t k = 0;
+    if (rec_check_t(st, gs, o, r, true) == REC_OK) {
+        if (rg.all) k = 1;
+        else if (r.tid < 0) k = rg.nocoor ? 1u : 0u;
+        else if (r.tid < rg.n_ref) {
+            int64_t rlen = 0;
+            if (!(r.flag & 4)) for (uint32_t j = 0; j < r.n_cigar_eff; j++) { const uint32_t c = gs.u32(r.cig_off + 4ull * j); if ((0x3C1A7u >> ((c & 0xf) << 1)) & 2u) rlen += c >> 4; }
+            if (rlen == 0) rlen = 1;
+            const int64_t beg = r.pos, end = (int64_t)r.pos + rlen;
+            uint32_t lo = rg.tid_first[r.tid], hi = rg.tid_first[r.tid + 1];
+            // first interval with iv.end > beg (ends are increasing after the merge), then test its begin
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rg.end[mid] > beg) hi = mid; else lo = mid + 1; }
+            if (lo < rg.tid_first[r.tid + 1] && end > rg.beg[lo]) k = 1;
+        }
+    }
+    keep[row] = k;
 }

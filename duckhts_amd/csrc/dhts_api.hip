@@ -17,6 +17,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
+#include <algorithm>
+#include <limits.h>
 
 #define TILE_BYTES 8192u
 #define PAD_BYTES 256u
@@ -66,6 +68,12 @@ struct dhts_ctx {
     std::vector<std::string> rg_id, rg_sm; std::vector<char> rg_has_sm; std::vector<const char *> rg_id_p, rg_sm_p;
     uint64_t first_rec_uoff = 0;
     DevBuf d_rg_off, d_rg_bytes;
+    // region filter (row A11)
+    bool rg_active = false, rg_all = false, rg_nocoor = false;
+    std::vector<int64_t> rg_beg, rg_end; std::vector<uint32_t> rg_tid_first;
+    DevBuf d_rg_beg, d_rg_end, d_rg_first, c_keep, c_rowmap;
+    bool rg_empty_window = false;          // the index shows no chunk for the regions: the scan yields nothing
+    uint64_t scan_first_uoff = 0;          // inflated offset of the first record of a non-speculative scan (header end, or an index chunk start)
     // read_bcf
     bool bcf_open = false; bool bcf_tidy_req = false;
     dhts::BcfHeader bh; dhts::BcfSchema bsch;
@@ -456,7 +464,7 @@ int dhts_bam_open(dhts_ctx *c) {
         } while (0);
         if (bad) return fail(c, "Failed to read SAM/BAM/CRAM header");
         if (need_more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; }
-        c->first_rec_uoff = p;
+        c->first_rec_uoff = p; c->scan_first_uoff = p;
         break;
     }
     c->ref_name_p.clear(); for (auto &s : c->ref_name) c->ref_name_p.push_back(s.c_str());
@@ -501,6 +509,7 @@ int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, in
 int dhts_bam_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculative_start) {
     if (!c || b0 < 0 || b1 < b0 || b1 > c->n_blocks) return -1;
     c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = speculative_start ? 1 : 0; c->shard_world = (b1 < c->n_blocks || speculative_start) ? 2 : 1;
+    c->scan_first_uoff = c->first_rec_uoff;
     return dhts_bam_rewind(c);
 }
 
@@ -513,15 +522,195 @@ int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
 
 // a scan that starts at the top of the file begins with the block that holds the first record (headers may span many blocks)
 static void skip_header_blocks(dhts_ctx *c) {
-    if (c->shard_rank != 0 || c->shard_b0 != 0 || c->n_blocks <= 0) return;
-    int64_t lo = 0, hi = c->n_blocks;                       // last block b with uoff[b] <= first_rec_uoff
-    while (hi - lo > 1) { int64_t mid = (lo + hi) / 2; if (c->h_uoff[mid] <= c->first_rec_uoff) lo = mid; else hi = mid; }
-    if (lo < c->shard_b1) c->next_block = lo;
+    if (c->shard_rank != 0 || c->n_blocks <= 0) return;
+    int64_t lo = 0, hi = c->n_blocks;                       // last block b with uoff[b] <= scan_first_uoff
+    while (hi - lo > 1) { int64_t mid = (lo + hi) / 2; if (c->h_uoff[mid] <= c->scan_first_uoff) lo = mid; else hi = mid; }
+    if (lo >= c->shard_b0 && lo < c->shard_b1) c->next_block = lo;
+}
+
+// ---- region queries: host side = region strings -> merged intervals, BAI -> scan window -------------------
+// hts_parse_decimal with HTS_PARSE_THOUSANDS_SEP (htslib hts.c:3884-3940)
+static long long parse_decimal_sep(const char *str, const char **strend) {
+    unsigned long long n = 0; int digits = 0, decimals = 0, e = 0; char sign = '+', esign = '+';
+    const char *s = str;
+    while (*s == ' ' || (*s >= '\t' && *s <= '\r')) s++;
+    if (*s == '+' || *s == '-') sign = *s++;
+    while (*s) { if (*s >= '0' && *s <= '9') { digits++; n = n * 10 + (unsigned)(*s++ - '0'); } else if (*s == ',') s++; else break; }
+    if (*s == '.') { s++; while (*s >= '0' && *s <= '9') { decimals++; digits++; n = n * 10 + (unsigned)(*s++ - '0'); } }
+    switch (*s) {
+    case 'e': case 'E': s++; if (*s == '+' || *s == '-') esign = *s++; while (*s >= '0' && *s <= '9') e = e * 10 + (*s++ - '0'); if (esign == '-') e = -e; break;
+    case 'k': case 'K': e += 3; s++; break;
+    case 'm': case 'M': e += 6; s++; break;
+    case 'g': case 'G': e += 9; s++; break;
+    }
+    e -= decimals;
+    while (e > 0) { n *= 10; e--; }
+    while (e < 0) { n /= 10; e++; }
+    *strend = digits > 0 ? s : str;
+    return sign == '+' ? (long long)n : -(long long)n;
+}
+
+// hts_parse_region (hts.c:3995-4150) for one region token; name lookup through `names`.  Returns false when the token does not
+// name a known reference / is malformed (hts_reglist_create then skips it with a warning, region.c:203-215).
+static bool parse_region_token(const std::vector<std::string> &names, const std::string &tok, int &tid, int64_t &beg, int64_t &end) {
+    auto getid = [&](const std::string &nm) -> int { for (size_t i = 0; i < names.size(); i++) if (names[i] == nm) return (int)i; return -1; };
+    const int64_t POS_MAX = ((((int64_t)INT32_MAX) << 32) | 0xffffffffll);       // HTS_POS_MAX = INT64_MAX in htslib >= 1.10
+    (void)POS_MAX;
+    const int64_t PMAX = INT64_MAX;
+    std::string s = tok; bool quoted = false; size_t colon = std::string::npos;
+    if (!s.empty() && s[0] == '{') {
+        size_t close = s.find('}');
+        if (close == std::string::npos) return false;
+        std::string name = s.substr(1, close - 1);
+        quoted = true;
+        if (close + 1 < s.size() && s[close + 1] == ':') colon = close + 1;
+        if (colon == std::string::npos) { beg = 0; end = PMAX; tid = getid(name); return tid >= 0; }
+        tid = getid(name);
+        if (tid < 0) return false;
+    } else {
+        colon = s.rfind(':');
+        if (colon == std::string::npos) { beg = 0; end = PMAX; tid = getid(s); return tid >= 0; }
+        beg = 0; end = PMAX;
+        if ((tid = getid(s)) >= 0) return getid(s.substr(0, colon)) < 0;       // whole string is a name; ambiguous if the prefix is one too
+        tid = getid(s.substr(0, colon));
+        if (tid < 0) return false;
+    }
+    (void)quoted;
+    const char *c1 = s.c_str() + colon + 1, *hy = nullptr;
+    beg = parse_decimal_sep(c1, &hy) - 1;
+    if (beg < 0) {
+        if (beg != -1 && *hy == '-' && *c1 != '\0') return false;               // "Coordinates must be > 0"
+        if ((*hy >= '0' && *hy <= '9') || *hy == '\0' || *hy == ',') { end = beg == -1 ? PMAX : -(beg + 1); beg = 0; return true; }   // chr:-100 = chr:1-100
+        else if (beg < -1) return false;
+    }
+    if (*hy == '\0') end = PMAX;
+    else if (*hy == '-') { const char *h2; end = parse_decimal_sep(hy + 1, &h2); if (*h2 != '\0' && *h2 != ',') return false; }
+    else return false;
+    if (end == 0) end = PMAX;
+    if (beg >= end) return false;
+    return true;
+}
+
+// read_bam(region := ...): comma split as src/bam_reader.c:318-348 (strtok: empty tokens vanish), then hts_reglist_create
+// (region.c:177-260: "." = everything, "*" = unplaced reads, unknown names skipped, intervals sorted and merged per tid).
+// Returns 0, or 1 when no usable region remains (the reference reports "No reads found for region(s): ...").
+int dhts_bam_set_regions(dhts_ctx *c, const char *regions) {
+    if (!c || !c->bam_open) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->rg_active = false; c->rg_all = false; c->rg_nocoor = false; c->rg_empty_window = false; c->rg_beg.clear(); c->rg_end.clear(); c->rg_tid_first.clear();
+    c->scan_first_uoff = c->first_rec_uoff; c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1;
+    if (!regions || !*regions) return dhts_bam_rewind(c);
+    const size_t n_ref = c->ref_name.size();
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> per(n_ref);
+    int usable = 0;
+    std::string all(regions); size_t p = 0;
+    while (p <= all.size()) {
+        size_t q = all.find(',', p); if (q == std::string::npos) q = all.size();
+        std::string tok = all.substr(p, q - p); p = q + 1;
+        if (tok.empty()) continue;
+        if (tok == ".") { c->rg_all = true; usable++; continue; }
+        if (tok == "*") { c->rg_nocoor = true; usable++; continue; }
+        int tid; int64_t b, e;
+        if (!parse_region_token(c->ref_name, tok, tid, b, e)) continue;
+        per[tid].push_back({b, e}); usable++;
+    }
+    if (!usable) return 1;
+    c->rg_tid_first.assign(n_ref + 1, 0);
+    for (size_t t = 0; t < n_ref; t++) {
+        auto &v = per[t];
+        std::sort(v.begin(), v.end());
+        c->rg_tid_first[t] = (uint32_t)c->rg_beg.size();
+        for (size_t j = 0; j < v.size(); j++) {
+            if (!c->rg_beg.empty() && c->rg_beg.size() > c->rg_tid_first[t] && !(c->rg_end.back() < v[j].first)) { if (c->rg_end.back() < v[j].second) c->rg_end.back() = v[j].second; }
+            else { c->rg_beg.push_back(v[j].first); c->rg_end.push_back(v[j].second); }
+        }
+    }
+    c->rg_tid_first[n_ref] = (uint32_t)c->rg_beg.size();
+    ENSURE(c, c->d_rg_beg, c->rg_beg.size() * 8 + 16); ENSURE(c, c->d_rg_end, c->rg_end.size() * 8 + 16); ENSURE(c, c->d_rg_first, (n_ref + 1) * 4 + 16);
+    if (!c->rg_beg.empty()) { HIPCHK(c, hipMemcpy(c->d_rg_beg.p, c->rg_beg.data(), c->rg_beg.size() * 8, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->d_rg_end.p, c->rg_end.data(), c->rg_end.size() * 8, hipMemcpyHostToDevice)); }
+    HIPCHK(c, hipMemcpy(c->d_rg_first.p, c->rg_tid_first.data(), (n_ref + 1) * 4, hipMemcpyHostToDevice));
+    c->rg_active = true;
+    return dhts_bam_rewind(c);
+}
+
+// BAI (SAM spec 5.2; htslib hts.c:2920-3055 loader): narrows the scan to the BGZF blocks between the smallest chunk start and the
+// largest chunk end of the bins the regions touch (reg2bins hts.c:3142-3213, linear index lower bound hts.c:3421-3470).  The
+// window is a superset of the iterator's chunk list; the device predicate decides the rows, so the result is exact.
+int dhts_bam_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
+    if (!c || !c->bam_open) return -1;
+    const uint8_t *d = (const uint8_t *)bytes; uint64_t p = 0;
+    auto need = [&](uint64_t k) { return p + k <= n; };
+    if (!need(8) || memcmp(d, "BAI\1", 4) != 0) return fail(c, "index is not a BAI file");
+    const int32_t n_ref = (int32_t)hle32(d + 4); p = 8;
+    auto hle64 = [&](const uint8_t *q) { return (uint64_t)hle32(q) | ((uint64_t)hle32(q + 4) << 32); };
+    uint64_t vmin = ~0ull, vmax = 0, last_end = 0; bool any = false;
+    const bool whole = !c->rg_active || c->rg_all;
+    for (int32_t t = 0; t < n_ref; t++) {
+        if (!need(4)) return fail(c, "truncated BAI");
+        const int32_t n_bin = (int32_t)hle32(d + p); p += 4;
+        // candidate bins of this reference's query intervals
+        std::vector<std::pair<uint32_t, uint32_t>> binr;      // inclusive bin id ranges per level
+        uint32_t i0 = 0, i1 = 0;
+        if (c->rg_active && (size_t)t + 1 < c->rg_tid_first.size()) { i0 = c->rg_tid_first[t]; i1 = c->rg_tid_first[t + 1]; }
+        for (uint32_t k = i0; k < i1; k++) {
+            int64_t b = c->rg_beg[k], e = c->rg_end[k]; if (e > (1ll << 29)) e = 1ll << 29; if (b >= e) continue; --e;
+            binr.push_back({0, 0});
+            for (int l = 1, tt = 1, sft = 26; l <= 5; l++, sft -= 3) { binr.push_back({(uint32_t)(tt + (b >> sft)), (uint32_t)(tt + (e >> sft))}); tt += 1 << (l * 3); }
+        }
+        struct Ch { uint64_t u, v; uint32_t bin; };
+        std::vector<Ch> chunks;
+        for (int32_t bi = 0; bi < n_bin; bi++) {
+            if (!need(8)) return fail(c, "truncated BAI");
+            const uint32_t bin = hle32(d + p); const int32_t n_chunk = (int32_t)hle32(d + p + 4); p += 8;
+            if (n_chunk < 0 || !need((uint64_t)n_chunk * 16)) return fail(c, "truncated BAI");
+            for (int32_t k = 0; k < n_chunk; k++) {
+                const uint64_t u = hle64(d + p), v = hle64(d + p + 8); p += 16;
+                if (bin == 37450) { if (k == 0 && v > last_end) last_end = v; continue; }     // metadata pseudo-bin: (ref_beg, ref_end), (n_mapped, n_unmapped)
+                if (v > last_end) last_end = v;
+                bool hit = whole;
+                for (auto &r : binr) if (bin >= r.first && bin <= r.second) { hit = true; break; }
+                if (hit) chunks.push_back({u, v, bin});
+            }
+        }
+        if (!need(4)) return fail(c, "truncated BAI");
+        const int32_t n_intv = (int32_t)hle32(d + p); p += 4;
+        if (n_intv < 0 || !need((uint64_t)n_intv * 8)) return fail(c, "truncated BAI");
+        uint64_t min_off = 0;
+        if (i1 > i0 && n_intv > 0) { int64_t w = c->rg_beg[i0] >> 14; if (w >= n_intv) w = n_intv - 1; min_off = hle64(d + p + (uint64_t)w * 8); }
+        p += (uint64_t)n_intv * 8;
+        for (auto &ch : chunks) {
+            if (ch.v <= min_off) continue;                       // entirely before the first alignment that can overlap (hts.c:3556-3563)
+            any = true;
+            if (ch.u < vmin) vmin = ch.u;
+            if (ch.v > vmax) vmax = ch.v;
+        }
+    }
+    int64_t b0 = 0, b1 = c->n_blocks; uint64_t first_uoff = c->first_rec_uoff;
+    auto block_of = [&](uint64_t coffset) -> int64_t {          // BGZF block whose compressed offset is coffset (or the next one)
+        int64_t lo = 0, hi = c->n_blocks;
+        while (lo < hi) { int64_t mid = (lo + hi) / 2; if (c->h_coff[mid] < coffset) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    if (!whole && !c->rg_nocoor) {
+        if (!any) { c->rg_empty_window = true; return dhts_bam_rewind(c); }
+        b0 = block_of(vmin >> 16); b1 = block_of(vmax >> 16) + 1; if (b1 > c->n_blocks) b1 = c->n_blocks;
+        if (b0 >= c->n_blocks || c->h_coff[b0] != (vmin >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(vmin >> 16));
+        first_uoff = c->h_uoff[b0] + (vmin & 0xffff);
+        if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
+    } else if (!whole && c->rg_nocoor) {
+        // mapped windows (if any) plus everything after the last mapped chunk: start at the earliest, run to the end of the file
+        uint64_t s0 = any ? vmin : last_end;
+        b0 = block_of(s0 >> 16); if (b0 >= c->n_blocks) b0 = c->n_blocks > 0 ? c->n_blocks - 1 : 0;
+        if (c->n_blocks > 0 && c->h_coff[b0] == (s0 >> 16)) first_uoff = c->h_uoff[b0] + (s0 & 0xffff); else { b0 = 0; first_uoff = c->first_rec_uoff; }
+        if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
+    }
+    c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = 0; c->shard_world = (b1 < c->n_blocks) ? 2 : 1; c->scan_first_uoff = first_uoff;
+    return dhts_bam_rewind(c);
 }
 
 int dhts_bam_rewind(dhts_ctx *c) {
     if (!c) return -1;
-    c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+    c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = c->rg_empty_window; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;            // a new pass redoes phase A (nothing is cached across scans)
     skip_header_blocks(c);
     return 0;
@@ -615,9 +804,9 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     TileOut to; to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
     TileOut to2; to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
     uint64_t start0;
-    if (c->first_batch) start0 = (c->shard_rank == 0) ? c->first_rec_uoff - out_base : NONE64;   // later shards speculate their first record
+    if (c->first_batch) start0 = (c->shard_rank == 0) ? c->scan_first_uoff - out_base : NONE64;   // later shards speculate their first record
     else start0 = 0;                                           // the carry begins on a record boundary
-    if (c->first_batch && c->shard_rank == 0 && c->first_rec_uoff < out_base) return fail(c, "internal: header beyond first batch");
+    if (c->first_batch && c->shard_rank == 0 && c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch");
     uint64_t res[4] = {0, 0, 0, 0};
     {
         KTimer tm(c, DHTS_K_TILES);
@@ -664,18 +853,43 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         bc.rg_valid = (uint64_t *)c->c_rgvalid.p; bc.len_qname = (uint32_t *)c->l_qname.p; bc.len_cigar = (uint32_t *)c->l_cigar.p; bc.len_seq = (uint32_t *)c->l_seq.p;
         bc.len_qual = (uint32_t *)c->l_qual.p; bc.len_rg = (uint32_t *)c->l_rg.p; bc.cig_rel = (uint32_t *)c->cig_rel.p; bc.ncig_eff = (uint32_t *)c->ncig_eff.p; bc.rg_rel = (uint32_t *)c->rg_rel.p;
         HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));     // first invalid row (none)
+        const bool filtered = c->rg_active && !c->rg_all;
+        const uint32_t *row_map = nullptr;
+        uint64_t kept_total = (uint64_t)nrows;
+        if (filtered) {
+            // region predicate per record, then a scan turns the keep flags into compacted row ids
+            ENSURE(c, c->c_keep, n * 4 + 16); ENSURE(c, c->c_rowmap, (n + 1) * 4 + 16);
+            RegionDev rg; rg.beg = (const int64_t *)c->d_rg_beg.p; rg.end = (const int64_t *)c->d_rg_end.p; rg.tid_first = (const uint32_t *)c->d_rg_first.p;
+            rg.n_ref = (int32_t)c->ref_name.size(); rg.all = 0; rg.nocoor = c->rg_nocoor ? 1 : 0; rg.pad = 0;
+            {
+                KTimer tm(c, DHTS_K_CORE);
+                hipLaunchKernelGGL(bam_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (const uint32_t *)c->t_rowbase.p,
+                                   (const uint64_t *)c->d_res.p, (uint32_t *)c->rec_off.p);
+                hipLaunchKernelGGL(bam_region_keep, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, rg, (const uint32_t *)c->rec_off.p, nrows, (uint32_t *)c->c_keep.p);
+            }
+            const uint32_t *kin[1] = {(const uint32_t *)c->c_keep.p}; uint32_t *kout[1] = {(uint32_t *)c->c_rowmap.p};
+            { KTimer tm(c, DHTS_K_SCAN); if (run_scan(c, 1, kin, kout, nullptr, nrows, &kept_total)) return -1; }
+            row_map = (const uint32_t *)c->c_rowmap.p;
+        }
         {
             KTimer tm(c, DHTS_K_CORE);
             hipLaunchKernelGGL(bam_tile_unpack, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, dict, ntiles, to, (const uint32_t *)c->t_rowbase.p,
-                               (const uint64_t *)c->d_res.p, nrows, (uint32_t *)c->rec_off.p, (uint8_t *)c->c_rgflag.p, bc, (unsigned long long *)((uint64_t *)c->d_res.p + 4));
+                               (const uint64_t *)c->d_res.p, nrows, (uint32_t *)c->rec_off.p, (uint8_t *)c->c_rgflag.p, bc, (unsigned long long *)((uint64_t *)c->d_res.p + 4), row_map);
         }
         {   // the first row that fails bam_read1's validation ends the scan there (rows before it are kept)
             unsigned long long bad = ~0ull;
             HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (bad < (unsigned long long)nrows) { nrows = (int64_t)bad; rec_err = true; }
+            if (bad < (unsigned long long)nrows) {
+                rec_err = true;
+                if (filtered) { uint32_t kb = 0; HIPCHK(c, hipMemcpy(&kb, (const uint32_t *)c->c_rowmap.p + bad, 4, hipMemcpyDeviceToHost)); kept_total = kb; }
+                nrows = (int64_t)bad;
+            }
         }
-        if (nrows > 0 && sharded_tail && out_base + ulen > shard_end_u) {
+        if (filtered) {
+            if (sharded_tail && out_base + ulen > shard_end_u && carry_start >= shard_end_u - out_base) shard_finished = true;   // rows past the index window never match
+            nrows = (int64_t)kept_total;
+        } else if (nrows > 0 && sharded_tail && out_base + ulen > shard_end_u) {
             // drop rows whose record starts at/after the shard end (they belong to the next shard): binary search on rec_off
             std::vector<uint32_t> ro(nrows);
             HIPCHK(c, hipMemcpyAsync(ro.data(), c->rec_off.p, nrows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -759,7 +973,7 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
     if (c->bh.has_vep_tag) return fail(c, "read_bcf: VEP/CSQ annotation columns are not supported by this build");
     dhts::bcf_build_schema(c->bh, tidy_format != 0, c->bsch);
     c->bcf_tidy_req = tidy_format != 0;
-    c->first_rec_uoff = text_end;
+    c->first_rec_uoff = text_end; c->scan_first_uoff = text_end;
     // host-visible dictionaries
     c->bcf_colinfo.clear(); c->bcf_ctg_p.clear(); c->bcf_dict_p.clear(); c->bcf_smp_p.clear();
     for (auto &col : c->bsch.cols) {
@@ -861,9 +1075,9 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     TileOut to; to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
     TileOut to2; to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
     uint64_t start0;
-    if (c->first_batch) start0 = (c->shard_rank == 0) ? c->first_rec_uoff - out_base : NONE64;
+    if (c->first_batch) start0 = (c->shard_rank == 0) ? c->scan_first_uoff - out_base : NONE64;
     else start0 = 0;
-    if (c->first_batch && c->shard_rank == 0 && c->first_rec_uoff < out_base) return fail(c, "internal: header beyond first batch");
+    if (c->first_batch && c->shard_rank == 0 && c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch");
     uint64_t res[4] = {0, 0, 0, 0};
     {
         KTimer tm(c, DHTS_K_TILES);

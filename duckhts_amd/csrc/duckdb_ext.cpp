@@ -32,7 +32,7 @@ static inline void set_null(duckdb_vector vec, idx_t row) {           // src/bam
 }
 
 struct BamBind {
-    std::string path;
+    std::string path, region, index_file;
     dhts_ctx *ctx = nullptr;          // resident file + header, reused by the scan (one GPU)
     dhts_bam_header hdr;
     int has_index = 0;
@@ -89,6 +89,7 @@ static void bam_read_bind(duckdb_bind_info info) {
     b->path = file_path;
     std::string idx = index_path ? index_path : "";
     bool has_region = region && strlen(region) > 0;
+    std::string region_copy = has_region ? region : "";
     dfree(file_path); if (region) dfree(region); if (index_path) dfree(index_path); if (reference) dfree(reference);
 
     char err[768];
@@ -107,12 +108,16 @@ static void bam_read_bind(duckdb_bind_info info) {
         set_error(info, "Failed to read SAM/BAM/CRAM header");                    // bam_reader.c:461 (also what SAM/CRAM input gets here)
         delete b; return;
     }
-    b->has_index = (!idx.empty() && file_exists(idx)) || file_exists(b->path + ".bai") || file_exists(b->path + ".csi");   // bam_reader.c:499-503
-    if (has_region) {
-        if (!b->has_index) set_error(info, "Region query requires an index (.bai/.csi/.crai)");                           // bam_reader.c:647-648
-        else set_error(info, "read_bam: region queries are not on the MI355X scan path yet");
-        delete b; return;
+    // index lookup order of sam_index_load3 (hts.c:4720-4790): explicit path, <file>.csi, <file>.bai, <file minus .bam>.bai/.csi
+    {
+        std::string stem = b->path.size() > 4 && b->path.compare(b->path.size() - 4, 4, ".bam") == 0 ? b->path.substr(0, b->path.size() - 4) : std::string();
+        std::vector<std::string> cand;
+        if (!idx.empty()) cand.push_back(idx);
+        else { cand.push_back(b->path + ".csi"); cand.push_back(b->path + ".bai"); if (!stem.empty()) { cand.push_back(stem + ".csi"); cand.push_back(stem + ".bai"); } }
+        for (auto &f : cand) if (file_exists(f)) { b->index_file = f; break; }
     }
+    b->has_index = !b->index_file.empty();                                       // bam_reader.c:499-503
+    if (has_region) b->region = region_copy;
     if (standard_tags || auxiliary_tags) { set_error(info, "read_bam: standard_tags / auxiliary_tags are not on the MI355X scan path yet"); delete b; return; }
 
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
@@ -141,7 +146,25 @@ static void bam_read_local_init(duckdb_init_info info) {
         l->column_ids.push_back(id);
         if (id < DHTS_BAM_CORE_COUNT) l->colmask |= 1u << id;
     }
-    if (dhts_bam_rewind(bind->ctx) != 0) { API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
+    auto init_error = API(void, duckdb_init_set_error, duckdb_init_info, const char *);
+    if (!bind->region.empty()) {
+        // bam_reader.c:639-668: a region needs an index; sam_itr_regarray failing reports "No reads found"
+        if (!bind->has_index) { init_error(info, "Region query requires an index (.bai/.csi/.crai)"); delete l; return; }
+        int rc = dhts_bam_set_regions(bind->ctx, bind->region.c_str());
+        if (rc != 0) {
+            char err[640]; snprintf(err, sizeof(err), "No reads found for region(s): %s", bind->region.c_str());
+            init_error(info, rc == 1 ? err : dhts_error(bind->ctx)); delete l; return;
+        }
+        // a BAI narrows the scan window (a CSI only satisfies the index requirement for now; the device predicate decides the rows)
+        FILE *f = fopen(bind->index_file.c_str(), "rb");
+        if (f) {
+            std::vector<uint8_t> ib; uint8_t tmp[65536]; size_t k;
+            while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) ib.insert(ib.end(), tmp, tmp + k);
+            fclose(f);
+            if (ib.size() >= 4 && memcmp(ib.data(), "BAI\1", 4) == 0 && dhts_bam_load_index(bind->ctx, ib.data(), ib.size()) != 0) { init_error(info, dhts_error(bind->ctx)); delete l; return; }
+        }
+    } else if (dhts_bam_set_regions(bind->ctx, nullptr) != 0) { init_error(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
+    if (bind->region.empty() && dhts_bam_rewind(bind->ctx) != 0) { init_error(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
     API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, l, destroy_local);
 }
 

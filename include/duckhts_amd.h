@@ -117,6 +117,13 @@ int dhts_bam_set_shard(dhts_ctx *, int rank, int world);           /* scan only 
 int dhts_bam_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);   /* explicit shard: blocks [b0,b1) */
 /* the shard cut itself (host arithmetic only): blocks [*b0,*b1) of rank, balanced by compressed bytes */
 int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, int rank, int world, int64_t *b0, int64_t *b1);
+/* region := 'chr:beg-end,...' (sam_itr_regarray, htslib sam.c:1763-1790 over hts_reglist_create region.c:177-260, hts_parse_region
+ * hts.c:3995-4150, the predicate of hts_itr_multi_next hts.c:4575-4592 + bam_endpos sam.c:668-673).  Rows are filtered on the device.
+ * Returns 0, 1 when no region names a known reference (reference: "No reads found for region(s): ..."), <0 on error.          */
+int dhts_bam_set_regions(dhts_ctx *, const char *regions);
+/* BAI bytes (hts_idx_load: hts.c:2920-3055): narrows the scan window to the chunks of the bins the regions touch (reg2bins
+ * hts.c:3142-3213 + linear index); optional for exactness, call after dhts_bam_set_regions.                                    */
+int dhts_bam_load_index(dhts_ctx *, const void *bai_bytes, uint64_t n);
 int dhts_bam_rewind(dhts_ctx *);
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 

@@ -1,0 +1,149 @@
+"""region_oracle.py -- CPU restatement (numpy) of the read_bam region semantics.  TEST INFRASTRUCTURE ONLY (see dhts_oracle.h).
+
+Follows, by reading: src/bam_reader.c:318-348 (comma split with strtok), htslib region.c:177-260 hts_reglist_create ("." / "*" /
+unknown names skipped, per-tid sort + merge region.c:100-120), hts.c:3995-4150 hts_parse_region and 3884-3940 hts_parse_decimal with
+thousands separators, the overlap test of hts_itr_multi_next hts.c:4575-4592 (end > iv.beg and iv.end > beg) with
+beg = pos, end = bam_endpos (sam.c:668-673).  Valid for coordinate-sorted, correctly indexed files, where the index only
+accelerates; pinned by test/sql/duckhts.test:139-161, 610-618 (18 / 2 / dedup / index_path).
+"""
+import re
+
+import numpy as np
+
+POS_MAX = (1 << 63) - 1
+
+
+def parse_decimal(s):
+    """-> (value, rest) like hts_parse_decimal(HTS_PARSE_THOUSANDS_SEP); (None, s) when no digits."""
+    m = re.match(r"\s*([+-]?)([0-9,]*)(\.[0-9]*)?", s)
+    sign, ip, fp = m.group(1), m.group(2) or "", (m.group(3) or "")[1:]
+    digits = ip.replace(",", "") + fp
+    if not digits:
+        return None, s
+    rest = s[m.end():]
+    e = 0
+    m2 = re.match(r"[eE]([+-]?[0-9]*)", rest)
+    if m2:
+        e = int(m2.group(1) or 0) if m2.group(1) not in ("", "+", "-") else 0
+        rest = rest[m2.end():]
+    elif rest[:1] in "kK" and rest[:1]:
+        e, rest = 3, rest[1:]
+    elif rest[:1] in "mM" and rest[:1]:
+        e, rest = 6, rest[1:]
+    elif rest[:1] in "gG" and rest[:1]:
+        e, rest = 9, rest[1:]
+    n = int(digits)
+    e -= len(fp)
+    n = n * 10 ** e if e >= 0 else n // 10 ** (-e)
+    return (-n if sign == "-" else n), rest
+
+
+def parse_region(names, tok):
+    """-> (tid, beg, end) or None (unknown reference / malformed)."""
+    def getid(nm):
+        return names.index(nm) if nm in names else -1
+    if tok.startswith("{"):
+        close = tok.find("}")
+        if close < 0:
+            return None
+        name = tok[1:close]
+        tid = getid(name)
+        if tok[close + 1:close + 2] != ":":
+            return (tid, 0, POS_MAX) if tid >= 0 else None
+        coords = tok[close + 2:]
+    else:
+        colon = tok.rfind(":")
+        if colon < 0:
+            tid = getid(tok)
+            return (tid, 0, POS_MAX) if tid >= 0 else None
+        if getid(tok) >= 0:
+            return None if getid(tok[:colon]) >= 0 else (getid(tok), 0, POS_MAX)
+        tid = getid(tok[:colon])
+        coords = tok[colon + 1:]
+    if tid < 0:
+        return None
+    v, rest = parse_decimal(coords)
+    beg = (0 if v is None else v) - 1
+    if beg < 0:
+        if beg != -1 and rest[:1] == "-" and coords != "":
+            return None
+        if rest[:1].isdigit() or rest == "" or rest[:1] == ",":
+            return (tid, 0, POS_MAX if beg == -1 else -(beg + 1))
+        if beg < -1:
+            return None
+    if rest == "":
+        end = POS_MAX
+    elif rest[0] == "-":
+        v2, r2 = parse_decimal(rest[1:])
+        end = 0 if v2 is None else v2
+        if r2 not in ("",) and r2[:1] != ",":
+            return None
+    else:
+        return None
+    if end == 0:
+        end = POS_MAX
+    if beg >= end:
+        return None
+    return tid, beg, end
+
+
+def reglist(names, region_string):
+    """-> (per-tid merged interval lists, all_flag, nocoor_flag) or None when nothing usable remains."""
+    per, allf, noc, usable = {}, False, False, 0
+    for tok in region_string.split(","):
+        if tok == "":
+            continue
+        if tok == ".":
+            allf, usable = True, usable + 1
+        elif tok == "*":
+            noc, usable = True, usable + 1
+        else:
+            r = parse_region(names, tok)
+            if r is None:
+                continue
+            per.setdefault(r[0], []).append((r[1], r[2]))
+            usable += 1
+    if not usable:
+        return None
+    for t, v in per.items():
+        v.sort()
+        out = [list(v[0])]
+        for b, e in v[1:]:
+            if out[-1][1] < b:
+                out.append([b, e])
+            elif out[-1][1] < e:
+                out[-1][1] = e
+        per[t] = out
+    return per, allf, noc
+
+
+def endpos(pos0, flag, cigar):
+    """bam_endpos: pos + reference length of the CIGAR (M D N = X), 1 if 0 or the read is unmapped; cigar = text column"""
+    rlen = 0
+    if not (flag & 4) and cigar != b"*":
+        for ln, op in re.findall(rb"([0-9]+)(.)", cigar):
+            if op in b"MDN=X":
+                rlen += int(ln)
+    return pos0 + (rlen or 1)
+
+
+def keep_mask(table, region_string):
+    """table = orc.bam_read(...) result -> boolean numpy mask of the rows read_bam(region := ...) returns (file order)."""
+    names = [bytes(x).decode() for x in table["ref_names"]]
+    rl = reglist(names, region_string)
+    if rl is None:
+        return None
+    per, allf, noc = rl
+    n = table["n_rows"]
+    keep = np.zeros(n, bool)
+    for i in range(n):
+        tid = int(table["tid"][i])
+        if allf:
+            keep[i] = True
+        elif tid < 0:
+            keep[i] = noc
+        elif tid in per:
+            beg = int(table["POS"][i]) - 1
+            end = endpos(beg, int(table["FLAG"][i]), table["CIGAR"][i])
+            keep[i] = any(end > b and e > beg for b, e in per[tid])
+    return keep

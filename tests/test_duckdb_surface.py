@@ -156,7 +156,39 @@ def test_read_bam_bind_errors_on_gpu(tmp_path):
     good = os.path.join(str(tmp_path), "noindex.bam")
     open(good, "wb").write(cases.case_basic(n=50))
     rc, out, _ = run_host(good, named=[("region", "chr1:1-100")])
-    assert rc == 3 and out == "ERROR bind: Region query requires an index (.bai/.csi/.crai)"   # bam_reader.c:647-648
+    assert rc == 3 and out == "ERROR init: Region query requires an index (.bai/.csi/.crai)"   # bam_reader.c:647-648 (raised by local_init)
+
+
+@pytest.mark.gpu
+def test_read_bam_region_through_the_surface(tmp_path):
+    """duckhts.test:139-161, 610-618 through bind/init/scan: counts 18 / 2 / dedup, explicit index_path, unknown reference"""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle
+    fn = os.path.join(str(tmp_path), "range.bam")
+    shutil.copy(os.path.join(GOLDEN, "range.bam"), fn)
+    shutil.copy(os.path.join(GOLDEN, "range.bam.bai"), fn + ".bai")
+    data = open(fn, "rb").read()
+    exp = orc.bam_read(data)
+    for region, want in (("CHROMOSOME_I", 18), ("CHROMOSOME_I:1-1000", 2), ("CHROMOSOME_I:1-1000,CHROMOSOME_I:1-1000", 2), ("CHROMOSOME_II:100-2000,CHROMOSOME_V", None)):
+        rc, out, dump = run_host(fn, named=[("region", region)])
+        assert rc == 0, out
+        keep = region_oracle.keep_mask(exp, region)
+        if want is not None:
+            assert int(keep.sum()) == want
+        assert f"rows={int(keep.sum())} " in out
+        schema, chunks = parse_chunks(dump)
+        got_q = [v for n, cols in chunks for v in cols[0][2]]
+        assert got_q == [q for q, m in zip(exp["QNAME"], keep) if m]
+        got_pos = np.concatenate([cols[3][2] for n, cols in chunks]) if chunks else np.zeros(0, np.int64)
+        assert np.array_equal(got_pos, exp["POS"][keep])
+    other = os.path.join(str(tmp_path), "elsewhere.bai")
+    shutil.move(fn + ".bai", other)
+    rc, out, _ = run_host(fn, named=[("region", "CHROMOSOME_I:1-1000"), ("index_path", other)])
+    assert rc == 0 and "rows=2 " in out
+    rc, out, _ = run_host(fn, named=[("region", "nosuch:1-5"), ("index_path", other)])
+    assert rc == 3 and out == "ERROR init: No reads found for region(s): nosuch:1-5"           # bam_reader.c:662-667
 
 
 # ---- read_bcf ---------------------------------------------------------------------------------------------------------

@@ -7,7 +7,10 @@ import pytest
 import cases
 import duckhts_amd
 import orc
-from conftest import read_golden
+import os
+
+from conftest import GOLDEN, ROOT, read_golden
+from duckhts_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -197,3 +200,43 @@ def test_full_size_properties():
             break
     assert status == 1 and rows == n and seq_bytes == 150 * n
     ctx.close()
+
+
+# ---- region queries (row A11) -----------------------------------------------------------------------------------------
+def _region_check(data, region, index=None, **kw):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle
+    exp = orc.bam_read(data)
+    keep = region_oracle.keep_mask(exp, region)
+    got = duckhts_amd.read_bam(data, region=region, index=index, **kw)
+    assert got["n_rows"] == int(keep.sum()), (region, got["n_rows"], int(keep.sum()))
+    for k in duckhts_amd.BAM_COLUMNS:
+        e = [x for x, m in zip(exp[k], keep) if m]
+        assert list(got[k]) == list(e), (region, k)
+    return got["n_rows"]
+
+
+@pytest.mark.gpu
+def test_region_golden_counts():
+    """duckhts.test:139-161, 610-618: full contig 18, sub-range 2, duplicate regions dedup, explicit index"""
+    data = open(os.path.join(GOLDEN, "range.bam"), "rb").read()
+    bai = open(os.path.join(GOLDEN, "range.bam.bai"), "rb").read()
+    for index in (None, bai):
+        assert _region_check(data, "CHROMOSOME_I", index) == 18
+        assert _region_check(data, "CHROMOSOME_I:1-1000", index) == 2
+        assert _region_check(data, "CHROMOSOME_I:1-1000,CHROMOSOME_I:1-1000", index) == 2
+        assert _region_check(data, "CHROMOSOME_II:2,000-3,500,CHROMOSOME_I:900-1000,nosuch:1-5,CHROMOSOME_V", index) > 0
+        assert _region_check(data, ".", index) == 112
+        assert _region_check(data, "*", index) == 0
+        _region_check(data, "CHROMOSOME_III:-1500", index)
+        _region_check(data, "CHROMOSOME_IV:1k-2K,{CHROMOSOME_X}:1-10", index)
+    with pytest.raises(duckhts_amd.DhtsError):
+        duckhts_amd.read_bam(data, region="nosuch")
+
+
+@pytest.mark.gpu
+def test_region_synthetic_with_unplaced_and_batches():
+    data = synth.bam_file(120000, seed=5)
+    for region in ("chr1:1,000,000-2,000,000", "chr2:5000000-5100000,chr2:5050000-6000000,chrX", "chrM,*", "chr21:1-1000,chr22"):
+        _region_check(data, region, max_blocks=7)

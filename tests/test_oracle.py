@@ -5,6 +5,7 @@ lines 127-149) and htslib's test.pl fixtures (ce#1.sam <-> bgzf_boundaries*.bam,
 range.out / range.out2, test.pl:911-929; no_hdr_sq_1.expected.sam).
 """
 import collections
+import os
 import random
 import struct
 import zlib
@@ -14,6 +15,7 @@ import pytest
 
 import bamwriter as bw
 import cases
+from conftest import ROOT
 import orc
 from conftest import read_golden
 
@@ -245,3 +247,23 @@ def test_synthetic_generator_roundtrip():
     b, _ = synth.bam_segment(10000, seed=7, total_n=20000, rec0=10000, with_header=False, threads=2)
     r2 = orc.bam_read(a.tobytes() + b.tobytes())
     assert r2["n_rows"] == 20000 and r2["QNAME"] == r["QNAME"] and np.array_equal(r2["POS"], r["POS"])
+
+
+def test_region_oracle_pins():
+    """read_bam(region := ...) restatement (oracle/region_oracle.py) against test/sql/duckhts.test:139-161"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle
+    t = orc.bam_read(read_golden("range.bam"))
+    cnt = lambda r: int(region_oracle.keep_mask(t, r).sum())
+    assert cnt("CHROMOSOME_I") == 18 and cnt("CHROMOSOME_I:1-1000") == 2 and cnt("CHROMOSOME_I:1-1000,CHROMOSOME_I:1-1000") == 2
+    assert cnt(".") == 112 and cnt("*") == 0
+    assert region_oracle.keep_mask(t, "nosuch") is None
+    names = ["chr1", "chr1:100-200", "a:b"]
+    assert region_oracle.parse_region(names, "chr1:1,000-2k") == (0, 999, 2000)
+    assert region_oracle.parse_region(names, "{chr1:100-200}") == (1, 0, region_oracle.POS_MAX)
+    assert region_oracle.parse_region(names, "chr1:100-200") is None          # ambiguous (hts.c:4075-4093)
+    assert region_oracle.parse_region(names, "a:b:5-") == (2, 4, region_oracle.POS_MAX)
+    assert region_oracle.parse_region(names, "chr1:-100") == (0, 0, 100)
+    assert region_oracle.parse_region(names, "chr1:0-5") == (0, -1, 5)            # falls through hts.c:4118-4131 with beg = -1
+    assert region_oracle.parse_region(names, "chr1:9-5") is None
