@@ -69,7 +69,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
            "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
-           "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range",
+           "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
 
@@ -116,6 +116,7 @@ def lib():
         L.dhts_bcf_set_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.dhts_bcf_set_block_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
         L.dhts_bcf_rewind.argtypes = [C.c_void_p]
+        L.dhts_bcf_set_region.argtypes = [C.c_void_p, C.c_char_p]
         L.dhts_bcf_next_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(BcfBatch)]
         _LIB = L
     return _LIB
@@ -329,6 +330,10 @@ class BcfScan:
     def rewind(self):
         self.ctx._chk(self.ctx.L.dhts_bcf_rewind(self.ctx.h))
 
+    def set_region(self, region):
+        """one region (the reference chains them); False when the region yields no iterator (unknown contig)"""
+        return self.ctx._chk(self.ctx.L.dhts_bcf_set_region(self.ctx.h, region.encode() if region else None)) == 0
+
     def next_batch(self, max_blocks=0):
         b = BcfBatch()
         self.ctx._chk(self.ctx.L.dhts_bcf_next_batch(self.ctx.h, max_blocks, C.byref(b)))
@@ -407,7 +412,7 @@ def _concat_tables(parts, schema_cols):
     return out
 
 
-def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=None):
+def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=None, region=None):
     """Full sequential read_bcf scan (every record in file order); returns the canonical column table.
     columns: optional projection (names or schema ids), like DuckDB's projection pushdown."""
     ctx = Context(device)
@@ -420,15 +425,20 @@ def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=
         if block_range is not None:
             sc.set_block_range(*block_range)
         parts, status, first, end = [], 0, None, None
-        while True:
-            b = sc.next_batch(max_blocks)
-            if b.n_rows:
-                parts.append(sc.batch_table(b))
-                first = b.first_rec_uoff if first is None else first
-            end = b.end_uoff
-            status = b.status
-            if b.status != 0:
-                break
+        # region := 'a,b': chained union of single-region scans in the given order (src/bcf_reader.c:1327-1345)
+        passes = [None] if region is None else [r for r in region.split(",") if r]
+        for rg in passes:
+            if rg is not None and not sc.set_region(rg):
+                continue
+            while True:
+                b = sc.next_batch(max_blocks)
+                if b.n_rows:
+                    parts.append(sc.batch_table(b))
+                    first = b.first_rec_uoff if first is None else first
+                end = b.end_uoff
+                status = b.status
+                if b.status != 0:
+                    break
         proj = [sc.schema[i] for i in sc.projection]
         cols = _concat_tables(parts, proj)
         if cols is None:

@@ -298,6 +298,7 @@ struct BcfCellArgs {
     int64_t nrows; int32_t tidy, n_smp;
     uint32_t *lens; const uint32_t *offs; uint32_t ostride;
     const BcfColDev *cols;
+    const uint32_t *sel;          // region filter: compacted list of kept record ids (nullptr = every record)
 };
 
 __device__ __forceinline__ uint32_t cstr_len(const uint8_t *p, uint32_t n) { uint32_t l = 0; while (l < n && p[l]) l++; return l; }
@@ -336,7 +337,8 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
     const BcfColDev cd = a.cols[blockIdx.y];
     if (WRITE && cd.sa_cnt < 0 && cd.sa_bytes < 0) return;
     const uint8_t *u = st.u;
-    const int64_t rec = a.tidy ? row / a.n_smp : row;
+    int64_t rec = a.tidy ? row / a.n_smp : row;
+    if (a.sel) rec = a.sel[rec];
     const int smp = cd.sample >= 0 ? cd.sample : (a.tidy ? (int)(row % a.n_smp) : 0);
     const uint64_t o = a.rec_off[rec];
     uint32_t cnt = 0, nbytes = 0; bool valid = true;
@@ -493,6 +495,32 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
         // closing offset of the child string table
         cd.child_off[a.offs[(size_t)cd.sa_cnt * a.ostride + a.nrows]] = a.offs[(size_t)cd.sa_bytes * a.ostride + a.nrows];
     }
+}
+
+// ---- region predicate (bcf_itr_querys -> hts_itr_next hts.c:4287-4300 over bcf_readrec vcf.c:2267-2276) ----------------------
+// keep[r] = rid == tid && end > beg_q && end_q > beg, beg = pos, end = pos + rlen (a negative rlen falls back to the REF allele
+// length, the first choice of get_rlen vcf.c:6440-6560); all != 0 keeps every record (region ".").
+extern "C" __global__ void __launch_bounds__(256)
+bcf_region_keep(BcfStream st, const uint32_t *rec_off, const uint32_t *dir, int64_t nrec, int32_t tid, int64_t qbeg, int64_t qend, int32_t all, uint32_t *keep) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint8_t *u = st.u; const uint64_t o = rec_off[r];
+    uint32_t k = 0;
+    if (all) k = 1;
+    else if ((int32_t)ldu32(u + o + 8) == tid) {
+        const uint32_t p32 = ldu32(u + o + 12);
+        const int64_t beg = p32 == 0xffffffffu ? -1 : (int64_t)p32;
+        int64_t rlen = (int32_t)ldu32(u + o + 16);
+        if (rlen < 0) { rlen = 0; const uint32_t d = dir[r]; if (d) { uint64_t p = o + d; int n, t; bcf_dec_size(u, p, n, t); rlen = n > 0 ? (int64_t)cstr_len(u + p, (uint32_t)n) : 0; } }
+        const int64_t end = beg + rlen;
+        if (end > qbeg && qend > beg) k = 1;
+    }
+    keep[r] = k;
+}
+extern "C" __global__ void __launch_bounds__(256)
+bcf_select(const uint32_t *map, int64_t nrec, uint32_t *sel) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrec && map[r + 1] > map[r]) sel[map[r]] = (uint32_t)r;
 }
 
 // ---- matrix exclusive scan: rows of `lens` (narr x stride) -> rows of `offs`, off[n] = total -------------------------------

@@ -79,6 +79,8 @@ struct dhts_ctx {
     dhts::BcfHeader bh; dhts::BcfSchema bsch;
     std::vector<dhts_bcf_colinfo> bcf_colinfo; std::vector<const char *> bcf_ctg_p, bcf_dict_p, bcf_smp_p;
     std::vector<int32_t> bcf_proj; std::vector<dhts_bcf_col> bcf_out;
+    bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
+    DevBuf b_keep, b_map, b_sel;
     DevBuf d_ctg_ok, d_id_ok, d_info_slot, d_fmt_slot, b_rec_off, b_dir, b_lens, b_offs, b_partial, b_total, b_coldev, b_fixed, b_valid, b_var;
     // scan position
     int64_t shard_b0 = 0, shard_b1 = 0;   // block range of this shard
@@ -1022,6 +1024,22 @@ int dhts_bcf_set_projection(dhts_ctx *c, const int32_t *col_ids, int32_t n) {
     return 0;
 }
 
+// one region of read_bcf(region := ...): bcf_itr_querys (htslib vcf.h:1391 -> hts_itr_querys hts.c:4179-4200, "." = everything).
+// Returns 0, 1 when the region yields no iterator (unknown contig / malformed: the reference skips it, bcf_reader.c:935-953), <0 on error.
+int dhts_bcf_set_region(dhts_ctx *c, const char *region) {
+    if (!c || !c->bcf_open) return -1;
+    c->bcf_rg_active = false; c->bcf_rg_all = false;
+    if (!region || !*region) return dhts_bcf_rewind(c);
+    std::string tok(region);
+    if (tok == ".") { c->bcf_rg_active = true; c->bcf_rg_all = true; return dhts_bcf_rewind(c); }
+    std::vector<std::string> names;
+    for (size_t i = 0; i < c->bh.ctg.size(); i++) names.push_back(c->bh.ctg_present[i] ? c->bh.ctg[i] : std::string("\x01"));
+    int tid; int64_t b, e;
+    if (!parse_region_token(names, tok, tid, b, e)) return 1;
+    c->bcf_rg_active = true; c->bcf_rg_tid = tid; c->bcf_rg_beg = b; c->bcf_rg_end = e;
+    return dhts_bcf_rewind(c);
+}
+
 int dhts_bcf_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculative_start) {
     if (!c || !c->bcf_open) return -1;
     if (b0 < 0 || b1 > c->n_blocks || b0 > b1) return fail(c, "bad block range");
@@ -1133,6 +1151,19 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
             if (lo < nrec) { carry_start = ro[lo]; nrec = lo; shard_finished = true; }
             else if (carry_start >= lim) shard_finished = true;
         }
+        const uint32_t *sel = nullptr;
+        if (nrec > 0 && c->bcf_rg_active && !c->bcf_rg_all) {
+            // region predicate per record -> compacted list of kept record ids (validation above covered every record read)
+            const size_t nn = (size_t)nrec;
+            ENSURE(c, c->b_keep, nn * 4 + 16); ENSURE(c, c->b_map, (nn + 1) * 4 + 16); ENSURE(c, c->b_sel, nn * 4 + 16);
+            hipLaunchKernelGGL(bcf_region_keep, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->b_rec_off.p, (const uint32_t *)c->b_dir.p, nrec,
+                               c->bcf_rg_tid, c->bcf_rg_beg, c->bcf_rg_end, 0, (uint32_t *)c->b_keep.p);
+            const uint32_t *kin[1] = {(const uint32_t *)c->b_keep.p}; uint32_t *kout[1] = {(uint32_t *)c->b_map.p}; uint64_t kept = 0;
+            if (run_scan(c, 1, kin, kout, nullptr, nrec, &kept)) return -1;
+            hipLaunchKernelGGL(bcf_select, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)c->b_map.p, nrec, (uint32_t *)c->b_sel.p);
+            sel = (const uint32_t *)c->b_sel.p;
+            nrec = (int64_t)kept;
+        }
         if (nrec > 0 && ncols > 0) {
             const int64_t nrows = nrec * reps;
             const uint32_t ostride = (uint32_t)(((size_t)nrows + 1 + 63) & ~(size_t)63);
@@ -1170,7 +1201,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
             BcfCellArgs ca; memset(&ca, 0, sizeof(ca));
             ca.rec_off = (const uint32_t *)c->b_rec_off.p; ca.dir = (const uint32_t *)c->b_dir.p; ca.stride = stride; ca.nrows = nrows; ca.tidy = c->bsch.tidy ? 1 : 0;
             ca.n_smp = c->bsch.n_samples > 0 ? c->bsch.n_samples : 1; ca.lens = (uint32_t *)c->b_lens.p; ca.offs = (const uint32_t *)c->b_offs.p; ca.ostride = ostride;
-            ca.cols = (const BcfColDev *)c->b_coldev.p;
+            ca.cols = (const BcfColDev *)c->b_coldev.p; ca.sel = sel;
             {
                 KTimer tm(c, DHTS_K_BCF_MEASURE);
                 hipLaunchKernelGGL(bcf_cells<false>, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream, st, ca);

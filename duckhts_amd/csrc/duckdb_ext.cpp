@@ -287,6 +287,7 @@ static void register_read_bam_function(duckdb_connection connection) {          
 // =====================================================================================================================
 struct BcfBind {
     std::string path, region;
+    std::vector<std::string> regions;    // comma split, empty tokens dropped (parse_regions_duckdb, bcf_reader.c:423-446)
     dhts_ctx *ctx = nullptr;
     dhts_bcf_info inf;
     int has_index = 0;
@@ -302,7 +303,16 @@ struct BcfLocal {
     std::vector<int> slot;               // output vector -> index into `cols` (or -1 for unknown ids)
     std::vector<HostCol> cols;           // projected (deduplicated) columns of the current batch
     bool done = false; int64_t n = 0, cur = 0; int status = 0;
+    size_t next_region = 0;              // chained single-region iterators (bcf_reader.c:1327-1345)
 };
+// advance to the next region that yields an iterator; false when none is left
+static bool bcf_next_region(BcfBind *bind, BcfLocal *l) {
+    while (l->next_region < bind->regions.size()) {
+        const std::string &rg = bind->regions[l->next_region++];
+        if (dhts_bcf_set_region(bind->ctx, rg.c_str()) == 0) return true;      // unknown contig / malformed: skipped (bcf_reader.c:944-953)
+    }
+    return false;
+}
 static void destroy_bcf_bind(void *p) { BcfBind *b = (BcfBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
 static void destroy_bcf_local(void *p) { delete (BcfLocal *)p; }
 
@@ -322,6 +332,11 @@ static void bcf_read_bind(duckdb_bind_info info) {
     const int tidy = get_named_bool(info, "tidy_format");
     BcfBind *b = new BcfBind();
     b->path = file_path; if (region) b->region = region;
+    for (size_t p0 = 0; p0 <= b->region.size() && !b->region.empty();) {
+        size_t q = b->region.find(',', p0); if (q == std::string::npos) q = b->region.size();
+        if (q > p0) b->regions.push_back(b->region.substr(p0, q - p0));
+        p0 = q + 1;
+    }
     std::string idx = index_path ? index_path : "";
     dfree(file_path); if (region) dfree(region); if (index_path) dfree(index_path);
     char err[768];
@@ -358,10 +373,9 @@ static void bcf_read_bind(duckdb_bind_info info) {
 
 static void bcf_read_global_init(duckdb_init_info info) {
     BcfBind *bind = (BcfBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
-    if (!bind->region.empty()) {
+    if (!bind->regions.empty() && !bind->has_index) {
         char err[900];
-        if (!bind->has_index) snprintf(err, sizeof(err), "Region query requires an index file (.tbi or .csi). Region: %s", bind->region.c_str());   // bcf_reader.c:922-923
-        else snprintf(err, sizeof(err), "read_bcf: region queries are not on the MI355X scan path yet. Region: %s", bind->region.c_str());
+        snprintf(err, sizeof(err), "Region query requires an index file (.tbi or .csi). Region: %s", bind->region.c_str());   // bcf_reader.c:922-923
         API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, err);
         return;
     }
@@ -385,9 +399,10 @@ static void bcf_read_local_init(duckdb_init_info info) {
         l->slot.push_back(sl);
     }
     l->cols.resize(proj.size());
-    if (dhts_bcf_set_projection(bind->ctx, proj.data(), (int32_t)proj.size()) != 0 || dhts_bcf_rewind(bind->ctx) != 0) {
+    if (dhts_bcf_set_projection(bind->ctx, proj.data(), (int32_t)proj.size()) != 0 || dhts_bcf_set_region(bind->ctx, nullptr) != 0) {
         API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, "Failed to open BCF/VCF file"); delete l; return;
     }
+    if (!bind->regions.empty() && !bcf_next_region(bind, l)) l->done = true;      // no region produced an iterator: zero rows (bcf_reader.c:955-959)
     API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, l, destroy_bcf_local);
 }
 
@@ -438,12 +453,15 @@ static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk outpu
     idx_t row_count = 0;
     while (row_count < vector_size) {
         if (l->cur >= l->n) {
-            if (l->status != 0) { l->done = true; break; }           // EOF, or silent stop at the first bad record (bcf_reader.c:1319-1349)
+            if (l->status != 0) {                                    // EOF, or silent stop at the first bad record (bcf_reader.c:1319-1349)
+                if (!bind->regions.empty() && bcf_next_region(bind, l)) { l->status = 0; l->n = l->cur = 0; }
+                else { l->done = true; break; }
+            }
             if (bcf_next_host_batch(bind, l) != 0) {
                 API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, dhts_error(bind->ctx));
                 l->done = true; set_size(output, 0); return;
             }
-            if (l->n == 0) { l->done = true; break; }
+            if (l->n == 0) { if (l->status != 0) continue; l->done = true; break; }
         }
         idx_t take = (idx_t)(l->n - l->cur); if (take > vector_size - row_count) take = vector_size - row_count;
         const int64_t s = l->cur;

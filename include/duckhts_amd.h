@@ -187,6 +187,10 @@ int dhts_bcf_open(dhts_ctx *, int tidy_format);                      /* header +
 int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
 int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /* default: every schema column */
 int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);
+/* ONE region of read_bcf(region := 'a,b,...'): the reference chains single-region iterators in the order given (src/bcf_reader.c:
+ * 1327-1345; overlapping regions repeat rows).  bcf_itr_querys + the overlap test of hts_itr_next (hts.c:4287-4300) over bcf_readrec
+ * (vcf.c:2267-2276).  0 = set, 1 = no iterator for this region (unknown contig: skipped by the reference), NULL/"" clears.       */
+int dhts_bcf_set_region(dhts_ctx *, const char *region);
 int dhts_bcf_rewind(dhts_ctx *);
 int dhts_bcf_next_batch(dhts_ctx *, int64_t max_blocks, dhts_bcf_batch *out);
 

@@ -451,6 +451,7 @@ typedef struct {
     int c_info0, c_sample, c_fmt0;
     int gt_id;
     int64_t n_rows, n_recs;
+    buf_t rec_rid, rec_pos, rec_rlen;      /* per emitted record: contig id, 0-based pos, rlen (region-oracle inputs) */
 } scan_t;
 
 static void scan_free(scan_t *s)
@@ -460,6 +461,7 @@ static void scan_free(scan_t *s)
     for (int i = 0; i < s->n_info; i++) free(s->info[i].name);
     for (int i = 0; i < s->n_fmt; i++) free(s->fmt[i].name);
     free(s->info); free(s->fmt);
+    free(s->rec_rid.p); free(s->rec_pos.p); free(s->rec_rlen.p);
     hdr_free(&s->h);
 }
 
@@ -670,6 +672,8 @@ static int scan_records(scan_t *s, const uint8_t *u, size_t ulen, size_t pos, in
         }
         if (bad || err) { status = -2; break; }
         s->n_recs++;
+        { int64_t rl = rd_i32(x + 16); if (rl < 0) rl = aln[0] > 0 ? (int64_t)char_len(al[0], aln[0]) : 0;
+          uint64_t a = (uint64_t)(int64_t)rid, b = (uint64_t)rpos, c2 = (uint64_t)rl; buf_u64(&s->rec_rid, a); buf_u64(&s->rec_pos, b); buf_u64(&s->rec_rlen, c2); }
         pos += 32 + (size_t)shared_len + indiv_len;
         if (!materialise) { s->n_rows += s->tidy && h->n_smp > 0 ? h->n_smp : 1; continue; }
 
@@ -773,15 +777,17 @@ static void ser_col(buf_t *o, const col_t *c, int64_t n)
 
 /* Canonical blob: u32 ncol, u64 nrows, i32 status, u64 first_rec_uoff, u32 n_samples; per column: u16 name_len, name, u8 type, u8 is_list,
  * valid[nrows]; scalar fixed: nrows x u64 raw bits | scalar varchar: (nrows+1) x u64 offsets + bytes | list: nrows x (u64 off, u64 len),
- * u64 child_n, child payload in the scalar encoding. */
+ * u64 child_n, child payload in the scalar encoding.  Trailer: u64 n_rec, then i64 rid[n_rec], i64 pos0[n_rec], i64 rlen[n_rec]. */
 int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, uint8_t **blob, size_t *blob_len, int64_t *n_rows)
 {
     orc_bgzf_t bz;
     if (blob) { *blob = NULL; *blob_len = 0; }
     if (n_rows) *n_rows = 0;
-    if (orc_bgzf_inflate_all(file, flen, &bz) < 0 && bz.len == 0) { orc_bgzf_free(&bz); return ORC_BCF_EOPEN; }
+    /* any content that is not a readable BCF2.2 header ends in "Failed to read BCF/VCF header" (bcf_reader.c:505); hts_open itself
+     * only fails for a missing file (ORC_BCF_EOPEN is kept for that case at the surface) */
+    if (orc_bgzf_inflate_all(file, flen, &bz) < 0 && bz.len == 0) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
     const uint8_t *u = bz.data; size_t ulen = bz.len;
-    if (ulen < 9 || memcmp(u, "BCF\2\2", 5)) { orc_bgzf_free(&bz); return ulen >= 3 && !memcmp(u, "BCF", 3) ? ORC_BCF_EHDR : ORC_BCF_EOPEN; }
+    if (ulen < 9 || memcmp(u, "BCF\2\2", 5)) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
     size_t hlen = rd_u32(u + 5);
     if (ulen - 9 < hlen) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
     char *txt = dupn((const char *)u + 9, hlen);
@@ -798,6 +804,7 @@ int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, ui
         uint32_t nc = (uint32_t)s.ncol; uint64_t nr = (uint64_t)s.n_rows, fr = 9 + hlen; int32_t st = status; uint32_t ns = (uint32_t)s.h.n_smp;
         buf_push(&o, &nc, 4); buf_push(&o, &nr, 8); buf_push(&o, &st, 4); buf_push(&o, &fr, 8); buf_push(&o, &ns, 4);
         for (int i = 0; i < s.ncol; i++) ser_col(&o, &s.col[i], s.n_rows);
+        { uint64_t nrec = (uint64_t)s.n_recs; buf_push(&o, &nrec, 8); buf_push(&o, s.rec_rid.p, s.rec_rid.n); buf_push(&o, s.rec_pos.p, s.rec_pos.n); buf_push(&o, s.rec_rlen.p, s.rec_rlen.n); }
         *blob = o.p; *blob_len = o.n;
     }
     scan_free(&s); orc_bgzf_free(&bz);

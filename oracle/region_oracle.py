@@ -147,3 +147,27 @@ def keep_mask(table, region_string):
             end = endpos(beg, int(table["FLAG"][i]), table["CIGAR"][i])
             keep[i] = any(end > b and e > beg for b, e in per[tid])
     return keep
+
+
+def bcf_region_rows(table, contigs, region_string, tidy_reps=1):
+    """read_bcf(region := 'a,b'): chained single-region iterators in the given order (src/bcf_reader.c:1327-1345, 935-953; unknown
+    regions are skipped; overlapping regions repeat rows).  Record test of hts_itr_next (hts.c:4287-4300): rid == tid and
+    end > beg_q and end_q > beg with beg = pos, end = pos + rlen (bcf_readrec vcf.c:2267-2276).
+    table = orc.bcf_read(...) result (its "rec" arrays); -> list of ROW indices in output order."""
+    rec = table["rec"]
+    out = []
+    for tok in region_string.split(","):
+        if tok == "":
+            continue
+        if tok == ".":
+            idx = np.arange(len(rec["rid"]))
+        else:
+            r = parse_region(contigs, tok)
+            if r is None:
+                continue
+            tid, b, e = r
+            beg, end = rec["pos0"], rec["pos0"] + rec["rlen"]
+            idx = np.nonzero((rec["rid"] == tid) & (end > b) & (e > beg))[0]
+        for i in idx:
+            out.extend(range(int(i) * tidy_reps, int(i) * tidy_reps + tidy_reps))
+    return out

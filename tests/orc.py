@@ -175,8 +175,10 @@ def decode_bcf_blob(blob: bytes):
             c["child_n"] = int(take(1, np.uint64)[0])
             payload(c, c["child_n"], "c")
         cols.append(c)
+    nrec = int(take(1, np.uint64)[0])
+    rec = {"rid": take(nrec, np.int64).copy(), "pos0": take(nrec, np.int64).copy(), "rlen": take(nrec, np.int64).copy()}
     assert pos == len(blob), (pos, len(blob))
-    return {"n_rows": n, "status": int(status), "first_rec_off": int(first), "n_samples": int(nsmp), "cols": cols,
+    return {"n_rows": n, "rec": rec, "status": int(status), "first_rec_off": int(first), "n_samples": int(nsmp), "cols": cols,
             "by_name": {c["name"]: c for c in cols}}
 
 
@@ -255,3 +257,35 @@ def bcf_cols_diff(a, b):
                 bad = np.nonzero(ca[k][:min(len(ca[k]), len(cb[k]))] != cb[k][:min(len(ca[k]), len(cb[k]))])[0]
                 return f"{ca['name']}: {k} differs (len {len(ca[k])} vs {len(cb[k])}, first at {bad[0] if len(bad) else 'tail'})"
     return None
+
+
+def bcf_take_rows(table, rows):
+    """Row subset (in the given order, repeats allowed) of a decoded table -> new table in the same canonical layout."""
+    rows = np.asarray(rows, np.int64)
+    cols = []
+    for c in table["cols"]:
+        o = {"name": c["name"], "type": c["type"], "is_list": c["is_list"], "valid": c["valid"][rows]}
+
+        def gather(off, data, idx):
+            ln = (off[1:] - off[:-1])[idx].astype(np.int64)
+            noff = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+            tot = int(noff[-1])
+            src = np.repeat(off[:-1][idx].astype(np.int64) - noff[:-1].astype(np.int64), ln) + np.arange(tot) if tot else np.zeros(0, np.int64)
+            return noff, data[src]
+        if not c["is_list"]:
+            if "fixed" in c:
+                o["fixed"] = c["fixed"][rows]
+            else:
+                o["soff"], o["sbytes"] = gather(c["soff"], c["sbytes"], rows)
+        else:
+            ln = c["llen"][rows].astype(np.int64)
+            noff = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+            o["loff"], o["llen"], o["child_n"] = noff[:-1].copy(), c["llen"][rows], int(noff[-1])
+            tot = int(noff[-1])
+            kid = np.repeat(c["loff"][rows].astype(np.int64) - noff[:-1].astype(np.int64), ln) + np.arange(tot) if tot else np.zeros(0, np.int64)
+            if "cfixed" in c:
+                o["cfixed"] = c["cfixed"][kid]
+            else:
+                o["csoff"], o["csbytes"] = gather(c["csoff"], c["csbytes"], kid)
+        cols.append(o)
+    return {"n_rows": len(rows), "cols": cols, "by_name": {c["name"]: c for c in cols}}

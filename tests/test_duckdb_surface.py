@@ -284,3 +284,22 @@ def test_read_bcf_errors_on_gpu(tmp_path):
     open(fn, "wb").write(open(os.path.join(GOLDEN, "vcf_file.bcf"), "rb").read())
     rc, out, _ = run_host(fn, named=[("region", "1:3000150-3000151")], fn="read_bcf")
     assert rc == 3 and out == "ERROR init: Region query requires an index file (.tbi or .csi). Region: 1:3000150-3000151"   # bcf_reader.c:922-923
+
+
+@pytest.mark.gpu
+def test_read_bcf_region_through_the_surface(tmp_path):
+    """duckhts.test:88-105, 600-607: region counts, chained multi-region, explicit index_path"""
+    import shutil
+    fn = os.path.join(str(tmp_path), "vcf_file.bcf")
+    shutil.copy(os.path.join(GOLDEN, "vcf_file.bcf"), fn)
+    shutil.copy(os.path.join(GOLDEN, "vcf_file.bcf.csi"), fn + ".csi")
+    for region, want in (("1:3000150-3000151", 2), ("1:3062915-3062915", 2), ("1:3000150-3000151,1:3062915-3062915", 4), ("nosuch,4", 2), ("nosuch", 0)):
+        rc, out, dump = run_host(fn, named=[("region", region)], fn="read_bcf", proj=[0, 1, 2])
+        assert rc == 0 and f"rows={want} " in out, (region, out)
+    rc, out, dump = run_host(fn, named=[("region", "1:3000150-3000151,1:3062915-3062915")], fn="read_bcf", proj=[1, 2])
+    schema, chunks = parse_chunks(dump)
+    assert list(chunks[0][1][0][2]) == [3000150, 3000151, 3062915, 3062915] and list(chunks[0][1][1][2]) == [None, None, b"id3D", b"idSNP"]
+    other = os.path.join(str(tmp_path), "moved.csi")
+    shutil.move(fn + ".csi", other)
+    rc, out, _ = run_host(fn, named=[("region", "1:3000150-3000151"), ("index_path", other)], fn="read_bcf")
+    assert rc == 0 and "rows=2 " in out

@@ -103,3 +103,40 @@ def test_synthetic_config3_shape(tidy):
     exp, got = _check(data, tidy, max_blocks=64)
     assert len(got["cols"]) == (7 + 8 + 1 + 6 if tidy else 7 + 8 + 96)
     assert got["n_rows"] == (30000 * 16 if tidy else 60000)
+
+
+def _region_check(data, region, tidy=False, **kw):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
+    import duckhts_amd
+    import region_oracle
+    exp = orc.bcf_read(data, tidy)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(data); ctx.bgzf_index()
+    contigs = [c.decode() if c else "\x01" for c in duckhts_amd.BcfScan(ctx, tidy).contigs]
+    ctx.close()
+    rows = region_oracle.bcf_region_rows(exp, contigs, region, exp["n_samples"] if tidy and exp["n_samples"] else 1)
+    want = orc.bcf_take_rows(exp, rows)
+    got = duckhts_amd.read_bcf(data, tidy=tidy, region=region, **kw)
+    d = orc.bcf_cols_diff(want, got)
+    assert d is None, (region, d)
+    return got["n_rows"]
+
+
+def test_region_golden_counts():
+    """duckhts.test:88-105: single region 2 rows; multi-region = chained union"""
+    data = _gold("vcf_file.bcf")
+    assert _region_check(data, "1:3000150-3000151") == 2
+    assert _region_check(data, "1:3062915-3062915") == 2
+    assert _region_check(data, "1:3000150-3000151,1:3062915-3062915") == 4
+    assert _region_check(data, "1:3000150-3000151,1:3000150-3000151") == 4          # overlapping regions repeat rows (bcf_reader.c:930-932)
+    assert _region_check(data, "nosuch,2,.") == 1 + 15
+    assert _region_check(data, "4:3,258,448", tidy=True) >= 0
+    assert _region_check(data, "nosuch") == 0
+
+
+def test_region_synthetic():
+    from duckhts_amd import synth
+    data = synth.bcf_file(40000, seed=9)
+    for region in ("chr1:1,000,000-30,000,000", "chr2,chrX:1-50000000", "chr21:1-1000"):
+        _region_check(data, region, max_blocks=16)

@@ -197,7 +197,7 @@ def test_bad_records_truncate():
 
 
 def test_header_errors():
-    exp = {"not_bgzf": -100, "bad_magic": -100, "bam_magic": -100, "truncated_header": -101, "no_chrom_line": -101, "dup_sample": -101, "idx_conflict": -101}
+    exp = {"not_bgzf": -101, "bad_magic": -101, "bam_magic": -101, "truncated_header": -101, "no_chrom_line": -101, "dup_sample": -101, "idx_conflict": -101}
     for name, data in bcf_cases.header_error_cases():
         assert orc.bcf_read(data)["status"] == exp[name], name
 
