@@ -32,7 +32,7 @@ class BamBatch(C.Structure):
                 ("tlen", C.c_void_p), ("tid", C.c_void_p), ("mtid", C.c_void_p), ("rg_idx", C.c_void_p),
                 ("rg_valid", C.c_void_p),
                 ("qname", StrCol), ("cigar", StrCol), ("seq", StrCol), ("qual", StrCol), ("rg", StrCol),
-                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64)]
+                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("reserved2", C.c_int32), ("tag_cols", C.c_void_p)]
 
 
 class BamHeader(C.Structure):
@@ -68,7 +68,7 @@ ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
-           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
+           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
@@ -103,6 +103,8 @@ def lib():
         L.dhts_shard_cut.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.dhts_bam_rewind.argtypes = [C.c_void_p]
         L.dhts_bam_set_regions.argtypes = [C.c_void_p, C.c_char_p]
+        L.dhts_bam_std_tag_info.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.dhts_bam_set_tag_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.dhts_bam_load_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bam_next_batch.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(BamBatch)]
         L.dhts_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -212,6 +214,33 @@ class Context:
 
     def rewind(self):
         self._chk(self.L.dhts_bam_rewind(self.h))
+
+    def set_tag_columns(self, ids):
+        arr = np.array(list(ids), np.int32)
+        self._chk(self.L.dhts_bam_set_tag_columns(self.h, arr.ctypes.data, len(arr)))
+        self._tag_ids = list(ids)
+
+    def tag_table(self, b):
+        """standard-tag columns of one batch -> canonical column table (layout of tests/orc.py decode_bcf_blob)"""
+        n = int(b.n_rows)
+        cols = []
+        arr = C.cast(b.tag_cols, C.POINTER(BcfCol))
+        for i in range(b.n_tag_cols):
+            dc = arr[i]
+            name, ty, _ = std_tags()[dc.col]
+            c = {"name": name, "type": 2 if ty in "iB" else 1, "is_list": 1 if ty == "B" else 0}
+            c["valid"] = self.d2h(dc.valid, n, np.uint8) if n else np.zeros(0, np.uint8)
+            if ty == "i":
+                c["fixed"] = self.d2h(dc.fixed, n, np.uint64) if n else np.zeros(0, np.uint64)
+            elif ty == "B":
+                off = self.d2h(dc.off, n + 1, np.uint32).astype(np.uint64) if n else np.zeros(1, np.uint64)
+                c["loff"], c["llen"], c["child_n"] = off[:-1].copy(), off[1:] - off[:-1], int(dc.child_n)
+                c["cfixed"] = self.d2h(dc.child_fixed, int(dc.child_n), np.uint64)
+            else:
+                c["soff"] = self.d2h(dc.off, n + 1, np.uint32).astype(np.uint64) if n else np.zeros(1, np.uint64)
+                c["sbytes"] = self.d2h(dc.bytes, int(dc.nbytes), np.uint8)
+            cols.append(c)
+        return {"n_rows": n, "status": int(b.status), "cols": cols}
 
     def set_regions(self, regions):
         """region := 'chr:beg-end,...'; returns False when no region names a known reference"""
@@ -464,7 +493,24 @@ def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=
         ctx.close()
 
 
-def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None):
+_STD_TAGS = None
+
+
+def std_tags():
+    """the reference's standard-tag table (src/bam_reader.c:54-70) as exposed by the library: [(name, type, subtype)]"""
+    global _STD_TAGS
+    if _STD_TAGS is None:
+        L = lib()
+        out = []
+        for i in range(L.dhts_bam_std_tag_count()):
+            nm, ty, sub = C.create_string_buffer(3), C.create_string_buffer(1), C.create_string_buffer(1)
+            L.dhts_bam_std_tag_info(i, nm, ty, sub)
+            out.append((nm.value.decode(), ty.raw.decode(), sub.raw.decode() if sub.raw != b"\0" else ""))
+        _STD_TAGS = out
+    return _STD_TAGS
+
+
+def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None):
     """Full sequential scan (reference mode (i)): all rows in file order.
     region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window."""
     ctx = Context(device)
@@ -479,16 +525,22 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None):
                 raise DhtsError(f"No reads found for region(s): {region}")
             if index is not None:
                 ctx.load_index(index)
-        parts = []
+        if std_tags_cols is not None:
+            ctx.set_tag_columns(std_tags_cols)
+        parts, tparts = [], []
         status = 0
         while True:
             b = ctx.next_batch(max_blocks)
             if b.n_rows:
                 parts.append(ctx.batch_to_host(b, hdr))
+                if std_tags_cols is not None:
+                    tparts.append(ctx.tag_table(b))
             status = b.status
             if b.status != 0:
                 break
         out = {"n_rows": sum(p["n_rows"] for p in parts), "status": status, "header": hdr}
+        if std_tags_cols is not None:
+            out["tags"] = {"n_rows": out["n_rows"], "cols": _concat_tables(tparts, None) or []}
         for k in BAM_COLUMNS + ["tid", "mtid"]:
             vals = [p[k] for p in parts]
             if not vals:

@@ -6,6 +6,7 @@
 #include "bam_records.hip"
 #include "bam_tiles_lds.hip"
 #include "bcf_records.hip"
+#include "bam_tags.hip"
 #include "bcf_header.h"
 
 #include <fcntl.h>
@@ -68,6 +69,9 @@ struct dhts_ctx {
     std::vector<std::string> rg_id, rg_sm; std::vector<char> rg_has_sm; std::vector<const char *> rg_id_p, rg_sm_p;
     uint64_t first_rec_uoff = 0;
     DevBuf d_rg_off, d_rg_bytes;
+    // standard-tag columns (row A5)
+    std::vector<int32_t> tag_sel; std::vector<dhts_col> tag_out;
+    DevBuf t_codes, t_dir, t_lens, t_offs, t_partial, t_total, t_coldev, t_fixed, t_valid, t_var;
     // region filter (row A11)
     bool rg_active = false, rg_all = false, rg_nocoor = false;
     std::vector<int64_t> rg_beg, rg_end; std::vector<uint32_t> rg_tid_first;
@@ -718,6 +722,107 @@ int dhts_bam_rewind(dhts_ctx *c) {
     return 0;
 }
 
+// ---- standard_tags (row A5): the reference's tag table src/bam_reader.c:54-70, in its order ---------------------------------
+struct StdTag { const char *tag; char type, subtype; };
+static const StdTag kStdTags[] = {
+    {"AM",'i',0},{"AS",'i',0},{"BC",'Z',0},{"BQ",'Z',0},{"BZ",'Z',0},{"CB",'Z',0},{"CC",'Z',0},{"CG",'B','I'},{"CM",'i',0},{"CO",'Z',0},{"CP",'i',0},{"CQ",'Z',0},
+    {"CR",'Z',0},{"CS",'Z',0},{"CT",'Z',0},{"CY",'Z',0},{"E2",'Z',0},{"FI",'i',0},{"FS",'Z',0},{"FZ",'B','S'},{"H0",'i',0},{"H1",'i',0},{"H2",'i',0},{"HI",'i',0},
+    {"IH",'i',0},{"LB",'Z',0},{"MC",'Z',0},{"MD",'Z',0},{"MI",'Z',0},{"ML",'B','C'},{"MM",'Z',0},{"MN",'i',0},{"MQ",'i',0},{"NH",'i',0},{"NM",'i',0},{"OA",'Z',0},
+    {"OC",'Z',0},{"OP",'i',0},{"OQ",'Z',0},{"OX",'Z',0},{"PG",'Z',0},{"PQ",'i',0},{"PT",'Z',0},{"PU",'Z',0},{"Q2",'Z',0},{"QT",'Z',0},{"QX",'Z',0},{"R2",'Z',0},
+    {"RG",'Z',0},{"RX",'Z',0},{"SA",'Z',0},{"SM",'i',0},{"TC",'i',0},{"TS",'A',0},{"U2",'Z',0},{"UQ",'i',0}};
+static const int kNStdTags = (int)(sizeof(kStdTags) / sizeof(kStdTags[0]));
+
+int dhts_bam_std_tag_count(void) { return kNStdTags; }
+int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype) {
+    if (idx < 0 || idx >= kNStdTags) return -1;
+    name[0] = kStdTags[idx].tag[0]; name[1] = kStdTags[idx].tag[1]; name[2] = 0;
+    if (type) *type = kStdTags[idx].type;
+    if (subtype) *subtype = kStdTags[idx].subtype;
+    return 0;
+}
+int dhts_bam_set_tag_columns(dhts_ctx *c, const int32_t *ids, int32_t n) {
+    if (!c) return -1;
+    std::vector<int32_t> v;
+    for (int32_t i = 0; i < n; i++) { if (ids[i] < 0 || ids[i] >= kNStdTags) return fail(c, "standard tag id %d out of range", ids[i]); v.push_back(ids[i]); }
+    c->tag_sel = v;
+    return 0;
+}
+
+// materialises the selected tag columns for the (final, compacted) rows of the current batch
+static int bam_tag_columns(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam_batch *out) {
+    const int nt = (int)c->tag_sel.size();
+    c->tag_out.assign(nt, dhts_col());
+    for (int i = 0; i < nt; i++) { memset(&c->tag_out[i], 0, sizeof(dhts_col)); c->tag_out[i].col = c->tag_sel[i]; c->tag_out[i].child_width = 8; }
+    out->n_tag_cols = nt; out->tag_cols = c->tag_out.data();
+    if (nt == 0 || nrows <= 0) return 0;
+    const size_t n = (size_t)nrows;
+    const uint32_t stride = (uint32_t)((n + 63) & ~(size_t)63), ostride = (uint32_t)((n + 1 + 63) & ~(size_t)63);
+    std::vector<uint16_t> codes(nt);
+    std::vector<TagColDev> cd(nt);
+    int nsa = 0; size_t nfixed = 0; std::vector<size_t> fixed_at(nt, 0);
+    for (int i = 0; i < nt; i++) {
+        const StdTag &t = kStdTags[c->tag_sel[i]];
+        codes[i] = (uint16_t)((uint8_t)t.tag[0] | ((uint8_t)t.tag[1] << 8));
+        memset(&cd[i], 0, sizeof(TagColDev));
+        cd[i].kind = t.type == 'H' ? 'Z' : t.type; cd[i].slot = i; cd[i].sa_cnt = cd[i].sa_bytes = -1;
+        if (t.type == 'B') cd[i].sa_cnt = nsa++;
+        else if (t.type == 'i') { fixed_at[i] = nfixed; nfixed += (n * 8 + 63) & ~(size_t)63; }
+        else cd[i].sa_bytes = nsa++;
+    }
+    ENSURE(c, c->t_codes, nt * 2 + 16); ENSURE(c, c->t_dir, (size_t)nt * stride * 4 + 16); ENSURE(c, c->t_valid, (size_t)nt * n + 64); ENSURE(c, c->t_fixed, nfixed + 64);
+    ENSURE(c, c->t_lens, (size_t)(nsa ? nsa : 1) * ostride * 4 + 64); ENSURE(c, c->t_offs, (size_t)(nsa ? nsa : 1) * ostride * 4 + 64); ENSURE(c, c->t_coldev, sizeof(TagColDev) * nt);
+    for (int i = 0; i < nt; i++) { cd[i].valid = (uint8_t *)c->t_valid.p + (size_t)i * n; if (cd[i].kind == 'i') cd[i].fixed = (int64_t *)((uint8_t *)c->t_fixed.p + fixed_at[i]); }
+    HIPCHK(c, hipMemcpyAsync(c->t_codes.p, codes.data(), nt * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->t_coldev.p, cd.data(), sizeof(TagColDev) * nt, hipMemcpyHostToDevice, c->stream));
+    TagCellArgs ta; memset(&ta, 0, sizeof(ta));
+    ta.rec_off = (const uint32_t *)c->rec_off.p; ta.dir = (const uint32_t *)c->t_dir.p; ta.stride = stride; ta.nrows = nrows;
+    ta.lens = (uint32_t *)c->t_lens.p; ta.offs = (const uint32_t *)c->t_offs.p; ta.ostride = ostride; ta.cols = (const TagColDev *)c->t_coldev.p;
+    {
+        KTimer tm(c, DHTS_K_CORE);
+        hipLaunchKernelGGL(bam_tag_dir, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, (const uint16_t *)c->t_codes.p, nt,
+                           (uint32_t *)c->t_dir.p, stride);
+        hipLaunchKernelGGL(bam_tag_cells<false>, dim3((unsigned)((nrows + 255) / 256), (unsigned)nt), dim3(256), 0, c->stream, st, ta);
+    }
+    std::vector<uint64_t> tot(nsa ? nsa : 1, 0);
+    if (nsa > 0) {
+        MScanArgs ma; ma.in = (const uint32_t *)c->t_lens.p; ma.out = (uint32_t *)c->t_offs.p; ma.stride = ostride; ma.n = nrows;
+        ma.nparts = (nrows + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS; if (ma.nparts < 1) ma.nparts = 1;
+        ENSURE(c, c->t_partial, (size_t)nsa * ma.nparts * 8 + 64); ENSURE(c, c->t_total, (size_t)nsa * 8 + 64);
+        ma.partial = (uint64_t *)c->t_partial.p; ma.total = (uint64_t *)c->t_total.p;
+        {
+            KTimer tm(c, DHTS_K_SCAN);
+            hipLaunchKernelGGL(mscan_reduce, dim3((unsigned)ma.nparts, (unsigned)nsa), dim3(256), 0, c->stream, ma);
+            hipLaunchKernelGGL(mscan_partials, dim3((unsigned)nsa), dim3(1024), 0, c->stream, ma);
+            hipLaunchKernelGGL(mscan_apply, dim3((unsigned)ma.nparts, (unsigned)nsa), dim3(256), 0, c->stream, ma);
+        }
+        HIPCHK(c, hipMemcpyAsync(tot.data(), c->t_total.p, (size_t)nsa * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        size_t var = 0; std::vector<size_t> at(nt, 0);
+        for (int i = 0; i < nt; i++) {
+            if (cd[i].sa_cnt >= 0) { if (tot[cd[i].sa_cnt] >= (1ull << 32)) return fail(c, "tag column too large for one batch"); at[i] = var; var += (tot[cd[i].sa_cnt] * 8 + 63) & ~(size_t)63; }
+            if (cd[i].sa_bytes >= 0) { if (tot[cd[i].sa_bytes] >= (1ull << 32)) return fail(c, "tag column too large for one batch"); at[i] = var; var += (tot[cd[i].sa_bytes] + 63) & ~(size_t)63; }
+        }
+        ENSURE(c, c->t_var, var + 64);
+        for (int i = 0; i < nt; i++) {
+            if (cd[i].sa_cnt >= 0) cd[i].child = (uint64_t *)((uint8_t *)c->t_var.p + at[i]);
+            if (cd[i].sa_bytes >= 0) cd[i].bytes = (uint8_t *)c->t_var.p + at[i];
+        }
+        HIPCHK(c, hipMemcpyAsync(c->t_coldev.p, cd.data(), sizeof(TagColDev) * nt, hipMemcpyHostToDevice, c->stream));
+        {
+            KTimer tm(c, DHTS_K_STRINGS);
+            hipLaunchKernelGGL(bam_tag_cells<true>, dim3((unsigned)((nrows + 255) / 256), (unsigned)nt), dim3(256), 0, c->stream, st, ta);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    for (int i = 0; i < nt; i++) {
+        dhts_col &o = c->tag_out[i];
+        o.valid = cd[i].valid; o.fixed = cd[i].fixed;
+        if (cd[i].sa_cnt >= 0) { o.off = (const uint32_t *)c->t_offs.p + (size_t)cd[i].sa_cnt * ostride; o.child_n = tot[cd[i].sa_cnt]; o.child_fixed = (const uint32_t *)cd[i].child; }
+        if (cd[i].sa_bytes >= 0) { o.off = (const uint32_t *)c->t_offs.p + (size_t)cd[i].sa_bytes * ostride; o.bytes = cd[i].bytes; o.nbytes = tot[cd[i].sa_bytes]; }
+    }
+    return 0;
+}
+
 // ---- one batch of inflated bytes: carry + blocks [b0, b0+nb), shared by the read_bam and read_bcf drivers ---------------
 struct Batch {
     int64_t b0 = 0, nb = 0; bool in_halo = false, last_of_stream = false, sharded_tail = false, final_batch = false;
@@ -935,6 +1040,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         out->qual = {o32[3], so.alen_qual, so.qual, tot[3]};
         out->rg = {o32[4], bc.len_rg, so.rg, tot[4]};
     }
+    if (bam_tag_columns(c, st, nrows, out)) return -1;
     out->n_rows = nrows;
     out->end_uoff = out_base + carry_start;
     {

@@ -36,6 +36,7 @@ struct BamBind {
     dhts_ctx *ctx = nullptr;          // resident file + header, reused by the scan (one GPU)
     dhts_bam_header hdr;
     int has_index = 0;
+    int standard_tags = 0;
 };
 
 struct HostStr { std::vector<uint32_t> off, len; std::vector<uint8_t> bytes; };
@@ -48,6 +49,10 @@ struct BamLocal {
     int status = 0;
     std::vector<uint16_t> flag; std::vector<int64_t> pos, pnext, tlen; std::vector<int32_t> mapq, tid, mtid, rgidx; std::vector<uint64_t> rgvalid;
     HostStr qname, cigar, seq, qual, rg;
+    std::vector<int32_t> tag_ids;        // standard-tag ids requested by the projection
+    std::vector<int> tag_slot;           // output vector -> index into tags (-1 = not a tag column)
+    struct HostTag { std::vector<uint8_t> valid, bytes; std::vector<int64_t> fixed; std::vector<uint32_t> off; std::vector<int64_t> child; };
+    std::vector<HostTag> tags;
 };
 
 static void destroy_bind(void *p) { BamBind *b = (BamBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
@@ -118,7 +123,8 @@ static void bam_read_bind(duckdb_bind_info info) {
     }
     b->has_index = !b->index_file.empty();                                       // bam_reader.c:499-503
     if (has_region) b->region = region_copy;
-    if (standard_tags || auxiliary_tags) { set_error(info, "read_bam: standard_tags / auxiliary_tags are not on the MI355X scan path yet"); delete b; return; }
+    if (auxiliary_tags) { set_error(info, "read_bam: auxiliary_tags (MAP of the remaining tags, %g text) is not on the MI355X scan path yet"); delete b; return; }
+    b->standard_tags = standard_tags;
 
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
     auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);
@@ -127,6 +133,15 @@ static void bam_read_bind(duckdb_bind_info info) {
     add(info, "QNAME", t_varchar); add(info, "FLAG", t_us); add(info, "RNAME", t_varchar); add(info, "POS", t_big); add(info, "MAPQ", t_int);   // bam_reader.c:514-526
     add(info, "CIGAR", t_varchar); add(info, "RNEXT", t_varchar); add(info, "PNEXT", t_big); add(info, "TLEN", t_big); add(info, "SEQ", t_varchar);
     add(info, "QUAL", t_varchar); add(info, "READ_GROUP_ID", t_varchar); add(info, "SAMPLE_ID", t_varchar);
+    if (b->standard_tags) {                                                                     // bam_reader.c:527-537 + bam_std_tag_type 88-104
+        auto mklist = API(duckdb_logical_type, duckdb_create_list_type, duckdb_logical_type);
+        duckdb_logical_type t_list = mklist(t_big);
+        for (int i = 0; i < dhts_bam_std_tag_count(); i++) {
+            char nm[3], ty, sub; dhts_bam_std_tag_info(i, nm, &ty, &sub);
+            add(info, nm, ty == 'i' ? t_big : ty == 'B' ? t_list : t_varchar);
+        }
+        rm(&t_list);
+    }
     rm(&t_varchar); rm(&t_int); rm(&t_big); rm(&t_us);
     API(void, duckdb_bind_set_bind_data, duckdb_bind_info, void *, duckdb_delete_callback_t)(info, b, destroy_bind);
 }
@@ -145,7 +160,16 @@ static void bam_read_local_init(duckdb_init_info info) {
         idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
         l->column_ids.push_back(id);
         if (id < DHTS_BAM_CORE_COUNT) l->colmask |= 1u << id;
+        int sl = -1;
+        if (bind->standard_tags && id >= DHTS_BAM_CORE_COUNT && id < (idx_t)(DHTS_BAM_CORE_COUNT + dhts_bam_std_tag_count())) {
+            const int32_t tid_ = (int32_t)(id - DHTS_BAM_CORE_COUNT);
+            for (size_t k = 0; k < l->tag_ids.size(); k++) if (l->tag_ids[k] == tid_) sl = (int)k;
+            if (sl < 0) { sl = (int)l->tag_ids.size(); l->tag_ids.push_back(tid_); }
+        }
+        l->tag_slot.push_back(sl);
     }
+    l->tags.resize(l->tag_ids.size());
+    dhts_bam_set_tag_columns(bind->ctx, l->tag_ids.data(), (int32_t)l->tag_ids.size());
     auto init_error = API(void, duckdb_init_set_error, duckdb_init_info, const char *);
     if (!bind->region.empty()) {
         // bam_reader.c:639-668: a region needs an index; sam_itr_regarray failing reports "No reads found"
@@ -194,6 +218,14 @@ static int next_host_batch(BamBind *bind, BamLocal *l) {
     if (fetch_str(c, b.qname, n, l->qname, m & (1u << DHTS_BAM_QNAME)) || fetch_str(c, b.cigar, n, l->cigar, m & (1u << DHTS_BAM_CIGAR)) ||
         fetch_str(c, b.seq, n, l->seq, m & (1u << DHTS_BAM_SEQ)) || fetch_str(c, b.qual, n, l->qual, m & (1u << DHTS_BAM_QUAL)) ||
         fetch_str(c, b.rg, n, l->rg, m & (1u << DHTS_BAM_READ_GROUP_ID))) return -1;
+    for (int i = 0; i < b.n_tag_cols; i++) {
+        const dhts_col &d = b.tag_cols[i]; BamLocal::HostTag &h = l->tags[i];
+        h.valid.resize(n); if (dhts_memcpy_d2h(c, h.valid.data(), d.valid, n)) return -1;
+        if (d.fixed) { h.fixed.resize(n); if (dhts_memcpy_d2h(c, h.fixed.data(), d.fixed, n * 8)) return -1; }
+        if (d.off) { h.off.resize(n + 1); if (dhts_memcpy_d2h(c, h.off.data(), d.off, (n + 1) * 4)) return -1; }
+        if (d.bytes || d.nbytes == 0) { h.bytes.resize(d.nbytes + 1); if (d.nbytes && dhts_memcpy_d2h(c, h.bytes.data(), d.bytes, d.nbytes)) return -1; }
+        if (d.child_fixed) { h.child.resize(d.child_n + 1); if (d.child_n && dhts_memcpy_d2h(c, h.child.data(), d.child_fixed, d.child_n * 8)) return -1; }
+    }
     return 0;
 }
 
@@ -249,7 +281,34 @@ static void bam_read_function(duckdb_function_info info, duckdb_data_chunk outpu
                     if (sm) assign_len(vec, row_count + r, sm, strlen(sm)); else set_null(vec, row_count + r);
                 }
                 break;
-            default: break;                                        // unknown ids (e.g. a row-id pseudo column) write nothing, like the reference's default arm
+            default: {
+                const int sl = l->tag_slot[ci];
+                if (sl < 0) break;                                 // unknown ids (e.g. a row-id pseudo column) write nothing, like the reference's default arm
+                const BamLocal::HostTag &h = l->tags[sl];
+                char nm[3], ty, sub; dhts_bam_std_tag_info(l->tag_ids[sl], nm, &ty, &sub);
+                if (ty == 'i') {                                    // bam_reader.c:946-950
+                    memcpy((int64_t *)get_data(vec) + row_count, h.fixed.data() + s, take * 8);
+                    for (idx_t r = 0; r < take; r++) if (!h.valid[s + r]) set_null(vec, row_count + r);
+                } else if (ty == 'B') {                             // bam_assign_list_int / _double bam_reader.c:106-138
+                    auto list_size = API(idx_t, duckdb_list_vector_get_size, duckdb_vector);
+                    duckdb_list_entry *le = (duckdb_list_entry *)get_data(vec);
+                    idx_t base = list_size(vec);
+                    const uint32_t c0 = h.off[s], c1 = h.off[s + take];
+                    if (c1 > c0) { API(duckdb_state, duckdb_list_vector_reserve, duckdb_vector, idx_t)(vec, base + (c1 - c0)); API(duckdb_state, duckdb_list_vector_set_size, duckdb_vector, idx_t)(vec, base + (c1 - c0)); }
+                    duckdb_vector child = API(duckdb_vector, duckdb_list_vector_get_child, duckdb_vector)(vec);
+                    for (idx_t r = 0; r < take; r++) {
+                        if (h.valid[s + r]) { le[row_count + r].offset = base + (h.off[s + r] - c0); le[row_count + r].length = h.off[s + r + 1] - h.off[s + r]; }
+                        else set_null(vec, row_count + r);          // absent tag: set_null only, the entry is left untouched (bam_reader.c:927-930)
+                    }
+                    if (c1 > c0) memcpy((int64_t *)get_data(child) + base, h.child.data() + c0, (size_t)(c1 - c0) * 8);
+                } else {
+                    for (idx_t r = 0; r < take; r++) {
+                        if (h.valid[s + r]) assign_len(vec, row_count + r, (const char *)h.bytes.data() + h.off[s + r], h.off[s + r + 1] - h.off[s + r]);
+                        else set_null(vec, row_count + r);
+                    }
+                }
+                break;
+            }
             }
         }
         row_count += take; l->cur += (int64_t)take;

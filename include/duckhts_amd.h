@@ -53,6 +53,22 @@ typedef struct {
     uint64_t nbytes;         /* off[n]                                                          */
 } dhts_strcol;
 
+/* One projected column of a batch; DEVICE pointers, valid until the next call on the context.
+ * scalar fixed-width : fixed[n_rows] in the native width of `type` (BOOLEAN 1 byte, INTEGER/FLOAT/ids 4, BIGINT/DOUBLE 8)
+ * scalar VARCHAR     : off[n_rows+1] byte offsets into bytes
+ * LIST               : off[n_rows+1] child offsets; children in child_fixed[child_n] (4-byte words) or, for
+ *                      LIST(VARCHAR) in plain encoding, child_off[child_n+1] byte offsets into bytes                   */
+typedef struct dhts_col {
+    int32_t col;             /* schema column id                                                            */
+    int32_t child_width;     /* bytes per child_fixed word: 0/4 = 4 (read_bcf), 8 = BIGINT children (read_bam tag lists)     */
+    const uint8_t *valid;    /* n_rows bytes, 1 = valid                                                     */
+    const void *fixed;
+    const uint32_t *off;
+    const uint8_t *bytes; uint64_t nbytes;
+    const uint32_t *child_fixed; const uint32_t *child_off; uint64_t child_n;
+} dhts_col;
+typedef dhts_col dhts_bcf_col;
+
 /* One decoded batch.  All pointers are DEVICE pointers owned by the context and stay valid
  * until the next dhts_bam_next_batch / dhts_bam_rewind / dhts_destroy on that context.        */
 typedef struct {
@@ -73,6 +89,9 @@ typedef struct {
     dhts_strcol qname, cigar, seq, qual, rg;
     uint64_t first_rec_uoff; /* absolute inflated-stream offset of the first row's record        */
     uint64_t end_uoff;       /* absolute inflated-stream offset just past the last row's record  */
+    int32_t n_tag_cols;      /* standard-tag columns selected by dhts_bam_set_tag_columns         */
+    int32_t reserved2;
+    const dhts_col *tag_cols;/* host array; BIGINT scalars in fixed (8 B), VARCHAR in off/bytes, LIST(BIGINT) in off/child_fixed (8 B words) */
 } dhts_bam_batch;
 
 /* Host copy of the BAM header dictionaries (pointers owned by the context).                   */
@@ -124,6 +143,10 @@ int dhts_bam_set_regions(dhts_ctx *, const char *regions);
 /* BAI bytes (hts_idx_load: hts.c:2920-3055): narrows the scan window to the chunks of the bins the regions touch (reg2bins
  * hts.c:3142-3213 + linear index); optional for exactness, call after dhts_bam_set_regions.                                    */
 int dhts_bam_load_index(dhts_ctx *, const void *bai_bytes, uint64_t n);
+/* standard_tags := true (src/bam_reader.c:54-70, 920-966): the reference's 56-entry tag table, in its order */
+int dhts_bam_std_tag_count(void);
+int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype);   /* type: 'i' BIGINT, 'Z'/'A' VARCHAR, 'B' LIST(BIGINT) */
+int dhts_bam_set_tag_columns(dhts_ctx *, const int32_t *std_tag_ids, int32_t n);  /* tag columns materialised by the next batches (default none) */
 int dhts_bam_rewind(dhts_ctx *);
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 
@@ -160,20 +183,6 @@ typedef struct {
     uint64_t first_rec_uoff;                                /* inflated offset of the first record             */
 } dhts_bcf_info;
 
-/* One projected column of a batch; DEVICE pointers, valid until the next call on the context.
- * scalar fixed-width : fixed[n_rows] in the native width of `type` (BOOLEAN 1 byte, INTEGER/FLOAT/ids 4, BIGINT/DOUBLE 8)
- * scalar VARCHAR     : off[n_rows+1] byte offsets into bytes
- * LIST               : off[n_rows+1] child offsets; children in child_fixed[child_n] (4-byte words) or, for
- *                      LIST(VARCHAR) in plain encoding, child_off[child_n+1] byte offsets into bytes                   */
-typedef struct {
-    int32_t col;             /* schema column id                                                            */
-    int32_t reserved;
-    const uint8_t *valid;    /* n_rows bytes, 1 = valid                                                     */
-    const void *fixed;
-    const uint32_t *off;
-    const uint8_t *bytes; uint64_t nbytes;
-    const uint32_t *child_fixed; const uint32_t *child_off; uint64_t child_n;
-} dhts_bcf_col;
 
 typedef struct {
     int64_t n_rows;

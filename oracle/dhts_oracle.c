@@ -424,6 +424,10 @@ static const char NT16[] = "=ACMGRSVTWYHKDBN";           /* htslib/hts.c:260 seq
 /* bam_cigar_type table 0x3C1A7 (htslib/sam.h:139-148): bit0 consumes query, bit1 consumes ref */
 #define CIGAR_TYPE(op) ((0x3C1A7 >> ((op) << 1)) & 3)
 
+/* per-row hook for the standard_tags table: receives the aux area as bam_aux_get sees it (CG spliced out after a long-CIGAR swap) */
+static void (*g_aux_hook)(const uint8_t *aux, const uint8_t *end, void *ud) = NULL;
+static void *g_aux_ud = NULL;
+
 static int bam_decode_stream(const uint8_t *u, size_t ulen, orc_bam_t *b) {
     size_t p = 0;
     /* ---- header: htslib/sam.c:229-342 bam_hdr_read ---- */
@@ -566,6 +570,15 @@ static int bam_decode_stream(const uint8_t *u, size_t ulen, orc_bam_t *b) {
                 } else { sc_push(&b->rg, "", 0, 0); sc_push(&b->sample, "", 0, 0); }
             }
         }
+        if (g_aux_hook) {
+            if (cg_tag_start) {
+                size_t l1 = (size_t)(cg_tag_start - aux), l2 = (size_t)(dend - cg_tag_end);
+                uint8_t *sp = (uint8_t *)malloc(l1 + l2 + 1);
+                memcpy(sp, aux, l1); memcpy(sp + l1, cg_tag_end, l2);
+                g_aux_hook(sp, sp + l1 + l2, g_aux_ud);
+                free(sp);
+            } else g_aux_hook(aux, dend, g_aux_ud);
+        }
         b->n_rows++;
         p += 4 + (size_t)block_len;
     }
@@ -611,4 +624,79 @@ int64_t orc_bam_scan_count(const uint8_t *file, size_t flen, int *status) {
     int64_t n = b.n_rows; if (status) *status = b.status;
     orc_bam_free(&b);
     return n;
+}
+
+
+/* ========================================================================
+ * standard_tags := true  (src/bam_reader.c:54-70 table, 88-104 types, 920-966 writers over bam_aux_get sam.c:4834-4855,
+ * bam_aux2i 5020-5034 (non-integer types yield 0), bam_aux2A 5118-5126 (non-'A' yields NUL => ""), bam_aux2Z 5134-5141
+ * (non Z/H => NULL), bam_auxB_len 5143-5150 (non-'B' => 0 elements), bam_auxB2i 5152-5160, bam_auxB2f 5162-5171)
+ * ======================================================================== */
+#include "orc_cols.h"
+typedef struct { const char *tag; char type, subtype; } std_tag_t;
+static const std_tag_t STD_TAGS[] = {
+    {"AM",'i',0},{"AS",'i',0},{"BC",'Z',0},{"BQ",'Z',0},{"BZ",'Z',0},{"CB",'Z',0},{"CC",'Z',0},{"CG",'B','I'},{"CM",'i',0},{"CO",'Z',0},{"CP",'i',0},{"CQ",'Z',0},
+    {"CR",'Z',0},{"CS",'Z',0},{"CT",'Z',0},{"CY",'Z',0},{"E2",'Z',0},{"FI",'i',0},{"FS",'Z',0},{"FZ",'B','S'},{"H0",'i',0},{"H1",'i',0},{"H2",'i',0},{"HI",'i',0},
+    {"IH",'i',0},{"LB",'Z',0},{"MC",'Z',0},{"MD",'Z',0},{"MI",'Z',0},{"ML",'B','C'},{"MM",'Z',0},{"MN",'i',0},{"MQ",'i',0},{"NH",'i',0},{"NM",'i',0},{"OA",'Z',0},
+    {"OC",'Z',0},{"OP",'i',0},{"OQ",'Z',0},{"OX",'Z',0},{"PG",'Z',0},{"PQ",'i',0},{"PT",'Z',0},{"PU",'Z',0},{"Q2",'Z',0},{"QT",'Z',0},{"QX",'Z',0},{"R2",'Z',0},
+    {"RG",'Z',0},{"RX",'Z',0},{"SA",'Z',0},{"SM",'i',0},{"TC",'i',0},{"TS",'A',0},{"U2",'Z',0},{"UQ",'i',0},{NULL,0,0}};
+#define N_STD_TAGS 56
+
+static int64_t aux_int_val(uint8_t type, const uint8_t *s, uint32_t idx, int *ok) {       /* get_int_aux_val sam.c:4997-5018 */
+    *ok = 1;
+    switch (type) {
+    case 'c': return (int8_t)s[idx];
+    case 'C': return s[idx];
+    case 's': return (int16_t)(s[2 * idx] | s[2 * idx + 1] << 8);
+    case 'S': return (uint16_t)(s[2 * idx] | s[2 * idx + 1] << 8);
+    case 'i': return (int32_t)le32(s + 4 * (size_t)idx);
+    case 'I': return (uint32_t)le32(s + 4 * (size_t)idx);
+    default: *ok = 0; return 0;
+    }
+}
+
+static void std_tags_row(const uint8_t *aux, const uint8_t *end, void *ud) {
+    col_t *cols = (col_t *)ud;
+    for (int t = 0; t < N_STD_TAGS; t++) {
+        col_t *c = &cols[t];
+        int bad; const uint8_t *a = aux_get(aux, end, STD_TAGS[t].tag, &bad);
+        if (!a) { col_null(c); continue; }
+        int ok;
+        switch (STD_TAGS[t].type) {
+        case 'A': { char ch = a[0] == 'A' ? (char)a[1] : 0; col_str(c, &ch, ch ? 1 : 0); break; }     /* assigned through the NUL-terminated API */
+        case 'Z': if (a[0] == 'Z' || a[0] == 'H') col_cstr(c, (const char *)a + 1); else col_null(c); break;
+        case 'i': { int64_t v = aux_int_val(a[0], a + 1, 0, &ok); col_fixed(c, (uint64_t)v, 1); break; }
+        case 'B': {
+            uint32_t len = a[0] == 'B' ? le32(a + 2) : 0;
+            list_begin(c);
+            for (uint32_t i = 0; i < len; i++) {
+                if (a[1] == 'f' || a[1] == 'd') {                        /* bam_assign_list_double writes doubles into the BIGINT child */
+                    double d = 0.0;
+                    if (a[1] == 'f') { uint32_t bits = le32(a + 6 + 4 * (size_t)i); float f; memcpy(&f, &bits, 4); d = f; }
+                    uint64_t b; memcpy(&b, &d, 8); list_fixed(c, b);
+                } else list_fixed(c, (uint64_t)aux_int_val(a[1], a + 6, i, &ok));
+            }
+            list_end(c);
+            break;
+        }
+        }
+    }
+}
+
+/* canonical blob (layout of orc_bcf_read) of the 56 standard-tag columns of every row orc_bam_read would return */
+int orc_bam_read_std_tags(const uint8_t *file, size_t flen, uint8_t **blob, size_t *blob_len) {
+    col_t cols[N_STD_TAGS];
+    for (int t = 0; t < N_STD_TAGS; t++)
+        col_init(&cols[t], STD_TAGS[t].tag, STD_TAGS[t].type == 'i' || STD_TAGS[t].type == 'B' ? T_BIGINT : T_VARCHAR, STD_TAGS[t].type == 'B');
+    g_aux_hook = std_tags_row; g_aux_ud = cols;
+    orc_bam_t b; int st = orc_bam_read(file, flen, &b);
+    g_aux_hook = NULL; g_aux_ud = NULL;
+    buf_t o = {0};
+    uint32_t nc = N_STD_TAGS; uint64_t nr = (uint64_t)b.n_rows, fr = (uint64_t)b.first_rec_off; int32_t s32 = st; uint32_t ns = 0;
+    buf_push(&o, &nc, 4); buf_push(&o, &nr, 8); buf_push(&o, &s32, 4); buf_push(&o, &fr, 8); buf_push(&o, &ns, 4);
+    for (int t = 0; t < N_STD_TAGS; t++) { ser_col(&o, &cols[t], b.n_rows); col_free(&cols[t]); }
+    uint64_t zero = 0; buf_push(&o, &zero, 8);
+    *blob = o.p; *blob_len = o.n;
+    orc_bam_free(&b);
+    return st;
 }

@@ -83,6 +83,9 @@ int64_t orc_bam_scan_count(const uint8_t *file, size_t flen, int *status);
 /* timing leg only: inflate + crc32 through system zlib (the reference's own dependency) instead of the RFC restatement */
 int orc_use_system_zlib(int on);
 
+/* read_bam(standard_tags := true): the 56 typed tag columns (src/bam_reader.c:54-70, 920-966) as a canonical column blob */
+int orc_bam_read_std_tags(const uint8_t *file, size_t flen, uint8_t **blob, size_t *blob_len);
+
 /* ---- read_bcf (bcf_oracle.c) ---------------------------------------------- */
 /* Sequential read_bcf scan of a whole BCF file; `blob` receives the canonical serialisation of every schema column
  * (layout documented above orc_bcf_read in bcf_oracle.c; free with orc_free).  materialise = 0 only frames and

@@ -289,3 +289,16 @@ def bcf_take_rows(table, rows):
                 o["csoff"], o["csbytes"] = gather(c["csoff"], c["csbytes"], kid)
         cols.append(o)
     return {"n_rows": len(rows), "cols": cols, "by_name": {c["name"]: c for c in cols}}
+
+
+def bam_read_std_tags(file_bytes: bytes):
+    """the 56 standard-tag columns (read_bam(standard_tags := true)) as a decoded canonical table"""
+    L = lib()
+    L.orc_bam_read_std_tags.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.orc_bam_read_std_tags.restype = C.c_int
+    L.orc_free.argtypes = [C.c_void_p]
+    blob, n = C.c_void_p(), C.c_size_t(0)
+    L.orc_bam_read_std_tags(file_bytes, len(file_bytes), C.byref(blob), C.byref(n))
+    data = C.string_at(blob, n.value)
+    L.orc_free(blob)
+    return decode_bcf_blob(data)

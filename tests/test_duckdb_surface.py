@@ -303,3 +303,43 @@ def test_read_bcf_region_through_the_surface(tmp_path):
     shutil.move(fn + ".csi", other)
     rc, out, _ = run_host(fn, named=[("region", "1:3000150-3000151"), ("index_path", other)], fn="read_bcf")
     assert rc == 0 and "rows=2 " in out
+
+
+@pytest.mark.gpu
+def test_read_bam_standard_tags_through_the_surface(tmp_path):
+    """read_bam(standard_tags := true): 13 + 56 columns (bam_reader.c:527-537), typed per bam_std_tag_type; duckhts.test:179-185 values"""
+    import tag_cases
+    for data in (tag_cases.aux_tags_sam_equivalent(), tag_cases.type_matrix(), tag_cases.fuzz(n=5000)):
+        fn = os.path.join(str(tmp_path), "t.bam")
+        open(fn, "wb").write(data)
+        exp = orc.bam_read_std_tags(data)
+        rc, out, dump = run_host(fn, named=[("standard_tags", "true")])
+        assert rc == 0, out
+        schema, chunks = parse_chunks(dump)
+        assert len(schema) == 13 + 56 and schema[:13] == SCHEMA
+        assert [s_[0] for s_ in schema[13:]] == [c["name"] for c in exp["cols"]]
+        assert schema[13 + 7] == ("CG", LIST, 5) and schema[13 + 34] == ("NM", 5) and schema[13 + 48] == ("RG", 17) and schema[13 + 53] == ("TS", 17)
+        c0 = 0
+        for nrows, cols in chunks:
+            for j, c in enumerate(exp["cols"]):
+                t, val, vals = cols[13 + j]
+                bits = np.array([(int(val[i >> 6]) >> (i & 63)) & 1 for i in range(nrows)], np.uint8)
+                assert np.array_equal(bits, c["valid"][c0:c0 + nrows]), c["name"]
+                if c["is_list"]:
+                    ent, ct, child = vals
+                    v = c["valid"][c0:c0 + nrows].astype(bool)
+                    k0 = int(c["loff"][c0]) if nrows else 0
+                    assert np.array_equal(ent[v, 0], (c["loff"][c0:c0 + nrows] - np.uint64(k0))[v]) and np.array_equal(ent[v, 1], c["llen"][c0:c0 + nrows][v]), c["name"]
+                    k1 = k0 + int(c["llen"][c0:c0 + nrows].sum())
+                    assert np.array_equal(child.astype(np.uint64), c["cfixed"][k0:k1]), c["name"]
+                elif c["type"] == 1:
+                    want = [bytes(c["sbytes"][int(c["soff"][i]):int(c["soff"][i + 1])]) if c["valid"][i] else None for i in range(c0, c0 + nrows)]
+                    assert list(vals) == want, c["name"]
+                else:
+                    assert np.array_equal(vals.astype(np.uint64), c["fixed"][c0:c0 + nrows]), c["name"]
+            c0 += nrows
+        assert c0 == exp["n_rows"]
+    rc, out, _ = run_host(fn, named=[("standard_tags", "true")], proj=[0, 13 + 34, 13 + 48])
+    assert rc == 0
+    rc, out, _ = run_host(fn, named=[("auxiliary_tags", "true")])
+    assert rc == 3 and "auxiliary_tags" in out

@@ -240,3 +240,23 @@ def test_region_synthetic_with_unplaced_and_batches():
     data = synth.bam_file(120000, seed=5)
     for region in ("chr1:1,000,000-2,000,000", "chr2:5000000-5100000,chr2:5050000-6000000,chrX", "chrM,*", "chr21:1-1000,chr22"):
         _region_check(data, region, max_blocks=7)
+
+
+# ---- standard_tags (row A5) ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["sam_equiv", "matrix", "fuzz", "fuzz_small_batches", "golden_range"])
+def test_std_tag_columns(which):
+    import tag_cases
+    data = {"sam_equiv": tag_cases.aux_tags_sam_equivalent, "matrix": tag_cases.type_matrix, "fuzz": tag_cases.fuzz, "fuzz_small_batches": tag_cases.fuzz,
+            "golden_range": lambda: read_golden("range.bam")}[which]()
+    exp = orc.bam_read_std_tags(data)
+    got = duckhts_amd.read_bam(data, std_tags_cols=list(range(56)), max_blocks=3 if which == "fuzz_small_batches" else 0)
+    assert got["n_rows"] == exp["n_rows"]
+    d = orc.bcf_cols_diff(exp, got["tags"])
+    assert d is None, d
+    # a projection of a few tag columns, in another order
+    sel = [34, 48, 29, 7, 53]
+    got = duckhts_amd.read_bam(data, std_tags_cols=sel)
+    sub = {"n_rows": exp["n_rows"], "cols": [exp["cols"][i] for i in sel]}
+    d = orc.bcf_cols_diff(sub, got["tags"])
+    assert d is None, d

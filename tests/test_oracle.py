@@ -267,3 +267,39 @@ def test_region_oracle_pins():
     assert region_oracle.parse_region(names, "chr1:-100") == (0, 0, 100)
     assert region_oracle.parse_region(names, "chr1:0-5") == (0, -1, 5)            # falls through hts.c:4118-4131 with beg = -1
     assert region_oracle.parse_region(names, "chr1:9-5") is None
+
+
+def test_std_tags_oracle_pins():
+    """read_bam(standard_tags := true): duckhts.test:179-185 (RG = x1, NM = 2 for aux_tags.sam's record) + getter semantics"""
+    import tag_cases
+    t = orc.bam_read_std_tags(tag_cases.aux_tags_sam_equivalent())
+    col = {c["name"]: orc.bcf_col_py(c) for c in t["cols"]}
+    assert len(t["cols"]) == 56 and [c["name"] for c in t["cols"]][:8] == ["AM", "AS", "BC", "BQ", "BZ", "CB", "CC", "CG"]
+    assert col["RG"] == [b"x1"] and col["NM"] == [2] and col["MD"] == [None]
+    types = {c["name"]: (c["type"], c["is_list"]) for c in t["cols"]}
+    assert types["NM"] == (2, 0) and types["RG"] == (1, 0) and types["TS"] == (1, 0) and types["ML"] == (2, 1) and types["CG"] == (2, 1)
+    t = orc.bam_read_std_tags(tag_cases.type_matrix())
+    col = {c["name"]: orc.bcf_col_py(c) for c in t["cols"]}
+    row = {n: i for i, n in enumerate(orc.bam_read(tag_cases.type_matrix())["QNAME"])}
+    r = row[b"ints"]
+    assert (col["AM"][r], col["AS"][r], col["CM"][r], col["CP"][r], col["FI"][r], col["H0"][r], col["NM"][r]) == (-5, 250, -30000, 65000, -2000000000, 4000000000, 7)
+    r = row[b"mismatch"]
+    assert col["NM"][r] == 0 and col["AS"][r] == 0 and col["MD"][r] is None and col["RG"][r] is None and col["TS"][r] == b"" and col["SM"][r] == 0
+    assert col["BC"][r] == b"1AE3" and col["UQ"][r] == 0
+    r = row[b"arrays"]
+    assert col["TS"][r] == b"+" and col["ML"][r] == [0, 128, 255] and col["FZ"][r] == [1, 65535] and col["CG"][r] == [-7, 9]
+    r = row[b"arrays2"]
+    import struct as st_
+    assert col["TS"][r] == b"" and col["FZ"][r] == [] and col["CG"][r] == [-1, 2, -3]
+    assert [st_.pack("<q", v) for v in col["ML"][r]] == [st_.pack("<d", float(np.float32(x))) for x in (0.5, -2.25, 1e30)]     # first ML wins: floats as double bits
+    r = row[b"dups"]
+    assert col["NM"][r] == 1 and col["LB"][r] == b"" and col["PU"][r] == b"unit" and col["PG"][r] == b"bwa" and len(col["ML"][r]) == 200
+    assert all(col[k][row[b"none"]] is None for k in col)
+    r = row[b"corrupt_mid"]
+    assert col["NM"][r] == 3 and col["MD"][r] == b"4" and col["AS"][r] is None
+    r = row[b"unterminated"]
+    assert col["NM"][r] == 4 and col["PG"][r] is None
+    r = row[b"b_overrun"]
+    assert col["AS"][r] == 5 and col["ML"][r] is None
+    r = row[b"longcig"]
+    assert col["CG"][r] is None and col["NM"][r] == 6 and col["MD"][r] == b"70000" and col["RG"][r] == b"g"
