@@ -72,6 +72,22 @@ __device__ __forceinline__ uint32_t br_take(BitR &b, uint32_t n) {   // n <= 32,
     return v;
 }
 
+#ifndef A_UNIFIED
+#define A_UNIFIED 1
+#endif
+// packed 16-bit helpers (v_pk_*): two independent u16 lanes per VGPR, no carries between the halves
+#ifdef HOSTSIM
+static inline uint32_t pk_subsat_u16(uint32_t a, uint32_t b) { uint32_t lo = (a & 0xffff) > (b & 0xffff) ? (a & 0xffff) - (b & 0xffff) : 0, hi = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0; return lo | (hi << 16); }
+static inline uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t lo = (a & 0xffff) < (b & 0xffff) ? (a & 0xffff) : (b & 0xffff), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16); return lo | (hi << 16); }
+static inline uint32_t pk_add_u16(uint32_t a, uint32_t b) { return ((a + b) & 0xffff) | ((((a >> 16) + (b >> 16)) & 0xffff) << 16); }
+static inline uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return (((a & 0xffff) * (b & 0xffff) + (c & 0xffff)) & 0xffff) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xffff) << 16); }
+#else
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#endif
+
 // 15 left-justified limits: lim[L-1] = (first_code[L] + count[L]) << (15 - L)
 struct Limits { uint32_t v[15]; };
 
@@ -85,13 +101,14 @@ __device__ __forceinline__ uint32_t code_len(const Limits &lm, uint32_t w15) {
 // builds limits (registers) + base table (LDS, [L][lane]) from cnt[L] (LDS); leaves cnt[L] = first
 // symbol index of length L (offs) for the placement pass.  Returns the Kraft remainder `left`
 // (0 complete, >0 incomplete, <0 over-subscribed).
-__device__ __forceinline__ int build_limits(Limits &lm, uint16_t *cnt, uint16_t *base, int lane, int maxlen) {
+__device__ __forceinline__ int build_limits(Limits &lm, uint16_t *cnt, uint16_t *base, int lane, int maxlen, uint32_t *bs) {
     uint32_t first = 0, offs = 0; int left = 1;
 #pragma unroll
     for (int L = 1; L <= 15; L++) {
         uint32_t c = (L <= maxlen) ? cnt[L * A_ST + lane] : 0;
         left = (left << 1) - (int)c;
         base[L * A_ST + lane] = (uint16_t)(offs - first);
+        bs[L] = (offs - first) & 0xffffu;
         lm.v[L - 1] = (first + c) << (15 - L);
         if (L <= maxlen) cnt[L * A_ST + lane] = (uint16_t)offs;
         offs += c;
@@ -271,7 +288,8 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         for (int L = 0; L < 16; L++) cnt[L * A_ST + lane] = 0;
         for (uint32_t i = 0; i < nl; i++) { uint32_t l = get_len(lens, lane, i); cnt[l * A_ST + lane]++; }
         uint32_t nz_l = nl - cnt[0 * A_ST + lane];
-        int left = build_limits(ll, cnt, lbase, lane, 15);
+        uint32_t bsl[16], bsd[16];
+        int left = build_limits(ll, cnt, lbase, lane, 15, bsl);
         if (left < 0 || (left > 0 && nz_l != 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
         for (int k = 0; k < 9; k++) lsym_hi[k * A_ST + lane] = 0;
         for (uint32_t i = 0; i < nl; i++) {
@@ -287,7 +305,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         for (int L = 0; L < 16; L++) cnt[L * A_ST + lane] = 0;
         for (uint32_t i = 0; i < nd; i++) { uint32_t l = get_len(lens, lane, nl + i); cnt[l * A_ST + lane]++; }
         uint32_t nz_d = nd - cnt[0 * A_ST + lane];
-        left = build_limits(dl, cnt, dbase, lane, 15);
+        left = build_limits(dl, cnt, dbase, lane, 15, bsd);
         if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
         for (uint32_t i = 0; i < nd; i++) {
             uint32_t l = get_len(lens, lane, nl + i);
@@ -298,6 +316,129 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         unsigned long long dA_s0 = clock64();
 #endif
         // ---- symbol loop ----
+#if A_UNIFIED
+        // ONE Huffman symbol per lane per iteration, from whichever alphabet the lane expects (mode 0 = literal/length,
+        // 1 = distance): a wave always holds lanes in both states, so separate literal and distance paths would both execute every
+        // iteration.  Code length = 16 - #{i : w < limit[i]}; the limits of BOTH alphabets sit in the two halves of 15 VGPRs and are
+        // compared with packed 16-bit saturating arithmetic (no VCC/SGPR round trips).  Malformed-stream tests only accumulate
+        // into `bad` (indices are clamped), so the body has three short divergent regions: literal store, length, distance + token.
+        // Input: per-lane 64-byte LDS window, refetched by the whole wave every 4 symbols (<= 28 bits per symbol, so a lane moves
+        // <= 16 bytes per period and can never leave the window parked one period earlier).
+        {
+            uint32_t *winA = (uint32_t *)lens;
+            const uint8_t *sp = br.p;
+            uint32_t wbase = br.pos, rbase = br.pos;
+            uint4 R0, R1, R2, R3;
+            __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
+            __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
+            // P[i]: limits of code length i+1 (literal/length | distance << 16).  DB[i]: telescoped deltas of the canonical
+            // base table, so that sum_i [w < limit_i] * DB[i] = base[L] (mod 2^16) without an LDS lookup.
+            uint32_t P[15], DB[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) {
+                P[i] = ll.v[i] | (dl.v[i] << 16);
+                const uint32_t dl_ = i < 14 ? (bsl[i + 1] - bsl[i + 2]) & 0xffffu : bsl[15];
+                const uint32_t dd_ = i < 14 ? (bsd[i + 1] - bsd[i + 2]) & 0xffffu : bsd[15];
+                DB[i] = dl_ | (dd_ << 16);
+            }
+            bool live = true; uint32_t mode = 0, want = 0, bad = 0, nw = 0;
+            bool primed = false;
+            while (__ballot(live) != 0ull) {
+                // park the previous fetch, start the next one
+                winA[0 * A_ST + lane] = R0.x; winA[1 * A_ST + lane] = R0.y; winA[2 * A_ST + lane] = R0.z; winA[3 * A_ST + lane] = R0.w;
+                winA[4 * A_ST + lane] = R1.x; winA[5 * A_ST + lane] = R1.y; winA[6 * A_ST + lane] = R1.z; winA[7 * A_ST + lane] = R1.w;
+                winA[8 * A_ST + lane] = R2.x; winA[9 * A_ST + lane] = R2.y; winA[10 * A_ST + lane] = R2.z; winA[11 * A_ST + lane] = R2.w;
+                winA[12 * A_ST + lane] = R3.x; winA[13 * A_ST + lane] = R3.y; winA[14 * A_ST + lane] = R3.z; winA[15 * A_ST + lane] = R3.w;
+                wbase = rbase; rbase = br.pos;
+#ifdef A_EXP_NOLOAD
+                rbase &= 0xffu;        /* experiment: refetch a tiny hot region (wrong data, timing only) */
+#endif
+                __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
+                __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
+                if (!primed) { nw = winA[(((br.pos - wbase) >> 2) & 15u) * A_ST + lane]; primed = true; }   // next unread word, always one ahead
+#pragma unroll 1
+                for (int sub = 0; sub < 4; sub++) {
+#ifdef DHTS_DIAG
+                    dA_it++;
+#endif
+                    if (live) {
+                        if (br.cnt <= 32) {
+                            br.buf |= (uint64_t)nw << br.cnt; br.pos += 4; br.cnt += 32;
+                            nw = winA[(((br.pos - wbase) >> 2) & 15u) * A_ST + lane];          // consumed one refill later: latency hidden
+                        }
+                        const uint32_t w = __brev((uint32_t)br.buf) >> 17;
+                        const uint32_t ww = w | (w << 16);
+                        uint32_t m[15];
+#pragma unroll
+                        for (int i = 0; i < 15; i++) m[i] = pk_subsat_u16(P[i], ww);
+#pragma unroll
+                        for (int i = 0; i < 15; i++) m[i] = pk_min_u16(m[i], 0x00010001u);         // [w < limit_i] per half
+                        uint32_t a0 = pk_add_u16(m[0], m[1]), a1 = pk_add_u16(m[2], m[3]), a2 = pk_add_u16(m[4], m[5]), a3 = pk_add_u16(m[6], m[7]);
+                        uint32_t a4 = pk_add_u16(m[8], m[9]), a5 = pk_add_u16(m[10], m[11]), a6 = pk_add_u16(m[12], m[13]);
+                        a0 = pk_add_u16(a0, a1); a2 = pk_add_u16(a2, a3); a4 = pk_add_u16(a4, a5); a6 = pk_add_u16(a6, m[14]);
+                        const uint32_t acc = pk_add_u16(pk_add_u16(a0, a2), pk_add_u16(a4, a6));
+                        uint32_t b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+                        for (int i = 0; i < 15; i += 3) { b0 = pk_mad_u16(m[i], DB[i], b0); b1 = pk_mad_u16(m[i + 1], DB[i + 1], b1); b2 = pk_mad_u16(m[i + 2], DB[i + 2], b2); }
+                        const uint32_t accB = pk_add_u16(pk_add_u16(b0, b1), b2);
+                        const uint32_t clt = mode ? (acc >> 16) : (acc & 0xffffu);          // #{limits > w}
+                        bad |= (clt == 0) ? 1u : 0u;
+                        uint32_t L = 16u - clt; L = L > 15u ? 15u : L;
+                        const uint32_t base = mode ? (accB >> 16) : (accB & 0xffffu);
+                        uint32_t o = (base + (w >> (15u - L))) & 0xffffu;
+                        const uint32_t omax = mode ? 31u : 287u;
+                        bad |= (o > omax) ? 1u : 0u;
+                        o = o > omax ? omax : o;
+                        const uint32_t sb = smem[(mode ? A_DSYM : A_LSYM_LO) + o * A_ST + lane];
+                        const uint32_t hw = lsym_hi[(o >> 5) * A_ST + lane];               // both reads in flight together
+                        const uint32_t sym = sb | (((hw >> (o & 31u)) << 8) & (mode ? 0u : 0x100u));
+                        br.buf >>= L; br.cnt -= L;
+                        if (!mode && sym < 256u) {
+                            // literal
+                            bad |= (outpos >= 65536u) ? 1u : 0u;
+                            litbuf |= sym << (8u * (nlit & 3u)); nlit++; outpos++;
+#ifndef A_EXP_NOSTORE
+                            if ((nlit & 3u) == 0u) { *(uint32_t *)(lit + nlit - 4) = litbuf; litbuf = 0; }
+                            if (++run == DHTS_TOK_PURE) { tok[ntok++] = DHTS_TOK_PURE << 23; run = 0; }
+#else
+                            if ((nlit & 3u) == 0u) litbuf = 0;
+                            if (++run == DHTS_TOK_PURE) { ntok++; run = 0; }
+#endif
+                        } else if (!mode && sym == 256u) {
+                            live = false;
+                        } else {
+                            // length (mode 0) or distance (mode 1): value = base(j) + extra bits, same arithmetic with k = 2 / 1
+                            const uint32_t j = mode ? sym : sym - 257u;
+                            bad |= (j >= (mode ? 30u : 29u)) ? 1u : 0u;
+                            const uint32_t k = mode ? 1u : 2u;
+                            const int32_t e = (int32_t)(j >> k) - 1;
+                            uint32_t eb = e < 0 ? 0u : (uint32_t)e;
+                            eb = eb > 13u ? 13u : eb;
+                            uint32_t val = e < 0 ? j : ((((1u << k) | (j & ((1u << k) - 1u))) << eb));
+                            val += mode ? 1u : 3u;
+                            if (!mode && j == 28u) { val = 258u; eb = 0; }
+                            val += (uint32_t)br.buf & ((1u << eb) - 1u);
+                            br.buf >>= eb; br.cnt -= eb;
+                            if (!mode) { want = val; mode = 1; }
+                            else {
+                                bad |= (val > outpos || outpos + want > 65536u) ? 1u : 0u;
+#ifndef A_EXP_NOSTORE
+                                if (!bad) { tok[ntok++] = (run << 23) | ((want - 3u) << 15) | (val - 1u); run = 0; outpos += want; }
+#else
+                                if (!bad) { ntok++; run = 0; outpos += want; }
+#endif
+                                mode = 0;
+                            }
+                        }
+                        bad |= (br.pos * 8u - br.cnt > payload_bits + 64u) ? 1u : 0u;   // ran off the payload
+                        if (bad) { status = DHTS_BLK_ERR_INFLATE; live = false; }
+                    }
+                }
+            }
+            // back to the plain reader for the next block header: re-prime its two look-ahead words
+            br.w0 = ld32_guard(br.p, br.pos, br.lim); br.w1 = ld32_guard(br.p, br.pos + 4, br.lim);
+        }
+#else
         // Input comes through an LDS window: every 4 iterations (wave-uniform) each lane fetches the 64 bytes at its own
         // stream position into registers, and the fetch of the previous period is parked in LDS ([dword][lane], aliasing
         // the code-length scratch, idle now).  Refills read that window, so the only vmcnt wait of the loop sits at the
@@ -379,6 +520,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
             // back to the plain reader for the next block header: re-prime its two look-ahead words
             br.w0 = ld32_guard(br.p, br.pos, br.lim); br.w1 = ld32_guard(br.p, br.pos + 4, br.lim);
         }
+#endif
 #ifdef DHTS_DIAG
         dA_sym += clock64() - dA_s0;
 #endif

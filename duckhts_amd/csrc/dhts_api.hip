@@ -1373,6 +1373,19 @@ int dhts_debug_diag(dhts_ctx *c, unsigned long long *out8) {
 }
 #endif
 // debugging aid (not part of the public header): phase-A metadata of scratch slot s
+// kernel experiments (tools/dbg): phase A alone over blocks [b0, b0+nb), `reps` launches; returns ms per launch
+extern "C" double dhts_debug_time_huff(dhts_ctx *c, int64_t b0, int64_t nb, int reps) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) return -1;
+    if (huff_blocks(c, b0, nb)) return -1;
+    (void)hipStreamSynchronize(c->stream);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; r++) if (huff_blocks(c, b0, nb)) return -1;
+    (void)hipEventRecord(e1, c->stream); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / reps;
+}
 int dhts_debug_meta(dhts_ctx *c, int64_t s, uint32_t *out4) {
     if (!c || s < 0 || s >= c->huff_nb) return -1;
     HIPCHK(c, hipMemcpy(out4, (InflateMeta *)c->meta.p + s, 16, hipMemcpyDeviceToHost));
