@@ -581,9 +581,26 @@ __device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {  
 // Window ring: 32 KiB of DEFLATE history + 2 KiB of batch span (a batch places its literals before its matches, so a
 // batch may run at most BR_SPAN bytes ahead of the oldest byte a match of the same batch can still need).
 // 34,816 + 4,096 (CRC tables) + 2,048 (literal ring) = 40,960 B: four workgroups per CU.
+#ifndef B_SMALLRING
+#define B_SMALLRING 1
+#endif
+#if B_SMALLRING
+// Power-of-two ring of 2^B_RING_LOG2 bytes, flushed progressively in half-ring chunks: it holds the unflushed tail (< half a ring
+// + one batch span) plus the most recent history.  Matches whose source is older than the ring read the bytes back from the
+// block's own output in HBM (such sources always lie below `flushed`, see BR_FLUSH).  8 KiB ring: 14,336 B of LDS per block
+// instead of 40,704, i.e. eleven workgroups per CU instead of four, so every SIMD holds 2-3 waves that fill each other's issue
+// slots (measured per 16,384-block launch: 6.1 ms with the full 34.5 KB window, 4.45 ms with 16 KiB, 3.5 ms with 8 KiB).
+#ifndef B_RING_LOG2
+#define B_RING_LOG2 13
+#endif
+#define BR_R (1u << B_RING_LOG2)
+#define BR_FLUSH (BR_R / 2u)             /* needs BR_R >= BR_FLUSH + BR_SPAN + 265 so that far sources are always flushed */
+#else
 #define BR_R 34560u
-#define BR_SPAN 1792u
 #define BR_FLUSH 8192u
+#endif
+#define BR_PIECE (BR_FLUSH / 64u)        /* bytes of a flush chunk CRC'd by one lane */
+#define BR_SPAN 1792u
 #define B_WIN 0
 #define B_CRCT (BR_R)                    /* u32 [4][256] slice-by-4 tables */
 #define B_RING (B_CRCT + 4096)           /* u8 [2048] literal staging ring */
@@ -606,7 +623,11 @@ __device__ unsigned long long g_diagt[8];
 #endif
 
 
+#if B_SMALLRING
+__device__ __forceinline__ uint32_t ridx(uint32_t p) { return p & (BR_R - 1u); }
+#else
 __device__ __forceinline__ uint32_t ridx(uint32_t p) { return p >= BR_R ? p - BR_R : p; }      // p < 2*BR_R
+#endif
 __device__ __forceinline__ uint64_t win_ld64(const uint8_t *win, uint32_t p) {
     const uint32_t i = ridx(p);
     if (i + 8 <= BR_R) return lds_ld64(win + i);
@@ -672,15 +693,15 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     uint8_t *dstp = out + (tab.uoff[bi] - out_base);
     uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
     // constants of the 8 KiB flush-chunk CRC: lane's 128-byte piece is followed by 128*(63-lane) bytes of the chunk
-    const uint32_t K_lane = crc_xpow8(128u * (63u - (uint32_t)lane));
+    const uint32_t K_lane = crc_xpow8(BR_PIECE * (63u - (uint32_t)lane));
     const uint32_t X_F = crc_xpow8(BR_FLUSH);
 
     // Flush the 8 KiB chunk [flushed, flushed + 8192): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
     // BR_R is a multiple of 128, so neither a lane's 128-byte CRC piece nor a 16-byte store unit wraps in the ring.
 #define FLUSH_CHUNK() do {                                                                                              \
-        const uint32_t pi_ = ridx(flushed + (uint32_t)lane * 128u);                                                     \
+        const uint32_t pi_ = ridx(flushed + (uint32_t)lane * BR_PIECE);                                                 \
         uint32_t c_ = (flushed == 0 && lane == 0) ? 0xffffffffu : 0u;                                                   \
-        for (uint32_t q_ = 0; q_ < 128; q_ += 4) {                                                                      \
+        for (uint32_t q_ = 0; q_ < BR_PIECE; q_ += 4) {                                                                      \
             uint32_t v_ = *(const uint32_t *)(win + pi_ + q_) ^ c_;                                                     \
             c_ = crct[768 + (v_ & 0xff)] ^ crct[512 + ((v_ >> 8) & 0xff)] ^ crct[256 + ((v_ >> 16) & 0xff)] ^ crct[v_ >> 24]; \
         }                                                                                                               \
@@ -692,6 +713,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             uint4 v4_ = *(const uint4 *)(win + ridx(p_));                                                               \
             __builtin_memcpy(dstp + p_, &v4_, 16);                                                                      \
         }                                                                                                               \
+        if (B_SMALLRING) __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0): the chunk is in L2 before any far-match read-back */ \
         flushed += BR_FLUSH;                                                                                            \
     } while (0)
 
@@ -741,15 +763,26 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
             uint32_t sh = 4; while ((tot_adv >> sh) > 63u) sh++;
             uint64_t dmask = 0, smask = 0;
+#if B_SMALLRING
+            // sources below rlo are overwritten in the ring by this batch's own output: they come from HBM (always < flushed)
+            const uint32_t bend = outpos + tot_adv, rlo = bend > BR_R ? bend - BR_R : 0u;
+            const bool farm = mlen > 0 && ms < rlo;
+            if (farm) {
+                for (uint32_t c = 0; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, dstp + ms + c, 8); win_st_n(win, md + c, v, mlen - c); }
+            }
+#else
+            const bool farm = false;
+#endif
             if (mlen > 0) {
                 const uint32_t lo = (md - outpos) >> sh, hi = (md - outpos + mlen - 1) >> sh;
                 dmask = ((~0ull) >> (63u - hi)) & ((~0ull) << lo);
-                if (ms + mspan > outpos) {
+                if (!farm && ms + mspan > outpos) {
                     const uint32_t slo = (ms > outpos ? ms - outpos : 0u) >> sh, shi = (ms + mspan - 1 - outpos) >> sh;
                     smask = ((~0ull) >> (63u - shi)) & ((~0ull) << slo);
                 }
             }
-            uint64_t P = __ballot(mlen > 0);
+            uint64_t P = __ballot(mlen > 0 && !farm);
+            if (B_SMALLRING) __syncthreads();                  // far copies are in the ring before anybody reads them
             while (P) {
                 const bool pending = (P >> lane) & 1ull;
                 const uint64_t e = pending ? dmask : 0ull;
@@ -801,8 +834,14 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
                 __syncthreads();
                 if (ml) {
                     const uint32_t src0 = outpos - di;
+#if B_SMALLRING
+                    const uint32_t thr = outpos + ml > BR_R ? outpos + ml - BR_R : 0u;      // older bytes are read back from HBM
+                    if (ml <= di) { for (uint32_t k = lane; k < ml; k += 64) { const uint32_t sx = src0 + k; win[ridx(outpos + k)] = sx < thr ? dstp[sx] : win[ridx(sx)]; } }
+                    else { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + (k % di))]; }          // overlapping: dist < 258, never far
+#else
                     if (ml <= di) { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + k)]; }
                     else { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + (k % di))]; }
+#endif
                     outpos += ml;
                     __syncthreads();
                 }
@@ -818,7 +857,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     {
         uint32_t rem = m.nlit - litpos;
         while (rem) {
-            const uint32_t n = rem < 4096u ? rem : 4096u;
+            const uint32_t n = rem < BR_FLUSH / 2u ? rem : BR_FLUSH / 2u;
             for (uint32_t k = lane; k < n; k += 64) win[ridx(outpos + k)] = lit[litpos + k];
             outpos += n; litpos += n; rem -= n;
             __syncthreads();
