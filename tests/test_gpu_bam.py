@@ -70,6 +70,40 @@ def test_bgzf_inflate_cases(case):
     ctx.close()
 
 
+def _lz_payloads():
+    """raw payloads that stress the LZ77 window: far sources (read back from flushed output), ring wrap, long and overlapping copies"""
+    import random
+    rnd = random.Random(11)
+    R = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+    a = R(32768 - 100)
+    out = {
+        "far_max_distance": a + a[:258] + R(50) + a[1000:1300],                   # distances just under 32 KiB
+        "far_many": b"".join(R(700) for _ in range(12)) * 7,                      # 8.4 KB period: every copy is older than the 8 KiB ring
+        "near_and_far": (R(5000) + b"ABCDEFGH" * 40 + R(3000)) * 6,
+        "zeros": b"\0" * 65280,                                                   # dist 1, len 258 chains
+        "period3": b"xyz" * 21000,
+        "period_300": R(300) * 217,
+        "random": R(65000),
+        "text": (b"the quick brown fox jumps over the lazy dog %d\n" * 1400) % tuple(range(1400)),
+        "long_literal_runs": b"".join(R(3000) + b"Q" * 600 for _ in range(17)),
+    }
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("name", sorted(_lz_payloads()))
+def test_bgzf_inflate_window_stress(name, level):
+    import bamwriter as bw
+    raw = _lz_payloads()[name]
+    d = bw.bgzf_file(raw, payload=65280, level=level)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(d)
+    nb = ctx.bgzf_index()
+    out, bst = ctx.bgzf_inflate(0, nb, len(raw))
+    ctx.close()
+    assert np.all(bst == 0) and out.tobytes() == raw
+
+
 def test_bgzf_errors_flagged_per_block():
     for maker, code in ((cases.case_bad_crc, -4), (cases.case_bad_deflate, None)):
         d = maker()
