@@ -9,7 +9,10 @@
 //             src/bam_reader.c:785-918 fixed-width writers and string-length bookkeeping.
 #pragma once
 
+#ifndef TL_TILE
 #define TL_TILE 8192u
+#endif
+#define TL_RECS (TL_TILE / 32u)            /* >= records per tile (36-byte minimum for BAM, 32 for BCF) */
 #define TL_HALO 1024u
 
 // global-memory accessor (records that do not fit the staged window)
@@ -261,7 +264,7 @@ extern "C" __global__ void __launch_bounds__(64)
 bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res,
                 int64_t nrows, uint32_t *rec_off, uint8_t *rg_flag, BamCols c, unsigned long long *bad_row, const uint32_t *row_map) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
-    __shared__ uint32_t recs[256];
+    __shared__ uint32_t recs[TL_RECS];
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
     if (t >= ntiles || (uint64_t)t > res[3]) return;
@@ -276,14 +279,14 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
     GSrc gs; gs.g = st.u;
     {   // record starts (the chain was validated by the scan / fix kernels)
         uint64_t o = first;
-        for (uint32_t k = 0; k < n; k++) { if (lane == 0 && k < 256) recs[k] = (uint32_t)o; o += 4ull + (((o - tb) + 4 <= (uint64_t)s.len) ? ls.u32(o) : gs.u32(o)); }
+        for (uint32_t k = 0; k < n; k++) { if (lane == 0 && k < TL_RECS) recs[k] = (uint32_t)o; o += 4ull + (((o - tb) + 4 <= (uint64_t)s.len) ? ls.u32(o) : gs.u32(o)); }
     }
     __syncthreads();
     for (uint32_t k = lane; k < n; k += 64) {
         const int64_t row = (int64_t)row0 + k;
         if (row >= nrows) break;
         uint64_t o;
-        if (k < 256) o = recs[k];
+        if (k < TL_RECS) o = recs[k];
         else { o = first; for (uint32_t j = 0; j < k; j++) o += 4ull + gs.u32(o); }    // > 256 records per tile cannot happen (36-byte minimum)
         const uint64_t rel = o - tb;
         bool fast = false;

@@ -21,7 +21,7 @@
 #include <algorithm>
 #include <limits.h>
 
-#define TILE_BYTES 8192u
+#define TILE_BYTES TL_TILE               /* record-stage tile = what bam_tiles_lds.hip stages per wave */
 #define PAD_BYTES 256u
 
 struct DevBuf {
