@@ -32,7 +32,12 @@ class BamBatch(C.Structure):
                 ("tlen", C.c_void_p), ("tid", C.c_void_p), ("mtid", C.c_void_p), ("rg_idx", C.c_void_p),
                 ("rg_valid", C.c_void_p),
                 ("qname", StrCol), ("cigar", StrCol), ("seq", StrCol), ("qual", StrCol), ("rg", StrCol),
-                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("reserved2", C.c_int32), ("tag_cols", C.c_void_p)]
+                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("reserved2", C.c_int32), ("aux_map", C.c_void_p), ("tag_cols", C.c_void_p)]
+
+
+class AuxMap(C.Structure):
+    _fields_ = [("valid", C.c_void_p), ("off", C.c_void_p), ("n_ent", C.c_uint64), ("key", C.c_void_p), ("kind", C.c_void_p), ("sub", C.c_void_p),
+                ("pay_off", C.c_void_p), ("payload", C.c_void_p), ("payload_bytes", C.c_uint64)]
 
 
 class BamHeader(C.Structure):
@@ -68,7 +73,7 @@ ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
-           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
+           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
@@ -105,6 +110,7 @@ def lib():
         L.dhts_bam_set_regions.argtypes = [C.c_void_p, C.c_char_p]
         L.dhts_bam_std_tag_info.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.dhts_bam_set_tag_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.dhts_bam_set_aux_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.dhts_bam_load_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bam_next_batch.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(BamBatch)]
         L.dhts_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -219,6 +225,49 @@ class Context:
         arr = np.array(list(ids), np.int32)
         self._chk(self.L.dhts_bam_set_tag_columns(self.h, arr.ctypes.data, len(arr)))
         self._tag_ids = list(ids)
+
+    def set_aux_map(self, enable=True, exclude_standard=True):
+        self._chk(self.L.dhts_bam_set_aux_map(self.h, int(enable), int(exclude_standard)))
+
+    def aux_table(self, b):
+        """AUXILIARY_TAGS of one batch: typed device entries -> keys / rendered value text (bam_aux_to_string, src/bam_reader.c:140-183;
+        the %g / %lld text is host-side formatting) as two LIST(VARCHAR) columns in the canonical layout"""
+        import struct as st_
+        n = int(b.n_rows)
+        am = C.cast(b.aux_map, C.POINTER(AuxMap)).contents
+        ne = int(am.n_ent)
+        valid = self.d2h(am.valid, n, np.uint8) if n else np.zeros(0, np.uint8)
+        off = self.d2h(am.off, n + 1, np.uint32).astype(np.uint64) if n else np.zeros(1, np.uint64)
+        key = self.d2h(am.key, ne, np.uint16)
+        kind = self.d2h(am.kind, ne, np.uint8)
+        sub = self.d2h(am.sub, ne, np.uint8)
+        po = self.d2h(am.pay_off, ne + 1, np.uint32) if n else np.zeros(1, np.uint32)
+        pay = self.d2h(am.payload, int(am.payload_bytes), np.uint8).tobytes()
+        keys, vals = [], []
+        for i in range(ne):
+            kb = bytes([int(key[i]) & 0xff, int(key[i]) >> 8]).split(b"\0")[0]
+            p = pay[int(po[i]):int(po[i + 1])]
+            k = int(kind[i])
+            if k == 0:
+                v = b"%d" % st_.unpack("<q", p)[0]
+            elif k == 1:
+                v = (b"%g" % st_.unpack("<d", p)[0])
+            elif k in (2, 3):
+                v = p
+            elif k == 4:
+                v = bytes([int(sub[i])]) + b"".join(b",%d" % x for x in st_.unpack("<%dq" % (len(p) // 8), p))
+            elif k == 5:
+                v = bytes([int(sub[i])]) + b"".join(b",%g" % x for x in st_.unpack("<%dd" % (len(p) // 8), p))
+            else:
+                v = b""
+            keys.append(kb)
+            vals.append(v.split(b"\0")[0])                    # assigned through the NUL-terminated API
+        cols = []
+        for name, items in (("AUX_KEYS", keys), ("AUX_VALUES", vals)):
+            lens = np.array([len(x) for x in items], np.int64)
+            cols.append({"name": name, "type": 1, "is_list": 1, "valid": valid, "loff": off[:-1].copy(), "llen": off[1:] - off[:-1], "child_n": ne,
+                         "csoff": np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64), "csbytes": np.frombuffer(b"".join(items), np.uint8)})
+        return {"n_rows": n, "cols": cols}
 
     def tag_table(self, b):
         """standard-tag columns of one batch -> canonical column table (layout of tests/orc.py decode_bcf_blob)"""
@@ -510,7 +559,7 @@ def std_tags():
     return _STD_TAGS
 
 
-def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None):
+def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None):
     """Full sequential scan (reference mode (i)): all rows in file order.
     region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window."""
     ctx = Context(device)
@@ -527,7 +576,9 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
                 ctx.load_index(index)
         if std_tags_cols is not None:
             ctx.set_tag_columns(std_tags_cols)
-        parts, tparts = [], []
+        if aux_map is not None:
+            ctx.set_aux_map(True, bool(aux_map == "exclude_standard"))
+        parts, tparts, aparts = [], [], []
         status = 0
         while True:
             b = ctx.next_batch(max_blocks)
@@ -535,12 +586,16 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
                 parts.append(ctx.batch_to_host(b, hdr))
                 if std_tags_cols is not None:
                     tparts.append(ctx.tag_table(b))
+                if aux_map is not None:
+                    aparts.append(ctx.aux_table(b))
             status = b.status
             if b.status != 0:
                 break
         out = {"n_rows": sum(p["n_rows"] for p in parts), "status": status, "header": hdr}
         if std_tags_cols is not None:
             out["tags"] = {"n_rows": out["n_rows"], "cols": _concat_tables(tparts, None) or []}
+        if aux_map is not None:
+            out["aux"] = {"n_rows": out["n_rows"], "cols": _concat_tables(aparts, None) or []}
         for k in BAM_COLUMNS + ["tid", "mtid"]:
             vals = [p[k] for p in parts]
             if not vals:

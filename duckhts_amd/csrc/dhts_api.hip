@@ -71,6 +71,8 @@ struct dhts_ctx {
     DevBuf d_rg_off, d_rg_bytes;
     // standard-tag columns (row A5)
     std::vector<int32_t> tag_sel; std::vector<dhts_col> tag_out;
+    bool aux_on = false, aux_excl_std = false; dhts_aux_map aux_out;
+    DevBuf x_excl, x_valid, x_le, x_lp, x_oe, x_op, x_key, x_kind, x_sub, x_payoff, x_payload;
     DevBuf t_codes, t_dir, t_lens, t_offs, t_partial, t_total, t_coldev, t_fixed, t_valid, t_var;
     // region filter (row A11)
     bool rg_active = false, rg_all = false, rg_nocoor = false;
@@ -748,6 +750,41 @@ int dhts_bam_set_tag_columns(dhts_ctx *c, const int32_t *ids, int32_t n) {
     return 0;
 }
 
+int dhts_bam_set_aux_map(dhts_ctx *c, int enable, int exclude_standard_tags) {
+    if (!c) return -1;
+    c->aux_on = enable != 0; c->aux_excl_std = exclude_standard_tags != 0;
+    return 0;
+}
+
+// AUXILIARY_TAGS: typed entries of the non-excluded tags for the (final, compacted) rows of the current batch
+static int bam_aux_map(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam_batch *out) {
+    out->aux_map = nullptr;
+    if (!c->aux_on) return 0;
+    memset(&c->aux_out, 0, sizeof(c->aux_out));
+    out->aux_map = &c->aux_out;
+    if (nrows <= 0) return 0;
+    const size_t n = (size_t)nrows;
+    std::vector<uint16_t> excl;
+    if (c->aux_excl_std) for (int i = 0; i < kNStdTags; i++) excl.push_back((uint16_t)((uint8_t)kStdTags[i].tag[0] | ((uint8_t)kStdTags[i].tag[1] << 8)));
+    ENSURE(c, c->x_excl, excl.size() * 2 + 16); ENSURE(c, c->x_valid, n + 64); ENSURE(c, c->x_le, n * 4 + 16); ENSURE(c, c->x_lp, n * 4 + 16);
+    ENSURE(c, c->x_oe, (n + 1) * 4 + 16); ENSURE(c, c->x_op, (n + 1) * 4 + 16);
+    if (!excl.empty()) HIPCHK(c, hipMemcpyAsync(c->x_excl.p, excl.data(), excl.size() * 2, hipMemcpyHostToDevice, c->stream));
+    AuxMapDev a; memset(&a, 0, sizeof(a));
+    a.excl = (const uint16_t *)c->x_excl.p; a.n_excl = (int32_t)excl.size(); a.valid = (uint8_t *)c->x_valid.p;
+    a.lens_ent = (uint32_t *)c->x_le.p; a.lens_pay = (uint32_t *)c->x_lp.p; a.off_ent = (const uint32_t *)c->x_oe.p; a.off_pay = (const uint32_t *)c->x_op.p;
+    { KTimer tm(c, DHTS_K_CORE); hipLaunchKernelGGL(bam_aux_list<false>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, a); }
+    const uint32_t *in[2] = {a.lens_ent, a.lens_pay}; uint32_t *o32[2] = {(uint32_t *)c->x_oe.p, (uint32_t *)c->x_op.p}; uint64_t tot[2] = {0, 0};
+    { KTimer tm(c, DHTS_K_SCAN); if (run_scan(c, 2, in, o32, nullptr, nrows, tot)) return -1; }
+    if (tot[0] >= (1ull << 32) || tot[1] >= (1ull << 32)) return fail(c, "AUXILIARY_TAGS too large for one batch");
+    ENSURE(c, c->x_key, tot[0] * 2 + 16); ENSURE(c, c->x_kind, tot[0] + 16); ENSURE(c, c->x_sub, tot[0] + 16); ENSURE(c, c->x_payoff, (tot[0] + 1) * 4 + 16); ENSURE(c, c->x_payload, tot[1] + 64);
+    a.key = (uint16_t *)c->x_key.p; a.kind = (uint8_t *)c->x_kind.p; a.sub = (uint8_t *)c->x_sub.p; a.pay_off = (uint32_t *)c->x_payoff.p; a.payload = (uint8_t *)c->x_payload.p;
+    { KTimer tm(c, DHTS_K_STRINGS); hipLaunchKernelGGL(bam_aux_list<true>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, a); }
+    HIPCHK(c, hipGetLastError());
+    c->aux_out.valid = a.valid; c->aux_out.off = a.off_ent; c->aux_out.n_ent = tot[0]; c->aux_out.key = a.key; c->aux_out.kind = a.kind; c->aux_out.sub = a.sub;
+    c->aux_out.pay_off = a.pay_off; c->aux_out.payload = a.payload; c->aux_out.payload_bytes = tot[1];
+    return 0;
+}
+
 // materialises the selected tag columns for the (final, compacted) rows of the current batch
 static int bam_tag_columns(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam_batch *out) {
     const int nt = (int)c->tag_sel.size();
@@ -1041,6 +1078,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         out->rg = {o32[4], bc.len_rg, so.rg, tot[4]};
     }
     if (bam_tag_columns(c, st, nrows, out)) return -1;
+    if (bam_aux_map(c, st, nrows, out)) return -1;
     out->n_rows = nrows;
     out->end_uoff = out_base + carry_start;
     {

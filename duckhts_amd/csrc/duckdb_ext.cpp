@@ -36,7 +36,8 @@ struct BamBind {
     dhts_ctx *ctx = nullptr;          // resident file + header, reused by the scan (one GPU)
     dhts_bam_header hdr;
     int has_index = 0;
-    int standard_tags = 0;
+    int standard_tags = 0, auxiliary_tags = 0;
+    idx_t aux_col_idx = (idx_t)-1;
 };
 
 struct HostStr { std::vector<uint32_t> off, len; std::vector<uint8_t> bytes; };
@@ -53,6 +54,9 @@ struct BamLocal {
     std::vector<int> tag_slot;           // output vector -> index into tags (-1 = not a tag column)
     struct HostTag { std::vector<uint8_t> valid, bytes; std::vector<int64_t> fixed; std::vector<uint32_t> off; std::vector<int64_t> child; };
     std::vector<HostTag> tags;
+    // AUXILIARY_TAGS of the current batch: list offsets + rendered key / value strings
+    bool want_aux = false;
+    std::vector<uint8_t> aux_valid; std::vector<uint32_t> aux_off; std::vector<std::string> aux_key, aux_val;
 };
 
 static void destroy_bind(void *p) { BamBind *b = (BamBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
@@ -123,8 +127,7 @@ static void bam_read_bind(duckdb_bind_info info) {
     }
     b->has_index = !b->index_file.empty();                                       // bam_reader.c:499-503
     if (has_region) b->region = region_copy;
-    if (auxiliary_tags) { set_error(info, "read_bam: auxiliary_tags (MAP of the remaining tags, %g text) is not on the MI355X scan path yet"); delete b; return; }
-    b->standard_tags = standard_tags;
+    b->standard_tags = standard_tags; b->auxiliary_tags = auxiliary_tags;
 
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
     auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);
@@ -141,6 +144,12 @@ static void bam_read_bind(duckdb_bind_info info) {
             add(info, nm, ty == 'i' ? t_big : ty == 'B' ? t_list : t_varchar);
         }
         rm(&t_list);
+    }
+    if (b->auxiliary_tags) {                                                                    // bam_reader.c:539-548
+        duckdb_logical_type t_map = API(duckdb_logical_type, duckdb_create_map_type, duckdb_logical_type, duckdb_logical_type)(t_varchar, t_varchar);
+        b->aux_col_idx = DHTS_BAM_CORE_COUNT + (b->standard_tags ? (idx_t)dhts_bam_std_tag_count() : 0);
+        add(info, "AUXILIARY_TAGS", t_map);
+        rm(&t_map);
     }
     rm(&t_varchar); rm(&t_int); rm(&t_big); rm(&t_us);
     API(void, duckdb_bind_set_bind_data, duckdb_bind_info, void *, duckdb_delete_callback_t)(info, b, destroy_bind);
@@ -170,6 +179,8 @@ static void bam_read_local_init(duckdb_init_info info) {
     }
     l->tags.resize(l->tag_ids.size());
     dhts_bam_set_tag_columns(bind->ctx, l->tag_ids.data(), (int32_t)l->tag_ids.size());
+    for (idx_t id : l->column_ids) if (bind->auxiliary_tags && id == bind->aux_col_idx) l->want_aux = true;
+    dhts_bam_set_aux_map(bind->ctx, l->want_aux ? 1 : 0, bind->standard_tags);
     auto init_error = API(void, duckdb_init_set_error, duckdb_init_info, const char *);
     if (!bind->region.empty()) {
         // bam_reader.c:639-668: a region needs an index; sam_itr_regarray failing reports "No reads found"
@@ -218,6 +229,34 @@ static int next_host_batch(BamBind *bind, BamLocal *l) {
     if (fetch_str(c, b.qname, n, l->qname, m & (1u << DHTS_BAM_QNAME)) || fetch_str(c, b.cigar, n, l->cigar, m & (1u << DHTS_BAM_CIGAR)) ||
         fetch_str(c, b.seq, n, l->seq, m & (1u << DHTS_BAM_SEQ)) || fetch_str(c, b.qual, n, l->qual, m & (1u << DHTS_BAM_QUAL)) ||
         fetch_str(c, b.rg, n, l->rg, m & (1u << DHTS_BAM_READ_GROUP_ID))) return -1;
+    if (l->want_aux && b.aux_map) {
+        // typed entries -> value text, bam_aux_to_string (bam_reader.c:140-183); assigned through the NUL-terminated API
+        const dhts_aux_map &am = *b.aux_map; const size_t ne = (size_t)am.n_ent;
+        std::vector<uint16_t> key(ne + 1); std::vector<uint8_t> kind(ne + 1), sub(ne + 1), pay(am.payload_bytes + 8); std::vector<uint32_t> po(ne + 2);
+        l->aux_valid.resize(n); l->aux_off.resize(n + 1);
+        if (dhts_memcpy_d2h(c, l->aux_valid.data(), am.valid, n) || dhts_memcpy_d2h(c, l->aux_off.data(), am.off, (n + 1) * 4)) return -1;
+        if (ne && (dhts_memcpy_d2h(c, key.data(), am.key, ne * 2) || dhts_memcpy_d2h(c, kind.data(), am.kind, ne) || dhts_memcpy_d2h(c, sub.data(), am.sub, ne))) return -1;
+        if (dhts_memcpy_d2h(c, po.data(), am.pay_off, (ne + 1) * 4)) return -1;
+        if (am.payload_bytes && dhts_memcpy_d2h(c, pay.data(), am.payload, am.payload_bytes)) return -1;
+        l->aux_key.assign(ne, std::string()); l->aux_val.assign(ne, std::string());
+        char tmp[64];
+        for (size_t i = 0; i < ne; i++) {
+            char kb[3] = {(char)(key[i] & 0xff), (char)(key[i] >> 8), 0};
+            l->aux_key[i] = kb;
+            const uint8_t *p = pay.data() + po[i]; const size_t pl = po[i + 1] - po[i];
+            std::string v;
+            int64_t iv; double dv;
+            switch (kind[i]) {
+            case 0: memcpy(&iv, p, 8); snprintf(tmp, sizeof tmp, "%lld", (long long)iv); v = tmp; break;
+            case 1: memcpy(&dv, p, 8); snprintf(tmp, sizeof tmp, "%g", dv); v = tmp; break;
+            case 2: case 3: v.assign((const char *)p, pl); break;
+            case 4: v.push_back((char)sub[i]); for (size_t q = 0; q < pl / 8; q++) { memcpy(&iv, p + 8 * q, 8); snprintf(tmp, sizeof tmp, ",%lld", (long long)iv); v += tmp; } break;
+            case 5: v.push_back((char)sub[i]); for (size_t q = 0; q < pl / 8; q++) { memcpy(&dv, p + 8 * q, 8); snprintf(tmp, sizeof tmp, ",%g", dv); v += tmp; } break;
+            default: break;
+            }
+            l->aux_val[i] = v.c_str();                              // C-string semantics: cut at the first NUL
+        }
+    }
     for (int i = 0; i < b.n_tag_cols; i++) {
         const dhts_col &d = b.tag_cols[i]; BamLocal::HostTag &h = l->tags[i];
         h.valid.resize(n); if (dhts_memcpy_d2h(c, h.valid.data(), d.valid, n)) return -1;
@@ -282,6 +321,25 @@ static void bam_read_function(duckdb_function_info info, duckdb_data_chunk outpu
                 }
                 break;
             default: {
+                if (l->want_aux && l->column_ids[ci] == bind->aux_col_idx) {               // bam_reader.c:967-1027
+                    auto list_size = API(idx_t, duckdb_list_vector_get_size, duckdb_vector);
+                    duckdb_list_entry *le = (duckdb_list_entry *)get_data(vec);
+                    idx_t base = list_size(vec);
+                    const uint32_t c0 = l->aux_off[s], c1 = l->aux_off[s + take];
+                    if (c1 > c0) { API(duckdb_state, duckdb_list_vector_reserve, duckdb_vector, idx_t)(vec, base + (c1 - c0)); API(duckdb_state, duckdb_list_vector_set_size, duckdb_vector, idx_t)(vec, base + (c1 - c0)); }
+                    duckdb_vector child = API(duckdb_vector, duckdb_list_vector_get_child, duckdb_vector)(vec);
+                    duckdb_vector kvec = API(duckdb_vector, duckdb_struct_vector_get_child, duckdb_vector, idx_t)(child, 0);
+                    duckdb_vector vvec = API(duckdb_vector, duckdb_struct_vector_get_child, duckdb_vector, idx_t)(child, 1);
+                    for (idx_t r = 0; r < take; r++) {
+                        le[row_count + r].offset = base + (l->aux_off[s + r] - c0); le[row_count + r].length = l->aux_off[s + r + 1] - l->aux_off[s + r];
+                        if (!l->aux_valid[s + r]) set_null(vec, row_count + r);            // no tags: NULL, entry {size, 0}
+                    }
+                    for (uint32_t k = c0; k < c1; k++) {
+                        assign_len(kvec, base + (k - c0), l->aux_key[k].data(), l->aux_key[k].size());
+                        assign_len(vvec, base + (k - c0), l->aux_val[k].data(), l->aux_val[k].size());
+                    }
+                    break;
+                }
                 const int sl = l->tag_slot[ci];
                 if (sl < 0) break;                                 // unknown ids (e.g. a row-id pseudo column) write nothing, like the reference's default arm
                 const BamLocal::HostTag &h = l->tags[sl];

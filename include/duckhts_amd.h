@@ -69,6 +69,20 @@ typedef struct dhts_col {
 } dhts_col;
 typedef dhts_col dhts_bcf_col;
 
+/* auxiliary_tags := true (src/bam_reader.c:967-1027): per row the tags that are not standard-tag columns, in record order, as TYPED
+ * entries; the caller renders the value text (bam_aux_to_string bam_reader.c:140-183: %lld / %g / "subtype,v,v..."), because %g is
+ * floating-point formatting.  kind: 0 int64, 1 f64 bits, 2 string bytes, 3 one char, 4 int64 array, 5 f64-bits array, 6 corrupt value
+ * (the reference reads past the field there; rendered empty).  Device pointers.                                                  */
+typedef struct {
+    const uint8_t *valid;        /* n_rows: 0 = no entries (the MAP cell is NULL)                          */
+    const uint32_t *off;         /* n_rows+1 entry offsets                                                 */
+    uint64_t n_ent;
+    const uint16_t *key;         /* two raw tag bytes, low byte first                                      */
+    const uint8_t *kind, *sub;   /* sub = B-array subtype character                                        */
+    const uint32_t *pay_off;     /* n_ent+1 payload offsets                                                */
+    const uint8_t *payload; uint64_t payload_bytes;
+} dhts_aux_map;
+
 /* One decoded batch.  All pointers are DEVICE pointers owned by the context and stay valid
  * until the next dhts_bam_next_batch / dhts_bam_rewind / dhts_destroy on that context.        */
 typedef struct {
@@ -91,6 +105,7 @@ typedef struct {
     uint64_t end_uoff;       /* absolute inflated-stream offset just past the last row's record  */
     int32_t n_tag_cols;      /* standard-tag columns selected by dhts_bam_set_tag_columns         */
     int32_t reserved2;
+    const dhts_aux_map *aux_map; /* NULL unless dhts_bam_set_aux_map enabled it                       */
     const dhts_col *tag_cols;/* host array; BIGINT scalars in fixed (8 B), VARCHAR in off/bytes, LIST(BIGINT) in off/child_fixed (8 B words) */
 } dhts_bam_batch;
 
@@ -147,6 +162,7 @@ int dhts_bam_load_index(dhts_ctx *, const void *bai_bytes, uint64_t n);
 int dhts_bam_std_tag_count(void);
 int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype);   /* type: 'i' BIGINT, 'Z'/'A' VARCHAR, 'B' LIST(BIGINT) */
 int dhts_bam_set_tag_columns(dhts_ctx *, const int32_t *std_tag_ids, int32_t n);  /* tag columns materialised by the next batches (default none) */
+int dhts_bam_set_aux_map(dhts_ctx *, int enable, int exclude_standard_tags);        /* AUXILIARY_TAGS entries in the next batches */
 int dhts_bam_rewind(dhts_ctx *);
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 

@@ -700,3 +700,77 @@ int orc_bam_read_std_tags(const uint8_t *file, size_t flen, uint8_t **blob, size
     orc_bam_free(&b);
     return st;
 }
+
+
+/* ========================================================================
+ * auxiliary_tags := true  (src/bam_reader.c:967-1027: bam_aux_first / bam_aux_next walk sam.c:4811-4832, tags that are standard
+ * columns excluded when standard_tags is on; values rendered by bam_aux_to_string bam_reader.c:140-183 and assigned through the
+ * NUL-terminated API).  Blob = two LIST(VARCHAR) columns AUX_KEYS / AUX_VALUES sharing list offsets; the MAP cell is NULL when the
+ * row lists no tag.  A tag whose value is corrupt ends the walk and is listed with an empty value (the reference renders bytes
+ * beyond the field there).
+ * ======================================================================== */
+typedef struct { col_t *keys, *vals; int excl_std; } auxmap_ud;
+static void aux_map_row(const uint8_t *aux, const uint8_t *end, void *ud_) {
+    auxmap_ud *ud = (auxmap_ud *)ud_;
+    col_t *K = ud->keys, *V = ud->vals;
+    uint64_t start = K->child_n; int n = 0;
+    if (end - aux > 2) {
+        const uint8_t *s = aux + 2;
+        for (;;) {
+            int skip = 0;
+            if (ud->excl_std) for (int t = 0; t < N_STD_TAGS; t++) if (s[-2] == (uint8_t)STD_TAGS[t].tag[0] && s[-1] == (uint8_t)STD_TAGS[t].tag[1]) { skip = 1; break; }
+            const uint8_t *e = skip_aux(s, end);
+            if (!skip) {
+                char key[3] = { (char)s[-2], (char)s[-1], 0 };
+                list_str(K, key, strlen(key));
+                char tmp[64]; buf_t v = {0};
+                if (e) {
+                    int ok; uint8_t ty = s[0];
+                    if (ty == 'A') { char ch = (char)s[1]; buf_push(&v, &ch, 1); }
+                    else if (ty == 'c' || ty == 'C' || ty == 's' || ty == 'S' || ty == 'i' || ty == 'I') { int l = snprintf(tmp, sizeof tmp, "%lld", (long long)aux_int_val(ty, s + 1, 0, &ok)); buf_push(&v, tmp, (size_t)l); }
+                    else if (ty == 'f') { uint32_t b = le32(s + 1); float f; memcpy(&f, &b, 4); int l = snprintf(tmp, sizeof tmp, "%g", (double)f); buf_push(&v, tmp, (size_t)l); }
+                    else if (ty == 'd') { double d; memcpy(&d, s + 1, 8); int l = snprintf(tmp, sizeof tmp, "%g", d); buf_push(&v, tmp, (size_t)l); }
+                    else if (ty == 'Z' || ty == 'H') { const uint8_t *z = s + 1; size_t l = 0; while (z + l < e && z[l]) l++; buf_push(&v, z, l); }
+                    else if (ty == 'B') {
+                        uint8_t sub = s[1]; uint32_t len = le32(s + 2);
+                        buf_push(&v, &sub, 1);
+                        for (uint32_t i = 0; i < len; i++) {
+                            int l;
+                            if (sub == 'f') { uint32_t b = le32(s + 6 + 4 * (size_t)i); float f; memcpy(&f, &b, 4); l = snprintf(tmp, sizeof tmp, ",%g", (double)f); }
+                            else if (sub == 'd') l = snprintf(tmp, sizeof tmp, ",%g", 0.0);
+                            else l = snprintf(tmp, sizeof tmp, ",%lld", (long long)aux_int_val(sub, s + 6, i, &ok));
+                            buf_push(&v, tmp, (size_t)l);
+                        }
+                    }
+                }
+                size_t vl = 0; while (vl < v.n && v.p[vl]) vl++;                       /* assigned as a C string */
+                list_str(V, v.p ? (const char *)v.p : "", vl);
+                free(v.p);
+                n++;
+            }
+            if (!e) break;
+            if (end - e <= 2) break;
+            s = e + 2;
+        }
+    }
+    g_list_start = start;
+    if (n) { list_end(K); g_list_start = start; list_end(V); }
+    else { col_null(K); col_null(V); }
+}
+
+int orc_bam_read_aux_map(const uint8_t *file, size_t flen, int exclude_standard, uint8_t **blob, size_t *blob_len) {
+    col_t cols[2];
+    col_init(&cols[0], "AUX_KEYS", T_VARCHAR, 1); col_init(&cols[1], "AUX_VALUES", T_VARCHAR, 1);
+    auxmap_ud ud = { &cols[0], &cols[1], exclude_standard };
+    g_aux_hook = aux_map_row; g_aux_ud = &ud;
+    orc_bam_t b; int st = orc_bam_read(file, flen, &b);
+    g_aux_hook = NULL; g_aux_ud = NULL;
+    buf_t o = {0};
+    uint32_t nc = 2; uint64_t nr = (uint64_t)b.n_rows, fr = (uint64_t)b.first_rec_off; int32_t s32 = st; uint32_t ns = 0;
+    buf_push(&o, &nc, 4); buf_push(&o, &nr, 8); buf_push(&o, &s32, 4); buf_push(&o, &fr, 8); buf_push(&o, &ns, 4);
+    for (int t = 0; t < 2; t++) { ser_col(&o, &cols[t], b.n_rows); col_free(&cols[t]); }
+    uint64_t zero = 0; buf_push(&o, &zero, 8);
+    *blob = o.p; *blob_len = o.n;
+    orc_bam_free(&b);
+    return st;
+}

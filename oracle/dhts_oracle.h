@@ -86,6 +86,9 @@ int orc_use_system_zlib(int on);
 /* read_bam(standard_tags := true): the 56 typed tag columns (src/bam_reader.c:54-70, 920-966) as a canonical column blob */
 int orc_bam_read_std_tags(const uint8_t *file, size_t flen, uint8_t **blob, size_t *blob_len);
 
+/* read_bam(auxiliary_tags := true): keys and rendered values of the non-standard tags (src/bam_reader.c:967-1027, 140-183) */
+int orc_bam_read_aux_map(const uint8_t *file, size_t flen, int exclude_standard, uint8_t **blob, size_t *blob_len);
+
 /* ---- read_bcf (bcf_oracle.c) ---------------------------------------------- */
 /* Sequential read_bcf scan of a whole BCF file; `blob` receives the canonical serialisation of every schema column
  * (layout documented above orc_bcf_read in bcf_oracle.c; free with orc_free).  materialise = 0 only frames and

@@ -23,7 +23,7 @@
 
 typedef struct LType { int id; struct LType *child; } LType;
 typedef struct Value { int is_null; int is_bool; int b; char *s; } Value;
-typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap; int child_type; struct Vec *child; idx_t list_size, list_cap; } Vec;
+typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap; int child_type; struct Vec *child; idx_t list_size, list_cap; struct Vec *kids[2]; } Vec;
 typedef struct Chunk { Vec *vecs; size_t ncol; idx_t size; } Chunk;
 typedef struct TF {
     char name[64]; duckdb_table_function_bind_t bind; duckdb_table_function_init_t init, local_init; duckdb_table_function_t func;
@@ -111,10 +111,15 @@ static int type_width(int t) {
 static void list_grow(Vec *x, idx_t need) {
     if (need <= x->list_cap) return;
     idx_t nc = x->list_cap ? x->list_cap : VSIZE; while (nc < need) nc *= 2;
-    size_t w = (size_t)type_width(x->child->type);
-    x->child->data = realloc(x->child->data, nc * w); memset((char *)x->child->data + x->list_cap * w, 0, (nc - x->list_cap) * w);
+    if (x->child->type == DUCKDB_TYPE_STRUCT) {                 /* MAP child = STRUCT{key VARCHAR, value VARCHAR} */
+        for (int k = 0; k < 2; k++) { Vec *c = x->child->kids[k]; c->data = realloc(c->data, nc * 16); memset((char *)c->data + x->list_cap * 16, 0, (nc - x->list_cap) * 16); }
+    } else {
+        size_t w = (size_t)type_width(x->child->type);
+        x->child->data = realloc(x->child->data, nc * w); memset((char *)x->child->data + x->list_cap * w, 0, (nc - x->list_cap) * w);
+    }
     x->list_cap = nc;
 }
+static duckdb_vector h_struct_get_child(duckdb_vector v, idx_t k) { return ((Vec *)v)->kids[k]; }
 static idx_t h_list_get_size(duckdb_vector v) { return ((Vec *)v)->list_size; }
 static duckdb_state h_list_reserve(duckdb_vector v, idx_t cap) { list_grow(v, cap); return DuckDBSuccess; }
 static duckdb_state h_list_set_size(duckdb_vector v, idx_t n) { list_grow(v, n); ((Vec *)v)->list_size = n; return DuckDBSuccess; }
@@ -145,7 +150,7 @@ int main(int argc, char **argv) {
     SET(duckdb_vector_ensure_validity_writable, h_vector_ensure_validity_writable); SET(duckdb_validity_set_row_invalid, h_validity_set_row_invalid);
     SET(duckdb_vector_assign_string_element, h_assign); SET(duckdb_vector_assign_string_element_len, h_assign_len);
     SET(duckdb_list_vector_get_size, h_list_get_size); SET(duckdb_list_vector_reserve, h_list_reserve); SET(duckdb_list_vector_set_size, h_list_set_size);
-    SET(duckdb_list_vector_get_child, h_list_get_child);
+    SET(duckdb_list_vector_get_child, h_list_get_child); SET(duckdb_struct_vector_get_child, h_struct_get_child);
 
     void *so = dlopen(argv[1], RTLD_NOW);
     if (!so) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
@@ -188,7 +193,12 @@ int main(int argc, char **argv) {
     for (;;) {
         Chunk c; c.ncol = g.nproj; c.size = 0; c.vecs = calloc(c.ncol, sizeof(Vec));
         for (size_t k = 0; k < c.ncol; k++) { int t = g.proj[k] < (idx_t)b.ncol ? b.coltype[g.proj[k]] : DUCKDB_TYPE_BIGINT; c.vecs[k].type = t; c.vecs[k].data = calloc(VSIZE, (size_t)type_width(t));
-            if (t == DUCKDB_TYPE_LIST) { Vec *ch = calloc(1, sizeof(Vec)); ch->type = b.colchild[g.proj[k]]; c.vecs[k].child = ch; c.vecs[k].child_type = ch->type; list_grow(&c.vecs[k], VSIZE); } }
+            if (t == DUCKDB_TYPE_LIST) { Vec *ch = calloc(1, sizeof(Vec)); ch->type = b.colchild[g.proj[k]]; c.vecs[k].child = ch; c.vecs[k].child_type = ch->type; list_grow(&c.vecs[k], VSIZE); }
+            if (t == DUCKDB_TYPE_MAP) {
+                Vec *ch = calloc(1, sizeof(Vec)); ch->type = DUCKDB_TYPE_STRUCT;
+                for (int q = 0; q < 2; q++) { ch->kids[q] = calloc(1, sizeof(Vec)); ch->kids[q]->type = DUCKDB_TYPE_VARCHAR; }
+                c.vecs[k].child = ch; c.vecs[k].child_type = DUCKDB_TYPE_STRUCT; list_grow(&c.vecs[k], VSIZE);
+            } }
         tf->func(&fi, &c);
         if (fi.has_err) { printf("ERROR scan: %s\n", fi.err); return 3; }
         uint64_t n = c.size;
@@ -198,6 +208,15 @@ int main(int argc, char **argv) {
                 Vec *v = &c.vecs[k]; uint32_t t = (uint32_t)v->type; fwrite(&t, 4, 1, fo);
                 uint64_t words = (n + 63) / 64;
                 for (uint64_t w = 0; w < words; w++) { uint64_t m = v->validity ? v->validity[w] : ~0ull; if (w == words - 1 && (n % 64)) m &= (1ull << (n % 64)) - 1; fwrite(&m, 8, 1, fo); }
+                if (v->type == DUCKDB_TYPE_MAP) {                 /* entries, child size, then keys and values in the VARCHAR child encoding */
+                    fwrite(v->data, 16, n, fo);
+                    uint64_t cn = v->list_size; fwrite(&cn, 8, 1, fo);
+                    for (int q = 0; q < 2; q++) for (uint64_t r = 0; r < cn; r++) {
+                        duckdb_string_t *d = (duckdb_string_t *)v->child->kids[q]->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo);
+                        fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo);
+                    }
+                    continue;
+                }
                 if (v->type == DUCKDB_TYPE_LIST) {
                     fwrite(v->data, 16, n, fo);
                     uint64_t cn = v->list_size; uint32_t ct = (uint32_t)v->child->type; fwrite(&cn, 8, 1, fo); fwrite(&ct, 4, 1, fo);
@@ -218,6 +237,10 @@ int main(int argc, char **argv) {
         }
         for (size_t k = 0; k < c.ncol; k++) {
             Vec *ch = c.vecs[k].child;
+            if (ch && ch->type == DUCKDB_TYPE_STRUCT) {
+                for (int q = 0; q < 2; q++) { Vec *kv = ch->kids[q]; for (size_t h = 0; h < kv->nheap; h++) free(kv->heap[h]); free(kv->heap); free(kv->data); free(kv); }
+                free(ch); ch = NULL;
+            }
             if (ch) { for (size_t h = 0; h < ch->nheap; h++) free(ch->heap[h]); free(ch->heap); free(ch->data); free(ch); }
             for (size_t h = 0; h < c.vecs[k].nheap; h++) free(c.vecs[k].heap[h]); free(c.vecs[k].heap); free(c.vecs[k].data); free(c.vecs[k].validity); }
         free(c.vecs);

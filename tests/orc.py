@@ -302,3 +302,16 @@ def bam_read_std_tags(file_bytes: bytes):
     data = C.string_at(blob, n.value)
     L.orc_free(blob)
     return decode_bcf_blob(data)
+
+
+def bam_read_aux_map(file_bytes: bytes, exclude_standard: bool = True):
+    """AUXILIARY_TAGS as two LIST(VARCHAR) columns (keys, rendered values) in the canonical table layout"""
+    L = lib()
+    L.orc_bam_read_aux_map.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.orc_bam_read_aux_map.restype = C.c_int
+    L.orc_free.argtypes = [C.c_void_p]
+    blob, n = C.c_void_p(), C.c_size_t(0)
+    L.orc_bam_read_aux_map(file_bytes, len(file_bytes), int(exclude_standard), C.byref(blob), C.byref(n))
+    data = C.string_at(blob, n.value)
+    L.orc_free(blob)
+    return decode_bcf_blob(data)

@@ -66,7 +66,12 @@ def parse_chunks(fn):
             (t,) = struct.unpack_from("<I", d, p); p += 4
             words = (n + 63) // 64
             val = np.frombuffer(d, np.uint64, words, p); p += 8 * words
-            if t == LIST:
+            if t == 26:                                            # MAP(VARCHAR, VARCHAR): entries, child size, keys, values
+                ent = np.frombuffer(d, np.uint64, 2 * n, p).reshape(n, 2).copy(); p += 16 * n
+                (cn,) = struct.unpack_from("<Q", d, p); p += 8
+                kk = payload(VARCHAR, cn)
+                vals = (ent, kk, payload(VARCHAR, cn))
+            elif t == LIST:
                 ent = np.frombuffer(d, np.uint64, 2 * n, p).reshape(n, 2).copy(); p += 16 * n
                 cn, ct = struct.unpack_from("<QI", d, p); p += 12
                 vals = (ent, ct, payload(ct, cn))
@@ -341,5 +346,43 @@ def test_read_bam_standard_tags_through_the_surface(tmp_path):
         assert c0 == exp["n_rows"]
     rc, out, _ = run_host(fn, named=[("standard_tags", "true")], proj=[0, 13 + 34, 13 + 48])
     assert rc == 0
-    rc, out, _ = run_host(fn, named=[("auxiliary_tags", "true")])
-    assert rc == 3 and "auxiliary_tags" in out
+
+
+MAP = 26
+
+
+@pytest.mark.gpu
+def test_read_bam_auxiliary_tags_through_the_surface(tmp_path):
+    """duckhts.test:179-185: RG = x1, NM = 2, map_extract(AUXILIARY_TAGS, 'XZ') = [foo] with standard_tags + auxiliary_tags"""
+    import tag_cases
+    for data in (tag_cases.aux_tags_sam_equivalent(), tag_cases.type_matrix(), tag_cases.fuzz(n=3000)):
+        fn = os.path.join(str(tmp_path), "a.bam")
+        open(fn, "wb").write(data)
+        for std in (True, False):
+            exp = orc.bam_read_aux_map(data, std)
+            named = [("auxiliary_tags", "true")] + ([("standard_tags", "true")] if std else [])
+            col = 13 + (56 if std else 0)
+            rc, out, dump = run_host(fn, named=named, proj=[col])
+            assert rc == 0, out
+            schema, chunks = parse_chunks(dump)
+            assert schema[col][:2] == ("AUXILIARY_TAGS", MAP) and len(schema) == col + 1
+            K, V = exp["cols"]
+            c0 = 0
+            for nrows, cols in chunks:
+                t, val, (ent, keys, vals) = cols[0]
+                bits = np.array([(int(val[i >> 6]) >> (i & 63)) & 1 for i in range(nrows)], np.uint8)
+                assert np.array_equal(bits, K["valid"][c0:c0 + nrows])
+                k0 = int(K["loff"][c0])
+                assert np.array_equal(ent[:, 0], K["loff"][c0:c0 + nrows] - np.uint64(k0)) and np.array_equal(ent[:, 1], K["llen"][c0:c0 + nrows])
+                k1 = k0 + int(K["llen"][c0:c0 + nrows].sum())
+                assert keys == [bytes(K["csbytes"][int(K["csoff"][i]):int(K["csoff"][i + 1])]) for i in range(k0, k1)]
+                assert vals == [bytes(V["csbytes"][int(V["csoff"][i]):int(V["csoff"][i + 1])]) for i in range(k0, k1)]
+                c0 += nrows
+            assert c0 == exp["n_rows"]
+    # the reference's own query shape on the SAM-equivalent record
+    fn = os.path.join(str(tmp_path), "q.bam")
+    open(fn, "wb").write(tag_cases.aux_tags_sam_equivalent())
+    rc, out, dump = run_host(fn, named=[("standard_tags", "true"), ("auxiliary_tags", "true")], proj=[13 + 48, 13 + 34, 13 + 56])
+    schema, chunks = parse_chunks(dump)
+    (t0, v0, rg), (t1, v1, nm), (t2, v2, (ent, keys, vals)) = chunks[0][1]
+    assert list(rg) == [b"x1"] and list(nm) == [2] and keys == [b"XZ"] and vals == [b"foo"]

@@ -294,3 +294,19 @@ def test_std_tag_columns(which):
     sub = {"n_rows": exp["n_rows"], "cols": [exp["cols"][i] for i in sel]}
     d = orc.bcf_cols_diff(sub, got["tags"])
     assert d is None, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("excl", [True, False])
+@pytest.mark.parametrize("which", ["sam_equiv", "matrix", "fuzz", "golden_range"])
+def test_auxiliary_tags_map(which, excl):
+    """AUXILIARY_TAGS (duckhts.test:179-185: map_extract(AUXILIARY_TAGS,'XZ') = [foo]) against the oracle"""
+    import tag_cases
+    data = {"sam_equiv": tag_cases.aux_tags_sam_equivalent, "matrix": tag_cases.type_matrix, "fuzz": tag_cases.fuzz, "golden_range": lambda: read_golden("range.bam")}[which]()
+    exp = orc.bam_read_aux_map(data, excl)
+    got = duckhts_amd.read_bam(data, aux_map="exclude_standard" if excl else "all", max_blocks=5)
+    d = orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": exp["cols"]}, got["aux"])
+    assert d is None, d
+    if which == "sam_equiv" and excl:
+        k, v = (orc.bcf_col_py(c) for c in got["aux"]["cols"])
+        assert k == [[b"XZ"]] and v == [[b"foo"]]
