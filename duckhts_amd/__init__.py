@@ -74,7 +74,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
            "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
-           "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region",
+           "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
 
@@ -125,6 +125,7 @@ def lib():
         L.dhts_bcf_set_block_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
         L.dhts_bcf_rewind.argtypes = [C.c_void_p]
         L.dhts_bcf_set_region.argtypes = [C.c_void_p, C.c_char_p]
+        L.dhts_bcf_load_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bcf_next_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(BcfBatch)]
         _LIB = L
     return _LIB
@@ -412,6 +413,11 @@ class BcfScan:
         """one region (the reference chains them); False when the region yields no iterator (unknown contig)"""
         return self.ctx._chk(self.ctx.L.dhts_bcf_set_region(self.ctx.h, region.encode() if region else None)) == 0
 
+    def load_index(self, index_bytes):
+        """CSI bytes: narrows the scan window of the region set last (call after set_region)"""
+        buf = np.frombuffer(index_bytes, dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.dhts_bcf_load_index(self.ctx.h, buf.ctypes.data, buf.nbytes))
+
     def next_batch(self, max_blocks=0):
         b = BcfBatch()
         self.ctx._chk(self.ctx.L.dhts_bcf_next_batch(self.ctx.h, max_blocks, C.byref(b)))
@@ -490,7 +496,7 @@ def _concat_tables(parts, schema_cols):
     return out
 
 
-def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=None, region=None):
+def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=None, region=None, index=None):
     """Full sequential read_bcf scan (every record in file order); returns the canonical column table.
     columns: optional projection (names or schema ids), like DuckDB's projection pushdown."""
     ctx = Context(device)
@@ -508,6 +514,8 @@ def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=
         for rg in passes:
             if rg is not None and not sc.set_region(rg):
                 continue
+            if rg is not None and index is not None:
+                sc.load_index(index)
             while True:
                 b = sc.next_batch(max_blocks)
                 if b.n_rows:

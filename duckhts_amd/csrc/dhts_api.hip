@@ -641,79 +641,136 @@ int dhts_bam_set_regions(dhts_ctx *c, const char *regions) {
     return dhts_bam_rewind(c);
 }
 
-// BAI (SAM spec 5.2; htslib hts.c:2920-3055 loader): narrows the scan to the BGZF blocks between the smallest chunk start and the
-// largest chunk end of the bins the regions touch (reg2bins hts.c:3142-3213, linear index lower bound hts.c:3421-3470).  The
-// window is a superset of the iterator's chunk list; the device predicate decides the rows, so the result is exact.
-int dhts_bam_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
-    if (!c || !c->bam_open) return -1;
-    const uint8_t *d = (const uint8_t *)bytes; uint64_t p = 0;
+// ---- index -> scan window ----------------------------------------------------------------------------------------------------
+// BAI (SAM spec 5.2) and CSI (CSIv1; BGZF-compressed, inflated here on the GPU through a scratch context) as loaded by
+// hts_idx_load (htslib hts.c:2920-3055).  For a set of query intervals the window is [smallest chunk start, largest chunk end] over
+// the bins the intervals touch (reg2bins hts.c:3142-3213, generalised to min_shift / depth), pruned by the BAI linear index
+// (hts.c:3556-3563).  It is a superset of the iterator's chunk list; the device predicate decides the rows, so results are exact.
+struct QIv { int32_t tid; int64_t beg, end; };
+struct IdxWindow { bool any = false; uint64_t vmin = ~0ull, vmax = 0, last_end = 0; };
+
+static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::vector<QIv> &q, bool whole, IdxWindow &w) {
+    std::vector<uint8_t> inflated;
+    if (n >= 18 && d[0] == 0x1f && d[1] == 0x8b) {                       // BGZF: inflate on the device
+        dhts_ctx *t = dhts_create(c->device);
+        if (!t) return fail(c, "cannot create a scratch context for the index");
+        int64_t nb = -1;
+        if (dhts_open_host(t, d, n) == 0) nb = dhts_bgzf_index(t);
+        if (nb <= 0) { dhts_destroy(t); return fail(c, "index is not readable BGZF"); }
+        uint64_t tot = t->h_uoff[nb];
+        inflated.resize(tot + 16);
+        std::vector<int32_t> bs(nb);
+        int64_t got = dhts_bgzf_inflate_to_host(t, 0, nb, inflated.data(), tot, bs.data());
+        dhts_destroy(t);
+        HIPCHK(c, hipSetDevice(c->device));
+        if (got < 0) return fail(c, "index inflate failed");
+        for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) return fail(c, "index inflate failed (block %lld)", (long long)k);
+        d = inflated.data(); n = tot;
+    }
+    uint64_t p = 0;
     auto need = [&](uint64_t k) { return p + k <= n; };
-    if (!need(8) || memcmp(d, "BAI\1", 4) != 0) return fail(c, "index is not a BAI file");
-    const int32_t n_ref = (int32_t)hle32(d + 4); p = 8;
-    auto hle64 = [&](const uint8_t *q) { return (uint64_t)hle32(q) | ((uint64_t)hle32(q + 4) << 32); };
-    uint64_t vmin = ~0ull, vmax = 0, last_end = 0; bool any = false;
-    const bool whole = !c->rg_active || c->rg_all;
+    auto hle64 = [&](const uint8_t *x) { return (uint64_t)hle32(x) | ((uint64_t)hle32(x + 4) << 32); };
+    int min_shift = 14, depth = 5; bool csi = false;
+    if (need(8) && memcmp(d, "BAI\1", 4) == 0) p = 4;
+    else if (need(16) && memcmp(d, "CSI\1", 4) == 0) {
+        csi = true; min_shift = (int32_t)hle32(d + 4); depth = (int32_t)hle32(d + 8); const uint32_t l_aux = hle32(d + 12); p = 16;
+        if (min_shift < 0 || depth < 0 || depth > 10 || !need(l_aux)) return fail(c, "bad CSI header");
+        p += l_aux;
+    } else return fail(c, "index is neither BAI nor CSI");
+    if (!need(4)) return fail(c, "truncated index");
+    const int32_t n_ref = (int32_t)hle32(d + p); p += 4;
+    const uint32_t meta_bin = (uint32_t)(((1ull << (depth * 3 + 3)) - 1) / 7 + 1);
+    const int maxs = min_shift + 3 * depth;
     for (int32_t t = 0; t < n_ref; t++) {
-        if (!need(4)) return fail(c, "truncated BAI");
+        if (!need(4)) return fail(c, "truncated index");
         const int32_t n_bin = (int32_t)hle32(d + p); p += 4;
-        // candidate bins of this reference's query intervals
-        std::vector<std::pair<uint32_t, uint32_t>> binr;      // inclusive bin id ranges per level
-        uint32_t i0 = 0, i1 = 0;
-        if (c->rg_active && (size_t)t + 1 < c->rg_tid_first.size()) { i0 = c->rg_tid_first[t]; i1 = c->rg_tid_first[t + 1]; }
-        for (uint32_t k = i0; k < i1; k++) {
-            int64_t b = c->rg_beg[k], e = c->rg_end[k]; if (e > (1ll << 29)) e = 1ll << 29; if (b >= e) continue; --e;
-            binr.push_back({0, 0});
-            for (int l = 1, tt = 1, sft = 26; l <= 5; l++, sft -= 3) { binr.push_back({(uint32_t)(tt + (b >> sft)), (uint32_t)(tt + (e >> sft))}); tt += 1 << (l * 3); }
+        std::vector<std::pair<uint32_t, uint32_t>> binr; int64_t first_beg = -1;
+        for (auto &iv : q) if (iv.tid == t) {
+            int64_t b = iv.beg < 0 ? 0 : iv.beg, e = iv.end; if (e > (1ll << maxs)) e = 1ll << maxs; if (b >= e) continue; --e;
+            if (first_beg < 0 || b < first_beg) first_beg = b;
+            uint32_t tt = 0;
+            for (int l = 0, sft = maxs; l <= depth; l++, sft -= 3) { binr.push_back({(uint32_t)(tt + (b >> sft)), (uint32_t)(tt + (e >> sft))}); tt += 1u << (l * 3); }
         }
-        struct Ch { uint64_t u, v; uint32_t bin; };
+        struct Ch { uint64_t u, v; };
         std::vector<Ch> chunks;
         for (int32_t bi = 0; bi < n_bin; bi++) {
-            if (!need(8)) return fail(c, "truncated BAI");
-            const uint32_t bin = hle32(d + p); const int32_t n_chunk = (int32_t)hle32(d + p + 4); p += 8;
-            if (n_chunk < 0 || !need((uint64_t)n_chunk * 16)) return fail(c, "truncated BAI");
+            if (!need(csi ? 16 : 8)) return fail(c, "truncated index");
+            const uint32_t bin = hle32(d + p); p += 4;
+            if (csi) p += 8;                                             // loffset: not needed for a superset window
+            const int32_t n_chunk = (int32_t)hle32(d + p); p += 4;
+            if (n_chunk < 0 || !need((uint64_t)n_chunk * 16)) return fail(c, "truncated index");
             for (int32_t k = 0; k < n_chunk; k++) {
                 const uint64_t u = hle64(d + p), v = hle64(d + p + 8); p += 16;
-                if (bin == 37450) { if (k == 0 && v > last_end) last_end = v; continue; }     // metadata pseudo-bin: (ref_beg, ref_end), (n_mapped, n_unmapped)
-                if (v > last_end) last_end = v;
+                if (bin == meta_bin) { if (k == 0 && v > w.last_end) w.last_end = v; continue; }   // pseudo-bin: (ref_beg, ref_end), (n_mapped, n_unmapped)
+                if (v > w.last_end) w.last_end = v;
                 bool hit = whole;
                 for (auto &r : binr) if (bin >= r.first && bin <= r.second) { hit = true; break; }
-                if (hit) chunks.push_back({u, v, bin});
+                if (hit) chunks.push_back({u, v});
             }
         }
-        if (!need(4)) return fail(c, "truncated BAI");
-        const int32_t n_intv = (int32_t)hle32(d + p); p += 4;
-        if (n_intv < 0 || !need((uint64_t)n_intv * 8)) return fail(c, "truncated BAI");
         uint64_t min_off = 0;
-        if (i1 > i0 && n_intv > 0) { int64_t w = c->rg_beg[i0] >> 14; if (w >= n_intv) w = n_intv - 1; min_off = hle64(d + p + (uint64_t)w * 8); }
-        p += (uint64_t)n_intv * 8;
+        if (!csi) {
+            if (!need(4)) return fail(c, "truncated index");
+            const int32_t n_intv = (int32_t)hle32(d + p); p += 4;
+            if (n_intv < 0 || !need((uint64_t)n_intv * 8)) return fail(c, "truncated index");
+            if (first_beg >= 0 && n_intv > 0) { int64_t wdw = first_beg >> 14; if (wdw >= n_intv) wdw = n_intv - 1; min_off = hle64(d + p + (uint64_t)wdw * 8); }
+            p += (uint64_t)n_intv * 8;
+        }
         for (auto &ch : chunks) {
-            if (ch.v <= min_off) continue;                       // entirely before the first alignment that can overlap (hts.c:3556-3563)
-            any = true;
-            if (ch.u < vmin) vmin = ch.u;
-            if (ch.v > vmax) vmax = ch.v;
+            if (ch.v <= min_off) continue;
+            w.any = true;
+            if (ch.u < w.vmin) w.vmin = ch.u;
+            if (ch.v > w.vmax) w.vmax = ch.v;
         }
     }
+    return 0;
+}
+
+// turns a window into the context's scan range; nocoor = also everything after the last mapped chunk ("*")
+static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor) {
     int64_t b0 = 0, b1 = c->n_blocks; uint64_t first_uoff = c->first_rec_uoff;
-    auto block_of = [&](uint64_t coffset) -> int64_t {          // BGZF block whose compressed offset is coffset (or the next one)
+    auto block_of = [&](uint64_t coffset) -> int64_t {
         int64_t lo = 0, hi = c->n_blocks;
         while (lo < hi) { int64_t mid = (lo + hi) / 2; if (c->h_coff[mid] < coffset) lo = mid + 1; else hi = mid; }
         return lo;
     };
-    if (!whole && !c->rg_nocoor) {
-        if (!any) { c->rg_empty_window = true; return dhts_bam_rewind(c); }
-        b0 = block_of(vmin >> 16); b1 = block_of(vmax >> 16) + 1; if (b1 > c->n_blocks) b1 = c->n_blocks;
-        if (b0 >= c->n_blocks || c->h_coff[b0] != (vmin >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(vmin >> 16));
-        first_uoff = c->h_uoff[b0] + (vmin & 0xffff);
+    c->rg_empty_window = false;
+    if (!whole && !nocoor) {
+        if (!w.any) { c->rg_empty_window = true; return 0; }
+        b0 = block_of(w.vmin >> 16); b1 = block_of(w.vmax >> 16) + 1; if (b1 > c->n_blocks) b1 = c->n_blocks;
+        if (b0 >= c->n_blocks || c->h_coff[b0] != (w.vmin >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(w.vmin >> 16));
+        first_uoff = c->h_uoff[b0] + (w.vmin & 0xffff);
         if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
-    } else if (!whole && c->rg_nocoor) {
-        // mapped windows (if any) plus everything after the last mapped chunk: start at the earliest, run to the end of the file
-        uint64_t s0 = any ? vmin : last_end;
+    } else if (!whole && nocoor) {
+        const uint64_t s0 = w.any ? w.vmin : w.last_end;
         b0 = block_of(s0 >> 16); if (b0 >= c->n_blocks) b0 = c->n_blocks > 0 ? c->n_blocks - 1 : 0;
         if (c->n_blocks > 0 && c->h_coff[b0] == (s0 >> 16)) first_uoff = c->h_uoff[b0] + (s0 & 0xffff); else { b0 = 0; first_uoff = c->first_rec_uoff; }
         if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
     }
     c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = 0; c->shard_world = (b1 < c->n_blocks) ? 2 : 1; c->scan_first_uoff = first_uoff;
+    return 0;
+}
+
+int dhts_bam_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
+    if (!c || !c->bam_open) return -1;
+    std::vector<QIv> q;
+    if (c->rg_active) for (size_t t = 0; t + 1 < c->rg_tid_first.size(); t++) for (uint32_t k = c->rg_tid_first[t]; k < c->rg_tid_first[t + 1]; k++) q.push_back({(int32_t)t, c->rg_beg[k], c->rg_end[k]});
+    const bool whole = !c->rg_active || c->rg_all;
+    IdxWindow w;
+    if (index_window(c, (const uint8_t *)bytes, n, q, whole, w)) return -1;
+    if (apply_window(c, w, whole, c->rg_nocoor)) return -1;
     return dhts_bam_rewind(c);
+}
+
+int dhts_bcf_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
+    if (!c || !c->bcf_open) return -1;
+    std::vector<QIv> q;
+    const bool whole = !c->bcf_rg_active || c->bcf_rg_all;
+    if (!whole) q.push_back({c->bcf_rg_tid, c->bcf_rg_beg, c->bcf_rg_end});
+    IdxWindow w;
+    if (index_window(c, (const uint8_t *)bytes, n, q, whole, w)) return -1;
+    if (apply_window(c, w, whole, false)) return -1;
+    return dhts_bcf_rewind(c);
 }
 
 int dhts_bam_rewind(dhts_ctx *c) {
@@ -1172,7 +1229,8 @@ int dhts_bcf_set_projection(dhts_ctx *c, const int32_t *col_ids, int32_t n) {
 // Returns 0, 1 when the region yields no iterator (unknown contig / malformed: the reference skips it, bcf_reader.c:935-953), <0 on error.
 int dhts_bcf_set_region(dhts_ctx *c, const char *region) {
     if (!c || !c->bcf_open) return -1;
-    c->bcf_rg_active = false; c->bcf_rg_all = false;
+    c->bcf_rg_active = false; c->bcf_rg_all = false; c->rg_empty_window = false;
+    c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1; c->scan_first_uoff = c->first_rec_uoff;
     if (!region || !*region) return dhts_bcf_rewind(c);
     std::string tok(region);
     if (tok == ".") { c->bcf_rg_active = true; c->bcf_rg_all = true; return dhts_bcf_rewind(c); }
@@ -1193,7 +1251,7 @@ int dhts_bcf_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculativ
 
 int dhts_bcf_rewind(dhts_ctx *c) {
     if (!c) return -1;
-    c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+    c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = c->rg_empty_window; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;
     skip_header_blocks(c);
     return 0;

@@ -190,13 +190,14 @@ static void bam_read_local_init(duckdb_init_info info) {
             char err[640]; snprintf(err, sizeof(err), "No reads found for region(s): %s", bind->region.c_str());
             init_error(info, rc == 1 ? err : dhts_error(bind->ctx)); delete l; return;
         }
-        // a BAI narrows the scan window (a CSI only satisfies the index requirement for now; the device predicate decides the rows)
+        // the index (BAI or CSI) narrows the scan window; the device predicate decides the rows
         FILE *f = fopen(bind->index_file.c_str(), "rb");
         if (f) {
             std::vector<uint8_t> ib; uint8_t tmp[65536]; size_t k;
             while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) ib.insert(ib.end(), tmp, tmp + k);
             fclose(f);
-            if (ib.size() >= 4 && memcmp(ib.data(), "BAI\1", 4) == 0 && dhts_bam_load_index(bind->ctx, ib.data(), ib.size()) != 0) { init_error(info, dhts_error(bind->ctx)); delete l; return; }
+            const bool known = ib.size() >= 4 && (memcmp(ib.data(), "BAI\1", 4) == 0 || memcmp(ib.data(), "CSI\1", 4) == 0 || (ib[0] == 0x1f && ib[1] == 0x8b));
+            if (known && dhts_bam_load_index(bind->ctx, ib.data(), ib.size()) != 0) { init_error(info, dhts_error(bind->ctx)); delete l; return; }
         }
     } else if (dhts_bam_set_regions(bind->ctx, nullptr) != 0) { init_error(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
     if (bind->region.empty() && dhts_bam_rewind(bind->ctx) != 0) { init_error(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
@@ -405,6 +406,7 @@ static void register_read_bam_function(duckdb_connection connection) {          
 struct BcfBind {
     std::string path, region;
     std::vector<std::string> regions;    // comma split, empty tokens dropped (parse_regions_duckdb, bcf_reader.c:423-446)
+    std::string index_file; std::vector<uint8_t> index_bytes;
     dhts_ctx *ctx = nullptr;
     dhts_bcf_info inf;
     int has_index = 0;
@@ -426,7 +428,10 @@ struct BcfLocal {
 static bool bcf_next_region(BcfBind *bind, BcfLocal *l) {
     while (l->next_region < bind->regions.size()) {
         const std::string &rg = bind->regions[l->next_region++];
-        if (dhts_bcf_set_region(bind->ctx, rg.c_str()) == 0) return true;      // unknown contig / malformed: skipped (bcf_reader.c:944-953)
+        if (dhts_bcf_set_region(bind->ctx, rg.c_str()) == 0) {                  // unknown contig / malformed: skipped (bcf_reader.c:944-953)
+            if (!bind->index_bytes.empty()) (void)dhts_bcf_load_index(bind->ctx, bind->index_bytes.data(), bind->index_bytes.size());   // window only: a failure keeps the full scan
+            return true;
+        }
     }
     return false;
 }
@@ -473,7 +478,12 @@ static void bcf_read_bind(duckdb_bind_info info) {
         set_error(info, (m && strstr(m, "VEP")) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505
         delete b; return;
     }
-    b->has_index = (!idx.empty() && file_exists(idx)) || file_exists(b->path + ".csi") || file_exists(b->path + ".tbi");
+    for (const std::string &f : {idx, b->path + ".csi", b->path + ".tbi"}) if (!f.empty() && file_exists(f)) { b->index_file = f; break; }
+    b->has_index = !b->index_file.empty();
+    if (b->has_index && !b->regions.empty() && (b->index_file.size() < 4 || b->index_file.compare(b->index_file.size() - 4, 4, ".tbi") != 0)) {
+        FILE *f = fopen(b->index_file.c_str(), "rb");
+        if (f) { uint8_t tmp[65536]; size_t k; while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) b->index_bytes.insert(b->index_bytes.end(), tmp, tmp + k); fclose(f); }
+    }
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
     auto mklist = API(duckdb_logical_type, duckdb_create_list_type, duckdb_logical_type);
     auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);

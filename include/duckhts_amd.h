@@ -155,9 +155,11 @@ int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, in
  * hts.c:3995-4150, the predicate of hts_itr_multi_next hts.c:4575-4592 + bam_endpos sam.c:668-673).  Rows are filtered on the device.
  * Returns 0, 1 when no region names a known reference (reference: "No reads found for region(s): ..."), <0 on error.          */
 int dhts_bam_set_regions(dhts_ctx *, const char *regions);
-/* BAI bytes (hts_idx_load: hts.c:2920-3055): narrows the scan window to the chunks of the bins the regions touch (reg2bins
- * hts.c:3142-3213 + linear index); optional for exactness, call after dhts_bam_set_regions.                                    */
-int dhts_bam_load_index(dhts_ctx *, const void *bai_bytes, uint64_t n);
+/* BAI or CSI bytes (hts_idx_load: hts.c:2920-3055; a BGZF-compressed CSI is inflated on the device): narrows the scan window to
+ * the chunks of the bins the regions touch (reg2bins hts.c:3142-3213 + BAI linear index); optional for exactness, call after
+ * dhts_bam_set_regions / dhts_bcf_set_region.                                                                                    */
+int dhts_bam_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
+int dhts_bcf_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
 /* standard_tags := true (src/bam_reader.c:54-70, 920-966): the reference's 56-entry tag table, in its order */
 int dhts_bam_std_tag_count(void);
 int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype);   /* type: 'i' BIGINT, 'Z'/'A' VARCHAR, 'B' LIST(BIGINT) */
