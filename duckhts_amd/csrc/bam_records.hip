@@ -6,10 +6,10 @@
 //   column writers bam_reader.c:785-918 (QNAME..SAMPLE_ID).
 //
 // The inflated BAM stream is a linked list (next = cur + 4 + block_size).  It is cut into
-// fixed TILE-byte tiles; one LANE per tile speculates the first record start inside its tile
-// (same predicates bam_read1 enforces, chained 3 deep) and walks to the tile end.  A fix-up
-// kernel then proves continuity tile-to-tile (end of tile t-1's chain == start of tile t) and
-// re-walks only the tiles whose speculation was wrong, so the result is exact.  Row ids come
+// fixed TILE-byte tiles; bam_tiles_lds.hip speculates the first record start inside each tile
+// (same predicates bam_read1 enforces, chained 3 deep) and walks to the tile end.  The fix-up
+// kernels here prove continuity tile-to-tile (end of tile t-1's chain == start of tile t) and
+// re-walk only the tiles whose speculation was wrong, so the result is exact.  Row ids come
 // from a prefix sum of per-tile counts; string columns are written with a length pass +
 // prefix sums + a 16-lanes-per-record write pass.  Integer/byte work only.
 #include "dhts_common.h"
@@ -40,53 +40,6 @@ __device__ __forceinline__ int aux_size(uint8_t t) {
     default: return 0;
     }
 }
-// htslib sam.c:4785-4809 skip_aux.  s points at the type byte.  Returns next tag position
-// (end if exhausted) or NONE64 on corrupt data.
-__device__ uint64_t aux_skip(const uint8_t *u, uint64_t s, uint64_t end) {
-    if (s >= end) return end;
-    uint8_t t = u[s]; ++s;
-    if (t == 'Z' || t == 'H') {
-        while (s < end && u[s] != 0) s++;
-        return s < end ? s + 1 : end;
-    }
-    if (t == 'B') {
-        if (end - s < 5) return NONE64;
-        int sz = aux_size(u[s]); if (u[s] == 'Z' || u[s] == 'H' || u[s] == 'B') sz = u[s];   // aux_type2size returns the letter itself
-        ++s;
-        uint64_t n = ldu32(u + s); s += 4;
-        if (sz == 0 || end - s < (uint64_t)sz * n) return NONE64;
-        return s + (uint64_t)sz * n;
-    }
-    int sz = aux_size(t);
-    if (sz == 0) return NONE64;
-    if (end - s < (uint64_t)sz) return NONE64;
-    return s + sz;
-}
-// htslib sam.c:4834-4855 bam_aux_get: returns offset of the type byte, NONE64 if absent; *bad on corrupt aux.
-__device__ uint64_t aux_find(const uint8_t *u, uint64_t aux, uint64_t end, uint8_t t0, uint8_t t1, bool *bad,
-                             uint64_t skip_beg, uint64_t skip_end) {
-    *bad = false;
-    // [skip_beg, skip_end) = a CG tag removed by bam_tag2cigar (sam.c:716-720); the walk behaves as if spliced out
-    uint64_t eff_len = (end - aux) - (skip_end - skip_beg);
-    if (eff_len <= 2) return NONE64;
-    uint64_t s = aux;
-    if (s == skip_beg) s = skip_end;
-    s += 2;
-    for (;;) {
-        if (u[s - 2] == t0 && u[s - 1] == t1) {
-            uint64_t e = aux_skip(u, s, end);
-            if (e == NONE64) { *bad = true; return NONE64; }
-            if ((u[s] == 'Z' || u[s] == 'H') && u[e - 1] != 0) { *bad = true; return NONE64; }
-            return s;
-        }
-        uint64_t nx = aux_skip(u, s, end);
-        if (nx == NONE64) { *bad = true; return NONE64; }
-        if (nx == skip_beg) nx = skip_end;
-        if (end - nx <= 2) return NONE64;
-        s = nx + 2;
-    }
-}
-
 struct RecInfo {
     uint32_t block_len, l_qname, n_cigar, flag, mapq;
     int32_t tid, pos, l_seq, mtid, mpos, tlen;
@@ -95,56 +48,7 @@ struct RecInfo {
     uint64_t cg_beg, cg_end;   // spliced-out CG tag, or (0,0)
 };
 
-// Restates bam_read1's checks.  `full` adds the CIGAR/qlen test, the CG swap and the tid range test.
-__device__ int rec_check(const BamStream &st, uint64_t o, RecInfo &r, bool full) {
-    const uint8_t *u = st.u;
-    if (st.ulen - o < 4) return REC_INCOMPLETE;
-    int32_t block_len = (int32_t)ldu32(u + o);
-    if (block_len < 32) return REC_INVALID;                           // sam.c:794
-    if (st.ulen - o - 4 < 32) return REC_INCOMPLETE;
-    const uint8_t *x = u + o + 4;
-    r.block_len = (uint32_t)block_len;
-    r.tid = (int32_t)ldu32(x); r.pos = (int32_t)ldu32(x + 4);
-    uint32_t x2 = ldu32(x + 8), x3 = ldu32(x + 12);
-    r.mapq = (x2 >> 8) & 0xff; r.l_qname = x2 & 0xff;
-    r.flag = x3 >> 16; r.n_cigar = x3 & 0xffff;
-    r.l_seq = (int32_t)ldu32(x + 16); r.mtid = (int32_t)ldu32(x + 20); r.mpos = (int32_t)ldu32(x + 24); r.tlen = (int32_t)ldu32(x + 28);
-    uint64_t body = (uint64_t)r.block_len - 32;
-    if (r.l_seq < 0 || r.l_qname < 1) return REC_INVALID;             // sam.c:820
-    if (((uint64_t)r.n_cigar << 2) + r.l_qname + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq > body) return REC_INVALID;  // :821-823
-    if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
-    r.cig_off = o + 36 + r.l_qname; r.n_cigar_eff = r.n_cigar; r.cg_beg = r.cg_end = 0;
-    if (!full) {
-        // speculation filter only: cheap header-range sanity (not part of exactness)
-        if (r.tid < -1 || r.tid >= st.n_ref || r.mtid < -1 || r.mtid >= st.n_ref) return REC_INVALID;
-        // heuristics (a wrong rejection only costs a repair round): NUL-terminated name, aux area of sane size
-        uint64_t core = ((uint64_t)r.n_cigar << 2) + r.l_qname + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq;
-        if (body - core > 8 * core + 65536) return REC_INVALID;
-        if (u[o + 36 + r.l_qname - 1] != 0) return REC_INVALID;
-        return REC_OK;
-    }
-    uint64_t end = o + 4 + r.block_len;
-    uint64_t aux = r.cig_off + 4ull * r.n_cigar + (((uint64_t)r.l_seq + 1) >> 1) + (uint64_t)r.l_seq;
-    // long-CIGAR swap (sam.c:675-730)
-    if (r.n_cigar > 0 && ldu32(u + r.cig_off) == (4u | ((uint32_t)r.l_seq << 4)) && r.tid >= 0 && r.pos >= 0) {
-        bool bad; uint64_t cg = aux_find(u, aux, end, 'C', 'G', &bad, 0, 0);
-        if (cg == NONE64 && bad) return REC_INVALID;
-        if (cg != NONE64 && u[cg] == 'B' && (u[cg + 1] == 'I' || u[cg + 1] == 'i')) {
-            uint32_t cgl = ldu32(u + cg + 2);
-            if (cgl >= r.n_cigar && cgl < (1u << 29)) {
-                r.cig_off = cg + 6; r.n_cigar_eff = cgl; r.cg_beg = cg - 2; r.cg_end = cg + 6 + 4ull * cgl;
-            }
-        }
-    }
-    if (r.n_cigar_eff > 0) {                                           // sam.c:842-852
-        int64_t qlen = 0;
-        for (uint32_t k = 0; k < r.n_cigar_eff; k++) { uint32_t c = ldu32(u + r.cig_off + 4ull * k); if (CIG_QUERY(c & 0xf)) qlen += c >> 4; }
-        if (r.l_seq > 0 && !(r.flag & 4) && qlen != r.l_seq) return REC_INVALID;
-    }
-    if (r.tid >= st.n_ref || r.tid < -1 || r.mtid >= st.n_ref || r.mtid < -1) return REC_INVALID;   // sam.c:4127-4131
-    return REC_OK;
-}
-
+// (the bam_read1 checks themselves live in bam_tiles_lds.hip: rec_check_t / rec_hop)
 struct TileOut {
     uint64_t *first;     // first record start in tile (absolute offset in this batch buffer) or NONE64
     uint64_t *end_next;  // where the chain leaves the tile (start of the first record at/after tile end, or stuck position)
@@ -180,37 +84,6 @@ __device__ void tile_walk(const BamStream &st, uint64_t start, uint64_t tile_end
         c++; o += 4ull + bl;
     }
     end_next = o; count = c;
-}
-
-extern "C" __global__ void __launch_bounds__(256)
-bam_tile_speculate(BamStream st, uint64_t start0, uint32_t tile_bytes, int64_t ntiles, TileOut out) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
-    uint64_t tb = (uint64_t)t * tile_bytes, te = tb + tile_bytes; if (te > st.ulen) te = st.ulen;
-    uint64_t first = NONE64;
-    if (t == 0 && start0 != NONE64) first = start0;
-    else {
-        // a shard that begins mid-stream speculates its very first record too; its tile 0 keeps looking past the tile
-        const uint64_t se = (t == 0) ? st.ulen : te;
-        for (uint64_t o = tb; o < se; o++) {
-            RecInfo r;
-            if (rec_check(st, o, r, false) != REC_OK) continue;
-            // chain two more records (or run off the buffer) before trusting the candidate
-            uint64_t o2 = o + 4ull + r.block_len; bool good = true;
-            for (int k = 0; k < 2 && good; k++) {
-                RecInfo r2; int rc = rec_check(st, o2, r2, false);
-                if (rc == REC_INVALID) good = false;
-                else if (rc == REC_INCOMPLETE) break;
-                else o2 += 4ull + r2.block_len;
-            }
-            if (good) { first = o; break; }
-        }
-    }
-    uint64_t en = NONE64; uint32_t cnt = 0; int err = 0;
-    if (first != NONE64 && first < te) tile_walk(st, first, te, en, cnt, err);
-    else if (first != NONE64) { en = first; }            // t == 0 with start0 beyond the tile
-    out.first[t] = (first != NONE64 && first < te) ? first : NONE64;
-    out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
 }
 
 // One round of continuity proof + repair, OUT OF PLACE (reads `in`, writes `out` for every tile; the host swaps), so a round
@@ -327,58 +200,6 @@ struct BamCols {
 
 __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
     return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) + (v >= 10000000) + (v >= 100000000);
-}
-
-extern "C" __global__ void __launch_bounds__(256)
-bam_core_unpack(BamStream st, BamDict dict, const uint32_t *rec_off, int64_t nrows, uint32_t colmask, BamCols c) {
-    int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool act = row < nrows;
-    bool rgv = false;
-    if (act) {
-        const uint8_t *u = st.u;
-        uint64_t o = rec_off[row];
-        RecInfo r; rec_check(st, o, r, true);
-        c.flag[row] = (uint16_t)r.flag;                            // bam_reader.c:792-796
-        c.pos[row] = (int64_t)r.pos + 1;                           // :807-811
-        c.mapq[row] = (int32_t)r.mapq;                             // :813-817
-        c.pnext[row] = (int64_t)r.mpos + 1;                        // :845-849
-        c.tlen[row] = (int64_t)r.tlen;                             // :851-855
-        c.tid[row] = r.tid; c.mtid[row] = r.mtid;
-        // QNAME: C string up to the first NUL within l_qname bytes (:785-790, sam.c:827-829)
-        uint32_t ql = 0; const uint8_t *qn = u + o + 36;
-        while (ql < r.l_qname && qn[ql] != 0) ql++;
-        c.len_qname[row] = ql;
-        // CIGAR text length (:819-834, cigar_to_kstring 375-383)
-        uint32_t cl = 0;
-        for (uint32_t k = 0; k < r.n_cigar_eff; k++) cl += ndigits(ldu32(u + r.cig_off + 4ull * k) >> 4) + 1;
-        c.len_cigar[row] = r.n_cigar_eff ? cl : 1;
-        c.cig_rel[row] = (uint32_t)(r.cig_off - o); c.ncig_eff[row] = r.n_cigar_eff;
-        // SEQ / QUAL reserved lengths (:857-877)
-        uint64_t seq = o + 36 + r.l_qname + 4ull * r.n_cigar;
-        uint64_t qual = seq + (((uint64_t)r.l_seq + 1) >> 1);
-        c.len_seq[row] = r.l_seq > 0 ? (uint32_t)r.l_seq : 1;
-        c.len_qual[row] = (r.l_seq > 0 && u[qual] != 255) ? (uint32_t)r.l_seq : 1;
-        // READ_GROUP_ID / SAMPLE_ID (:879-918)
-        uint64_t aux = qual + (uint64_t)r.l_seq, end = o + 4ull + r.block_len;
-        bool bad; uint64_t rg = aux_find(u, aux, end, 'R', 'G', &bad, r.cg_beg, r.cg_end);
-        uint32_t rl = 0; int32_t rgi = -1;
-        if (rg != NONE64 && (u[rg] == 'Z' || u[rg] == 'H')) {     // bam_aux2Z sam.c:5134-5141
-            rgv = true;
-            const uint8_t *z = u + rg + 1;
-            while (z[rl] != 0) rl++;
-            for (int32_t k = 0; k < dict.n_rg; k++) {
-                uint32_t a = dict.rg_off[k], b = dict.rg_off[k + 1];
-                if (b - a != rl) continue;
-                bool eq = true;
-                for (uint32_t q = 0; q < rl; q++) if (dict.rg_bytes[a + q] != z[q]) { eq = false; break; }
-                if (eq) { rgi = k; break; }
-            }
-            c.rg_rel[row] = (uint32_t)(rg + 1 - o);
-        } else c.rg_rel[row] = 0;
-        c.len_rg[row] = rl; c.rg_idx[row] = rgi;
-    }
-    uint64_t m = __ballot(rgv);
-    if ((threadIdx.x & 63) == 0 && ((row >> 6) << 6) < nrows) c.rg_valid[row >> 6] = m;
 }
 
 // ---- generic multi-array exclusive scan (u32 in; u32 or u64 out), 3 launches for up to 8 arrays at once ----
