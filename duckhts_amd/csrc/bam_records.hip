@@ -258,76 +258,108 @@ struct BamStrOut {
     uint32_t *alen_qual;     // actual QUAL length (the reference assigns through a NUL-terminated API: byte 223 (+33 == 0) truncates)
 };
 
-__device__ __forceinline__ void group_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int gl) {
-    for (uint32_t b = gl * 16; b < n; b += 256) {
-        if (b + 16 <= n) { uint4 v; __builtin_memcpy(&v, src + b, 16); __builtin_memcpy(dst + b, &v, 16); }
-        else for (uint32_t k = b; k < n; k++) dst[k] = src[k];
+// SEQ: 16 bases (8 packed bytes p0,p1) -> 16 chars; "=ACMGRSVTWYHKDBN" (hts.c:260), high nibble first (sam.h:325).
+// The 16-entry byte table is held in four dwords; v_perm_b32 gathers 4 table bytes per instruction.
+__device__ __forceinline__ void seq16(uint32_t p0, uint32_t p1, uint32_t w[4]) {
+    const uint32_t T0 = 0x4d43413du, T1 = 0x56535247u, T2 = 0x48595754u, T3 = 0x4e42444bu;   // "=ACM" "GRSV" "TWYH" "KDBN"
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t x = ((k & 2) ? p1 : p0) >> ((k & 1) * 16);                   // two packed bytes = four bases
+        uint32_t sel = ((x >> 4) & 0xfu) | ((x & 0xfu) << 8) | (((x >> 12) & 0xfu) << 16) | (((x >> 8) & 0xfu) << 24);
+        uint32_t lo = __builtin_amdgcn_perm(T1, T0, sel & 0x07070707u);
+        uint32_t hi = __builtin_amdgcn_perm(T3, T2, sel & 0x07070707u);
+        uint32_t m = ((sel >> 3) & 0x01010101u) * 0xffu;
+        w[k] = (hi & m) | (lo & ~m);
+    }
+}
+// QUAL: bytewise +33 without cross-byte carry; returns true if some byte became NUL
+__device__ __forceinline__ bool qual16(uint32_t w[4]) {
+    bool z = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t x = w[k];
+        uint32_t t = ((x & 0x7f7f7f7fu) + 0x21212121u) ^ (x & 0x80808080u);
+        w[k] = t;
+        z |= (((t - 0x01010101u) & ~t & 0x80808080u) != 0);
+    }
+    return z;
+}
+__device__ __forceinline__ void store_n16(uint8_t *d, const uint32_t w[4], uint32_t n) {
+    if (n >= 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(d, &v, 16); }
+    else {
+        // exact-length tail without a byte loop: 8 / 4 / 2 / 1 pieces
+        uint32_t k = 0;
+        if (n & 8) { uint2 v = make_uint2(w[0], w[1]); __builtin_memcpy(d, &v, 8); k = 2; }
+        if (n & 4) { __builtin_memcpy(d + 4 * k, &w[k == 2 ? 2 : 0], 4); k++; }
+        const uint32_t rem = n & 3u, x = (k == 0) ? w[0] : (k == 1) ? w[1] : (k == 2) ? w[2] : w[3];
+        uint8_t *q = d + 4 * k;
+        if (rem & 2) { uint16_t h = (uint16_t)x; __builtin_memcpy(q, &h, 2); q += 2; }
+        if (rem & 1) *q = (uint8_t)(x >> ((rem & 2) ? 16 : 0));
     }
 }
 
+// 16 lanes per record.  Every input of a record (row metadata, the first 16-byte chunk of each field) is loaded BEFORE the first
+// store: stores may alias the inputs as far as the compiler knows, so interleaving them serialises ~15 dependent HBM round trips
+// per record (PMC: 82 % of the wave time was s_waitcnt).  Fields longer than one pass (> 256 bytes / > 16 CIGAR ops) loop after.
 extern "C" __global__ void __launch_bounds__(256)
 bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t colmask, BamCols c, BamStrOut s) {
     const int gl = threadIdx.x & 15;                                  // lane within the 16-lane group
     int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    bool act = row < nrows;
+    const bool act = row < nrows;
+    const int64_t r = act ? row : 0;
     const uint8_t *u = st.u;
-    uint64_t o = act ? rec_off[row] : 0;
-    uint32_t x2 = act ? ldu32(u + o + 12) : 0, x3 = act ? ldu32(u + o + 16) : 0;
-    uint32_t l_qname = x2 & 0xff, n_cigar = x3 & 0xffff;
-    int32_t l_seq = act ? (int32_t)ldu32(u + o + 20) : 0;
+    // ---- level 1: everything addressed by the row id ----
+    const uint64_t o = rec_off[r];
+    const uint32_t off_qn = s.off_qname[r], len_qn = c.len_qname[r], rl = c.len_rg[r], off_rg = s.off_rg[r], rg_rel = c.rg_rel[r];
+    const uint32_t off_seq = s.off_seq[r], off_qual = s.off_qual[r], ne = act ? c.ncig_eff[r] : 0, cig_rel = c.cig_rel[r], off_cig = s.off_cigar[r];
+    // ---- level 2: the record ----
+    const uint32_t x2 = ldu32(u + o + 12), x3 = ldu32(u + o + 16);
+    const int32_t l_seq = (int32_t)ldu32(u + o + 20);
+    const uint32_t l_qname = x2 & 0xff, n_cigar = x3 & 0xffff;
+    const uint8_t *seq = u + o + 36 + l_qname + 4ull * n_cigar;
+    const uint8_t *qual = seq + (((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) >> 1);
+    const uint8_t *cig = u + o + cig_rel;
+    const uint32_t b0 = (uint32_t)gl * 16u;
+    uint4 vq = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
+    if (act && b0 < len_qn) __builtin_memcpy(&vq, u + o + 36 + b0, 16);               // reads past short fields stay inside the padded buffer
+    if (act && b0 < rl) __builtin_memcpy(&vr, u + o + rg_rel + b0, 16);
+    uint32_t p0 = 0, p1 = 0, wq[4] = {0, 0, 0, 0};
+    const bool in_seq = act && l_seq > 0 && b0 < (uint32_t)l_seq;
+    if (in_seq) { p0 = ldu32(seq + (b0 >> 1)); p1 = ldu32(seq + (b0 >> 1) + 4); __builtin_memcpy(wq, qual + b0, 16); }
+    const uint8_t q0 = (act && l_seq > 0) ? qual[0] : 255;
+    const uint32_t op0 = ((uint32_t)gl < ne) ? ldu32(cig + 4ull * gl) : 0;
+    // ---- stores ----
     if (act) {
-        // QNAME
-        group_copy(s.qname + s.off_qname[row], u + o + 36, c.len_qname[row], gl);
-        // READ_GROUP_ID
-        uint32_t rl = c.len_rg[row];
-        if (rl) group_copy(s.rg + s.off_rg[row], u + o + c.rg_rel[row], rl, gl);
-        // SEQ: 4-bit -> "=ACMGRSVTWYHKDBN" (hts.c:260), high nibble first (sam.h:325); 8 packed bytes -> 16 chars per lane
-        const uint8_t *seq = u + o + 36 + l_qname + 4ull * n_cigar;
-        uint8_t *dseq = s.seq + s.off_seq[row];
+        // QNAME / READ_GROUP_ID
+        if (b0 < len_qn) { const uint32_t w4[4] = {vq.x, vq.y, vq.z, vq.w}; store_n16(s.qname + off_qn + b0, w4, len_qn - b0); }
+        for (uint32_t b = b0 + 256; b < len_qn; b += 256) { uint32_t w4[4]; __builtin_memcpy(w4, u + o + 36 + b, 16); store_n16(s.qname + off_qn + b, w4, len_qn - b); }
+        if (b0 < rl) { const uint32_t w4[4] = {vr.x, vr.y, vr.z, vr.w}; store_n16(s.rg + off_rg + b0, w4, rl - b0); }
+        for (uint32_t b = b0 + 256; b < rl; b += 256) { uint32_t w4[4]; __builtin_memcpy(w4, u + o + rg_rel + b, 16); store_n16(s.rg + off_rg + b, w4, rl - b); }
+        // SEQ
+        uint8_t *dseq = s.seq + off_seq;
         if (l_seq <= 0) { if (gl == 0) dseq[0] = '*'; }
         else {
-            // 16-entry byte table held in four dwords; v_perm_b32 gathers 4 table bytes per instruction
-            const uint32_t T0 = 0x4d43413du, T1 = 0x56535247u, T2 = 0x48595754u, T3 = 0x4e42444bu;   // "=ACM" "GRSV" "TWYH" "KDBN"
-            for (uint32_t b = gl * 16; b < (uint32_t)l_seq; b += 256) {
-                uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
-                uint32_t p0 = ldu32(seq + (b >> 1)), p1 = ldu32(seq + (b >> 1) + 4);   // may read past the field; the buffer is padded
-                uint32_t w[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t x = ((k & 2) ? p1 : p0) >> ((k & 1) * 16);                   // two packed bytes = four bases
-                    uint32_t sel = ((x >> 4) & 0xfu) | ((x & 0xfu) << 8) | (((x >> 12) & 0xfu) << 16) | (((x >> 8) & 0xfu) << 24);
-                    uint32_t lo = __builtin_amdgcn_perm(T1, T0, sel & 0x07070707u);
-                    uint32_t hi = __builtin_amdgcn_perm(T3, T2, sel & 0x07070707u);
-                    uint32_t m = ((sel >> 3) & 0x01010101u) * 0xffu;
-                    w[k] = (hi & m) | (lo & ~m);
-                }
-                if (n == 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(dseq + b, &v, 16); }
-                else for (uint32_t k = 0; k < n; k++) dseq[b + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-            }
+            if (in_seq) { uint32_t w[4]; seq16(p0, p1, w); store_n16(dseq + b0, w, (uint32_t)l_seq - b0); }
+            for (uint32_t b = b0 + 256; b < (uint32_t)l_seq; b += 256) { uint32_t w[4]; seq16(ldu32(seq + (b >> 1)), ldu32(seq + (b >> 1) + 4), w); store_n16(dseq + b, w, (uint32_t)l_seq - b); }
         }
     }
     // QUAL (+33), truncated at the first byte that becomes NUL
     {
-        const uint8_t *qual = u + o + 36 + l_qname + 4ull * n_cigar + (((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) >> 1);
         uint32_t firstnul = 0xffffffffu;
-        bool star = act && !(l_seq > 0 && qual[0] != 255);
-        uint8_t *dq = act ? s.qual + s.off_qual[row] : nullptr;
+        const bool star = act && !(l_seq > 0 && q0 != 255);
+        uint8_t *dq = s.qual + off_qual;
         if (act && star) { if (gl == 0) dq[0] = '*'; }
         else if (act) {
-            for (uint32_t b = gl * 16; b < (uint32_t)l_seq; b += 256) {
-                uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
-                uint32_t w[4]; __builtin_memcpy(w, qual + b, 16);                  // padded buffer
-                bool z = false;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t x = w[k];
-                    uint32_t t = ((x & 0x7f7f7f7fu) + 0x21212121u) ^ (x & 0x80808080u);   // bytewise +33 without cross-byte carry
-                    w[k] = t;
-                    z |= (((t - 0x01010101u) & ~t & 0x80808080u) != 0);
-                }
-                if (z) for (uint32_t k = 0; k < n; k++) if (((w[k >> 2] >> (8 * (k & 3))) & 0xff) == 0) { if (firstnul == 0xffffffffu) firstnul = b + k; }
-                if (n == 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(dq + b, &v, 16); }
-                else for (uint32_t k = 0; k < n; k++) dq[b + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            if (in_seq) {
+                const uint32_t n = (uint32_t)l_seq - b0 < 16 ? (uint32_t)l_seq - b0 : 16;
+                if (qual16(wq)) for (uint32_t k = 0; k < n; k++) if (((wq[k >> 2] >> (8 * (k & 3))) & 0xff) == 0) { if (firstnul == 0xffffffffu) firstnul = b0 + k; }
+                store_n16(dq + b0, wq, n);
+            }
+            for (uint32_t b = b0 + 256; b < (uint32_t)l_seq; b += 256) {
+                const uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
+                uint32_t w[4]; __builtin_memcpy(w, qual + b, 16);
+                if (qual16(w)) for (uint32_t k = 0; k < n; k++) if (((w[k >> 2] >> (8 * (k & 3))) & 0xff) == 0) { if (firstnul == 0xffffffffu) firstnul = b + k; }
+                store_n16(dq + b, w, n);
             }
         }
 #pragma unroll
@@ -336,9 +368,7 @@ bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t 
     }
     // CIGAR text: 16 ops per pass, group prefix sum of the per-op text widths
     {
-        uint32_t ne = act ? c.ncig_eff[row] : 0;
-        const uint8_t *cig = u + o + (act ? c.cig_rel[row] : 0);
-        uint8_t *dc = act ? s.cigar + s.off_cigar[row] : nullptr;
+        uint8_t *dc = s.cigar + off_cig;
         if (act && ne == 0 && gl == 0) dc[0] = '*';
         // trip count must be uniform across the 16-lane group (it is: ne is per-row) but groups differ: use max over the wave
         uint32_t nmax = ne;
@@ -347,7 +377,7 @@ bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t 
         uint32_t base = 0;
         for (uint32_t k0 = 0; k0 < nmax; k0 += 16) {
             uint32_t k = k0 + gl; bool has = k < ne;
-            uint32_t op = has ? ldu32(cig + 4ull * k) : 0;
+            uint32_t op = has ? (k0 == 0 ? op0 : ldu32(cig + 4ull * k)) : 0;
             uint32_t ol = op >> 4, w = has ? ndigits(ol) + 1 : 0;
             uint32_t inc = w;
 #pragma unroll

@@ -143,6 +143,48 @@ template <class S> __device__ __forceinline__ int rec_hop(const BamStream &st, c
     return REC_OK;
 }
 
+// rec_hop for a record whose 36-byte core lies inside the staged window, evaluated wave-uniformly: ONE (unaligned) LDS read
+// fetches the core as dwords across lanes 0..8, v_readlane moves the six fields into SGPRs and the tests run on the scalar unit.
+// Same predicates, same order of outcomes as rec_hop.
+__device__ __forceinline__ int rec_hop_uniform(const BamStream &st, const PSrc &ls, uint64_t o, int lane, uint32_t &bl) {
+    if (st.ulen - o < 4) return REC_INCOMPLETE;
+    const uint32_t v = ls.u32(o + 4u * (uint32_t)(lane & 15));
+    const int32_t b = (int32_t)__builtin_amdgcn_readlane((int)v, 0);
+    if (b < 32) return REC_INVALID;
+    if (st.ulen - o - 4 < 32) return REC_INCOMPLETE;
+    const int32_t tid = __builtin_amdgcn_readlane((int)v, 1), l_seq = __builtin_amdgcn_readlane((int)v, 5), mtid = __builtin_amdgcn_readlane((int)v, 6);
+    const uint32_t l_qname = (uint32_t)__builtin_amdgcn_readlane((int)v, 3) & 0xff, n_cigar = (uint32_t)__builtin_amdgcn_readlane((int)v, 4) & 0xffff;
+    const uint64_t body = (uint64_t)(uint32_t)b - 32;
+    if (l_seq < 0 || l_qname < 1) return REC_INVALID;
+    if (((uint64_t)n_cigar << 2) + l_qname + (((uint64_t)l_seq + 1) >> 1) + (uint64_t)l_seq > body) return REC_INVALID;
+    if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
+    if (tid >= st.n_ref || tid < -1 || mtid >= st.n_ref || mtid < -1) return REC_INVALID;
+    bl = (uint32_t)b;
+    return REC_OK;
+}
+
+// speculation filter on a candidate inside the staged window: the core dwords are read up front (no branch between the LDS
+// reads), then the same tests as rec_check_t(full = false).  Returns REC_OK / REC_INVALID / REC_INCOMPLETE and the block length.
+__device__ __forceinline__ int spec_check_lds(const BamStream &st, const PSrc &ls, uint64_t o, uint32_t &bl) {
+    const uint32_t w0 = ls.u32(o), w1 = ls.u32(o + 4), w3 = ls.u32(o + 12), w4 = ls.u32(o + 16), w5 = ls.u32(o + 20), w6 = ls.u32(o + 24);
+    if (st.ulen - o < 4) return REC_INCOMPLETE;
+    const int32_t block_len = (int32_t)w0;
+    if (block_len < 32) return REC_INVALID;
+    if (st.ulen - o - 4 < 32) return REC_INCOMPLETE;
+    const int32_t tid = (int32_t)w1, l_seq = (int32_t)w5, mtid = (int32_t)w6;
+    const uint32_t l_qname = w3 & 0xff, n_cigar = w4 & 0xffff;
+    const uint64_t body = (uint64_t)(uint32_t)block_len - 32;
+    if (l_seq < 0 || l_qname < 1) return REC_INVALID;
+    const uint64_t core = ((uint64_t)n_cigar << 2) + l_qname + (((uint64_t)l_seq + 1) >> 1) + (uint64_t)l_seq;
+    if (core > body) return REC_INVALID;
+    if (tid < -1 || tid >= st.n_ref || mtid < -1 || mtid >= st.n_ref) return REC_INVALID;
+    if (body - core > 8 * core + 65536) return REC_INVALID;
+    if (st.ulen - o - 36 < body) return REC_INCOMPLETE;
+    if (ls.u8(o + 36 + l_qname - 1) != 0) return REC_INVALID;
+    bl = (uint32_t)block_len;
+    return REC_OK;
+}
+
 __device__ __forceinline__ void tile_stage(const BamStream &st, uint64_t tb, uint8_t *buf, LSrc &s, int lane) {
     uint64_t left = st.ulen - tb;
     uint32_t avail = left < (uint64_t)(TL_TILE + TL_HALO) ? (uint32_t)left : (TL_TILE + TL_HALO);
@@ -172,20 +214,22 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
             const uint64_t o = base + (uint64_t)lane;
             bool ok = false;
             if (o < lim) {
-                RecInfo r;
+                RecInfo r; uint32_t bl0 = 0;
                 // the cheap test touches <= 36 + 255 bytes: straight LDS when that lies inside the staged window
                 const bool inw = (o - tb) + 300u <= (uint64_t)s.len;
-                const int rc0 = inw ? rec_check_t(st, ls, o, r, false) : rec_check_t(st, gs, o, r, false);
+                int rc0;
+                if (inw) rc0 = spec_check_lds(st, ls, o, bl0); else { rc0 = rec_check_t(st, gs, o, r, false); bl0 = r.block_len; }
                 if (rc0 == REC_OK) {
                     ok = true;
-                    uint64_t o2 = o + 4ull + r.block_len;
+                    uint64_t o2 = o + 4ull + bl0;
                     for (int k = 0; k < 2 && ok; k++) {
-                        RecInfo r2;
+                        RecInfo r2; uint32_t bl2 = 0;
                         const bool inw2 = (o2 >= tb) && (o2 - tb) + 300u <= (uint64_t)s.len;
-                        const int rc = inw2 ? rec_check_t(st, ls, o2, r2, false) : rec_check_t(st, gs, o2, r2, false);
+                        int rc;
+                        if (inw2) rc = spec_check_lds(st, ls, o2, bl2); else { rc = rec_check_t(st, gs, o2, r2, false); bl2 = r2.block_len; }
                         if (rc == REC_INVALID) ok = false;
                         else if (rc == REC_INCOMPLETE) break;
-                        else o2 += 4ull + r2.block_len;
+                        else o2 += 4ull + bl2;
                     }
                 }
             }
@@ -199,7 +243,7 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
         uint64_t o = first;
         while (o < te) {
             uint32_t bl = 0;
-            const int rc = ((o - tb) + 36 <= (uint64_t)s.len) ? rec_hop(st, ls, o, bl) : rec_hop(st, gs, o, bl);
+            const int rc = ((o - tb) + 64 <= (uint64_t)s.len) ? rec_hop_uniform(st, ls, o, lane, bl) : rec_hop(st, gs, o, bl);
             if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }
             if (rc == REC_INVALID) { err = 1; break; }
             cnt++; o += 4ull + bl;
