@@ -5,17 +5,18 @@
 //
 //  phase A  bgzf_huff_decode : ONE LANE PER BGZF BLOCK (64 independent DEFLATE streams per
 //           wave64).  Each lane walks its stream with canonical-code arithmetic (no big
-//           LUTs): the 15 left-justified code limits of the literal/length and distance
-//           alphabets live in VGPRs, the sorted symbol lists in LDS ([entry][lane] layout,
-//           ~40 KB per wave => 4 waves per CU).  Output is append-only: literal bytes and
-//           one 32-bit token per LZ77 match.  No loads depend on earlier stores, so lanes
-//           never stall on the LZ77 window.
+//           LUTs): the 15 left-justified code limits of BOTH alphabets live in the two 16-bit
+//           halves of 15 VGPRs, the canonical base values in 15 more (telescoped deltas), the
+//           sorted symbol lists in LDS ([entry][lane] layout, 36 KB per wave => 4 waves per
+//           CU).  One symbol per lane per iteration from whichever alphabet the lane expects.
+//           Output is append-only: literal bytes and one 32-bit token per LZ77 match.  No
+//           loads depend on earlier stores, so lanes never stall on the LZ77 window.
 //  phase B  bgzf_lz_resolve  : ONE WAVE PER BGZF BLOCK.  Tokens are consumed 64 at a time
 //           (coalesced), wave prefix sums give every token's destination, literals are
-//           placed lane-parallel, matches are replayed by the whole wave in the LDS window
-//           (64 KiB, the full block), then the block is CRC-32'd from LDS (slice-by-4,
-//           per-lane chunks combined with x^(8n) mod P) and flushed to HBM with 16-byte
-//           coalesced stores.
+//           placed lane-parallel, matches are replayed in dependency rounds in an 8 KiB LDS
+//           ring (older sources are read back from the block's own flushed output), every
+//           half ring is CRC-32'd from LDS (slice-by-4, per-lane pieces combined with
+//           x^(8n) mod P) and flushed to HBM with 16-byte coalesced stores.
 #include "dhts_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -33,13 +34,11 @@
 #define A_LSYM_LO 0                        /* u8  [288][SL] */
 #define A_LSYM_HI (A_LSYM_LO + 288 * A_ST) /* u32 [9][SL]   */
 #define A_DSYM (A_LSYM_HI + 9 * A_ST * 4)  /* u8  [32][SL]  */
-#define A_LBASE (A_DSYM + 32 * A_ST)       /* u16 [16][SL]  */
-#define A_DBASE (A_LBASE + 16 * A_ST * 2)  /* u16 [16][SL]  */
-#define A_CNT (A_DBASE + 16 * A_ST * 2)    /* u16 [16][SL]  */
+#define A_CNT (A_DSYM + 32 * A_ST)         /* u16 [16][SL]  */
 #define A_LENS (A_CNT + 16 * A_ST * 2)     /* u8  [160][SL] nibble-packed code lengths */
 #define A_CLSYM (A_LENS + 160 * A_ST)      /* u8  [19][SL]  */
 #define A_LDS_RAW (A_CLSYM + 19 * A_ST)
-#define A_LDS_BYTES ((A_LDS_RAW + A_LDS_ROUND - 1) / A_LDS_ROUND * A_LDS_ROUND)  /* 40,384 B at SL=64: four waves per CU */
+#define A_LDS_BYTES ((A_LDS_RAW + A_LDS_ROUND - 1) / A_LDS_ROUND * A_LDS_ROUND)  /* 36,288 B at SL=64: four waves per CU */
 
 struct BitR {
     const uint8_t *p;   // stream base (deflate payload start)
@@ -72,9 +71,6 @@ __device__ __forceinline__ uint32_t br_take(BitR &b, uint32_t n) {   // n <= 32,
     return v;
 }
 
-#ifndef A_UNIFIED
-#define A_UNIFIED 1
-#endif
 // packed 16-bit helpers (v_pk_*): two independent u16 lanes per VGPR, no carries between the halves
 #ifdef HOSTSIM
 static inline uint32_t pk_subsat_u16(uint32_t a, uint32_t b) { uint32_t lo = (a & 0xffff) > (b & 0xffff) ? (a & 0xffff) - (b & 0xffff) : 0, hi = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0; return lo | (hi << 16); }
@@ -98,16 +94,15 @@ __device__ __forceinline__ uint32_t code_len(const Limits &lm, uint32_t w15) {
     return c + 1;   // 16 => invalid code
 }
 
-// builds limits (registers) + base table (LDS, [L][lane]) from cnt[L] (LDS); leaves cnt[L] = first
+// builds limits + canonical base values (registers) from cnt[L] (LDS); leaves cnt[L] = first
 // symbol index of length L (offs) for the placement pass.  Returns the Kraft remainder `left`
 // (0 complete, >0 incomplete, <0 over-subscribed).
-__device__ __forceinline__ int build_limits(Limits &lm, uint16_t *cnt, uint16_t *base, int lane, int maxlen, uint32_t *bs) {
+__device__ __forceinline__ int build_limits(Limits &lm, uint16_t *cnt, int lane, int maxlen, uint32_t *bs) {
     uint32_t first = 0, offs = 0; int left = 1;
 #pragma unroll
     for (int L = 1; L <= 15; L++) {
         uint32_t c = (L <= maxlen) ? cnt[L * A_ST + lane] : 0;
         left = (left << 1) - (int)c;
-        base[L * A_ST + lane] = (uint16_t)(offs - first);
         bs[L] = (offs - first) & 0xffffu;
         lm.v[L - 1] = (first + c) << (15 - L);
         if (L <= maxlen) cnt[L * A_ST + lane] = (uint16_t)offs;
@@ -137,8 +132,6 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
     uint8_t *lsym_lo = smem + A_LSYM_LO;
     uint32_t *lsym_hi = (uint32_t *)(smem + A_LSYM_HI);
     uint8_t *dsym = smem + A_DSYM;
-    uint16_t *lbase = (uint16_t *)(smem + A_LBASE);
-    uint16_t *dbase = (uint16_t *)(smem + A_DBASE);
     uint16_t *cnt = (uint16_t *)(smem + A_CNT);
     uint8_t *lens = smem + A_LENS;
     uint8_t *clsym = smem + A_CLSYM;
@@ -289,7 +282,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         for (uint32_t i = 0; i < nl; i++) { uint32_t l = get_len(lens, lane, i); cnt[l * A_ST + lane]++; }
         uint32_t nz_l = nl - cnt[0 * A_ST + lane];
         uint32_t bsl[16], bsd[16];
-        int left = build_limits(ll, cnt, lbase, lane, 15, bsl);
+        int left = build_limits(ll, cnt, lane, 15, bsl);
         if (left < 0 || (left > 0 && nz_l != 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
         for (int k = 0; k < 9; k++) lsym_hi[k * A_ST + lane] = 0;
         for (uint32_t i = 0; i < nl; i++) {
@@ -305,7 +298,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         for (int L = 0; L < 16; L++) cnt[L * A_ST + lane] = 0;
         for (uint32_t i = 0; i < nd; i++) { uint32_t l = get_len(lens, lane, nl + i); cnt[l * A_ST + lane]++; }
         uint32_t nz_d = nd - cnt[0 * A_ST + lane];
-        left = build_limits(dl, cnt, dbase, lane, 15, bsd);
+        left = build_limits(dl, cnt, lane, 15, bsd);
         if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
         for (uint32_t i = 0; i < nd; i++) {
             uint32_t l = get_len(lens, lane, nl + i);
@@ -316,7 +309,6 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         unsigned long long dA_s0 = clock64();
 #endif
         // ---- symbol loop ----
-#if A_UNIFIED
         // ONE Huffman symbol per lane per iteration, from whichever alphabet the lane expects (mode 0 = literal/length,
         // 1 = distance): a wave always holds lanes in both states, so separate literal and distance paths would both execute every
         // iteration.  Code length = 16 - #{i : w < limit[i]}; the limits of BOTH alphabets sit in the two halves of 15 VGPRs and are
@@ -438,89 +430,6 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
             // back to the plain reader for the next block header: re-prime its two look-ahead words
             br.w0 = ld32_guard(br.p, br.pos, br.lim); br.w1 = ld32_guard(br.p, br.pos + 4, br.lim);
         }
-#else
-        // Input comes through an LDS window: every 4 iterations (wave-uniform) each lane fetches the 64 bytes at its own
-        // stream position into registers, and the fetch of the previous period is parked in LDS ([dword][lane], aliasing
-        // the code-length scratch, idle now).  Refills read that window, so the only vmcnt wait of the loop sits at the
-        // period boundary, one whole period after the loads (and the scattered literal/token stores) were issued.
-        {
-            uint32_t *winA = (uint32_t *)lens;
-            const uint8_t *sp = br.p;
-            uint32_t wbase = br.pos, rbase = br.pos;
-            uint4 R0, R1, R2, R3;
-            __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
-            __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
-            bool live = true;
-#define WIN_PARK() do {                                                                                         \
-                winA[0 * A_ST + lane] = R0.x; winA[1 * A_ST + lane] = R0.y; winA[2 * A_ST + lane] = R0.z; winA[3 * A_ST + lane] = R0.w;       \
-                winA[4 * A_ST + lane] = R1.x; winA[5 * A_ST + lane] = R1.y; winA[6 * A_ST + lane] = R1.z; winA[7 * A_ST + lane] = R1.w;       \
-                winA[8 * A_ST + lane] = R2.x; winA[9 * A_ST + lane] = R2.y; winA[10 * A_ST + lane] = R2.z; winA[11 * A_ST + lane] = R2.w;     \
-                winA[12 * A_ST + lane] = R3.x; winA[13 * A_ST + lane] = R3.y; winA[14 * A_ST + lane] = R3.z; winA[15 * A_ST + lane] = R3.w;   \
-                wbase = rbase; } while (0)
-#define WIN_REFILL() do { if (br.cnt <= 32) {                                                                   \
-                const uint32_t word_ = winA[(((br.pos - wbase) >> 2) & 15u) * A_ST + lane];                       \
-                br.buf |= (uint64_t)word_ << br.cnt; br.pos += 4; br.cnt += 32; } } while (0)
-#define WIN_FETCH() do { rbase = br.pos;                                                                        \
-                __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);                 \
-                __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16); } while (0)
-            WIN_PARK();
-            for (uint32_t it = 0; __ballot(live) != 0ull; it++) {
-#ifdef DHTS_DIAG
-                dA_it++;
-#endif
-                if ((it & 3u) == 0u) {
-                    if (it) WIN_PARK();
-                    WIN_FETCH();
-                } else if (__ballot(live && (br.pos - wbase) > 48u) != 0ull) {
-                    // rare (streams of very long codes): a lane could outrun its window within this iteration (<= 8 bytes):
-                    // refetch for the whole wave, synchronously
-                    WIN_FETCH(); WIN_PARK(); WIN_FETCH();
-                }
-                if (!live) continue;
-                WIN_REFILL();
-                uint32_t w = __brev((uint32_t)br.buf) >> 17;
-                uint32_t L = code_len(ll, w);
-                if (L > 15) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                uint32_t o = (uint32_t)(uint16_t)(lbase[L * A_ST + lane] + (uint16_t)(w >> (15 - L)));
-                if (o >= 288) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                uint32_t sym = lsym_lo[o * A_ST + lane] | (((lsym_hi[(o >> 5) * A_ST + lane] >> (o & 31)) & 1u) << 8);
-                br_take(br, L);
-                if (sym < 256) {
-                    EMIT_LIT(sym);
-                    if (status != 0) { live = false; continue; }
-                } else if (sym == 256) {
-                    live = false; continue;
-                } else {
-                    uint32_t i = sym - 257;
-                    if (i >= 29) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                    uint32_t eb = (i < 8 || i == 28) ? 0 : (i >> 2) - 1;
-                    uint32_t len = (i < 8) ? 3 + i : (i == 28) ? 258 : 3 + ((4 + (i & 3)) << eb);
-                    len += br_take(br, eb);
-                    WIN_REFILL();
-                    uint32_t wd = __brev((uint32_t)br.buf) >> 17;
-                    uint32_t Ld = code_len(dl, wd);
-                    if (Ld > 15) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                    uint32_t od = (uint32_t)(uint16_t)(dbase[Ld * A_ST + lane] + (uint16_t)(wd >> (15 - Ld)));
-                    if (od >= 32) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                    uint32_t ds = dsym[od * A_ST + lane];
-                    br_take(br, Ld);
-                    if (ds >= 30) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                    uint32_t deb = (ds < 4) ? 0 : (ds >> 1) - 1;
-                    uint32_t dist = (ds < 4) ? 1 + ds : 1 + ((2 + (ds & 1)) << deb);
-                    dist += br_take(br, deb);
-                    if (dist > outpos || outpos + len > 65536u) { status = DHTS_BLK_ERR_INFLATE; live = false; continue; }
-                    tok[ntok++] = (run << 23) | ((len - 3) << 15) | (dist - 1);
-                    run = 0; outpos += len;
-                }
-                if (br.pos * 8 - br.cnt > payload_bits + 64) { status = DHTS_BLK_ERR_INFLATE; live = false; }   // ran off the payload
-            }
-#undef WIN_PARK
-#undef WIN_REFILL
-#undef WIN_FETCH
-            // back to the plain reader for the next block header: re-prime its two look-ahead words
-            br.w0 = ld32_guard(br.p, br.pos, br.lim); br.w1 = ld32_guard(br.p, br.pos + 4, br.lim);
-        }
-#endif
 #ifdef DHTS_DIAG
         dA_sym += clock64() - dA_s0;
 #endif

@@ -20,7 +20,10 @@ for lib in sys.argv[1:] or [os.path.join(ROOT, "duckhts_amd", "libduckhts_amd.so
     L.dhts_debug_time_huff.restype = C.c_double
     L.dhts_debug_time_huff.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
     h = L.dhts_create(0)
-    L.dhts_open_tiled(C.c_void_p(h), head.ctypes.data, head.nbytes, body.ctypes.data, body.nbytes, 4, tail.ctypes.data, tail.nbytes)
+    L.dhts_open_tiled(C.c_void_p(h), head.ctypes.data, head.nbytes, body.ctypes.data, body.nbytes, 8, tail.ctypes.data, tail.nbytes)
     nb = L.dhts_bgzf_index(C.c_void_p(h))
-    ms = L.dhts_debug_time_huff(C.c_void_p(h), 1, 65536, 3)
-    print(f"{os.path.basename(lib):40s} blocks={nb} huff_decode {ms:8.3f} ms / 65536 blocks", flush=True)
+    for nblk in (65536, 131072):
+        if nblk + 1 > nb:
+            continue
+        ms = L.dhts_debug_time_huff(C.c_void_p(h), 1, nblk, 2)
+        print(f"{os.path.basename(lib):40s} blocks={nb} huff_decode {ms:8.3f} ms / {nblk} blocks = {ms / nblk * 65536:7.3f} ms per 65536", flush=True)
