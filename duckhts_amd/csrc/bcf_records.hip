@@ -299,6 +299,7 @@ struct BcfCellArgs {
     uint32_t *lens; const uint32_t *offs; uint32_t ostride;
     const BcfColDev *cols;
     const uint32_t *sel;          // region filter: compacted list of kept record ids (nullptr = every record)
+    uint32_t ncols;
 };
 
 __device__ __forceinline__ uint32_t cstr_len(const uint8_t *p, uint32_t n) { uint32_t l = 0; while (l < n && p[l]) l++; return l; }
@@ -332,9 +333,12 @@ __device__ __forceinline__ uint32_t dec_len_i32(int32_t v) {
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 1-D grid, column index fastest: the blocks that evaluate the same rows for different columns are dispatched back to back,
+    // so a record's cache lines are fetched from HBM once and served from L2 for the other columns
+    const uint32_t colb = blockIdx.x % a.ncols;
+    const int64_t row = (int64_t)(blockIdx.x / a.ncols) * blockDim.x + threadIdx.x;
     if (row >= a.nrows) return;
-    const BcfColDev cd = a.cols[blockIdx.y];
+    const BcfColDev cd = a.cols[colb];
     if (WRITE && cd.sa_cnt < 0 && cd.sa_bytes < 0) return;
     const uint8_t *u = st.u;
     int64_t rec = a.tidy ? row / a.n_smp : row;

@@ -1403,10 +1403,10 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
             BcfCellArgs ca; memset(&ca, 0, sizeof(ca));
             ca.rec_off = (const uint32_t *)c->b_rec_off.p; ca.dir = (const uint32_t *)c->b_dir.p; ca.stride = stride; ca.nrows = nrows; ca.tidy = c->bsch.tidy ? 1 : 0;
             ca.n_smp = c->bsch.n_samples > 0 ? c->bsch.n_samples : 1; ca.lens = (uint32_t *)c->b_lens.p; ca.offs = (const uint32_t *)c->b_offs.p; ca.ostride = ostride;
-            ca.cols = (const BcfColDev *)c->b_coldev.p; ca.sel = sel;
+            ca.cols = (const BcfColDev *)c->b_coldev.p; ca.sel = sel; ca.ncols = (uint32_t)ncols;
             {
                 KTimer tm(c, DHTS_K_BCF_MEASURE);
-                hipLaunchKernelGGL(bcf_cells<false>, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream, st, ca);
+                hipLaunchKernelGGL(bcf_cells<false>, dim3((unsigned)(((nrows + 255) / 256) * ncols)), dim3(256), 0, c->stream, st, ca);
             }
             std::vector<uint64_t> tot(nsa ? nsa : 1, 0);
             if (nsa > 0) {
@@ -1440,7 +1440,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                 HIPCHK(c, hipMemcpyAsync(c->b_coldev.p, cd.data(), sizeof(BcfColDev) * ncols, hipMemcpyHostToDevice, c->stream));
                 {
                     KTimer tm(c, DHTS_K_BCF_WRITE);
-                    hipLaunchKernelGGL(bcf_cells<true>, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream, st, ca);
+                    hipLaunchKernelGGL(bcf_cells<true>, dim3((unsigned)(((nrows + 255) / 256) * ncols)), dim3(256), 0, c->stream, st, ca);
                 }
             }
             HIPCHK(c, hipGetLastError());
