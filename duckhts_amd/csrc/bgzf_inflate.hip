@@ -7,8 +7,9 @@
 //           wave64).  Each lane walks its stream with canonical-code arithmetic (no big
 //           LUTs): the 15 left-justified code limits of BOTH alphabets live in the two 16-bit
 //           halves of 15 VGPRs, the canonical base values in 15 more (telescoped deltas), the
-//           sorted symbol lists in LDS ([entry][lane] layout, 36 KB per wave => 4 waves per
-//           CU).  One symbol per lane per iteration from whichever alphabet the lane expects.
+//           sorted symbol lists in LDS ([entry][lane] layout, 26,880 B per wave => 6 waves per
+//           CU; the tables are built in two passes over the code-length stream so that no
+//           per-symbol length array has to be kept).  One symbol per lane per iteration from whichever alphabet the lane expects.
 //           Output is append-only: literal bytes and one 32-bit token per LZ77 match.  No
 //           loads depend on earlier stores, so lanes never stall on the LZ77 window.
 //  phase B  bgzf_lz_resolve  : ONE WAVE PER BGZF BLOCK.  Tokens are consumed 64 at a time
@@ -31,14 +32,14 @@
 #ifndef A_ST
 #define A_ST A_SL                           /* LDS row stride in lanes */
 #endif
-#define A_LSYM_LO 0                        /* u8  [288][SL] */
-#define A_LSYM_HI (A_LSYM_LO + 288 * A_ST) /* u32 [9][SL]   */
-#define A_DSYM (A_LSYM_HI + 9 * A_ST * 4)  /* u8  [32][SL]  */
-#define A_CNT (A_DSYM + 32 * A_ST)         /* u16 [16][SL]  */
-#define A_LENS (A_CNT + 16 * A_ST * 2)     /* u8  [160][SL] nibble-packed code lengths */
-#define A_CLSYM (A_LENS + 160 * A_ST)      /* u8  [19][SL]  */
-#define A_LDS_RAW (A_CLSYM + 19 * A_ST)
-#define A_LDS_BYTES ((A_LDS_RAW + A_LDS_ROUND - 1) / A_LDS_ROUND * A_LDS_ROUND)  /* 36,288 B at SL=64: four waves per CU */
+#define A_LSYM_LO 0                        /* u8  [288][SL] sorted literal/length symbols, low 8 bits */
+#define A_LSYM_HI (A_LSYM_LO + 288 * A_ST) /* u32 [9][SL]   bit 8 of the same, one bit per entry */
+#define A_DSYM (A_LSYM_HI + 9 * A_ST * 4)  /* u8  [32][SL]  sorted distance symbols */
+#define A_WIN (A_DSYM + 32 * A_ST)         /* u32 [16][SL]  64-byte input window; while the tables are built it holds: */
+#define A_CNTL A_WIN                       /* u16 [15][SL]  literal/length count, then running offset, of code lengths 1..15 */
+#define A_CNTD (A_CNTL + 15 * A_ST * 2)    /* u8  [15][SL]  distance ditto */
+#define A_CLSYM (A_CNTD + 15 * A_ST)       /* u8  [19][SL]  sorted code-length-code symbols */
+#define A_LDS_BYTES (A_WIN + 16 * A_ST * 4) /* 26,880 B = 420 B per stream: SIX waves per CU (6 x 26,880 = 161,280 <= 163,840) */
 
 struct BitR {
     const uint8_t *p;   // stream base (deflate payload start)
@@ -94,32 +95,22 @@ __device__ __forceinline__ uint32_t code_len(const Limits &lm, uint32_t w15) {
     return c + 1;   // 16 => invalid code
 }
 
-// builds limits + canonical base values (registers) from cnt[L] (LDS); leaves cnt[L] = first
-// symbol index of length L (offs) for the placement pass.  Returns the Kraft remainder `left`
-// (0 complete, >0 incomplete, <0 over-subscribed).
-__device__ __forceinline__ int build_limits(Limits &lm, uint16_t *cnt, int lane, int maxlen, uint32_t *bs) {
+// builds limits + canonical base values (registers) from cnt[L-1] (LDS); leaves cnt[L-1] = first sorted index of length L
+// for the placement pass.  Returns the Kraft remainder `left` (0 complete, >0 incomplete, <0 over-subscribed).
+template <typename T>
+__device__ __forceinline__ int build_limits(Limits &lm, T *cnt, int lane, uint32_t *bs) {
     uint32_t first = 0, offs = 0; int left = 1;
 #pragma unroll
     for (int L = 1; L <= 15; L++) {
-        uint32_t c = (L <= maxlen) ? cnt[L * A_ST + lane] : 0;
+        const uint32_t c = cnt[(L - 1) * A_ST + lane];
         left = (left << 1) - (int)c;
         bs[L] = (offs - first) & 0xffffu;
         lm.v[L - 1] = (first + c) << (15 - L);
-        if (L <= maxlen) cnt[L * A_ST + lane] = (uint16_t)offs;
+        cnt[(L - 1) * A_ST + lane] = (T)offs;
         offs += c;
         first = (first + c) << 1;
     }
     return left;
-}
-
-__device__ __forceinline__ uint32_t get_len(const uint8_t *lens, int lane, uint32_t i) {
-    uint32_t b = lens[(i >> 1) * A_ST + lane];
-    return (i & 1) ? (b >> 4) : (b & 15);
-}
-__device__ __forceinline__ void set_len(uint8_t *lens, int lane, uint32_t i, uint32_t v) {
-    uint32_t idx = (i >> 1) * A_ST + lane;
-    uint32_t b = lens[idx];
-    lens[idx] = (uint8_t)((i & 1) ? ((b & 0x0f) | (v << 4)) : ((b & 0xf0) | v));
 }
 
 #ifdef DHTS_DIAG
@@ -132,8 +123,8 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
     uint8_t *lsym_lo = smem + A_LSYM_LO;
     uint32_t *lsym_hi = (uint32_t *)(smem + A_LSYM_HI);
     uint8_t *dsym = smem + A_DSYM;
-    uint16_t *cnt = (uint16_t *)(smem + A_CNT);
-    uint8_t *lens = smem + A_LENS;
+    uint16_t *cntl = (uint16_t *)(smem + A_CNTL);
+    uint8_t *cntd = smem + A_CNTD;
     uint8_t *clsym = smem + A_CLSYM;
 
     const int lane = threadIdx.x;
@@ -190,17 +181,20 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         }
         if (type == 3) { status = DHTS_BLK_ERR_INFLATE; break; }
 
+        // ---- code lengths -> canonical tables, in TWO passes over the code-length stream (RFC 1951 3.2.6 / 3.2.7) ----
+        // Pass 0 only counts the symbols of every code length; the limits / bases follow from the counts; pass 1 decodes the same
+        // bits again and drops every symbol into its sorted slot.  Nothing per-symbol is kept in between, which is what lets the
+        // whole per-stream LDS state fit 420 bytes.
         uint32_t nl, nd;
+        uint32_t climit[7], cbase[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) { climit[i] = 0; cbase[i] = 0; }
         if (type == 1) {
-            // ---- fixed code lengths (RFC 1951 3.2.6) ----
             nl = 288; nd = 32;                               // 32 five-bit distance codes; 30/31 are rejected on use
-            for (uint32_t i = 0; i < 288; i++) set_len(lens, lane, i, i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
-            for (uint32_t i = 0; i < 32; i++) set_len(lens, lane, 288 + i, 5);
         } else {
-            // ---- dynamic: code-length code, then the two length vectors (3.2.7) ----
             br_refill(br);
             nl = br_take(br, 5) + 257; nd = br_take(br, 5) + 1;
-            uint32_t nc = br_take(br, 4) + 4;
+            const uint32_t nc = br_take(br, 4) + 4;
             if (nl > 286 || nd > 30) { status = DHTS_BLK_ERR_INFLATE; break; }
             uint32_t cl[19];
 #pragma unroll
@@ -224,7 +218,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
 #pragma unroll
                 for (int L = 1; L < 8; L++) ccount[L] += (cl[i] == (uint32_t)L) ? 1u : 0u;
             }
-            uint32_t climit[7], cbase[7], coffs[8];
+            uint32_t coffs[8];
             {
                 uint32_t first = 0, offs = 0; int left = 1;
 #pragma unroll
@@ -245,65 +239,70 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                     if (cl[i] == (uint32_t)L) { clsym[coffs[L] * A_ST + lane] = (uint8_t)i; coffs[L]++; }
                 }
             }
-            // decode nl+nd code lengths
-            uint32_t idx = 0, total = nl + nd, prev = 0;
+        }
+#pragma unroll
+        for (int L = 0; L < 15; L++) { cntl[L * A_ST + lane] = 0; cntd[L * A_ST + lane] = 0; }
+        uint32_t nz_l = 0, nz_d = 0, bsl[16], bsd[16];
+        bool has_eob = false;
+        const BitR br0 = br;                                 // start of the code-length stream
+        const uint32_t total = nl + nd;
+#pragma unroll 1
+        for (int pass = 0; pass < 2 && status == 0; pass++) {
+            if (pass == 1) {
+                int left = build_limits(ll, cntl, lane, bsl);
+                if (left < 0 || (left > 0 && nz_l != 1) || !has_eob) { status = DHTS_BLK_ERR_INFLATE; break; }
+                left = build_limits(dl, cntd, lane, bsd);
+                if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
+                for (int k = 0; k < 9; k++) lsym_hi[k * A_ST + lane] = 0;
+                br = br0;
+            }
+            uint32_t idx = 0, prev = 0;
             while (idx < total) {
-                br_refill(br);
-                uint32_t w7 = __brev((uint32_t)br.buf) >> 25;
-                uint32_t c = 0;
+                uint32_t val, rep;
+                if (type == 1) {
+                    const uint32_t stop = idx < 144u ? 144u : idx < 256u ? 256u : idx < 280u ? 280u : idx < 288u ? 288u : 320u;
+                    val = idx < 144u ? 8u : idx < 256u ? 9u : idx < 280u ? 7u : idx < 288u ? 8u : 5u;
+                    rep = stop - idx;
+                } else {
+                    br_refill(br);
+                    const uint32_t w7 = __brev((uint32_t)br.buf) >> 25;
+                    uint32_t c = 0;
 #pragma unroll
-                for (int i = 0; i < 7; i++) c += (w7 >= climit[i]) ? 1u : 0u;
-                if (c >= 7) { status = DHTS_BLK_ERR_INFLATE; break; }
-                uint32_t L = c + 1;
-                uint32_t cb = 0;
+                    for (int i = 0; i < 7; i++) c += (w7 >= climit[i]) ? 1u : 0u;
+                    if (c >= 7) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    const uint32_t CL = c + 1;
+                    uint32_t cb = 0;
 #pragma unroll
-                for (int i = 0; i < 7; i++) cb = (c == (uint32_t)i) ? cbase[i] : cb;
-                uint32_t ci = cb + (w7 >> (7 - L)); if (ci > 18) ci = 18;
-                uint32_t sym = clsym[ci * A_ST + lane];
-                br_take(br, L);
-                if (sym < 16) { set_len(lens, lane, idx++, sym); prev = sym; }
-                else {
-                    uint32_t rep, val = 0;
-                    if (sym == 16) { if (idx == 0) { status = DHTS_BLK_ERR_INFLATE; break; } val = prev; rep = 3 + br_take(br, 2); }
-                    else if (sym == 17) rep = 3 + br_take(br, 3);
-                    else rep = 11 + br_take(br, 7);
+                    for (int i = 0; i < 7; i++) cb = (c == (uint32_t)i) ? cbase[i] : cb;
+                    uint32_t ci = cb + (w7 >> (7 - CL)); if (ci > 18) ci = 18;
+                    const uint32_t sym = clsym[ci * A_ST + lane];
+                    br_take(br, CL);
+                    if (sym < 16) { val = sym; rep = 1; }
+                    else if (sym == 16) { if (idx == 0) { status = DHTS_BLK_ERR_INFLATE; break; } val = prev; rep = 3 + br_take(br, 2); }
+                    else if (sym == 17) { val = 0; rep = 3 + br_take(br, 3); }
+                    else { val = 0; rep = 11 + br_take(br, 7); }
                     if (idx + rep > total) { status = DHTS_BLK_ERR_INFLATE; break; }
-                    for (uint32_t k = 0; k < rep; k++) set_len(lens, lane, idx++, val);
                     prev = val;
                 }
-            }
-            if (status != 0) break;
-            if (get_len(lens, lane, 256) == 0) { status = DHTS_BLK_ERR_INFLATE; break; }
-        }
-
-        // ---- canonical tables: literal/length ----
-#pragma unroll
-        for (int L = 0; L < 16; L++) cnt[L * A_ST + lane] = 0;
-        for (uint32_t i = 0; i < nl; i++) { uint32_t l = get_len(lens, lane, i); cnt[l * A_ST + lane]++; }
-        uint32_t nz_l = nl - cnt[0 * A_ST + lane];
-        uint32_t bsl[16], bsd[16];
-        int left = build_limits(ll, cnt, lane, 15, bsl);
-        if (left < 0 || (left > 0 && nz_l != 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
-        for (int k = 0; k < 9; k++) lsym_hi[k * A_ST + lane] = 0;
-        for (uint32_t i = 0; i < nl; i++) {
-            uint32_t l = get_len(lens, lane, i);
-            if (l) {
-                uint32_t o = cnt[l * A_ST + lane]; cnt[l * A_ST + lane] = (uint16_t)(o + 1);
-                lsym_lo[o * A_ST + lane] = (uint8_t)i;
-                if (i & 256) lsym_hi[(o >> 5) * A_ST + lane] |= 1u << (o & 31);
+                if (val == 0) { idx += rep; continue; }
+                for (uint32_t k = 0; k < rep; k++) {
+                    const uint32_t i = idx++;
+                    if (i < nl) {
+                        const uint32_t o = cntl[(val - 1) * A_ST + lane]; cntl[(val - 1) * A_ST + lane] = (uint16_t)(o + 1);
+                        if (pass == 0) { nz_l++; has_eob |= (i == 256u); }
+                        else {
+                            lsym_lo[(o > 287u ? 287u : o) * A_ST + lane] = (uint8_t)i;
+                            if (i & 256) lsym_hi[((o >> 5) > 8u ? 8u : (o >> 5)) * A_ST + lane] |= 1u << (o & 31);
+                        }
+                    } else {
+                        const uint32_t o = cntd[(val - 1) * A_ST + lane]; cntd[(val - 1) * A_ST + lane] = (uint8_t)(o + 1);
+                        if (pass == 0) nz_d++;
+                        else dsym[(o & 31) * A_ST + lane] = (uint8_t)(i - nl);
+                    }
+                }
             }
         }
-        // ---- canonical tables: distance ----
-#pragma unroll
-        for (int L = 0; L < 16; L++) cnt[L * A_ST + lane] = 0;
-        for (uint32_t i = 0; i < nd; i++) { uint32_t l = get_len(lens, lane, nl + i); cnt[l * A_ST + lane]++; }
-        uint32_t nz_d = nd - cnt[0 * A_ST + lane];
-        left = build_limits(dl, cnt, lane, 15, bsd);
-        if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
-        for (uint32_t i = 0; i < nd; i++) {
-            uint32_t l = get_len(lens, lane, nl + i);
-            if (l) { uint32_t o = cnt[l * A_ST + lane]; cnt[l * A_ST + lane] = (uint16_t)(o + 1); dsym[(o & 31) * A_ST + lane] = (uint8_t)i; }
-        }
+        if (status != 0) break;
 
 #ifdef DHTS_DIAG
         unsigned long long dA_s0 = clock64();
@@ -317,7 +316,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         // Input: per-lane 64-byte LDS window, refetched by the whole wave every 4 symbols (<= 28 bits per symbol, so a lane moves
         // <= 16 bytes per period and can never leave the window parked one period earlier).
         {
-            uint32_t *winA = (uint32_t *)lens;
+            uint32_t *winA = (uint32_t *)(smem + A_WIN);
             const uint8_t *sp = br.p;
             uint32_t wbase = br.pos, rbase = br.pos;
             uint4 R0, R1, R2, R3;
@@ -517,12 +516,12 @@ __device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {  
 #define B_NULLTOK 0xffffffffu
 #ifdef DHTS_DIAG
 __device__ unsigned long long g_diag[8];   // batches, rounds, easy, hard, lit_iters, long_lit
-#define DIAG_ADD(i, v) do { unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_diag[i], v_); } while (0)
+#define DIAG_ADD(i, v) do { dcnt[i] += (unsigned long long)(v); } while (0)
 #define DIAG_T(var) unsigned long long var = clock64()
 __device__ unsigned long long g_diagt[8];
 #define DIAG_TADD(i, a, b) do { dacc[i] += (b) - (a); } while (0)
-#define DIAG_DECL unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define DIAG_FLUSH do { if (lane == 0) for (int q_ = 0; q_ < 8; q_++) atomicAdd(&g_diagt[q_], dacc[q_]); } while (0)
+#define DIAG_DECL unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DIAG_FLUSH do { if (lane == 0) for (int q_ = 0; q_ < 8; q_++) { atomicAdd(&g_diagt[q_], dacc[q_]); atomicAdd(&g_diag[q_], dcnt[q_]); } } while (0)
 #else
 #define DIAG_DECL do {} while (0)
 #define DIAG_FLUSH do {} while (0)
@@ -648,11 +647,13 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         const uint32_t lsrc = litpos + lit_i - lrun;               // absolute index of its first literal byte
         DIAG_T(t_a);
         if (tot_adv <= BR_SPAN && tot_lit <= 1024u) {
+            DIAG_ADD(0, 1);
             // ---- literals ----
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
             __syncthreads();
             // 8 bytes per lane per step: one (usually unaligned) 64-bit ring read, then an exact-length store
             for (uint32_t q0 = 0; __ballot(q0 < lrun) != 0ull; q0 += 8) {
+                DIAG_ADD(4, 1);
                 if (q0 < lrun) {
                     const uint32_t ri = (lsrc + q0) & 2047u;
                     uint64_t v;
@@ -691,8 +692,12 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
                 }
             }
             uint64_t P = __ballot(mlen > 0 && !farm);
+            DIAG_T(t_b2);
+            DIAG_TADD(7, t_b, t_b2);
             if (B_SMALLRING) __syncthreads();                  // far copies are in the ring before anybody reads them
+            DIAG_ADD(6, __popcll(P)); DIAG_ADD(5, __popcll(__ballot(farm)));
             while (P) {
+                DIAG_ADD(1, 1);
                 const bool pending = (P >> lane) & 1ull;
                 const uint64_t e = pending ? dmask : 0ull;
                 const uint32_t el = wave_shr1(wave_incl_scan_or((uint32_t)e)), eh = wave_shr1(wave_incl_scan_or((uint32_t)(e >> 32)));
@@ -719,6 +724,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
                 }
                 // (b) the rest of the ready set, one at a time, replayed by the whole wave
                 uint64_t H = __ballot(ready && !easy);
+                DIAG_ADD(2, __popcll(__ballot(easy))); DIAG_ADD(3, __popcll(H));
                 while (H) {
                     const int i = __ffsll((unsigned long long)H) - 1; H &= H - 1;
                     const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
@@ -736,6 +742,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             while (outpos - flushed >= BR_FLUSH) FLUSH_CHUNK();
         } else {
             // ---- oversized batch (long literal runs / long matches): strict stream order, one token at a time ----
+            DIAG_ADD(7, 1);
             for (int i = 0; i < 64; i++) {
                 const uint32_t lr = RDLANE(lrun, i), ml = RDLANE(mlen, i), di = RDLANE(mdist, i);
                 for (uint32_t k = lane; k < lr; k += 64) win[ridx(outpos + k)] = lit[litpos + k];

@@ -50,7 +50,8 @@ struct dhts_ctx {
     // inflate scratch
     DevBuf lit, tok, meta;
     int64_t huff_b0 = 0, huff_nb = 0;     // block range whose tokens are in the scratch
-    int64_t super_blocks = 65536;        // phase A runs ahead over this many blocks so that 4 waves/CU are resident
+    int64_t super_blocks = 524288;       // phase A runs ahead over up to this many blocks (1,536 waves are resident at once, six per CU;
+                                         // a long launch keeps every SIMD backfilled).  Scratch is 152 KiB per block: see inflate_blocks.
     // inflated stream double buffer (carry moves between them)
     DevBuf ubuf[2]; int ucur = 0; uint64_t carry_len = 0;
     // tiles
@@ -361,7 +362,19 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
     if (nb <= 0) return 0;
     for (int64_t b = b0; b < b0 + nb; b++) if (c->h_isize[b] > 65536u) return fail(c, "BGZF block %lld claims ISIZE %u > 65536", (long long)b, c->h_isize[b]);
     if (!(b0 >= c->huff_b0 && b0 + nb <= c->huff_b0 + c->huff_nb)) {
-        int64_t want = c->super_blocks > nb ? c->super_blocks : nb;
+        static const int64_t env_super = getenv("DHTS_SUPER_BLOCKS") ? atoll(getenv("DHTS_SUPER_BLOCKS")) : 0;   // tuning knob
+        int64_t sb = env_super > 0 ? env_super : c->super_blocks;
+        {
+            // the token/literal scratch of a super-batch may take at most 45 % of the HBM that is free (or already ours)
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                const double per_block = ((double)DHTS_LIT_STRIDE + (double)DHTS_TOK_STRIDE * 4 + sizeof(InflateMeta)) * 1.125;
+                const int64_t fit = (int64_t)(0.45 * ((double)fr + (double)c->lit.cap + (double)c->tok.cap) / per_block);
+                if (sb > fit) sb = fit;
+            }
+            if (sb < 16384) sb = 16384;
+        }
+        int64_t want = sb > nb ? sb : nb;
         if (b0 + want > ahead_limit) want = ahead_limit - b0;
         if (want < nb) want = nb;
         if (huff_blocks(c, b0, want)) return -1;

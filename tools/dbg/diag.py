@@ -10,11 +10,11 @@ while True:
     if b.status != 0: break
 d = (C.c_ulonglong*24)()
 ctx.L.dhts_debug_diag(C.c_void_p(ctx.h), d)
-names=['batches','rounds','easy','hard','-','-','matches','out_bytes']
+names=['batches','rounds','easy','hard','lit_iters','far','matches','oversized']
 print(rows, nb, {n:int(v) for n,v in zip(names,d)})
 
 t=[int(x) for x in d[8:16]]
-names=['crc_tables','literals','matches','token_loop','crc','flush','total']
+names=['crc_tables','literals','matches','token_loop','crc','flush','total','match_prep(far)']
 for n,v in zip(names,t): print(n, v/nb, 'clk/block', round(100*v/max(t[6],1),1),'%')
 
 a=[int(x) for x in d[16:24]]
