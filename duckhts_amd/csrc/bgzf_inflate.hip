@@ -555,6 +555,37 @@ __device__ __forceinline__ uint32_t crc_xpow8(uint32_t nbytes) {
     return pw;
 }
 
+// Block-independent CRC constants, computed once per context by crc_const_init:
+//   [0,64)  K_lane = x^(8*BR_PIECE*(63-lane)),  [64] x^(8*BR_FLUSH),  [65,82) x^(8*2^k) for k < 17,  [96,1120) slice-by-4 tables
+#define CRCC_K 0
+#define CRCC_XF 64
+#define CRCC_XP2 65
+#define CRCC_TAB 96
+__device__ uint32_t g_crcc[96 + 1024];
+extern "C" __global__ void __launch_bounds__(64) crc_const_init() {
+    const uint32_t lane = threadIdx.x;
+    g_crcc[CRCC_K + lane] = crc_xpow8(BR_PIECE * (63u - lane));
+    if (lane == 0) g_crcc[CRCC_XF] = crc_xpow8(BR_FLUSH);
+    if (lane < 17) g_crcc[CRCC_XP2 + lane] = crc_xpow8(1u << lane);
+    for (uint32_t k = lane; k < 256; k += 64) {
+        uint32_t t[4], c = k;
+        for (int j = 0; j < 8; j++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+        t[0] = c;
+        for (int q = 1; q < 4; q++) {            // t[q][k] = CRC of byte k followed by q zero bytes
+            uint32_t z = t[q - 1] & 0xffu, zc = z;
+            for (int j = 0; j < 8; j++) zc = (zc & 1u) ? (0xEDB88320u ^ (zc >> 1)) : (zc >> 1);
+            t[q] = zc ^ (t[q - 1] >> 8);
+        }
+        for (int q = 0; q < 4; q++) g_crcc[CRCC_TAB + 256 * q + k] = t[q];
+    }
+}
+// x^(8*nbytes) mod P from the table of squares: one multiplication per set bit of nbytes (< 2^17)
+__device__ __forceinline__ uint32_t crc_xpow8_tab(uint32_t nbytes) {
+    uint32_t pw = 0x80000000u;
+    for (uint32_t k = 0; nbytes; k++, nbytes >>= 1) if (nbytes & 1u) pw = crc_mulmod(pw, g_crcc[CRCC_XP2 + k]);
+    return pw;
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                 const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
@@ -574,20 +605,9 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     DIAG_DECL;
     DIAG_T(t_begin);
 
-    // slice-by-4 tables (built per workgroup: 4 entries per lane per table)
-    for (int k = lane; k < 256; k += 64) {
-        uint32_t c = (uint32_t)k;
+    // slice-by-4 tables: 4 KiB copied from the per-device constants
 #pragma unroll
-        for (int j = 0; j < 8; j++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-        crct[k] = c;
-    }
-    __syncthreads();
-    for (int k = lane; k < 256; k += 64) {
-        uint32_t c = crct[k];
-        c = crct[c & 0xff] ^ (c >> 8); crct[256 + k] = c;
-        c = crct[c & 0xff] ^ (c >> 8); crct[512 + k] = c;
-        c = crct[c & 0xff] ^ (c >> 8); crct[768 + k] = c;
-    }
+    for (int q = 0; q < 4; q++) *(uint4 *)(crct + q * 256 + lane * 4) = *(const uint4 *)(g_crcc + CRCC_TAB + q * 256 + lane * 4);
     __syncthreads();
     DIAG_T(t_tab);
     DIAG_TADD(0, t_begin, t_tab);
@@ -601,8 +621,8 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     uint8_t *dstp = out + (tab.uoff[bi] - out_base);
     uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
     // constants of the 8 KiB flush-chunk CRC: lane's 128-byte piece is followed by 128*(63-lane) bytes of the chunk
-    const uint32_t K_lane = crc_xpow8(BR_PIECE * (63u - (uint32_t)lane));
-    const uint32_t X_F = crc_xpow8(BR_FLUSH);
+    const uint32_t K_lane = g_crcc[CRCC_K + lane];
+    const uint32_t X_F = g_crcc[CRCC_XF];
 
     // Flush the 8 KiB chunk [flushed, flushed + 8192): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
     // BR_R is a multiple of 128, so neither a lane's 128-byte CRC piece nor a 16-byte store unit wraps in the ring.
@@ -678,7 +698,18 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             const uint32_t bend = outpos + tot_adv, rlo = bend > BR_R ? bend - BR_R : 0u;
             const bool farm = mlen > 0 && ms < rlo;
             if (farm) {
-                for (uint32_t c = 0; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, dstp + ms + c, 8); win_st_n(win, md + c, v, mlen - c); }
+                // (the block's own output is always readable 40 bytes past a far source: ms + 40 < bend)
+                const uint8_t *g = dstp + ms;
+                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+                __builtin_memcpy(&v0, g, 8);
+                if (mlen > 8u) __builtin_memcpy(&v1, g + 8, 8);
+                if (mlen > 16u) __builtin_memcpy(&v2, g + 16, 8);
+                if (mlen > 24u) __builtin_memcpy(&v3, g + 24, 8);
+                win_st_n(win, md, v0, mlen);
+                if (mlen > 8u) win_st_n(win, md + 8, v1, mlen - 8u);
+                if (mlen > 16u) win_st_n(win, md + 16, v2, mlen - 16u);
+                if (mlen > 24u) win_st_n(win, md + 24, v3, mlen - 24u);
+                for (uint32_t c = 32; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, g + c, 8); win_st_n(win, md + c, v, mlen - c); }
             }
 #else
             const bool farm = false;
@@ -796,10 +827,10 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         c = crct[768 + (v & 0xff)] ^ crct[512 + ((v >> 8) & 0xff)] ^ crct[256 + ((v >> 16) & 0xff)] ^ crct[v >> 24];
     }
     for (; q < end; q++) c = crct[(c ^ win[ridx(flushed + q)]) & 0xff] ^ (c >> 8);
-    c = crc_mulmod(c, crc_xpow8(n - end));
+    c = crc_mulmod(c, crc_xpow8_tab(n - end));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
-    c ^= crc_mulmod(crc_run, crc_xpow8(n));
+    c ^= crc_mulmod(crc_run, crc_xpow8_tab(n));
     c ^= 0xffffffffu;
     uint32_t want; __builtin_memcpy(&want, comp + tab.coff[bi] + clen - 8, 4);
     if (c != want) st = DHTS_BLK_ERR_CRC;

@@ -147,6 +147,8 @@ dhts_ctx *dhts_create(int device_id) {
         hipFuncSetAttribute((const void *)bgzf_huff_decode, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return nullptr;     // no gfx950 code object for this device
     }
+    hipLaunchKernelGGL(crc_const_init, dim3(1), dim3(64), 0, c->stream);      // per-device CRC constants (idempotent)
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     return c;
 }
 
