@@ -14,7 +14,7 @@
 //           loads depend on earlier stores, so lanes never stall on the LZ77 window.
 //  phase B  bgzf_lz_resolve  : ONE WAVE PER BGZF BLOCK.  Tokens are consumed 64 at a time
 //           (coalesced), wave prefix sums give every token's destination, literals are
-//           placed lane-parallel, matches are replayed in dependency rounds in an 8 KiB LDS
+//           placed lane-parallel, matches are replayed in dependency rounds in a 4 KiB LDS
 //           ring (older sources are read back from the block's own flushed output), every
 //           half ring is CRC-32'd from LDS (slice-by-4, per-lane pieces combined with
 //           x^(8n) mod P) and flushed to HBM with 16-byte coalesced stores.
@@ -495,11 +495,12 @@ __device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {  
 #if B_SMALLRING
 // Power-of-two ring of 2^B_RING_LOG2 bytes, flushed progressively in half-ring chunks: it holds the unflushed tail (< half a ring
 // + one batch span) plus the most recent history.  Matches whose source is older than the ring read the bytes back from the
-// block's own output in HBM (such sources always lie below `flushed`, see BR_FLUSH).  8 KiB ring: 14,336 B of LDS per block
-// instead of 40,704, i.e. eleven workgroups per CU instead of four, so every SIMD holds 2-3 waves that fill each other's issue
-// slots (measured per 16,384-block launch: 6.1 ms with the full 34.5 KB window, 4.45 ms with 16 KiB, 3.5 ms with 8 KiB).
+// block's own output in HBM (such sources always lie below `flushed`, see BR_FLUSH).  4 KiB ring: 10,240 B of LDS per block
+// instead of 40,704, i.e. sixteen workgroups per CU instead of four, so every SIMD holds four waves that fill each other's issue
+// slots (measured per 16,384-block launch: 6.1 ms with the full 34.5 KB window, 4.45 ms with 16 KiB, 3.5 ms with 8 KiB; with the
+// far loads issued together 3.17 ms at 8 KiB and 2.48 ms at 4 KiB).
 #ifndef B_RING_LOG2
-#define B_RING_LOG2 13
+#define B_RING_LOG2 12
 #endif
 #define BR_R (1u << B_RING_LOG2)
 #define BR_FLUSH (BR_R / 2u)             /* needs BR_R >= BR_FLUSH + BR_SPAN + 265 so that far sources are always flushed */
@@ -508,7 +509,10 @@ __device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {  
 #define BR_FLUSH 8192u
 #endif
 #define BR_PIECE (BR_FLUSH / 64u)        /* bytes of a flush chunk CRC'd by one lane */
-#define BR_SPAN 1792u
+#ifndef BR_SPAN
+#define BR_SPAN 1536u
+#endif
+static_assert(!B_SMALLRING || BR_R >= BR_FLUSH + BR_SPAN + 265u, "far sources must always be flushed");
 #define B_WIN 0
 #define B_CRCT (BR_R)                    /* u32 [4][256] slice-by-4 tables */
 #define B_RING (B_CRCT + 4096)           /* u8 [2048] literal staging ring */
@@ -620,12 +624,12 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     const uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
     uint8_t *dstp = out + (tab.uoff[bi] - out_base);
     uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
-    // constants of the 8 KiB flush-chunk CRC: lane's 128-byte piece is followed by 128*(63-lane) bytes of the chunk
+    // constants of the flush-chunk CRC: lane's BR_PIECE-byte piece is followed by BR_PIECE*(63-lane) bytes of the chunk
     const uint32_t K_lane = g_crcc[CRCC_K + lane];
     const uint32_t X_F = g_crcc[CRCC_XF];
 
-    // Flush the 8 KiB chunk [flushed, flushed + 8192): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
-    // BR_R is a multiple of 128, so neither a lane's 128-byte CRC piece nor a 16-byte store unit wraps in the ring.
+    // Flush the chunk [flushed, flushed + BR_FLUSH): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
+    // BR_R is a multiple of BR_PIECE, so neither a lane's CRC piece nor a 16-byte store unit wraps in the ring.
 #define FLUSH_CHUNK() do {                                                                                              \
         const uint32_t pi_ = ridx(flushed + (uint32_t)lane * BR_PIECE);                                                 \
         uint32_t c_ = (flushed == 0 && lane == 0) ? 0xffffffffu : 0u;                                                   \
