@@ -626,20 +626,19 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
     // constants of the flush-chunk CRC: lane's BR_PIECE-byte piece is followed by BR_PIECE*(63-lane) bytes of the chunk
     const uint32_t K_lane = g_crcc[CRCC_K + lane];
-    const uint32_t X_F = g_crcc[CRCC_XF];
 
     // Flush the chunk [flushed, flushed + BR_FLUSH): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
     // BR_R is a multiple of BR_PIECE, so neither a lane's CRC piece nor a 16-byte store unit wraps in the ring.
 #define FLUSH_CHUNK() do {                                                                                              \
         const uint32_t pi_ = ridx(flushed + (uint32_t)lane * BR_PIECE);                                                 \
-        uint32_t c_ = (flushed == 0 && lane == 0) ? 0xffffffffu : 0u;                                                   \
+        uint32_t c_ = lane == 0 ? (flushed == 0 ? 0xffffffffu : crc_run) : 0u;   /* lane 0 continues the running CRC */      \
         for (uint32_t q_ = 0; q_ < BR_PIECE; q_ += 4) {                                                                      \
             uint32_t v_ = *(const uint32_t *)(win + pi_ + q_) ^ c_;                                                     \
             c_ = crct[768 + (v_ & 0xff)] ^ crct[512 + ((v_ >> 8) & 0xff)] ^ crct[256 + ((v_ >> 16) & 0xff)] ^ crct[v_ >> 24]; \
         }                                                                                                               \
         c_ = crc_mulmod(c_, K_lane);                                                                                    \
         _Pragma("unroll") for (int d_ = 32; d_ >= 1; d_ >>= 1) c_ ^= __shfl_xor(c_, d_, 64);                           \
-        crc_run = crc_mulmod(crc_run, X_F) ^ c_;                                                                        \
+        crc_run = c_;                                                                                                   \
         for (uint32_t k_ = 0; k_ < BR_FLUSH; k_ += 1024) {                                                              \
             const uint32_t p_ = flushed + k_ + (uint32_t)lane * 16u;                                                    \
             uint4 v4_ = *(const uint4 *)(win + ridx(p_));                                                               \
@@ -824,7 +823,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     const uint32_t chunk = ((n + 63) / 64 + 3) & ~3u;          // multiple of 4; flushed is a multiple of 4, so dwords never wrap
     uint32_t beg = lane * chunk; if (beg > n) beg = n;
     uint32_t end = beg + chunk; if (end > n) end = n;
-    uint32_t c = (flushed == 0 && lane == 0) ? 0xffffffffu : 0u;
+    uint32_t c = lane == 0 ? (flushed == 0 ? 0xffffffffu : crc_run) : 0u;      // lane 0 continues the running CRC
     uint32_t q = beg;
     for (; q + 4 <= end; q += 4) {
         uint32_t v = *(const uint32_t *)(win + ridx(flushed + q)) ^ c;
@@ -834,7 +833,6 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     c = crc_mulmod(c, crc_xpow8_tab(n - end));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
-    c ^= crc_mulmod(crc_run, crc_xpow8_tab(n));
     c ^= 0xffffffffu;
     uint32_t want; __builtin_memcpy(&want, comp + tab.coff[bi] + clen - 8, 4);
     if (c != want) st = DHTS_BLK_ERR_CRC;
