@@ -131,33 +131,48 @@ extern "C" __global__ void bam_tile_fix_seq(BamStream st, uint32_t tile_bytes, i
     }
 }
 
-// Single-workgroup finalize: first error tile E, exclusive prefix of counts (cut after E), totals.
-// res[0] = total rows, res[1] = stream position after the last good record (carry start),
+// Single-workgroup finalize: first error tile E, exclusive prefix of counts, totals (rows of tiles after E are never used).
+// res[0] = total rows (tiles 0..E), res[1] = stream position after the last good record (carry start),
 // res[2] = 1 if the chain stopped on an error, res[3] = E (or ntiles)
+// 16 consecutive tiles per thread, DPP wave scans, one LDS exchange per 16,384 tiles.
 extern "C" __global__ void __launch_bounds__(1024)
 bam_tile_finalize(int64_t ntiles, TileOut out, uint32_t *rowbase, uint64_t *res) {
-    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t shw[16];
     __shared__ unsigned long long shE;
-    __shared__ uint32_t carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) { shE = (unsigned long long)ntiles; carry = 0; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) shE = (unsigned long long)ntiles;
     __syncthreads();
-    for (int64_t t = tid; t < ntiles; t += 1024) if (out.err[t]) atomicMin(&shE, (unsigned long long)t);
-    __syncthreads();
-    const int64_t E = (int64_t)shE;
-    for (int64_t base = 0; base < ntiles; base += 1024) {
-        int64_t t = base + tid;
-        uint32_t v = (t < ntiles && t <= E) ? out.count[t] : 0;
-        sh[tid] = v; __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) { uint32_t a = (tid >= d) ? sh[tid - d] : 0; __syncthreads(); sh[tid] += a; __syncthreads(); }
-        if (t < ntiles) rowbase[t] = carry + sh[tid] - v;
+    uint32_t carry = 0;
+    unsigned long long myE = (unsigned long long)ntiles;
+    for (int64_t base = 0; base < ntiles; base += 16384) {
+        const int64_t t0 = base + (int64_t)tid * 16;
+        uint32_t v[16], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t t = t0 + k;
+            v[k] = t < ntiles ? out.count[t] : 0u;
+            if (t < ntiles && out.err[t] && (unsigned long long)t < myE) myE = (unsigned long long)t;
+            sum += v[k];
+        }
+        const uint32_t incl = wave_incl_scan(sum, lane);
+        if (lane == 63) shw[wave] = incl;
         __syncthreads();
-        if (tid == 1023) carry += sh[1023];
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const uint32_t x = shw[w]; total += x; if (w < wave) woff += x; }
+        uint32_t run = carry + woff + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const int64_t t = t0 + k; if (t < ntiles) rowbase[t] = run; run += v[k]; }
+        carry += total;
         __syncthreads();
     }
+    if (myE < (unsigned long long)ntiles) atomicMin(&shE, myE);
+    __threadfence_block();
+    __syncthreads();
     if (tid == 0) {
-        res[0] = carry;
-        int64_t last = (E < ntiles) ? E : ntiles - 1;
+        const int64_t E = (int64_t)shE;
+        const int64_t last = (E < ntiles) ? E : ntiles - 1;
+        res[0] = (E < ntiles) ? (uint64_t)rowbase[E] + out.count[E] : (uint64_t)carry;
         res[1] = out.end_next[last];
         res[2] = (E < ntiles) ? 1 : 0;
         res[3] = (uint64_t)E;
@@ -287,14 +302,12 @@ __device__ __forceinline__ bool qual16(uint32_t w[4]) {
 __device__ __forceinline__ void store_n16(uint8_t *d, const uint32_t w[4], uint32_t n) {
     if (n >= 16) { uint4 v = make_uint4(w[0], w[1], w[2], w[3]); __builtin_memcpy(d, &v, 16); }
     else {
-        // exact-length tail without a byte loop: 8 / 4 / 2 / 1 pieces
-        uint32_t k = 0;
-        if (n & 8) { uint2 v = make_uint2(w[0], w[1]); __builtin_memcpy(d, &v, 8); k = 2; }
-        if (n & 4) { __builtin_memcpy(d + 4 * k, &w[k == 2 ? 2 : 0], 4); k++; }
-        const uint32_t rem = n & 3u, x = (k == 0) ? w[0] : (k == 1) ? w[1] : (k == 2) ? w[2] : w[3];
-        uint8_t *q = d + 4 * k;
-        if (rem & 2) { uint16_t h = (uint16_t)x; __builtin_memcpy(q, &h, 2); q += 2; }
-        if (rem & 1) *q = (uint8_t)(x >> ((rem & 2) ? 16 : 0));
+        // exact-length tail without a byte loop: 8 / 4 / 2 / 1 pieces, register moves only (no indexed access to w)
+        uint32_t a0 = w[0], a1 = w[1];
+        if (n & 8) { uint2 v = make_uint2(a0, a1); __builtin_memcpy(d, &v, 8); d += 8; a0 = w[2]; a1 = w[3]; }
+        if (n & 4) { __builtin_memcpy(d, &a0, 4); d += 4; a0 = a1; }
+        if (n & 2) { uint16_t h = (uint16_t)a0; __builtin_memcpy(d, &h, 2); d += 2; a0 >>= 16; }
+        if (n & 1) *d = (uint8_t)a0;
     }
 }
 

@@ -343,6 +343,163 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
     }
 }
 
+// ---- string write pass, tile-centric (QNAME, CIGAR, SEQ, QUAL, READ_GROUP_ID heaps) ---------------------------------------
+// One wave per tile, the tile staged in LDS like the other passes.  Rows are taken 64 at a time (one lane per row loads the row's
+// offsets and parses its core); SEQ and QUAL are then written by CHUNK: the 16-byte output chunks of all rows of the group are
+// numbered consecutively (wave prefix sum, chunk -> row map in LDS) and dealt to the lanes 64 at a time, so every lane converts
+// and stores 16 bytes per step whatever the read length, and consecutive lanes store consecutive heap bytes.  QNAME, the RG
+// value and the CIGAR text are short and written by the row's own lane.  Fields longer than TS_LONG bytes are streamed by the
+// whole wave from HBM afterwards.  Same bytes as seq_to_string / qual_to_string / cigar_to_kstring (src/bam_reader.c:560-640).
+#define TS_LONG 512u
+#define TS_MAPN (64u * (TS_LONG / 16u))
+struct TsSrc {                 // bytes of the inflated stream by absolute offset: LDS inside the staged window, HBM outside
+    const uint8_t *l, *g; uint64_t base; uint32_t len;
+    __device__ __forceinline__ uint64_t u64(uint64_t o) const {
+        uint64_t v; const uint64_t rel = o - base;
+        if (rel + 8 <= (uint64_t)len) __builtin_memcpy(&v, l + (uint32_t)rel, 8); else __builtin_memcpy(&v, g + o, 8);   // HBM side is padded
+        return v;
+    }
+    __device__ __forceinline__ uint32_t u32(uint64_t o) const {
+        uint32_t v; const uint64_t rel = o - base;
+        if (rel + 4 <= (uint64_t)len) __builtin_memcpy(&v, l + (uint32_t)rel, 4); else __builtin_memcpy(&v, g + o, 4);
+        return v;
+    }
+};
+__device__ __forceinline__ void ts_seq_chunk(const TsSrc &src, uint64_t seq, uint32_t l_seq, uint32_t k, uint8_t *d) {
+    const uint64_t p = src.u64(seq + 8ull * k);
+    uint32_t w[4]; seq16((uint32_t)p, (uint32_t)(p >> 32), w);
+    store_n16(d + 16u * k, w, l_seq - 16u * k);
+}
+// returns the index of the first byte that became NUL (absolute in the field) or 0xffffffff
+__device__ __forceinline__ uint32_t ts_qual_chunk(const TsSrc &src, uint64_t qual, uint32_t l_seq, uint32_t k, uint8_t *d) {
+    const uint64_t a = src.u64(qual + 16ull * k), b = src.u64(qual + 16ull * k + 8);
+    uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    const uint32_t n = l_seq - 16u * k < 16u ? l_seq - 16u * k : 16u;
+    uint32_t fz = 0xffffffffu;
+    if (qual16(w)) {
+#pragma unroll
+        for (int q = 3; q >= 0; q--) {
+            const uint32_t z = (w[q] - 0x01010101u) & ~w[q] & 0x80808080u;      // lowest set bit marks the first zero byte exactly
+            if (z) fz = 4u * q + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+        }
+        fz = fz < n ? 16u * k + fz : 0xffffffffu;
+    }
+    store_n16(d + 16u * k, w, n);
+    return fz;
+}
+extern "C" __global__ void __launch_bounds__(64)
+bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res, int64_t nrows_all, int64_t nrows,
+                 const uint32_t *rec_off, const uint32_t *row_map, BamCols c, BamStrOut s) {
+    __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
+    __shared__ uint32_t r_seq[64], r_lseq[64], r_oseq[64], r_oqual[64], r_c0[64], r_nul[64];
+    __shared__ uint8_t cmap[TS_MAPN];
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    if (t >= ntiles || (uint64_t)t > res[3]) return;
+    const uint32_t n = out.count[t];
+    if (out.first[t] == NONE64 || n == 0) return;
+    const int64_t row0 = rowbase[t];
+    if (row0 >= nrows_all) return;
+    int64_t row1 = row0 + n; if (row1 > nrows_all) row1 = nrows_all;
+    int64_t d0 = row_map ? (int64_t)row_map[row0] : row0, d1 = row_map ? (int64_t)row_map[row1] : row1;
+    if (d1 > nrows) d1 = nrows;
+    if (d0 >= d1) return;
+    const uint64_t tb = (uint64_t)t * TL_TILE;
+    // the first row group's offsets are requested before the tile is staged: both HBM round trips overlap
+    struct RowIn { uint32_t o, len_seq, len_qn, rl, rg_rel, ne, cig_rel, off_qn, off_rg, off_cig, off_seq, off_qual; };
+    auto row_in = [&](int64_t r) {
+        RowIn q; q.o = rec_off[r];
+        q.len_seq = c.len_seq[r]; q.len_qn = c.len_qname[r]; q.rl = c.len_rg[r]; q.rg_rel = c.rg_rel[r]; q.ne = c.ncig_eff[r]; q.cig_rel = c.cig_rel[r];
+        q.off_qn = s.off_qname[r]; q.off_rg = s.off_rg[r]; q.off_cig = s.off_cigar[r]; q.off_seq = s.off_seq[r]; q.off_qual = s.off_qual[r];
+        return q;
+    };
+    RowIn ri = row_in(d0 + lane < d1 ? d0 + lane : d0);
+    LSrc ss; tile_stage(st, tb, buf, ss, lane);
+    TsSrc src; src.l = buf; src.g = st.u; src.base = tb; src.len = ss.len;
+
+    for (int64_t g0 = d0; g0 < d1; g0 += 64) {
+        const int64_t d = g0 + lane;
+        const bool act = d < d1;
+        if (g0 != d0) ri = row_in(act ? d : g0);
+        // ---- one lane per row: offsets, core fields ----
+        const uint64_t o = ri.o;
+        const uint32_t len_seq = ri.len_seq, len_qn = ri.len_qn, rl = ri.rl, rg_rel = ri.rg_rel, ne = ri.ne, cig_rel = ri.cig_rel;
+        const uint32_t off_qn = ri.off_qn, off_rg = ri.off_rg, off_cig = ri.off_cig, off_seq = ri.off_seq, off_qual = ri.off_qual;
+        const bool ok = act && len_seq != 0;                       // rows that failed validation reserve nothing
+        const uint32_t x2 = src.u32(o + 12), x3 = src.u32(o + 16);
+        const int32_t l_seq_raw = (int32_t)src.u32(o + 20);
+        const uint32_t l_seq = (ok && l_seq_raw > 0) ? (uint32_t)l_seq_raw : 0u;
+        const uint64_t seq = o + 36 + (x2 & 0xff) + 4ull * (x3 & 0xffff);
+        const uint64_t qual = seq + (((uint64_t)l_seq + 1) >> 1);
+        const bool star = !(l_seq > 0 && (uint8_t)src.u32(qual) != 255);
+        const bool lng = l_seq > TS_LONG;
+        const uint32_t nch = (ok && !lng) ? (l_seq + 15u) >> 4 : 0u;
+        const uint32_t cinc = wave_incl_scan(nch, lane);
+        const uint32_t T = RDLANE(cinc, 63), c0 = cinc - nch;
+        r_seq[lane] = (uint32_t)(seq - tb); r_lseq[lane] = star ? (l_seq | 0x80000000u) : l_seq; r_oseq[lane] = off_seq; r_oqual[lane] = off_qual;
+        r_c0[lane] = c0; r_nul[lane] = 0xffffffffu;
+        for (uint32_t k = 0; k < nch; k++) cmap[c0 + k] = (uint8_t)lane;
+        __syncthreads();
+        // ---- SEQ / QUAL by chunk ----
+        for (uint32_t cb = 0; cb < T; cb += 64) {
+            const uint32_t ch = cb + lane;
+            if (ch < T) {
+                const uint32_t j = cmap[ch], k = ch - r_c0[j], ls = r_lseq[j], lq = ls & 0x7fffffffu;
+                const uint64_t sq = tb + r_seq[j];
+                ts_seq_chunk(src, sq, lq, k, s.seq + r_oseq[j]);
+                if (!(ls >> 31)) {
+                    const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + r_oqual[j]);
+                    if (fz != 0xffffffffu) atomicMin(&r_nul[j], fz);
+                }
+            }
+        }
+        // ---- per-row pieces ----
+        if (ok) {
+            if (l_seq == 0) s.seq[off_seq] = '*';
+            if (star) s.qual[off_qual] = '*';
+            for (uint32_t b = 0; b < len_qn; b += 16) {
+                const uint64_t a = src.u64(o + 36 + b), e = src.u64(o + 36 + b + 8);
+                const uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)e, (uint32_t)(e >> 32)};
+                store_n16(s.qname + off_qn + b, w, len_qn - b);
+            }
+            for (uint32_t b = 0; b < rl; b += 16) {
+                const uint64_t a = src.u64(o + rg_rel + b), e = src.u64(o + rg_rel + b + 8);
+                const uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)e, (uint32_t)(e >> 32)};
+                store_n16(s.rg + off_rg + b, w, rl - b);
+            }
+            uint8_t *dc = s.cigar + off_cig;
+            if (ne == 0) dc[0] = '*';
+            uint32_t p = 0;
+            for (uint32_t q = 0; q < ne; q++) {
+                const uint32_t op = src.u32(o + cig_rel + 4ull * q);
+                uint32_t ol = op >> 4; const uint32_t nd = ndigits(ol);
+                for (uint32_t z = 0; z < nd; z++) { dc[p + nd - 1 - z] = (uint8_t)('0' + ol % 10); ol /= 10; }
+                // sam.h:112 BAM_CIGAR_STR "MIDNSHP=XB", '?' beyond; byte gather with v_perm_b32
+                const uint32_t C0 = 0x4e44494du, C1 = 0x3d504853u, C2 = 0x3f3f4258u, C3 = 0x3f3f3f3fu;
+                const uint32_t oc = op & 0xf, selb = (oc & 7u) | 0x0c0c0c00u;
+                dc[p + nd] = (uint8_t)((oc & 8u) ? __builtin_amdgcn_perm(C3, C2, selb) : __builtin_amdgcn_perm(C1, C0, selb));
+                p += nd + 1;
+            }
+        }
+        // ---- long fields: the whole wave streams one row at a time ----
+        uint64_t LM = __ballot(ok && lng);
+        while (LM) {
+            const int i = __ffsll((unsigned long long)LM) - 1; LM &= LM - 1;
+            const uint32_t lq = RDLANE(l_seq, i), st_i = RDLANE((uint32_t)star, i), os = RDLANE(off_seq, i), oq = RDLANE(off_qual, i);
+            const uint64_t sq = ((uint64_t)RDLANE((uint32_t)(seq >> 32), i) << 32) | RDLANE((uint32_t)seq, i);
+            uint32_t fzm = 0xffffffffu;
+            for (uint32_t k = lane; k < (lq + 15u) >> 4; k += 64) {
+                ts_seq_chunk(src, sq, lq, k, s.seq + os);
+                if (!st_i) { const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + oq); fzm = fz < fzm ? fz : fzm; }
+            }
+            if (fzm != 0xffffffffu) atomicMin(&r_nul[i], fzm);
+        }
+        __syncthreads();
+        if (ok) { const uint32_t fz = r_nul[lane]; s.alen_qual[d] = star ? 1u : (fz != 0xffffffffu ? fz : l_seq); }
+        __syncthreads();
+    }
+}
+
 // validity words from the per-row flags
 extern "C" __global__ void __launch_bounds__(256)
 bam_pack_validity(const uint8_t *flag, int64_t nrows, uint64_t *words) {

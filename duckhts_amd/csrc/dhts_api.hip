@@ -1055,6 +1055,8 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
 
     // ---- rows ----
     BamCols bc; memset(&bc, 0, sizeof(bc));
+    const int64_t nrows_scan = nrows;                          // rows the tile pass counted (before the region filter / a bad row / the shard cut)
+    const uint32_t *row_map_s = nullptr;
     if (nrows > 0) {
         size_t n = (size_t)nrows;
         ENSURE(c, c->rec_off, n * 4 + 16); ENSURE(c, c->c_rgflag, n + 64);
@@ -1085,7 +1087,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
             }
             const uint32_t *kin[1] = {(const uint32_t *)c->c_keep.p}; uint32_t *kout[1] = {(uint32_t *)c->c_rowmap.p};
             { KTimer tm(c, DHTS_K_SCAN); if (run_scan(c, 1, kin, kout, nullptr, nrows, &kept_total)) return -1; }
-            row_map = (const uint32_t *)c->c_rowmap.p;
+            row_map = (const uint32_t *)c->c_rowmap.p; row_map_s = row_map;
         }
         {
             KTimer tm(c, DHTS_K_CORE);
@@ -1138,7 +1140,10 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         so.alen_qual = (uint32_t *)c->alen_qual.p;
         {
             KTimer tm(c, DHTS_K_STRINGS);
-            hipLaunchKernelGGL(bam_string_write, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, colmask, bc, so);
+            static const bool legacy = getenv("DHTS_LEGACY_STRINGS") != nullptr;      // the row-centric kernel, kept for A/B timing
+            if (legacy) hipLaunchKernelGGL(bam_string_write, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, colmask, bc, so);
+            else hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
+                                    nrows_scan, nrows, (const uint32_t *)c->rec_off.p, row_map_s, bc, so);
         }
         HIPCHK(c, hipGetLastError());
         out->flag = bc.flag; out->pos = bc.pos; out->mapq = bc.mapq; out->pnext = bc.pnext; out->tlen = bc.tlen; out->tid = bc.tid; out->mtid = bc.mtid;
