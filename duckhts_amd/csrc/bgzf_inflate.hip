@@ -85,6 +85,16 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_
 __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 #endif
 
+// 64-bit logical right shift by n < 32: v_alignbit_b32 + v_lshrrev_b32 (full rate) instead of v_lshrrev_b64 (quarter rate)
+__device__ __forceinline__ uint64_t shr64_small(uint64_t v, uint32_t n) {
+#ifdef HOSTSIM
+    return v >> n;
+#else
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return ((uint64_t)(hi >> n) << 32) | __builtin_amdgcn_alignbit(hi, lo, n);
+#endif
+}
+
 // 15 left-justified limits: lim[L-1] = (first_code[L] + count[L]) << (15 - L)
 struct Limits { uint32_t v[15]; };
 
@@ -323,14 +333,15 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
             __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
             __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
             // P[i]: limits of code length i+1 (literal/length | distance << 16).  DB[i]: telescoped deltas of the canonical
-            // base table, so that sum_i [w < limit_i] * DB[i] = base[L] (mod 2^16) without an LDS lookup.
+            // base table, so that sum_i [w < limit_i] * DB[i] = base[L] (mod 2^12) without an LDS lookup.
             uint32_t P[15], DB[15];
 #pragma unroll
             for (int i = 0; i < 15; i++) {
                 P[i] = ll.v[i] | (dl.v[i] << 16);
-                const uint32_t dl_ = i < 14 ? (bsl[i + 1] - bsl[i + 2]) & 0xffffu : bsl[15];
-                const uint32_t dd_ = i < 14 ? (bsd[i + 1] - bsd[i + 2]) & 0xffffu : bsd[15];
-                DB[i] = dl_ | (dd_ << 16);
+                // 12 bits of base delta above a 4-bit "1": one multiply-add per limit accumulates base (mod 4096) AND the count
+                const uint32_t dl_ = (i < 14 ? (bsl[i + 1] - bsl[i + 2]) : bsl[15]) & 0xfffu;
+                const uint32_t dd_ = (i < 14 ? (bsd[i + 1] - bsd[i + 2]) : bsd[15]) & 0xfffu;
+                DB[i] = ((dl_ << 4) | 1u) | (((dd_ << 4) | 1u) << 16);
             }
             bool live = true; uint32_t mode = 0, want = 0, bad = 0, nw = 0;
             bool primed = false;
@@ -364,26 +375,22 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                         for (int i = 0; i < 15; i++) m[i] = pk_subsat_u16(P[i], ww);
 #pragma unroll
                         for (int i = 0; i < 15; i++) m[i] = pk_min_u16(m[i], 0x00010001u);         // [w < limit_i] per half
-                        uint32_t a0 = pk_add_u16(m[0], m[1]), a1 = pk_add_u16(m[2], m[3]), a2 = pk_add_u16(m[4], m[5]), a3 = pk_add_u16(m[6], m[7]);
-                        uint32_t a4 = pk_add_u16(m[8], m[9]), a5 = pk_add_u16(m[10], m[11]), a6 = pk_add_u16(m[12], m[13]);
-                        a0 = pk_add_u16(a0, a1); a2 = pk_add_u16(a2, a3); a4 = pk_add_u16(a4, a5); a6 = pk_add_u16(a6, m[14]);
-                        const uint32_t acc = pk_add_u16(pk_add_u16(a0, a2), pk_add_u16(a4, a6));
                         uint32_t b0 = 0, b1 = 0, b2 = 0;
 #pragma unroll
                         for (int i = 0; i < 15; i += 3) { b0 = pk_mad_u16(m[i], DB[i], b0); b1 = pk_mad_u16(m[i + 1], DB[i + 1], b1); b2 = pk_mad_u16(m[i + 2], DB[i + 2], b2); }
                         const uint32_t accB = pk_add_u16(pk_add_u16(b0, b1), b2);
-                        const uint32_t clt = mode ? (acc >> 16) : (acc & 0xffffu);          // #{limits > w}
+                        const uint32_t accM = mode ? (accB >> 16) : (accB & 0xffffu);
+                        const uint32_t clt = accM & 15u;                                     // #{limits > w}
                         bad |= (clt == 0) ? 1u : 0u;
                         uint32_t L = 16u - clt; L = L > 15u ? 15u : L;
-                        const uint32_t base = mode ? (accB >> 16) : (accB & 0xffffu);
-                        uint32_t o = (base + (w >> (15u - L))) & 0xffffu;
+                        uint32_t o = ((accM >> 4) + (w >> (15u - L))) & 0xfffu;
                         const uint32_t omax = mode ? 31u : 287u;
                         bad |= (o > omax) ? 1u : 0u;
                         o = o > omax ? omax : o;
                         const uint32_t sb = smem[(mode ? A_DSYM : A_LSYM_LO) + o * A_ST + lane];
                         const uint32_t hw = lsym_hi[(o >> 5) * A_ST + lane];               // both reads in flight together
                         const uint32_t sym = sb | (((hw >> (o & 31u)) << 8) & (mode ? 0u : 0x100u));
-                        br.buf >>= L; br.cnt -= L;
+                        br.buf = shr64_small(br.buf, L); br.cnt -= L;
                         if (!mode && sym < 256u) {
                             // literal
                             bad |= (outpos >= 65536u) ? 1u : 0u;
@@ -409,7 +416,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                             val += mode ? 1u : 3u;
                             if (!mode && j == 28u) { val = 258u; eb = 0; }
                             val += (uint32_t)br.buf & ((1u << eb) - 1u);
-                            br.buf >>= eb; br.cnt -= eb;
+                            br.buf = shr64_small(br.buf, eb); br.cnt -= eb;
                             if (!mode) { want = val; mode = 1; }
                             else {
                                 bad |= (val > outpos || outpos + want > 65536u) ? 1u : 0u;
