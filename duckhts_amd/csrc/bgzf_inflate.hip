@@ -152,6 +152,30 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
     const uint32_t payload_bits = clen >= 26 ? (clen - 26) * 8 : 0;
 
     uint32_t nlit = 0, ntok = 0, outpos = 0, run = 0, litbuf = 0;
+    // Output staging: literals and tokens leave a lane 16 bytes at a time (aligned global_store_dwordx4).  A 4-byte store per
+    // lane per dword costs the memory pipeline one cache-line transaction per active lane; 16-byte pieces quarter that.
+    uint32_t lq0 = 0, lq1 = 0, lq2 = 0, tq0 = 0, tq1 = 0, tq2 = 0;
+#ifndef A_EXP_NOSTORE
+#define A_ST16(ptr_, a_, b_, c_, d_) do { const uint4 v16_ = make_uint4(a_, b_, c_, d_); *(uint4 *)(ptr_) = v16_; } while (0)
+#else
+#define A_ST16(ptr_, a_, b_, c_, d_) do { } while (0)
+#endif
+#define PUSH_LIT(byte_)                                                                              \
+    do {                                                                                             \
+        litbuf |= (uint32_t)(byte_) << (8u * (nlit & 3u)); nlit++;                                   \
+        if ((nlit & 3u) == 0u) {                                                                     \
+            const uint32_t q_ = (nlit >> 2) & 3u;                                                    \
+            if (q_ == 1u) lq0 = litbuf; else if (q_ == 2u) lq1 = litbuf; else if (q_ == 3u) lq2 = litbuf; \
+            else A_ST16(lit + nlit - 16, lq0, lq1, lq2, litbuf);                                     \
+            litbuf = 0;                                                                              \
+        }                                                                                            \
+    } while (0)
+#define PUSH_TOK(val_)                                                                               \
+    do {                                                                                             \
+        const uint32_t q_ = ntok & 3u, tv_ = (val_); ntok++;                                         \
+        if (q_ == 0u) tq0 = tv_; else if (q_ == 1u) tq1 = tv_; else if (q_ == 2u) tq2 = tv_;         \
+        else A_ST16(tok + ntok - 4, tq0, tq1, tq2, tv_);                                             \
+    } while (0)
 #ifdef DHTS_DIAG
     unsigned long long dA_t0 = clock64(), dA_sym = 0, dA_it = 0, dA_build = 0;
 #endif
@@ -163,9 +187,8 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
     do {                                                                                             \
         if (outpos >= 65536u) { status = DHTS_BLK_ERR_INFLATE; }                                     \
         else {                                                                                       \
-            litbuf |= (uint32_t)(byte_) << (8 * (nlit & 3)); nlit++; outpos++;                       \
-            if ((nlit & 3) == 0) { *(uint32_t *)(lit + nlit - 4) = litbuf; litbuf = 0; }             \
-            if (++run == DHTS_TOK_PURE) { tok[ntok++] = DHTS_TOK_PURE << 23; run = 0; }              \
+            PUSH_LIT(byte_); outpos++;                                                               \
+            if (++run == DHTS_TOK_PURE) { PUSH_TOK(DHTS_TOK_PURE << 23); run = 0; }                  \
         }                                                                                            \
     } while (0)
 
@@ -323,15 +346,26 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         // iteration.  Code length = 16 - #{i : w < limit[i]}; the limits of BOTH alphabets sit in the two halves of 15 VGPRs and are
         // compared with packed 16-bit saturating arithmetic (no VCC/SGPR round trips).  Malformed-stream tests only accumulate
         // into `bad` (indices are clamped), so the body has three short divergent regions: literal store, length, distance + token.
-        // Input: per-lane 64-byte LDS window, refetched by the whole wave every 4 symbols (<= 28 bits per symbol, so a lane moves
-        // <= 16 bytes per period and can never leave the window parked one period earlier).
+        // Input: per-lane 64-byte LDS ring of four 16-byte granules, topped up one granule per period of 4 symbols (<= 28 bits per
+        // symbol, so a lane moves <= 14 bytes per period): every compressed byte is requested from memory once.
         {
             uint32_t *winA = (uint32_t *)(smem + A_WIN);
             const uint8_t *sp = br.p;
-            uint32_t wbase = br.pos, rbase = br.pos;
-            uint4 R0, R1, R2, R3;
-            __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
-            __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
+            // Input ring: granule G = stream bytes [16G, 16G+16) lives in window words 4(G&3)..4(G&3)+3.  Primed with four granules;
+            // afterwards a lane fetches ONE granule (16 bytes) per period, and only while it has less than 40 bytes ahead of its read
+            // position: a period consumes <= 14 bytes and looks <= 8 bytes ahead, so >= 24 bytes ahead at the start of every period
+            // is enough, and a granule is overwritten only when its bytes lie behind the read position (16*G - pos < 40 <= 45).
+            uint32_t gnext = (br.pos >> 4) + 4u, gpend = 0; bool fpend = false;
+            uint4 R0;
+            {
+                uint4 q0, q1, q2, q3; const uint8_t *g0p = sp + ((br.pos >> 4) << 4);
+                __builtin_memcpy(&q0, g0p, 16); __builtin_memcpy(&q1, g0p + 16, 16); __builtin_memcpy(&q2, g0p + 32, 16); __builtin_memcpy(&q3, g0p + 48, 16);
+                const uint32_t s0 = ((br.pos >> 4) & 3u) * 4u, s1 = (s0 + 4u) & 15u, s2 = (s0 + 8u) & 15u, s3 = (s0 + 12u) & 15u;
+                winA[(s0 + 0) * A_ST + lane] = q0.x; winA[(s0 + 1) * A_ST + lane] = q0.y; winA[(s0 + 2) * A_ST + lane] = q0.z; winA[(s0 + 3) * A_ST + lane] = q0.w;
+                winA[(s1 + 0) * A_ST + lane] = q1.x; winA[(s1 + 1) * A_ST + lane] = q1.y; winA[(s1 + 2) * A_ST + lane] = q1.z; winA[(s1 + 3) * A_ST + lane] = q1.w;
+                winA[(s2 + 0) * A_ST + lane] = q2.x; winA[(s2 + 1) * A_ST + lane] = q2.y; winA[(s2 + 2) * A_ST + lane] = q2.z; winA[(s2 + 3) * A_ST + lane] = q2.w;
+                winA[(s3 + 0) * A_ST + lane] = q3.x; winA[(s3 + 1) * A_ST + lane] = q3.y; winA[(s3 + 2) * A_ST + lane] = q3.z; winA[(s3 + 3) * A_ST + lane] = q3.w;
+            }
             // P[i]: limits of code length i+1 (literal/length | distance << 16).  DB[i]: telescoped deltas of the canonical
             // base table, so that sum_i [w < limit_i] * DB[i] = base[L] (mod 2^12) without an LDS lookup.
             uint32_t P[15], DB[15];
@@ -344,20 +378,15 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                 DB[i] = ((dl_ << 4) | 1u) | (((dd_ << 4) | 1u) << 16);
             }
             bool live = true; uint32_t mode = 0, want = 0, bad = 0, nw = 0;
-            bool primed = false;
+            nw = winA[((br.pos >> 2) & 15u) * A_ST + lane];                   // next unread word, always one ahead
             while (__ballot(live) != 0ull) {
-                // park the previous fetch, start the next one
-                winA[0 * A_ST + lane] = R0.x; winA[1 * A_ST + lane] = R0.y; winA[2 * A_ST + lane] = R0.z; winA[3 * A_ST + lane] = R0.w;
-                winA[4 * A_ST + lane] = R1.x; winA[5 * A_ST + lane] = R1.y; winA[6 * A_ST + lane] = R1.z; winA[7 * A_ST + lane] = R1.w;
-                winA[8 * A_ST + lane] = R2.x; winA[9 * A_ST + lane] = R2.y; winA[10 * A_ST + lane] = R2.z; winA[11 * A_ST + lane] = R2.w;
-                winA[12 * A_ST + lane] = R3.x; winA[13 * A_ST + lane] = R3.y; winA[14 * A_ST + lane] = R3.z; winA[15 * A_ST + lane] = R3.w;
-                wbase = rbase; rbase = br.pos;
-#ifdef A_EXP_NOLOAD
-                rbase &= 0xffu;        /* experiment: refetch a tiny hot region (wrong data, timing only) */
-#endif
-                __builtin_memcpy(&R0, sp + rbase, 16); __builtin_memcpy(&R1, sp + rbase + 16, 16);
-                __builtin_memcpy(&R2, sp + rbase + 32, 16); __builtin_memcpy(&R3, sp + rbase + 48, 16);
-                if (!primed) { nw = winA[(((br.pos - wbase) >> 2) & 15u) * A_ST + lane]; primed = true; }   // next unread word, always one ahead
+                // park the granule fetched during the previous period, then fetch the next one if this lane is running low
+                if (fpend) {
+                    const uint32_t sl = (gpend & 3u) * 4u;
+                    winA[(sl + 0) * A_ST + lane] = R0.x; winA[(sl + 1) * A_ST + lane] = R0.y; winA[(sl + 2) * A_ST + lane] = R0.z; winA[(sl + 3) * A_ST + lane] = R0.w;
+                    fpend = false;
+                }
+                if (live && 16u * gnext - br.pos < 40u) { __builtin_memcpy(&R0, sp + 16u * gnext, 16); gpend = gnext; gnext++; fpend = true; }
 #pragma unroll 1
                 for (int sub = 0; sub < 4; sub++) {
 #ifdef DHTS_DIAG
@@ -366,7 +395,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                     if (live) {
                         if (br.cnt <= 32) {
                             br.buf |= (uint64_t)nw << br.cnt; br.pos += 4; br.cnt += 32;
-                            nw = winA[(((br.pos - wbase) >> 2) & 15u) * A_ST + lane];          // consumed one refill later: latency hidden
+                            nw = winA[((br.pos >> 2) & 15u) * A_ST + lane];                    // consumed one refill later: latency hidden
                         }
                         const uint32_t w = __brev((uint32_t)br.buf) >> 17;
                         const uint32_t ww = w | (w << 16);
@@ -394,14 +423,8 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                         if (!mode && sym < 256u) {
                             // literal
                             bad |= (outpos >= 65536u) ? 1u : 0u;
-                            litbuf |= sym << (8u * (nlit & 3u)); nlit++; outpos++;
-#ifndef A_EXP_NOSTORE
-                            if ((nlit & 3u) == 0u) { *(uint32_t *)(lit + nlit - 4) = litbuf; litbuf = 0; }
-                            if (++run == DHTS_TOK_PURE) { tok[ntok++] = DHTS_TOK_PURE << 23; run = 0; }
-#else
-                            if ((nlit & 3u) == 0u) litbuf = 0;
-                            if (++run == DHTS_TOK_PURE) { ntok++; run = 0; }
-#endif
+                            PUSH_LIT(sym); outpos++;
+                            if (++run == DHTS_TOK_PURE) { PUSH_TOK(DHTS_TOK_PURE << 23); run = 0; }
                         } else if (!mode && sym == 256u) {
                             live = false;
                         } else {
@@ -420,11 +443,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                             if (!mode) { want = val; mode = 1; }
                             else {
                                 bad |= (val > outpos || outpos + want > 65536u) ? 1u : 0u;
-#ifndef A_EXP_NOSTORE
-                                if (!bad) { tok[ntok++] = (run << 23) | ((want - 3u) << 15) | (val - 1u); run = 0; outpos += want; }
-#else
-                                if (!bad) { ntok++; run = 0; outpos += want; }
-#endif
+                                if (!bad) { PUSH_TOK((run << 23) | ((want - 3u) << 15) | (val - 1u)); run = 0; outpos += want; }
                                 mode = 0;
                             }
                         }
@@ -444,10 +463,18 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
 #ifdef DHTS_DIAG
     if (lane == 0) { atomicAdd(&g_diagA[0], dA_sym); atomicAdd(&g_diagA[1], dA_it); atomicAdd(&g_diagA[3], clock64() - dA_t0); atomicAdd(&g_diagA[4], 1ull); }
 #endif
-    if (nlit & 3) *(uint32_t *)(lit + (nlit & ~3u)) = litbuf;
+    // (a block that failed is never read by phase B; its open group could lie one byte past the 64 KiB literal slot)
+    if (status == 0 && (nlit & 15u)) {                  // the open 16-byte group: complete dwords, then the partial one
+        const uint32_t cq = (nlit >> 2) & 3u;
+        A_ST16(lit + (nlit & ~15u), cq == 0u ? litbuf : lq0, cq == 1u ? litbuf : lq1, cq == 2u ? litbuf : lq2, litbuf);
+    }
+    if (status == 0 && (ntok & 3u)) A_ST16(tok + (ntok & ~3u), tq0, tq1, tq2, 0u);
     InflateMeta m; m.ntok = ntok; m.nlit = nlit; m.outlen = outpos; m.status = status;
     meta[s] = m;
 #undef EMIT_LIT
+#undef PUSH_LIT
+#undef PUSH_TOK
+#undef A_ST16
 }
 
 // ------------------------------------------------------------------------------------

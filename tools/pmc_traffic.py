@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def load(d, counter):
-    rows = defaultdict(lambda: [0.0, 0])
+    rows = defaultdict(lambda: [0.0, 0, 0])
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         seen = set()
         for r in csv.DictReader(open(fn)):
@@ -26,6 +26,7 @@ def load(d, counter):
             if did not in seen:
                 seen.add(did)
                 rows[k][1] += 1
+                rows[k][2] += int(r.get("Grid_Size") or 0)
     return rows
 
 
@@ -36,10 +37,21 @@ def main():
     res = {"note": "bytes = counter x 1024; fetch additionally x2 (gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced reads; uncalibrated for narrow ones)",
            "run": extra, "kernels": {}}
     for k in sorted(set(f) | set(w)):
-        fl, wl = f.get(k, [0, 0]), w.get(k, [0, 0])
+        fl, wl = f.get(k, [0, 0, 0]), w.get(k, [0, 0, 0])
         n = max(fl[1], wl[1], 1)
         res["kernels"][k] = {"launches": n, "fetch_bytes_per_launch": fl[0] * 1024 * 2 / n, "write_bytes_per_launch": wl[0] * 1024 / n,
                              "fetch_counter_sum": fl[0], "write_counter_sum": wl[0]}
+    # per BGZF block figures of the two inflate kernels (bench.py multiplies them by the blocks of a step): phase A runs one
+    # LANE per block (blocks = grid threads, rounded up to 64), phase B one 64-lane workgroup per block
+    res["per_block"] = {}
+    for k, lanes_per_block in (("bgzf_huff_decode", 1), ("bgzf_lz_resolve", 64)):
+        fl, wl = f.get(k), w.get(k)
+        if not fl or not wl or not fl[2]:
+            continue
+        blocks_f, blocks_w = fl[2] / lanes_per_block, wl[2] / lanes_per_block
+        res["per_block"][k] = {"launch_blocks": blocks_f / max(fl[1], 1), "fetch_bytes_raw": fl[0] * 1024 / blocks_f,
+                               "fetch_bytes_corrected": fl[0] * 1024 * 2 / blocks_f, "write_bytes": wl[0] * 1024 / blocks_w,
+                               "launches_sampled": fl[1]}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(f"{k:32s} n={v['launches']:5d} fetch/launch={v['fetch_bytes_per_launch'] / 1e6:10.2f} MB write/launch={v['write_bytes_per_launch'] / 1e6:10.2f} MB")
