@@ -17,6 +17,7 @@ static thread_local dim3s threadIdx, blockIdx;
 static inline uint32_t __brev(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 #define HOSTSIM 1
 struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline unsigned long long __ballot(bool b) { return b ? 1ull : 0ull; }
 static uint8_t *g_smem;
 #define HIP_RUNTIME_STUB
@@ -61,7 +62,31 @@ int main(int argc, char **argv) {
         }
 #endif
     }
-    for (int64_t b = 0; b < nb; b++) if (meta[b].status) { bad++; }
-    printf("blocks %lld bad %d (SL=%d LDS=%d)\n", (long long)nb, bad, A_SL, (int)A_LDS_BYTES);
-    return bad ? 1 : 0;
+    // replay the tokens (what phase B does) and check every block against its CRC32 / ISIZE trailer
+    uint32_t crct[256];
+    for (uint32_t k = 0; k < 256; k++) { uint32_t c = k; for (int j = 0; j < 8; j++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1); crct[k] = c; }
+    int mism = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        if (meta[b].status) { bad++; continue; }
+        const uint8_t *L = lit.data() + (size_t)b * DHTS_LIT_STRIDE; const uint32_t *T = tok.data() + (size_t)b * DHTS_TOK_STRIDE;
+        std::vector<uint8_t> out; out.reserve(65536);
+        uint32_t lp = 0;
+        for (uint32_t i = 0; i < meta[b].ntok; i++) {
+            const uint32_t t = T[i], run = t >> 23;
+            for (uint32_t k = 0; k < run; k++) out.push_back(L[lp++]);
+            if (run != DHTS_TOK_PURE) {
+                const uint32_t len = ((t >> 15) & 255u) + 3, dist = (t & 0x7fffu) + 1;
+                if (dist > out.size()) { mism++; break; }
+                for (uint32_t k = 0; k < len; k++) out.push_back(out[out.size() - dist]);
+            }
+        }
+        while (lp < meta[b].nlit) out.push_back(L[lp++]);
+        uint32_t c = 0xffffffffu; for (uint8_t x : out) c = crct[(c ^ x) & 0xff] ^ (c >> 8);
+        c ^= 0xffffffffu;
+        const uint8_t *tr = d.data() + coff[b] + clen[b] - 8;
+        const uint32_t want_crc = tr[0] | (tr[1] << 8) | (tr[2] << 16) | ((uint32_t)tr[3] << 24), want_len = tr[4] | (tr[5] << 8) | (tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (out.size() != want_len || out.size() != meta[b].outlen || c != want_crc) mism++;
+    }
+    printf("blocks %lld failed %d mismatching %d (SL=%d LDS=%d)\n", (long long)nb, bad, mism, A_SL, (int)A_LDS_BYTES);
+    return (bad || mism) ? 1 : 0;
 }
