@@ -146,14 +146,22 @@ bam_tile_finalize(int64_t ntiles, TileOut out, uint32_t *rowbase, uint64_t *res)
     unsigned long long myE = (unsigned long long)ntiles;
     for (int64_t base = 0; base < ntiles; base += 16384) {
         const int64_t t0 = base + (int64_t)tid * 16;
-        uint32_t v[16], sum = 0;
+        uint32_t v[16], e[16], sum = 0;
+        if (t0 + 16 <= ntiles) {                      // 4 + 4 aligned 16-byte loads, all in flight together
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int64_t t = t0 + k;
-            v[k] = t < ntiles ? out.count[t] : 0u;
-            if (t < ntiles && out.err[t] && (unsigned long long)t < myE) myE = (unsigned long long)t;
-            sum += v[k];
+            for (int q = 0; q < 4; q++) {
+                const uint4 a = *(const uint4 *)(out.count + t0 + 4 * q), b = *(const uint4 *)((const uint32_t *)out.err + t0 + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+                e[4 * q] = b.x; e[4 * q + 1] = b.y; e[4 * q + 2] = b.z; e[4 * q + 3] = b.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { const int64_t t = t0 + k; v[k] = t < ntiles ? out.count[t] : 0u; e[k] = t < ntiles ? (uint32_t)out.err[t] : 0u; }
         }
+#pragma unroll
+        for (int k = 15; k >= 0; k--) if (e[k] && (unsigned long long)(t0 + k) < myE) myE = (unsigned long long)(t0 + k);
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += v[k];
         const uint32_t incl = wave_incl_scan(sum, lane);
         if (lane == 63) shw[wave] = incl;
         __syncthreads();
@@ -161,8 +169,16 @@ bam_tile_finalize(int64_t ntiles, TileOut out, uint32_t *rowbase, uint64_t *res)
 #pragma unroll
         for (int w = 0; w < 16; w++) { const uint32_t x = shw[w]; total += x; if (w < wave) woff += x; }
         uint32_t run = carry + woff + incl - sum;
+        if (t0 + 16 <= ntiles) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) { const int64_t t = t0 + k; if (t < ntiles) rowbase[t] = run; run += v[k]; }
+            for (int q = 0; q < 4; q++) {
+                uint4 o4; o4.x = run; run += v[4 * q]; o4.y = run; run += v[4 * q + 1]; o4.z = run; run += v[4 * q + 2]; o4.w = run; run += v[4 * q + 3];
+                *(uint4 *)(rowbase + t0 + 4 * q) = o4;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { const int64_t t = t0 + k; if (t < ntiles) rowbase[t] = run; run += v[k]; }
+        }
         carry += total;
         __syncthreads();
     }
