@@ -32,7 +32,8 @@ class BamBatch(C.Structure):
                 ("tlen", C.c_void_p), ("tid", C.c_void_p), ("mtid", C.c_void_p), ("rg_idx", C.c_void_p),
                 ("rg_valid", C.c_void_p),
                 ("qname", StrCol), ("cigar", StrCol), ("seq", StrCol), ("qual", StrCol), ("rg", StrCol),
-                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("reserved2", C.c_int32), ("aux_map", C.c_void_p), ("tag_cols", C.c_void_p)]
+                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("reserved2", C.c_int32), ("aux_map", C.c_void_p), ("tag_cols", C.c_void_p),
+                ("ov_off", C.c_void_p), ("ov_ids", C.c_void_p), ("n_ov", C.c_uint64)]
 
 
 class AuxMap(C.Structure):
@@ -73,7 +74,7 @@ ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
-           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
+           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_set_overlap_intervals", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
@@ -111,6 +112,7 @@ def lib():
         L.dhts_bam_std_tag_info.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.dhts_bam_set_tag_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.dhts_bam_set_aux_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.dhts_bam_set_overlap_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.dhts_bam_load_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bam_next_batch.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(BamBatch)]
         L.dhts_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -226,6 +228,19 @@ class Context:
         arr = np.array(list(ids), np.int32)
         self._chk(self.L.dhts_bam_set_tag_columns(self.h, arr.ctypes.data, len(arr)))
         self._tag_ids = list(ids)
+
+    def set_overlap_intervals(self, tid, beg, end):
+        """Interval overlap join (cgranges cr_overlap semantics): intervals (tid, beg, end) half-open 0-based, tid = BAM header index."""
+        tid = np.ascontiguousarray(tid, np.int32); beg = np.ascontiguousarray(beg, np.int64); end = np.ascontiguousarray(end, np.int64)
+        assert len(tid) == len(beg) == len(end)
+        self._chk(self.L.dhts_bam_set_overlap_intervals(self.h, tid.ctypes.data, beg.ctypes.data, end.ctypes.data, len(tid)))
+
+    def overlap_lists(self, b):
+        """(offsets u32[n_rows+1], ids u32[n_ov]) of one batch; ids are positions in the arrays given to set_overlap_intervals"""
+        n = int(b.n_rows)
+        if not b.ov_off:                               # join switched off (no intervals): every row has an empty list
+            return np.zeros(n + 1, np.uint32), np.zeros(0, np.uint32)
+        return self.d2h(b.ov_off, n + 1, np.uint32), self.d2h(b.ov_ids, int(b.n_ov), np.uint32)
 
     def set_aux_map(self, enable=True, exclude_standard=True):
         self._chk(self.L.dhts_bam_set_aux_map(self.h, int(enable), int(exclude_standard)))
@@ -567,7 +582,7 @@ def std_tags():
     return _STD_TAGS
 
 
-def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None):
+def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None, overlap=None):
     """Full sequential scan (reference mode (i)): all rows in file order.
     region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window."""
     ctx = Context(device)
@@ -586,7 +601,9 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
             ctx.set_tag_columns(std_tags_cols)
         if aux_map is not None:
             ctx.set_aux_map(True, bool(aux_map == "exclude_standard"))
-        parts, tparts, aparts = [], [], []
+        if overlap is not None:
+            ctx.set_overlap_intervals(*overlap)          # (tid, beg, end) arrays: out["OVERLAPS"] = per-row arrays of interval ids
+        parts, tparts, aparts, oparts = [], [], [], []
         status = 0
         while True:
             b = ctx.next_batch(max_blocks)
@@ -596,6 +613,8 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
                     tparts.append(ctx.tag_table(b))
                 if aux_map is not None:
                     aparts.append(ctx.aux_table(b))
+                if overlap is not None:
+                    oparts.append(ctx.overlap_lists(b))
             status = b.status
             if b.status != 0:
                 break
@@ -604,6 +623,8 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
             out["tags"] = {"n_rows": out["n_rows"], "cols": _concat_tables(tparts, None) or []}
         if aux_map is not None:
             out["aux"] = {"n_rows": out["n_rows"], "cols": _concat_tables(aparts, None) or []}
+        if overlap is not None:
+            out["OVERLAPS"] = [ids[off[i]:off[i + 1]] for off, ids in oparts for i in range(len(off) - 1)]
         for k in BAM_COLUMNS + ["tid", "mtid"]:
             vals = [p[k] for p in parts]
             if not vals:

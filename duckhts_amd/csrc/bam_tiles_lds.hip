@@ -541,3 +541,44 @@ bam_region_keep(BamStream st, RegionDev rg, const uint32_t *rec_off, int64_t nro
     }
     keep[row] = k;
 }
+
+// ---- interval overlap join ----------------------------------------------------------------
+// For every row the ids of the caller's intervals that overlap the read, with the semantics of cgranges' cr_overlap
+// (ref: third_party/cgranges/cgranges.c:255-297; the test is `st < en_i && st_i < en`, half-open, same contig).  The read's
+// interval is the one the region iterator uses: [pos, bam_endpos) (htslib sam.c:668-673).  Intervals arrive sorted by
+// (tid, start) with a per-contig running maximum of their ends, which replaces the implicit max-end tree: candidates are
+// [first index whose running max end > beg, first index whose start >= end) and each is tested for en_i > beg.
+// Ids come out in (start, input order) order, not in cgranges' tree-walk order: the result is a set per row.
+struct OverlapDev { const int64_t *beg, *end, *pmax, *bmax; const uint32_t *id; const uint32_t *tid_first; int32_t n_ref, pad; };   // bmax: max end of every 64 sorted intervals
+
+template <bool WRITE> __global__ void __launch_bounds__(256)
+bam_overlap_cells(BamStream st, OverlapDev ov, const uint32_t *rec_off, BamCols c, int64_t nrows, uint32_t *cnt, const uint32_t *off, uint32_t *ids) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    // the row was validated and unpacked by bam_tile_unpack: tid / POS / FLAG and the effective CIGAR location come from its columns
+    const int32_t tid = c.tid[row];
+    uint32_t n = 0;
+    if (tid >= 0 && tid < ov.n_ref && c.len_seq[row] != 0) {
+        const uint8_t *cig = st.u + rec_off[row] + c.cig_rel[row];
+        const uint32_t ne = c.ncig_eff[row];
+        int64_t rlen = 0;
+        if (!(c.flag[row] & 4)) for (uint32_t j = 0; j < ne; j++) { const uint32_t op = ldu32(cig + 4ull * j); if ((0x3C1A7u >> ((op & 0xf) << 1)) & 2u) rlen += op >> 4; }
+        if (rlen == 0) rlen = 1;
+        const int64_t beg = c.pos[row] - 1, end = beg + rlen;
+        const uint32_t f0 = ov.tid_first[tid], f1 = ov.tid_first[tid + 1];
+        uint32_t lo = f0, hi = f1;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ov.beg[mid] >= end) hi = mid; else lo = mid + 1; }
+        const uint32_t stop = lo;                                   // intervals [f0, stop) start before the read ends
+        lo = f0; hi = stop;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ov.pmax[mid] > beg) hi = mid; else lo = mid + 1; }
+        uint32_t w = WRITE ? off[row] : 0u;
+        // candidates [lo, stop): 64-interval blocks whose largest end does not reach the read are skipped whole (long nested
+        // intervals make the running-max bound loose; the block maxima keep the walk proportional to the blocks that can match)
+        for (uint32_t i = lo; i < stop;) {
+            const uint32_t be = (i | 63u) + 1u < stop ? (i | 63u) + 1u : stop;
+            if (ov.bmax[i >> 6] > beg) { for (; i < be; i++) if (ov.end[i] > beg) { if (WRITE) ids[w++] = ov.id[i]; n++; } }
+            i = be;
+        }
+    }
+    if (!WRITE) cnt[row] = n;
+}

@@ -49,6 +49,9 @@ struct dhts_ctx {
     std::vector<uint64_t> h_coff, h_uoff; std::vector<uint32_t> h_clen, h_isize;
     // inflate scratch
     DevBuf lit, tok, meta;
+    // interval overlap join
+    bool ov_active = false; int64_t ov_n = 0;
+    DevBuf ov_beg, ov_end, ov_pmax, ov_bmax, ov_id, ov_first, ov_cnt, ov_off, ov_ids;
     int64_t huff_b0 = 0, huff_nb = 0;     // block range whose tokens are in the scratch
     int64_t super_blocks = 524288;       // phase A runs ahead over up to this many blocks (1,536 waves are resident at once, six per CU;
                                          // a long launch keeps every SIMD backfilled).  Scratch is 152 KiB per block: see inflate_blocks.
@@ -158,6 +161,8 @@ void dhts_destroy(dhts_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     timing_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    DevBuf *ovb[] = {&c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
+    for (auto b : ovb) b->release();
     DevBuf *all[] = {&c->comp, &c->coff, &c->clen, &c->isize, &c->uoff, &c->blk_status, &c->lit, &c->tok, &c->meta, &c->ubuf[0], &c->ubuf[1],
                      &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
                      &c->c_mapq, &c->c_pnext, &c->c_tlen, &c->c_tid, &c->c_mtid, &c->c_rgidx, &c->c_rgvalid, &c->l_qname, &c->l_cigar, &c->l_seq,
@@ -858,6 +863,71 @@ static int bam_aux_map(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam
 }
 
 // materialises the selected tag columns for the (final, compacted) rows of the current batch
+// ---- interval overlap join ------------------------------------------------------------------------------------------------
+int dhts_bam_set_overlap_intervals(dhts_ctx *c, const int32_t *tid, const int64_t *beg, const int64_t *end, int64_t n) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ov_active = false; c->ov_n = 0;
+    if (n <= 0) return 0;
+    if (!tid || !beg || !end) return fail(c, "overlap intervals: null array");
+    if (n > 0xfffffff0ll) return fail(c, "overlap intervals: too many intervals");
+    const int32_t n_ref = (int32_t)c->ref_name.size();
+    std::vector<uint32_t> order; order.reserve((size_t)n);
+    for (int64_t i = 0; i < n; i++) if (tid[i] >= 0 && tid[i] < n_ref) order.push_back((uint32_t)i);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tid[a] != tid[b] ? tid[a] < tid[b] : beg[a] < beg[b]; });
+    const size_t m = order.size();
+    std::vector<int64_t> sb(m), se(m), pm(m), bm((m + 63) / 64 + 1, INT64_MIN); std::vector<uint32_t> first((size_t)n_ref + 1, 0);
+    for (size_t k = 0; k < m; k++) {
+        const uint32_t i = order[k];
+        sb[k] = beg[i]; se[k] = end[i];
+        pm[k] = (k > 0 && tid[order[k - 1]] == tid[i] && pm[k - 1] > end[i]) ? pm[k - 1] : end[i];
+        if (end[i] > bm[k >> 6]) bm[k >> 6] = end[i];
+        first[(size_t)tid[i] + 1]++;
+    }
+    for (int32_t t = 0; t < n_ref; t++) first[(size_t)t + 1] += first[t];
+    ENSURE(c, c->ov_beg, m * 8 + 64); ENSURE(c, c->ov_end, m * 8 + 64); ENSURE(c, c->ov_pmax, m * 8 + 64); ENSURE(c, c->ov_bmax, bm.size() * 8 + 64); ENSURE(c, c->ov_id, m * 4 + 64); ENSURE(c, c->ov_first, ((size_t)n_ref + 1) * 4 + 64);
+    if (m) {
+        HIPCHK(c, hipMemcpy(c->ov_beg.p, sb.data(), m * 8, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->ov_end.p, se.data(), m * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->ov_pmax.p, pm.data(), m * 8, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->ov_id.p, order.data(), m * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMemcpy(c->ov_bmax.p, bm.data(), bm.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ov_first.p, first.data(), ((size_t)n_ref + 1) * 4, hipMemcpyHostToDevice));
+    c->ov_active = true; c->ov_n = (int64_t)m;
+    return 0;
+}
+
+static int bam_overlap_join(dhts_ctx *c, const BamStream &st, const BamCols &bc, int64_t nrows, dhts_bam_batch *out) {
+    out->ov_off = nullptr; out->ov_ids = nullptr; out->n_ov = 0;
+    if (!c->ov_active) return 0;
+    const size_t n = (size_t)(nrows > 0 ? nrows : 0);
+    ENSURE(c, c->ov_cnt, (n + 1) * 4 + 64); ENSURE(c, c->ov_off, (n + 1) * 4 + 64);
+    uint64_t total = 0;
+    OverlapDev ov; ov.beg = (const int64_t *)c->ov_beg.p; ov.end = (const int64_t *)c->ov_end.p; ov.pmax = (const int64_t *)c->ov_pmax.p; ov.bmax = (const int64_t *)c->ov_bmax.p; ov.id = (const uint32_t *)c->ov_id.p;
+    ov.tid_first = (const uint32_t *)c->ov_first.p; ov.n_ref = (int32_t)c->ref_name.size(); ov.pad = 0;
+    if (nrows > 0) {
+        {
+            KTimer tm(c, DHTS_K_CORE);
+            hipLaunchKernelGGL(bam_overlap_cells<false>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, ov, (const uint32_t *)c->rec_off.p, bc, nrows,
+                               (uint32_t *)c->ov_cnt.p, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+        }
+        const uint32_t *in[1] = {(const uint32_t *)c->ov_cnt.p}; uint32_t *o32[1] = {(uint32_t *)c->ov_off.p};
+        { KTimer tm(c, DHTS_K_SCAN); if (run_scan(c, 1, in, o32, nullptr, nrows, &total)) return -1; }
+        if (total > 0xfffffff0ull) return fail(c, "overlap join: more than 2^32 pairs in one batch");
+        ENSURE(c, c->ov_ids, total * 4 + 64);
+        if (total) {
+            KTimer tm(c, DHTS_K_CORE);
+            hipLaunchKernelGGL(bam_overlap_cells<true>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, ov, (const uint32_t *)c->rec_off.p, bc, nrows,
+                               (uint32_t *)nullptr, (const uint32_t *)c->ov_off.p, (uint32_t *)c->ov_ids.p);
+        }
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->ov_off.p, 0, 4, c->stream));
+        ENSURE(c, c->ov_ids, 64);
+    }
+    out->ov_off = (const uint32_t *)c->ov_off.p; out->ov_ids = (const uint32_t *)c->ov_ids.p; out->n_ov = total;
+    return 0;
+}
+
 static int bam_tag_columns(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam_batch *out) {
     const int nt = (int)c->tag_sel.size();
     c->tag_out.assign(nt, dhts_col());
@@ -1156,6 +1226,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     }
     if (bam_tag_columns(c, st, nrows, out)) return -1;
     if (bam_aux_map(c, st, nrows, out)) return -1;
+    if (bam_overlap_join(c, st, bc, nrows, out)) return -1;
     out->n_rows = nrows;
     out->end_uoff = out_base + carry_start;
     {

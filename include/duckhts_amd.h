@@ -107,6 +107,9 @@ typedef struct {
     int32_t reserved2;
     const dhts_aux_map *aux_map; /* NULL unless dhts_bam_set_aux_map enabled it                       */
     const dhts_col *tag_cols;/* host array; BIGINT scalars in fixed (8 B), VARCHAR in off/bytes, LIST(BIGINT) in off/child_fixed (8 B words) */
+    const uint32_t *ov_off;  /* overlap join (dhts_bam_set_overlap_intervals): n_rows+1 offsets into ov_ids, NULL when off */
+    const uint32_t *ov_ids;  /* ids (positions in the caller's interval arrays) of the intervals overlapping each row     */
+    uint64_t n_ov;
 } dhts_bam_batch;
 
 /* Host copy of the BAM header dictionaries (pointers owned by the context).                   */
@@ -166,6 +169,14 @@ int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype);   /
 int dhts_bam_set_tag_columns(dhts_ctx *, const int32_t *std_tag_ids, int32_t n);  /* tag columns materialised by the next batches (default none) */
 int dhts_bam_set_aux_map(dhts_ctx *, int enable, int exclude_standard_tags);        /* AUXILIARY_TAGS entries in the next batches */
 int dhts_bam_rewind(dhts_ctx *);
+/* Interval overlap join on the scan (SURVEY 8(f) item 1 / BASELINE config 5).  The reference vendors cgranges
+ * (third_party/cgranges, cr_add / cr_index / cr_overlap cgranges.c:255-297) as the model for joining read_bam rows with
+ * read_bed intervals (src/interval_udf.c:344-426) but registers no SQL function for it yet; this entry point is what such a
+ * function would bind.  Intervals are (tid, beg, end) half-open, 0-based, tid = index in the BAM header's reference table
+ * (intervals with tid outside it never match).  Every following batch carries, per row, the ids of the intervals i with
+ * beg_i < read_end && read_beg < end_i on the read's contig (read interval = [pos, bam_endpos)), i.e. cr_overlap's answer as
+ * a set.  n = 0 switches the join off.  Host pointers; copied.                                                              */
+int dhts_bam_set_overlap_intervals(dhts_ctx *, const int32_t *tid, const int64_t *beg, const int64_t *end, int64_t n);
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 
 /* ---- read_bcf ------------------------------------------------------------------------------

@@ -171,3 +171,61 @@ def bcf_region_rows(table, contigs, region_string, tidy_reps=1):
         for i in idx:
             out.extend(range(int(i) * tidy_reps, int(i) * tidy_reps + tidy_reps))
     return out
+
+
+def overlap_join(table, tid, beg, end):
+    """Interval overlap join of read_bam rows with intervals (tid, beg, end) (half-open, 0-based, tid = header index).
+    Semantics = cgranges cr_overlap (ref: third_party/cgranges/cgranges.c:255-297): interval i of the read's contig is reported iff
+    st_i < en && st < en_i, where [st, en) = [pos, bam_endpos) of the read (htslib sam.c:668-673).
+    table = orc.bam_read(...) result -> list (per row) of sorted interval ids."""
+    tid = np.asarray(tid, np.int64); beg = np.asarray(beg, np.int64); end = np.asarray(end, np.int64)
+    by_tid = {}
+    for t in np.unique(tid):
+        idx = np.nonzero(tid == t)[0]
+        by_tid[int(t)] = (idx, beg[idx], end[idx])
+    out = []
+    for i in range(table["n_rows"]):
+        t = int(table["tid"][i])
+        if t < 0 or t not in by_tid:
+            out.append(np.zeros(0, np.int64))
+            continue
+        st = int(table["POS"][i]) - 1
+        en = endpos(st, int(table["FLAG"][i]), table["CIGAR"][i])
+        idx, b, e = by_tid[t]
+        out.append(np.sort(idx[(b < en) & (st < e)]))
+    return out
+
+
+def cgranges_overlap(lib_path, names, tid, beg, end, queries):
+    """The REFERENCE's own cgranges (oracle/_ref/libcgranges.so, compiled from /root/reference by oracle/Makefile) through
+    ctypes: cr_add every interval with label = its id, cr_index, then cr_overlap per query (name, st, en) -> sorted labels."""
+    import ctypes as C
+    L = C.CDLL(lib_path)
+    L.cr_init.restype = C.c_void_p
+    L.cr_add.restype = C.c_void_p
+    L.cr_add.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+    L.cr_index.argtypes = [C.c_void_p]
+    L.cr_destroy.argtypes = [C.c_void_p]
+    L.cr_overlap.restype = C.c_int64
+    L.cr_overlap.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]
+
+    class Intv(C.Structure):                      # cr_intv_t (cgranges.h): x, y:31/rev:1, label
+        _fields_ = [("x", C.c_uint64), ("y", C.c_uint32), ("label", C.c_int32)]
+
+    class Cr(C.Structure):                        # cgranges_t head: n_r, m_r, r
+        _fields_ = [("n_r", C.c_int64), ("m_r", C.c_int64), ("r", C.POINTER(Intv))]
+
+    cr = L.cr_init()
+    for i in range(len(tid)):
+        L.cr_add(cr, names[int(tid[i])].encode(), int(beg[i]), int(end[i]), i)
+    L.cr_index(cr)
+    r = C.cast(cr, C.POINTER(Cr)).contents.r
+    b = C.POINTER(C.c_int64)()
+    mb = C.c_int64(0)
+    out = []
+    for name, st, en in queries:
+        n = L.cr_overlap(cr, name.encode(), int(st), int(en), C.byref(b), C.byref(mb))
+        out.append(np.sort(np.array([r[b[k]].label for k in range(n)], np.int64)))
+    C.CDLL(None).free(b)
+    L.cr_destroy(cr)
+    return out

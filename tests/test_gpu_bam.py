@@ -276,6 +276,57 @@ def test_region_synthetic_with_unplaced_and_batches():
         _region_check(data, region, max_blocks=7)
 
 
+# ---- interval overlap join ----------------------------------------------------------------
+def _overlap_check(data, tid, beg, end, region=None, max_blocks=0):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle as ro
+    t = orc.bam_read(data)
+    exp = ro.overlap_join(t, tid, beg, end)
+    if region is not None:
+        keep = ro.keep_mask(t, region)
+        exp = [e for e, k in zip(exp, keep) if k]
+    got = duckhts_amd.read_bam(data, overlap=(tid, beg, end), region=region, max_blocks=max_blocks)
+    assert got["n_rows"] == len(exp)
+    assert len(got["OVERLAPS"]) == len(exp)
+    for i, (a, b) in enumerate(zip(got["OVERLAPS"], exp)):
+        assert np.sort(a).tolist() == b.tolist(), (i, a, b)
+    return sum(len(x) for x in exp)
+
+
+@pytest.mark.gpu
+def test_overlap_join_golden_cgranges_vector():
+    """the pairs the reference's own cgranges reports for 400 intervals x the reads of range.bam (tests/golden/overlap_range_bam.json)"""
+    import json
+    g = json.loads(read_golden("overlap_range_bam.json"))
+    data = read_golden("range.bam")
+    got = duckhts_amd.read_bam(data, overlap=(g["tid"], g["beg"], g["end"]))
+    assert got["n_rows"] == 112 and sum(len(x) for x in got["OVERLAPS"]) == 866
+    for a, b in zip(got["OVERLAPS"], g["overlaps"]):
+        assert np.sort(a).tolist() == b
+    # intervals on contigs the header does not have never match; an empty set switches the join off
+    got = duckhts_amd.read_bam(data, overlap=([99, -1], [0, 0], [10 ** 9, 10 ** 9]))
+    assert sum(len(x) for x in got["OVERLAPS"]) == 0
+    assert "OVERLAPS" in duckhts_amd.read_bam(data, overlap=([], [], []))
+
+
+@pytest.mark.gpu
+def test_overlap_join_synthetic_batches_and_regions():
+    data = synth.bam_file(60000, seed=9)
+    hdr = duckhts_amd.read_bam(data, max_blocks=0)["header"]
+    n_ref = len(hdr["ref_names"])
+    rng = np.random.default_rng(21)
+    n = 20000
+    tid = rng.integers(0, n_ref, n).astype(np.int32)
+    beg = rng.integers(0, 60_000_000, n).astype(np.int64)
+    end = beg + rng.choice([0, 1, 100, 1000, 50_000, 5_000_000], n)      # nested long intervals exercise the running-max bound
+    assert _overlap_check(data, tid, beg, end, max_blocks=5) > 0
+    assert _overlap_check(data, tid, beg, end, region="chr1:1-30,000,000,chr2", max_blocks=3) > 0
+    # duplicates and identical starts keep their own ids
+    tid2 = np.zeros(6, np.int32); beg2 = np.array([0, 0, 0, 10, 10, 10], np.int64); end2 = np.array([10 ** 9] * 6, np.int64)
+    _overlap_check(data, tid2, beg2, end2)
+
+
 # ---- standard_tags (row A5) ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["sam_equiv", "matrix", "fuzz", "fuzz_small_batches", "golden_range"])

@@ -303,3 +303,49 @@ def test_std_tags_oracle_pins():
     assert col["AS"][r] == 5 and col["ML"][r] is None
     r = row[b"longcig"]
     assert col["CG"][r] is None and col["NM"][r] == 6 and col["MD"][r] == b"70000" and col["RG"][r] == b"g"
+
+
+# ---- interval overlap join: restatement pinned on the reference's own cgranges ----------------------
+def _overlap_golden():
+    import json
+    return json.loads(read_golden("overlap_range_bam.json"))
+
+
+def test_overlap_join_matches_cgranges_golden():
+    """tests/golden/overlap_range_bam.json = cr_overlap answers of the reference's vendored cgranges (generated by make_overlap_golden.py)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle as ro
+    g = _overlap_golden()
+    t = orc.bam_read(read_golden("range.bam"))
+    got = ro.overlap_join(t, g["tid"], g["beg"], g["end"])
+    assert len(got) == len(g["overlaps"]) == 112
+    assert sum(len(x) for x in got) == 866
+    for a, b in zip(got, g["overlaps"]):
+        assert a.tolist() == b
+    # the query intervals themselves: [pos, bam_endpos)
+    names = [bytes(x).decode() for x in t["ref_names"]]
+    for i, (nm, st, en) in enumerate(g["queries"]):
+        assert nm == names[int(t["tid"][i])] and st == int(t["POS"][i]) - 1 and en == ro.endpos(st, int(t["FLAG"][i]), t["CIGAR"][i])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libcgranges.so")), reason="reference cgranges not built here")
+def test_overlap_join_matches_reference_build_on_random_intervals():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle as ro
+    lib = os.path.join(ROOT, "oracle", "_ref", "libcgranges.so")
+    t = orc.bam_read(read_golden("range.bam"))
+    names = [bytes(x).decode() for x in t["ref_names"]]
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 2000):
+        tid = rng.integers(0, len(names), n).astype(np.int32)
+        beg = rng.integers(0, 30000, n).astype(np.int64)
+        end = beg + rng.choice([0, 1, 2, 30, 700, 20000], n)
+        q = []
+        for i in range(t["n_rows"]):
+            st = int(t["POS"][i]) - 1
+            q.append((names[int(t["tid"][i])], st, ro.endpos(st, int(t["FLAG"][i]), t["CIGAR"][i])))
+        ref = ro.cgranges_overlap(lib, names, tid, beg, end, q)
+        got = ro.overlap_join(t, tid, beg, end)
+        assert all(a.tolist() == b.tolist() for a, b in zip(got, ref))
