@@ -196,8 +196,9 @@ __device__ __forceinline__ void tile_stage(const BamStream &st, uint64_t tb, uin
 
 // One wave per tile: speculate the first record start (64 candidates per step), walk the chain.
 extern "C" __global__ void __launch_bounds__(64)
-bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
+bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16_t *tile_recs, uint64_t *tile_recs_first) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
+    __shared__ uint16_t rl[TL_RECS];                          // record starts found by the walk, relative to the tile
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
     if (t >= ntiles) return;
@@ -246,6 +247,7 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
             const int rc = ((o - tb) + 64 <= (uint64_t)s.len) ? rec_hop_uniform(st, ls, o, lane, bl) : rec_hop(st, gs, o, bl);
             if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }
             if (rc == REC_INVALID) { err = 1; break; }
+            if (lane == 0 && cnt < TL_RECS) rl[cnt] = (uint16_t)(o - tb);
             cnt++; o += 4ull + bl;
         }
         en = o;
@@ -253,7 +255,11 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out) {
     if (lane == 0) {
         out.first[t] = (first != NONE64 && first < te) ? first : NONE64;
         out.end_next[t] = en; out.count[t] = cnt; out.err[t] = err;
+        tile_recs_first[t] = (first != NONE64 && first < te) ? first : NONE64;   // the list below belongs to a walk from here
     }
+    // hand the record starts to bam_tile_unpack (it falls back to its own walk when a repair round moved `first`)
+    __syncthreads();
+    for (uint32_t k = lane; k < cnt && k < TL_RECS; k += 64) tile_recs[(size_t)t * TL_RECS + k] = rl[k];
 }
 
 template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &st, const S &s, const BamDict &dict, uint64_t o, int64_t row,
@@ -306,7 +312,8 @@ template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &s
 // string lengths and the per-row scratch of the string pass.  rg_flag is one byte per row (packed to validity words later).
 extern "C" __global__ void __launch_bounds__(64)
 bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res,
-                int64_t nrows, uint32_t *rec_off, uint8_t *rg_flag, BamCols c, unsigned long long *bad_row, const uint32_t *row_map) {
+                int64_t nrows, uint32_t *rec_off, uint8_t *rg_flag, BamCols c, unsigned long long *bad_row, const uint32_t *row_map,
+                const uint16_t *tile_recs, const uint64_t *tile_recs_first) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
     __shared__ uint32_t recs[TL_RECS];
     const int lane = threadIdx.x;
@@ -321,7 +328,10 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
     LSrc s; tile_stage(st, tb, buf, s, lane);
     PSrc ls; ls.l = buf; ls.base = tb;
     GSrc gs; gs.g = st.u;
-    {   // record starts (the chain was validated by the scan / fix kernels)
+    if (tile_recs_first[t] == first) {
+        // record starts left by bam_tile_scan's walk from this same `first` (one coalesced load instead of a serial chain of hops)
+        for (uint32_t k = lane; k < n && k < TL_RECS; k += 64) recs[k] = (uint32_t)(tb + tile_recs[(size_t)t * TL_RECS + k]);
+    } else {   // the tile was re-walked by a repair round: walk again (the chain was validated by the scan / fix kernels)
         uint64_t o = first;
         for (uint32_t k = 0; k < n; k++) { if (lane == 0 && k < TL_RECS) recs[k] = (uint32_t)o; o += 4ull + (((o - tb) + 4 <= (uint64_t)s.len) ? ls.u32(o) : gs.u32(o)); }
     }

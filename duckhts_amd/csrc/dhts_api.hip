@@ -58,7 +58,7 @@ struct dhts_ctx {
     // inflated stream double buffer (carry moves between them)
     DevBuf ubuf[2]; int ucur = 0; uint64_t carry_len = 0;
     // tiles
-    DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed;
+    DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed, t_recs, t_recs_first;
     DevBuf t2_first, t2_end, t2_count, t2_err;      // second tile table: repair rounds are out of place
     // rows
     DevBuf c_rgflag;
@@ -161,7 +161,7 @@ void dhts_destroy(dhts_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     timing_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf *ovb[] = {&c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
+    DevBuf *ovb[] = {&c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
     for (auto b : ovb) b->release();
     DevBuf *all[] = {&c->comp, &c->coff, &c->clen, &c->isize, &c->uoff, &c->blk_status, &c->lit, &c->tok, &c->meta, &c->ubuf[0], &c->ubuf[1],
                      &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
@@ -1086,6 +1086,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     int64_t ntiles = (int64_t)((ulen + TILE_BYTES - 1) / TILE_BYTES); if (ntiles < 1) ntiles = 1;
     ENSURE(c, c->t_first, ntiles * 8); ENSURE(c, c->t_end, ntiles * 8); ENSURE(c, c->t_count, ntiles * 4); ENSURE(c, c->t_err, ntiles * 4);
     ENSURE(c, c->t_rowbase, ntiles * 4 + 16); ENSURE(c, c->d_res, 64); ENSURE(c, c->d_nfixed, 64);
+    ENSURE(c, c->t_recs, (size_t)ntiles * TL_RECS * 2 + 64); ENSURE(c, c->t_recs_first, ntiles * 8 + 64);
     ENSURE(c, c->t2_first, ntiles * 8); ENSURE(c, c->t2_end, ntiles * 8); ENSURE(c, c->t2_count, ntiles * 4); ENSURE(c, c->t2_err, ntiles * 4);
     TileOut to; to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
     TileOut to2; to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
@@ -1096,7 +1097,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     uint64_t res[4] = {0, 0, 0, 0};
     {
         KTimer tm(c, DHTS_K_TILES);
-        hipLaunchKernelGGL(bam_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to);
+        hipLaunchKernelGGL(bam_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to, (uint16_t *)c->t_recs.p, (uint64_t *)c->t_recs_first.p);
         int rounds = 0;
         for (;;) {
             (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
@@ -1162,7 +1163,8 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         {
             KTimer tm(c, DHTS_K_CORE);
             hipLaunchKernelGGL(bam_tile_unpack, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, dict, ntiles, to, (const uint32_t *)c->t_rowbase.p,
-                               (const uint64_t *)c->d_res.p, nrows, (uint32_t *)c->rec_off.p, (uint8_t *)c->c_rgflag.p, bc, (unsigned long long *)((uint64_t *)c->d_res.p + 4), row_map);
+                               (const uint64_t *)c->d_res.p, nrows, (uint32_t *)c->rec_off.p, (uint8_t *)c->c_rgflag.p, bc, (unsigned long long *)((uint64_t *)c->d_res.p + 4), row_map,
+                               (const uint16_t *)c->t_recs.p, (const uint64_t *)c->t_recs_first.p);
         }
         {   // the first row that fails bam_read1's validation ends the scan there (rows before it are kept)
             unsigned long long bad = ~0ull;
