@@ -282,7 +282,7 @@ extern "C" __global__ void __launch_bounds__(256) scan_apply(ScanArgs a) {
     }
 }
 
-// ---- string write pass: 16 lanes per record ----
+// ---- string write pass (bam_tile_strings in bam_tiles_lds.hip): outputs and 16-byte converters ----
 struct BamStrOut {
     const uint32_t *off_qname, *off_cigar, *off_seq, *off_qual, *off_rg;
     uint8_t *qname, *cigar, *seq, *qual, *rg;
@@ -324,105 +324,6 @@ __device__ __forceinline__ void store_n16(uint8_t *d, const uint32_t w[4], uint3
         if (n & 4) { __builtin_memcpy(d, &a0, 4); d += 4; a0 = a1; }
         if (n & 2) { uint16_t h = (uint16_t)a0; __builtin_memcpy(d, &h, 2); d += 2; a0 >>= 16; }
         if (n & 1) *d = (uint8_t)a0;
-    }
-}
-
-// 16 lanes per record.  Every input of a record (row metadata, the first 16-byte chunk of each field) is loaded BEFORE the first
-// store: stores may alias the inputs as far as the compiler knows, so interleaving them serialises ~15 dependent HBM round trips
-// per record (PMC: 82 % of the wave time was s_waitcnt).  Fields longer than one pass (> 256 bytes / > 16 CIGAR ops) loop after.
-extern "C" __global__ void __launch_bounds__(256)
-bam_string_write(BamStream st, const uint32_t *rec_off, int64_t nrows, uint32_t colmask, BamCols c, BamStrOut s) {
-    const int gl = threadIdx.x & 15;                                  // lane within the 16-lane group
-    int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const bool act = row < nrows;
-    const int64_t r = act ? row : 0;
-    const uint8_t *u = st.u;
-    // ---- level 1: everything addressed by the row id ----
-    const uint64_t o = rec_off[r];
-    const uint32_t off_qn = s.off_qname[r], len_qn = c.len_qname[r], rl = c.len_rg[r], off_rg = s.off_rg[r], rg_rel = c.rg_rel[r];
-    const uint32_t off_seq = s.off_seq[r], off_qual = s.off_qual[r], ne = act ? c.ncig_eff[r] : 0, cig_rel = c.cig_rel[r], off_cig = s.off_cigar[r];
-    // ---- level 2: the record ----
-    const uint32_t x2 = ldu32(u + o + 12), x3 = ldu32(u + o + 16);
-    const int32_t l_seq = (int32_t)ldu32(u + o + 20);
-    const uint32_t l_qname = x2 & 0xff, n_cigar = x3 & 0xffff;
-    const uint8_t *seq = u + o + 36 + l_qname + 4ull * n_cigar;
-    const uint8_t *qual = seq + (((uint64_t)(l_seq > 0 ? l_seq : 0) + 1) >> 1);
-    const uint8_t *cig = u + o + cig_rel;
-    const uint32_t b0 = (uint32_t)gl * 16u;
-    uint4 vq = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
-    if (act && b0 < len_qn) __builtin_memcpy(&vq, u + o + 36 + b0, 16);               // reads past short fields stay inside the padded buffer
-    if (act && b0 < rl) __builtin_memcpy(&vr, u + o + rg_rel + b0, 16);
-    uint32_t p0 = 0, p1 = 0, wq[4] = {0, 0, 0, 0};
-    const bool in_seq = act && l_seq > 0 && b0 < (uint32_t)l_seq;
-    if (in_seq) { p0 = ldu32(seq + (b0 >> 1)); p1 = ldu32(seq + (b0 >> 1) + 4); __builtin_memcpy(wq, qual + b0, 16); }
-    const uint8_t q0 = (act && l_seq > 0) ? qual[0] : 255;
-    const uint32_t op0 = ((uint32_t)gl < ne) ? ldu32(cig + 4ull * gl) : 0;
-    // ---- stores ----
-    if (act) {
-        // QNAME / READ_GROUP_ID
-        if (b0 < len_qn) { const uint32_t w4[4] = {vq.x, vq.y, vq.z, vq.w}; store_n16(s.qname + off_qn + b0, w4, len_qn - b0); }
-        for (uint32_t b = b0 + 256; b < len_qn; b += 256) { uint32_t w4[4]; __builtin_memcpy(w4, u + o + 36 + b, 16); store_n16(s.qname + off_qn + b, w4, len_qn - b); }
-        if (b0 < rl) { const uint32_t w4[4] = {vr.x, vr.y, vr.z, vr.w}; store_n16(s.rg + off_rg + b0, w4, rl - b0); }
-        for (uint32_t b = b0 + 256; b < rl; b += 256) { uint32_t w4[4]; __builtin_memcpy(w4, u + o + rg_rel + b, 16); store_n16(s.rg + off_rg + b, w4, rl - b); }
-        // SEQ
-        uint8_t *dseq = s.seq + off_seq;
-        if (l_seq <= 0) { if (gl == 0) dseq[0] = '*'; }
-        else {
-            if (in_seq) { uint32_t w[4]; seq16(p0, p1, w); store_n16(dseq + b0, w, (uint32_t)l_seq - b0); }
-            for (uint32_t b = b0 + 256; b < (uint32_t)l_seq; b += 256) { uint32_t w[4]; seq16(ldu32(seq + (b >> 1)), ldu32(seq + (b >> 1) + 4), w); store_n16(dseq + b, w, (uint32_t)l_seq - b); }
-        }
-    }
-    // QUAL (+33), truncated at the first byte that becomes NUL
-    {
-        uint32_t firstnul = 0xffffffffu;
-        const bool star = act && !(l_seq > 0 && q0 != 255);
-        uint8_t *dq = s.qual + off_qual;
-        if (act && star) { if (gl == 0) dq[0] = '*'; }
-        else if (act) {
-            if (in_seq) {
-                const uint32_t n = (uint32_t)l_seq - b0 < 16 ? (uint32_t)l_seq - b0 : 16;
-                if (qual16(wq)) for (uint32_t k = 0; k < n; k++) if (((wq[k >> 2] >> (8 * (k & 3))) & 0xff) == 0) { if (firstnul == 0xffffffffu) firstnul = b0 + k; }
-                store_n16(dq + b0, wq, n);
-            }
-            for (uint32_t b = b0 + 256; b < (uint32_t)l_seq; b += 256) {
-                const uint32_t n = (uint32_t)l_seq - b < 16 ? (uint32_t)l_seq - b : 16;
-                uint32_t w[4]; __builtin_memcpy(w, qual + b, 16);
-                if (qual16(w)) for (uint32_t k = 0; k < n; k++) if (((w[k >> 2] >> (8 * (k & 3))) & 0xff) == 0) { if (firstnul == 0xffffffffu) firstnul = b + k; }
-                store_n16(dq + b, w, n);
-            }
-        }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) { uint32_t t = __shfl_xor(firstnul, d, 64); firstnul = t < firstnul ? t : firstnul; }
-        if (act && gl == 0) s.alen_qual[row] = star ? 1u : (firstnul != 0xffffffffu ? firstnul : (uint32_t)l_seq);
-    }
-    // CIGAR text: 16 ops per pass, group prefix sum of the per-op text widths
-    {
-        uint8_t *dc = s.cigar + off_cig;
-        if (act && ne == 0 && gl == 0) dc[0] = '*';
-        // trip count must be uniform across the 16-lane group (it is: ne is per-row) but groups differ: use max over the wave
-        uint32_t nmax = ne;
-#pragma unroll
-        for (int d = 32; d >= 16; d >>= 1) { uint32_t t = __shfl_xor(nmax, d, 64); nmax = t > nmax ? t : nmax; }
-        uint32_t base = 0;
-        for (uint32_t k0 = 0; k0 < nmax; k0 += 16) {
-            uint32_t k = k0 + gl; bool has = k < ne;
-            uint32_t op = has ? (k0 == 0 ? op0 : ldu32(cig + 4ull * k)) : 0;
-            uint32_t ol = op >> 4, w = has ? ndigits(ol) + 1 : 0;
-            uint32_t inc = w;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { uint32_t t = __shfl_up(inc, d, 16); if (gl >= d) inc += t; }
-            uint32_t tot = __shfl(inc, 15, 16);
-            if (has) {
-                uint32_t p = base + inc - w, nd = w - 1;
-                for (uint32_t q = 0; q < nd; q++) { dc[p + nd - 1 - q] = (uint8_t)('0' + ol % 10); ol /= 10; }
-                // sam.h:112 BAM_CIGAR_STR "MIDNSHP=XB", '?' beyond; byte gather with v_perm_b32
-                const uint32_t C0 = 0x4e44494du, C1 = 0x3d504853u, C2 = 0x3f3f4258u, C3 = 0x3f3f3f3fu;
-                uint32_t oc = op & 0xf, selb = (oc & 7u) | 0x0c0c0c00u;
-                uint32_t chv = (oc & 8u) ? __builtin_amdgcn_perm(C3, C2, selb) : __builtin_amdgcn_perm(C1, C0, selb);
-                dc[p + nd] = (uint8_t)chv;
-            }
-            base += tot;
-        }
     }
 }
 

@@ -399,7 +399,9 @@ __device__ __forceinline__ uint32_t ts_qual_chunk(const TsSrc &src, uint64_t qua
 }
 extern "C" __global__ void __launch_bounds__(64)
 bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res, int64_t nrows_all, int64_t nrows,
-                 const uint32_t *rec_off, const uint32_t *row_map, BamCols c, BamStrOut s) {
+                 const uint32_t *rec_off, const uint32_t *row_map, BamCols c, BamStrOut s, uint32_t colmask) {
+    // colmask: projection pushdown (bit = read_bam column id): heaps of columns that are not projected are not written
+    const bool w_qn = colmask & (1u << 0), w_cig = colmask & (1u << 5), w_seq = colmask & (1u << 9), w_qual = colmask & (1u << 10), w_rg = colmask & (1u << 11);
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
     __shared__ uint32_t r_seq[64], r_lseq[64], r_oseq[64], r_oqual[64], r_c0[64], r_nul[64];
     __shared__ uint8_t cmap[TS_MAPN];
@@ -443,7 +445,7 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
         const uint64_t qual = seq + (((uint64_t)l_seq + 1) >> 1);
         const bool star = !(l_seq > 0 && (uint8_t)src.u32(qual) != 255);
         const bool lng = l_seq > TS_LONG;
-        const uint32_t nch = (ok && !lng) ? (l_seq + 15u) >> 4 : 0u;
+        const uint32_t nch = (ok && !lng && (w_seq || w_qual)) ? (l_seq + 15u) >> 4 : 0u;
         const uint32_t cinc = wave_incl_scan(nch, lane);
         const uint32_t T = RDLANE(cinc, 63), c0 = cinc - nch;
         r_seq[lane] = (uint32_t)(seq - tb); r_lseq[lane] = star ? (l_seq | 0x80000000u) : l_seq; r_oseq[lane] = off_seq; r_oqual[lane] = off_qual;
@@ -456,8 +458,8 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
             if (ch < T) {
                 const uint32_t j = cmap[ch], k = ch - r_c0[j], ls = r_lseq[j], lq = ls & 0x7fffffffu;
                 const uint64_t sq = tb + r_seq[j];
-                ts_seq_chunk(src, sq, lq, k, s.seq + r_oseq[j]);
-                if (!(ls >> 31)) {
+                if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + r_oseq[j]);
+                if (w_qual && !(ls >> 31)) {
                     const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + r_oqual[j]);
                     if (fz != 0xffffffffu) atomicMin(&r_nul[j], fz);
                 }
@@ -465,22 +467,22 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
         }
         // ---- per-row pieces ----
         if (ok) {
-            if (l_seq == 0) s.seq[off_seq] = '*';
-            if (star) s.qual[off_qual] = '*';
-            for (uint32_t b = 0; b < len_qn; b += 16) {
+            if (w_seq && l_seq == 0) s.seq[off_seq] = '*';
+            if (w_qual && star) s.qual[off_qual] = '*';
+            for (uint32_t b = 0; w_qn && b < len_qn; b += 16) {
                 const uint64_t a = src.u64(o + 36 + b), e = src.u64(o + 36 + b + 8);
                 const uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)e, (uint32_t)(e >> 32)};
                 store_n16(s.qname + off_qn + b, w, len_qn - b);
             }
-            for (uint32_t b = 0; b < rl; b += 16) {
+            for (uint32_t b = 0; w_rg && b < rl; b += 16) {
                 const uint64_t a = src.u64(o + rg_rel + b), e = src.u64(o + rg_rel + b + 8);
                 const uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)e, (uint32_t)(e >> 32)};
                 store_n16(s.rg + off_rg + b, w, rl - b);
             }
             uint8_t *dc = s.cigar + off_cig;
-            if (ne == 0) dc[0] = '*';
+            if (w_cig && ne == 0) dc[0] = '*';
             uint32_t p = 0;
-            for (uint32_t q = 0; q < ne; q++) {
+            for (uint32_t q = 0; w_cig && q < ne; q++) {
                 const uint32_t op = src.u32(o + cig_rel + 4ull * q);
                 uint32_t ol = op >> 4; const uint32_t nd = ndigits(ol);
                 for (uint32_t z = 0; z < nd; z++) { dc[p + nd - 1 - z] = (uint8_t)('0' + ol % 10); ol /= 10; }
@@ -492,20 +494,20 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
             }
         }
         // ---- long fields: the whole wave streams one row at a time ----
-        uint64_t LM = __ballot(ok && lng);
+        uint64_t LM = __ballot(ok && lng && (w_seq || w_qual));
         while (LM) {
             const int i = __ffsll((unsigned long long)LM) - 1; LM &= LM - 1;
             const uint32_t lq = RDLANE(l_seq, i), st_i = RDLANE((uint32_t)star, i), os = RDLANE(off_seq, i), oq = RDLANE(off_qual, i);
             const uint64_t sq = ((uint64_t)RDLANE((uint32_t)(seq >> 32), i) << 32) | RDLANE((uint32_t)seq, i);
             uint32_t fzm = 0xffffffffu;
             for (uint32_t k = lane; k < (lq + 15u) >> 4; k += 64) {
-                ts_seq_chunk(src, sq, lq, k, s.seq + os);
-                if (!st_i) { const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + oq); fzm = fz < fzm ? fz : fzm; }
+                if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + os);
+                if (w_qual && !st_i) { const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + oq); fzm = fz < fzm ? fz : fzm; }
             }
             if (fzm != 0xffffffffu) atomicMin(&r_nul[i], fzm);
         }
         __syncthreads();
-        if (ok) { const uint32_t fz = r_nul[lane]; s.alen_qual[d] = star ? 1u : (fz != 0xffffffffu ? fz : l_seq); }
+        if (ok && w_qual) { const uint32_t fz = r_nul[lane]; s.alen_qual[d] = star ? 1u : (fz != 0xffffffffu ? fz : l_seq); }
         __syncthreads();
     }
 }

@@ -520,33 +520,23 @@ __device__ __forceinline__ void lds_st_n(uint8_t *p, uint64_t v, uint32_t n) {  
     if (n & 1) *p = (uint8_t)v;
 }
 
-// Window ring: 32 KiB of DEFLATE history + 2 KiB of batch span (a batch places its literals before its matches, so a
-// batch may run at most BR_SPAN bytes ahead of the oldest byte a match of the same batch can still need).
-// 34,816 + 4,096 (CRC tables) + 2,048 (literal ring) = 40,960 B: four workgroups per CU.
-#ifndef B_SMALLRING
-#define B_SMALLRING 1
-#endif
-#if B_SMALLRING
-// Power-of-two ring of 2^B_RING_LOG2 bytes, flushed progressively in half-ring chunks: it holds the unflushed tail (< half a ring
-// + one batch span) plus the most recent history.  Matches whose source is older than the ring read the bytes back from the
-// block's own output in HBM (such sources always lie below `flushed`, see BR_FLUSH).  4 KiB ring: 10,240 B of LDS per block
-// instead of 40,704, i.e. sixteen workgroups per CU instead of four, so every SIMD holds four waves that fill each other's issue
-// slots (measured per 16,384-block launch: 6.1 ms with the full 34.5 KB window, 4.45 ms with 16 KiB, 3.5 ms with 8 KiB; with the
-// far loads issued together 3.17 ms at 8 KiB and 2.48 ms at 4 KiB).
+// Window ring: a power-of-two ring of 2^B_RING_LOG2 bytes, flushed progressively in half-ring chunks: it holds the unflushed tail
+// (< half a ring + one batch span) plus the most recent history.  A batch places its literals before its matches, so it may run at
+// most BR_SPAN bytes ahead of the oldest byte one of its own matches can still need.  Matches whose source is older than the ring
+// read the bytes back from the block's own output in HBM (such sources always lie below `flushed`, see the static_assert).
+// 4 KiB ring: 10,240 B of LDS per block, i.e. sixteen workgroups per CU, so every SIMD holds four waves that fill each other's
+// issue slots (measured per 16,384-block launch: 6.1 ms with a full 34.5 KB DEFLATE window in LDS, 4.45 ms with a 16 KiB ring,
+// 3.5 ms with 8 KiB; with the far loads issued together 3.17 ms at 8 KiB and 2.48 ms at 4 KiB).
 #ifndef B_RING_LOG2
 #define B_RING_LOG2 12
 #endif
 #define BR_R (1u << B_RING_LOG2)
-#define BR_FLUSH (BR_R / 2u)             /* needs BR_R >= BR_FLUSH + BR_SPAN + 265 so that far sources are always flushed */
-#else
-#define BR_R 34560u
-#define BR_FLUSH 8192u
-#endif
+#define BR_FLUSH (BR_R / 2u)
 #define BR_PIECE (BR_FLUSH / 64u)        /* bytes of a flush chunk CRC'd by one lane */
 #ifndef BR_SPAN
 #define BR_SPAN 1536u
 #endif
-static_assert(!B_SMALLRING || BR_R >= BR_FLUSH + BR_SPAN + 265u, "far sources must always be flushed");
+static_assert(BR_R >= BR_FLUSH + BR_SPAN + 265u, "far sources must always be flushed");
 #define B_WIN 0
 #define B_CRCT (BR_R)                    /* u32 [4][256] slice-by-4 tables */
 #define B_RING (B_CRCT + 4096)           /* u8 [2048] literal staging ring */
@@ -569,11 +559,7 @@ __device__ unsigned long long g_diagt[8];
 #endif
 
 
-#if B_SMALLRING
 __device__ __forceinline__ uint32_t ridx(uint32_t p) { return p & (BR_R - 1u); }
-#else
-__device__ __forceinline__ uint32_t ridx(uint32_t p) { return p >= BR_R ? p - BR_R : p; }      // p < 2*BR_R
-#endif
 __device__ __forceinline__ uint64_t win_ld64(const uint8_t *win, uint32_t p) {
     const uint32_t i = ridx(p);
     if (i + 8 <= BR_R) return lds_ld64(win + i);
@@ -678,7 +664,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             uint4 v4_ = *(const uint4 *)(win + ridx(p_));                                                               \
             __builtin_memcpy(dstp + p_, &v4_, 16);                                                                      \
         }                                                                                                               \
-        if (B_SMALLRING) __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0): the chunk is in L2 before any far-match read-back */ \
+        __builtin_amdgcn_s_waitcnt(0x0f70);                   /* vmcnt(0): the chunk is in L2 before any far-match read-back */ \
         flushed += BR_FLUSH;                                                                                            \
     } while (0)
 
@@ -730,7 +716,6 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
             uint32_t sh = 4; while ((tot_adv >> sh) > 63u) sh++;
             uint64_t dmask = 0, smask = 0;
-#if B_SMALLRING
             // sources below rlo are overwritten in the ring by this batch's own output: they come from HBM (always < flushed)
             const uint32_t bend = outpos + tot_adv, rlo = bend > BR_R ? bend - BR_R : 0u;
             const bool farm = mlen > 0 && ms < rlo;
@@ -748,9 +733,6 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
                 if (mlen > 24u) win_st_n(win, md + 24, v3, mlen - 24u);
                 for (uint32_t c = 32; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, g + c, 8); win_st_n(win, md + c, v, mlen - c); }
             }
-#else
-            const bool farm = false;
-#endif
             if (mlen > 0) {
                 const uint32_t lo = (md - outpos) >> sh, hi = (md - outpos + mlen - 1) >> sh;
                 dmask = ((~0ull) >> (63u - hi)) & ((~0ull) << lo);
@@ -762,7 +744,7 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             uint64_t P = __ballot(mlen > 0 && !farm);
             DIAG_T(t_b2);
             DIAG_TADD(7, t_b, t_b2);
-            if (B_SMALLRING) __syncthreads();                  // far copies are in the ring before anybody reads them
+            __syncthreads();                                   // far copies are in the ring before anybody reads them
             DIAG_ADD(6, __popcll(P)); DIAG_ADD(5, __popcll(__ballot(farm)));
             while (P) {
                 DIAG_ADD(1, 1);
@@ -818,14 +800,9 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
                 __syncthreads();
                 if (ml) {
                     const uint32_t src0 = outpos - di;
-#if B_SMALLRING
                     const uint32_t thr = outpos + ml > BR_R ? outpos + ml - BR_R : 0u;      // older bytes are read back from HBM
                     if (ml <= di) { for (uint32_t k = lane; k < ml; k += 64) { const uint32_t sx = src0 + k; win[ridx(outpos + k)] = sx < thr ? dstp[sx] : win[ridx(sx)]; } }
                     else { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + (k % di))]; }          // overlapping: dist < 258, never far
-#else
-                    if (ml <= di) { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + k)]; }
-                    else { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + (k % di))]; }
-#endif
                     outpos += ml;
                     __syncthreads();
                 }

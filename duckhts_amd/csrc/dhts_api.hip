@@ -1196,26 +1196,25 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
             KTimer tm(c, DHTS_K_CORE);
             hipLaunchKernelGGL(bam_pack_validity, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->c_rgflag.p, nrows, (uint64_t *)c->c_rgvalid.p);
         }
-        const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
         uint32_t *o32[5] = {(uint32_t *)c->o_qname.p, (uint32_t *)c->o_cigar.p, (uint32_t *)c->o_seq.p, (uint32_t *)c->o_qual.p, (uint32_t *)c->o_rg.p};
         uint64_t tot[5] = {0, 0, 0, 0, 0};
-        {
-            KTimer tm(c, DHTS_K_SCAN);
-            if (run_scan(c, 5, in, o32, nullptr, nrows, nullptr)) return -1;
-        }
-        HIPCHK(c, hipMemcpyAsync(tot, c->scan_total.p, 40, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        ENSURE(c, c->a_qname, tot[0] + PAD_BYTES); ENSURE(c, c->a_cigar, tot[1] + PAD_BYTES); ENSURE(c, c->a_seq, tot[2] + PAD_BYTES);
-        ENSURE(c, c->a_qual, tot[3] + PAD_BYTES); ENSURE(c, c->a_rg, tot[4] + PAD_BYTES);
-        BamStrOut so; so.off_qname = o32[0]; so.off_cigar = o32[1]; so.off_seq = o32[2]; so.off_qual = o32[3]; so.off_rg = o32[4];
-        so.qname = (uint8_t *)c->a_qname.p; so.cigar = (uint8_t *)c->a_cigar.p; so.seq = (uint8_t *)c->a_seq.p; so.qual = (uint8_t *)c->a_qual.p; so.rg = (uint8_t *)c->a_rg.p;
-        so.alen_qual = (uint32_t *)c->alen_qual.p;
-        {
+        BamStrOut so; memset(&so, 0, sizeof(so));
+        so.off_qname = o32[0]; so.off_cigar = o32[1]; so.off_seq = o32[2]; so.off_qual = o32[3]; so.off_rg = o32[4]; so.alen_qual = (uint32_t *)c->alen_qual.p;
+        const uint32_t str_cols = (1u << DHTS_BAM_QNAME) | (1u << DHTS_BAM_CIGAR) | (1u << DHTS_BAM_SEQ) | (1u << DHTS_BAM_QUAL) | (1u << DHTS_BAM_READ_GROUP_ID);
+        if (colmask & str_cols) {      // projection pushdown: with no string column projected the whole string pass is skipped
+            const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
+            {
+                KTimer tm(c, DHTS_K_SCAN);
+                if (run_scan(c, 5, in, o32, nullptr, nrows, nullptr)) return -1;
+            }
+            HIPCHK(c, hipMemcpyAsync(tot, c->scan_total.p, 40, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            ENSURE(c, c->a_qname, tot[0] + PAD_BYTES); ENSURE(c, c->a_cigar, tot[1] + PAD_BYTES); ENSURE(c, c->a_seq, tot[2] + PAD_BYTES);
+            ENSURE(c, c->a_qual, tot[3] + PAD_BYTES); ENSURE(c, c->a_rg, tot[4] + PAD_BYTES);
+            so.qname = (uint8_t *)c->a_qname.p; so.cigar = (uint8_t *)c->a_cigar.p; so.seq = (uint8_t *)c->a_seq.p; so.qual = (uint8_t *)c->a_qual.p; so.rg = (uint8_t *)c->a_rg.p;
             KTimer tm(c, DHTS_K_STRINGS);
-            static const bool legacy = getenv("DHTS_LEGACY_STRINGS") != nullptr;      // the row-centric kernel, kept for A/B timing
-            if (legacy) hipLaunchKernelGGL(bam_string_write, dim3((unsigned)((nrows * 16 + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nrows, colmask, bc, so);
-            else hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
-                                    nrows_scan, nrows, (const uint32_t *)c->rec_off.p, row_map_s, bc, so);
+            hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
+                               nrows_scan, nrows, (const uint32_t *)c->rec_off.p, row_map_s, bc, so, colmask);
         }
         HIPCHK(c, hipGetLastError());
         out->flag = bc.flag; out->pos = bc.pos; out->mapq = bc.mapq; out->pnext = bc.pnext; out->tlen = bc.tlen; out->tid = bc.tid; out->mtid = bc.mtid;

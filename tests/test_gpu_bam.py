@@ -276,6 +276,44 @@ def test_region_synthetic_with_unplaced_and_batches():
         _region_check(data, region, max_blocks=7)
 
 
+# ---- projection pushdown into the string pass ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cols", [("QNAME", "SEQ"), ("QUAL",), ("CIGAR", "READ_GROUP_ID"), ("FLAG", "POS")])
+def test_projected_string_columns(cols):
+    """dhts_bam_next_batch(colmask): heaps of unprojected string columns are not written; projected ones are unchanged"""
+    data = synth.bam_file(30000, seed=3)
+    exp = orc.bam_read(data)
+    ids = {"QNAME": 0, "FLAG": 1, "POS": 3, "CIGAR": 5, "SEQ": 9, "QUAL": 10, "READ_GROUP_ID": 11}
+    mask = 0
+    for c in cols:
+        mask |= 1 << ids[c]
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(data); ctx.bgzf_index(); ctx.bam_open()
+        row = 0
+        while True:
+            b = ctx.next_batch(5, colmask=mask)
+            n = int(b.n_rows)
+            for c in cols:
+                if c in ("FLAG", "POS"):
+                    got = ctx.d2h(b.flag if c == "FLAG" else b.pos, n, np.uint16 if c == "FLAG" else np.int64)
+                    assert got.tolist() == list(exp[c][row:row + n])
+                    continue
+                col = {"QNAME": b.qname, "CIGAR": b.cigar, "SEQ": b.seq, "QUAL": b.qual, "READ_GROUP_ID": b.rg}[c]
+                off = ctx.d2h(col.off, n + 1, np.uint32); ln = ctx.d2h(col.len, n, np.uint32)
+                heap = ctx.d2h(col.bytes, int(col.nbytes), np.uint8).tobytes()
+                for i in range(n):
+                    e = exp[c][row + i]
+                    if e is not None:
+                        assert heap[off[i]:off[i] + ln[i]] == bytes(e), (c, row + i)
+            row += n
+            if b.status != 0:
+                break
+        assert row == exp["n_rows"]
+    finally:
+        ctx.close()
+
+
 # ---- interval overlap join (SURVEY 8(f) item 1, config 5) ----------------------------------------------------------------
 def _overlap_check(data, tid, beg, end, region=None, max_blocks=0):
     import sys
