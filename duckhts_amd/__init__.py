@@ -74,7 +74,7 @@ ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
-           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_set_overlap_intervals", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
+           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_set_overlap_intervals", "dhts_bam_build_index", "dhts_bam_index_bytes", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch"]
 
@@ -112,6 +112,9 @@ def lib():
         L.dhts_bam_std_tag_info.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.dhts_bam_set_tag_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.dhts_bam_set_aux_map.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.dhts_bam_build_index.restype = C.c_int64
+        L.dhts_bam_build_index.argtypes = [C.c_void_p]
+        L.dhts_bam_index_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bam_set_overlap_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.dhts_bam_load_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.dhts_bam_next_batch.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.POINTER(BamBatch)]
@@ -228,6 +231,13 @@ class Context:
         arr = np.array(list(ids), np.int32)
         self._chk(self.L.dhts_bam_set_tag_columns(self.h, arr.ctypes.data, len(arr)))
         self._tag_ids = list(ids)
+
+    def build_index(self):
+        """BAI bytes for the open BAM (one whole-file scan; hts_idx_push / hts_idx_finish restated on the host)"""
+        n = self._chk(self.L.dhts_bam_build_index(self.h))
+        out = np.empty(n, np.uint8)
+        self._chk(self.L.dhts_bam_index_bytes(self.h, out.ctypes.data, n))
+        return out.tobytes()
 
     def set_overlap_intervals(self, tid, beg, end):
         """Interval overlap join (cgranges cr_overlap semantics): intervals (tid, beg, end) half-open 0-based, tid = BAM header index."""

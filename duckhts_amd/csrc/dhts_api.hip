@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
+#include <map>
 #include <algorithm>
 #include <limits.h>
 
@@ -49,6 +50,8 @@ struct dhts_ctx {
     std::vector<uint64_t> h_coff, h_uoff; std::vector<uint32_t> h_clen, h_isize;
     // inflate scratch
     DevBuf lit, tok, meta;
+    // index writer
+    std::vector<uint8_t> built_index; DevBuf ix_end; BamStream last_stream;   // last_stream: the inflated buffer of the latest batch
     // interval overlap join
     bool ov_active = false; int64_t ov_n = 0;
     DevBuf ov_beg, ov_end, ov_pmax, ov_bmax, ov_id, ov_first, ov_cnt, ov_off, ov_ids;
@@ -161,7 +164,7 @@ void dhts_destroy(dhts_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     timing_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf *ovb[] = {&c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
+    DevBuf *ovb[] = {&c->ix_end, &c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
     for (auto b : ovb) b->release();
     DevBuf *all[] = {&c->comp, &c->coff, &c->clen, &c->isize, &c->uoff, &c->blk_status, &c->lit, &c->tok, &c->meta, &c->ubuf[0], &c->ubuf[1],
                      &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
@@ -863,6 +866,178 @@ static int bam_aux_map(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam
 }
 
 // materialises the selected tag columns for the (final, compacted) rows of the current batch
+// ---- BAI writer ----------------------------------------------------------------------------------------
+// Restates samtools-style index building: sam_index (htslib sam.c:989-1027) = hts_idx_init + hts_idx_push per record +
+// hts_idx_finish (hts.c:2400-2690: insert_to_b / insert_to_l 2315-2363, update_loff 2426-2455, compress_binning 2457-2508) and
+// idx_save_core (hts.c:2754-2818).  The scan supplies (tid, pos, bam_endpos, mapped) per record; virtual offsets follow
+// bgzf_tell's rule (bgzf.c bgzf_read: a read that ends exactly at a block end reports the NEXT block's address with offset 0).
+// Bins are written in ascending order (the reference writes them in khash order; readers do not depend on it).
+namespace {
+struct BaiBuild {
+    int n_ref = 0; const int min_shift = 14, n_lvls = 5; const uint32_t n_bins = ((1u << (3 * 5 + 3)) - 1) / 7;
+    struct Ch { uint64_t u, v; };
+    std::vector<std::map<uint32_t, std::vector<Ch>>> bidx; std::vector<char> has_b; std::vector<std::vector<uint64_t>> lidx;
+    int32_t save_tid = -1, last_tid = -1; uint32_t save_bin = 0xffffffffu, last_bin = 0xffffffffu;
+    uint64_t save_off = 0, last_off = 0, off_beg = 0, off_end = 0, n_mapped = 0, n_unmapped = 0, n_no_coor = 0; int64_t last_coor = 0xffffffffll;
+    std::string err;
+    void init(int n, uint64_t offset0) { n_ref = n; bidx.assign(n, {}); has_b.assign(n, 0); lidx.assign(n, {}); save_off = last_off = off_beg = off_end = offset0; }
+    static uint32_t reg2bin(int64_t beg, int64_t end) {                    // hts_reg2bin, min_shift 14, 5 levels
+        int s = 14; uint32_t t = ((1u << 15) - 1) / 7;
+        --end;
+        for (int l = 5; l > 0; --l, s += 3, t -= 1u << ((l << 1) + l)) if ((beg >> s) == (end >> s)) return t + (uint32_t)(beg >> s);
+        return 0;
+    }
+    bool push(int32_t tid, int64_t beg, int64_t end, uint64_t offset, bool mapped) {
+        if (tid < 0) { beg = -1; end = 0; }
+        const int64_t maxpos = 1ll << (14 + 15);
+        if (tid >= 0 && !(beg <= maxpos && end <= maxpos)) { err = "Region cannot be stored in a bai index. Try using a csi index"; return false; }
+        if (tid >= n_ref) { err = "record refers to a reference beyond the header"; return false; }
+        if (last_tid != tid || (last_tid >= 0 && tid < 0)) {
+            if (tid >= 0 && n_no_coor) { err = "NO_COOR reads not in a single block at the end"; return false; }
+            if (tid >= 0 && has_b[tid]) { err = "Chromosome blocks not continuous"; return false; }
+            last_tid = tid; last_bin = 0xffffffffu;
+        } else if (tid >= 0 && last_coor > beg) { err = "Unsorted positions"; return false; }
+        if (end < beg) { err = "Invalid record: end < begin"; return false; }
+        if (tid >= 0) {
+            has_b[tid] = 1;
+            if (beg < 0) beg = 0;
+            if (end <= 0) end = 1;
+            std::vector<uint64_t> &l = lidx[tid];
+            const int64_t b = beg >> 14, e = (end - 1) >> 14;
+            if ((int64_t)l.size() < e + 1) l.resize((size_t)e + 1, ~0ull);
+            for (int64_t i = b; i <= e; i++) if (l[(size_t)i] == ~0ull) l[(size_t)i] = last_off;
+        } else n_no_coor++;
+        const uint32_t bin = reg2bin(beg, end);
+        if (last_bin != bin) {
+            if (save_bin != 0xffffffffu) bidx[save_tid][save_bin].push_back({save_off, last_off});
+            if (last_bin == 0xffffffffu && save_bin != 0xffffffffu) {
+                off_end = last_off;
+                bidx[save_tid][n_bins + 1].push_back({off_beg, off_end});
+                bidx[save_tid][n_bins + 1].push_back({n_mapped, n_unmapped});
+                n_mapped = n_unmapped = 0; off_beg = off_end;
+            }
+            save_off = last_off; save_bin = last_bin = bin; save_tid = tid;
+        }
+        if (mapped) ++n_mapped; else ++n_unmapped;
+        last_off = offset; last_coor = beg;
+        return true;
+    }
+    void finish(uint64_t final_offset) {
+        if (save_tid >= 0) {
+            bidx[save_tid][save_bin].push_back({save_off, final_offset});
+            bidx[save_tid][n_bins + 1].push_back({off_beg, final_offset});
+            bidx[save_tid][n_bins + 1].push_back({n_mapped, n_unmapped});
+        }
+        for (int i = 0; i < n_ref; i++) {
+            std::vector<uint64_t> &l = lidx[i];
+            for (int64_t k = (int64_t)l.size() - 2; k >= 0; k--) if (l[(size_t)k] == ~0ull) l[(size_t)k] = l[(size_t)k + 1];   // update_loff
+            if (!has_b[i]) continue;
+            auto &B = bidx[i];
+            auto by_u = [](const Ch &a, const Ch &b) { return a.u < b.u; };
+            for (int lv = n_lvls; lv > 0; --lv) {                                    // compress_binning
+                const uint32_t start = ((1u << ((lv << 1) + lv)) - 1) / 7;
+                std::vector<uint32_t> keys;
+                for (auto &kv : B) if (kv.first < n_bins && kv.first >= start) keys.push_back(kv.first);
+                for (uint32_t key : keys) {
+                    auto it = B.find(key); if (it == B.end()) continue;
+                    std::vector<Ch> &p = it->second;
+                    if (lv < n_lvls && p.size() > 1) std::sort(p.begin(), p.end(), by_u);
+                    if ((p.back().v >> 16) - (p.front().u >> 16) < 0x10000ull) {
+                        auto q = B.find((key - 1) >> 3);
+                        if (q == B.end()) continue;
+                        q->second.insert(q->second.end(), p.begin(), p.end());
+                        B.erase(it);
+                    }
+                }
+            }
+            auto z = B.find(0); if (z != B.end()) std::sort(z->second.begin(), z->second.end(), by_u);
+            for (auto &kv : B) {                                                     // merge adjacent chunks that start from the same BGZF block
+                if (kv.first >= n_bins) continue;
+                std::vector<Ch> &p = kv.second; size_t m = 0;
+                for (size_t l2 = 1; l2 < p.size(); ++l2) {
+                    if ((p[m].v >> 16) >= (p[l2].u >> 16)) { if (p[m].v < p[l2].v) p[m].v = p[l2].v; }
+                    else p[++m] = p[l2];
+                }
+                p.resize(m + 1);
+            }
+        }
+    }
+    void save(std::vector<uint8_t> &o) const {
+        auto w32 = [&](uint32_t x) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(x >> (8 * k))); };
+        auto w64 = [&](uint64_t x) { for (int k = 0; k < 8; k++) o.push_back((uint8_t)(x >> (8 * k))); };
+        o.clear(); o.push_back('B'); o.push_back('A'); o.push_back('I'); o.push_back(1);
+        w32((uint32_t)n_ref);
+        for (int i = 0; i < n_ref; i++) {
+            w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
+            if (has_b[i]) for (auto &kv : bidx[i]) { w32(kv.first); w32((uint32_t)kv.second.size()); for (auto &ch : kv.second) { w64(ch.u); w64(ch.v); } }
+            w32((uint32_t)lidx[i].size());
+            for (uint64_t x : lidx[i]) w64(x);
+        }
+        w64(n_no_coor);
+    }
+};
+}  // namespace
+
+// Builds a BAI for the open BAM with one full scan (the scan state is rewound before and after).  Returns the index size.
+int64_t dhts_bam_build_index(dhts_ctx *c) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->rg_active || c->shard_b0 != 0 || c->shard_b1 != c->n_blocks || c->ov_active) return fail(c, "index build needs a whole-file scan (no region, shard or join)");
+    if (dhts_bam_rewind(c)) return -1;
+    const int64_t nb = c->n_blocks;
+    auto tell = [&](uint64_t u) -> uint64_t {                                        // bgzf_tell after having read up to inflated offset u
+        const uint64_t *uo = c->h_uoff.data();
+        int64_t lo = 0, hi = nb + 1;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (uo[mid] < u) lo = mid + 1; else hi = mid; }
+        if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
+        return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
+    };
+    BaiBuild ib; ib.init((int)c->ref_name.size(), tell(c->first_rec_uoff));
+    std::vector<int32_t> tid; std::vector<int64_t> pos, endp; std::vector<uint16_t> flag; std::vector<uint32_t> ro;
+    dhts_bam_batch b;
+    bool ok = true;
+    for (;;) {
+        const uint32_t mask = (1u << DHTS_BAM_FLAG) | (1u << DHTS_BAM_RNAME) | (1u << DHTS_BAM_POS);
+        if (dhts_bam_next_batch(c, 0, mask, &b)) return -1;
+        const int64_t n = b.n_rows;
+        if (n > 0) {
+            ENSURE(c, c->ix_end, (size_t)n * 8 + 64);
+            tid.resize(n); pos.resize(n); endp.resize(n); flag.resize(n); ro.resize(n);
+            BamCols bc; memset(&bc, 0, sizeof(bc));
+            bc.flag = (uint16_t *)c->c_flag.p; bc.pos = (int64_t *)c->c_pos.p; bc.cig_rel = (uint32_t *)c->cig_rel.p; bc.ncig_eff = (uint32_t *)c->ncig_eff.p;
+            hipLaunchKernelGGL(bam_index_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->last_stream, (const uint32_t *)c->rec_off.p, bc, n, (int64_t *)c->ix_end.p);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(endp.data(), c->ix_end.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(tid.data(), b.tid, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(pos.data(), b.pos, n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(flag.data(), b.flag, n * 2, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(ro.data(), c->rec_off.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const uint64_t base = b.first_rec_uoff - ro[0];
+            for (int64_t i = 0; i < n && ok; i++) {
+                const uint64_t u_end = (i + 1 < n) ? base + ro[i + 1] : b.end_uoff;      // records are contiguous: end = next start
+                ok = ib.push(tid[i], pos[i] - 1, endp[i], tell(u_end), !(flag[i] & 4));
+            }
+            if (!ok) break;
+        }
+        if (b.status != 0) { if (b.status < 0) { dhts_bam_rewind(c); return fail(c, "index build: the scan ended on an error (status %d)", b.status); } break; }
+    }
+    dhts_bam_rewind(c);
+    if (!ok) return fail(c, "index build: %s", ib.err.c_str());
+    // hts_idx_finish(idx, bgzf_tell(fp)) after the failing read at EOF: the address of the last trailing empty block, else the file size
+    uint64_t fin = c->comp_len;
+    if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
+    ib.finish(fin << 16);
+    ib.save(c->built_index);
+    return (int64_t)c->built_index.size();
+}
+int dhts_bam_index_bytes(dhts_ctx *c, uint8_t *out, uint64_t cap) {
+    if (!c || !out) return -1;
+    if (cap < c->built_index.size()) return fail(c, "index buffer too small");
+    memcpy(out, c->built_index.data(), c->built_index.size());
+    return 0;
+}
+
 // ---- interval overlap join ------------------------------------------------------------------------------------------------
 int dhts_bam_set_overlap_intervals(dhts_ctx *c, const int32_t *tid, const int64_t *beg, const int64_t *end, int64_t n) {
     if (!c) return -1;
@@ -1081,6 +1256,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     const bool sharded_tail = B.sharded_tail, final_batch = B.final_batch;
     uint8_t *u = B.u; uint64_t ulen = B.ulen; const uint64_t out_base = B.out_base;
     BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0;
+    c->last_stream = st;
 
     // ---- tiles ----
     int64_t ntiles = (int64_t)((ulen + TILE_BYTES - 1) / TILE_BYTES); if (ntiles < 1) ntiles = 1;

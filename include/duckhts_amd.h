@@ -169,6 +169,11 @@ int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype);   /
 int dhts_bam_set_tag_columns(dhts_ctx *, const int32_t *std_tag_ids, int32_t n);  /* tag columns materialised by the next batches (default none) */
 int dhts_bam_set_aux_map(dhts_ctx *, int enable, int exclude_standard_tags);        /* AUXILIARY_TAGS entries in the next batches */
 int dhts_bam_rewind(dhts_ctx *);
+/* BAI writer (the reference: src/hts_index_builder.c over sam_index_build, htslib sam.c:989-1027 +
+ * hts_idx_push / hts_idx_finish / idx_save_core hts.c:2315-2818).  One whole-file scan of the open BAM; returns the size of the
+ * index (bytes of a .bai file) kept in the context, or <0 (unsorted input, a record beyond 2^29, ... as in hts_idx_push).       */
+int64_t dhts_bam_build_index(dhts_ctx *);
+int dhts_bam_index_bytes(dhts_ctx *, uint8_t *out, uint64_t cap);
 /* Interval overlap join on the scan (SURVEY 8(f) item 1 / BASELINE config 5).  The reference vendors cgranges
  * (third_party/cgranges, cr_add / cr_index / cr_overlap cgranges.c:255-297) as the model for joining read_bam rows with
  * read_bed intervals (src/interval_udf.c:344-426) but registers no SQL function for it yet; this entry point is what such a
