@@ -24,7 +24,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--intervals", type=int, default=1_000_000)
     ap.add_argument("--regions", type=int, default=10_000)
-    ap.add_argument("--queries", default="region,overlap,both")
+    ap.add_argument("--indexed-records", type=int, default=8_000_000, help="records of the (single-segment, coordinate-sorted) file of the indexed queries")
+    ap.add_argument("--queries", default="region,overlap,both,indexed1,unindexed1")
     args = ap.parse_args()
     import duckhts_amd
     from duckhts_amd import synth
@@ -37,11 +38,25 @@ def main():
     rng = np.random.default_rng(7)
     for q in args.queries.split(","):
         ctx = duckhts_amd.Context(0)
-        ctx.open_tiled(head, body, reps, tail)
+        if q in ("indexed1", "unindexed1"):        # an index needs a coordinate-sorted file: one segment, not the tiled one
+            sorted_file = synth.bam_file(args.indexed_records, seed=42)
+            ctx.open(sorted_file)
+            n_q, bytes_q = args.indexed_records, len(sorted_file)
+        else:
+            ctx.open_tiled(head, body, reps, tail)
+            n_q, bytes_q = n_records, head.nbytes + body.nbytes * reps
         nb = ctx.bgzf_index()
         hdr = ctx.bam_open()
         names = [x.decode() for x in hdr["ref_names"]]
         lens = np.array(hdr["ref_len"], np.int64)
+        build_s = None
+        if q in ("indexed1", "unindexed1"):
+            # one 1 Mb region; "indexed1" first builds a BAI for the file (dhts_bam_build_index) and lets it narrow the scan window
+            if q == "indexed1":
+                t1 = time.perf_counter(); bai = ctx.build_index(); build_s = time.perf_counter() - t1
+            ctx.set_regions(f"{names[1]}:20,000,000-21,000,000")
+            if q == "indexed1":
+                ctx.load_index(bai)
         if q in ("region", "both"):
             t = rng.choice(len(names), args.regions, p=lens / lens.sum())          # regions / intervals fall on contigs in proportion to their length
             b = (rng.random(args.regions) * np.maximum(lens[t] - 20000, 1)).astype(np.int64) + 1
@@ -54,7 +69,8 @@ def main():
             ctx.set_overlap_intervals(t, b, e)
 
         def step():
-            ctx.bgzf_index()
+            if q not in ("indexed1", "unindexed1"):       # (re-indexing the BGZF container would reset the index window)
+                ctx.bgzf_index()
             ctx.rewind()
             rows = pairs = 0
             while True:
@@ -74,9 +90,9 @@ def main():
             rows, pairs = step()
         ctx.L.dhts_sync(ctx.h)
         dt = (time.perf_counter() - t0) / args.steps
-        print(json.dumps({"metric": "read_bam_records_per_sec", "query": q, "value": round(n_records / dt, 1), "unit": "records/s (records scanned)",
-                          "ms_per_step": round(dt * 1e3, 2), "rows_out": int(rows), "pairs_out": int(pairs), "pairs_per_s": round(pairs / dt, 1),
-                          "config": {"workload": f"read_bam {q}: synthetic {head.nbytes + body.nbytes * reps:,} B BGZF BAM, {n_records} records, {nb} blocks; "
+        print(json.dumps({"metric": "read_bam_records_per_sec", "query": q, "value": round(n_q / dt, 1), "unit": "records/s (records scanned)",
+                          "ms_per_step": round(dt * 1e3, 2), "index_build_s": None if build_s is None else round(build_s, 2), "rows_out": int(rows), "pairs_out": int(pairs), "pairs_per_s": round(pairs / dt, 1),
+                          "config": {"workload": f"read_bam {q}: synthetic {bytes_q:,} B BGZF BAM, {n_q} records, {nb} blocks; "
                                                  f"{args.regions if q != 'overlap' else 0} regions, {args.intervals if q != 'region' else 0} intervals",
                                      "inputs": "resident in HBM", "outputs": "13 core columns + pair lists in HBM"}}), flush=True)
         ctx.close()
