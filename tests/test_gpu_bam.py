@@ -337,6 +337,68 @@ def test_bai_writer_synthetic_index_drives_region_queries():
         assert a["n_rows"] == b["n_rows"] and a["QNAME"] == b["QNAME"] and list(a["POS"]) == list(b["POS"])
 
 
+# ---- string pass: read lengths around the chunk-map limits ---------------------------------------------------------------
+@pytest.mark.gpu
+def test_string_pass_mixed_read_lengths():
+    """SEQ/QUAL lengths 0..1500 incl. 511/512/513 (whole-wave streaming starts above 512), '*' QUAL, QUAL bytes that become NUL"""
+    import random
+    import bamwriter as bw
+    rng = random.Random(23)
+    lens = [0, 1, 15, 16, 17, 31, 32, 33, 255, 256, 257, 511, 512, 513, 514, 1023, 1024, 1025, 1500] + [rng.randrange(0, 1500) for _ in range(400)]
+    recs = []
+    for i, n in enumerate(lens):
+        seq = "".join(rng.choice("ACGTN") for _ in range(n)) if n else "*"
+        if n and i % 7 == 3:
+            qual = None                                        # 0xff fill => '*'
+        elif n:
+            qual = "".join(chr(33 + rng.randrange(0, 60)) for _ in range(n))
+        else:
+            qual = None
+        recs.append(bw.record(qname=f"q{i}", flag=4, tid=-1, pos=-1, seq=seq, qual=qual))
+    data = bw.bam_bytes([("ref", 100000)], recs, text="@HD\tVN:1.6\n@SQ\tSN:ref\tLN:100000\n", payload=20000, level=6)
+    exp = orc.bam_read(data)
+    for mb in (0, 2):
+        got = duckhts_amd.read_bam(data, max_blocks=mb)
+        assert got["n_rows"] == exp["n_rows"] == len(lens)
+        for k in ("QNAME", "CIGAR", "SEQ", "QUAL"):
+            assert got[k] == exp[k], k
+
+
+# ---- edge cases of the index writer and the join ---------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_index_writer_and_join_edge_cases():
+    hdr_only = cases.case_header_only()
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(hdr_only); ctx.bgzf_index(); ctx.bam_open()
+        refs, nnc = _parse_bai(ctx.build_index())
+        assert nnc == 0 and all(not b and not l for b, l in refs)
+    finally:
+        ctx.close()
+    got = duckhts_amd.read_bam(hdr_only, overlap=([0], [0], [100]))
+    assert got["n_rows"] == 0 and got["OVERLAPS"] == []
+    # unplaced reads only: no bins, n_no_coor counts them (hts_idx_push: tid < 0)
+    un = cases.case_no_refs_unmapped()
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(un); ctx.bgzf_index(); ctx.bam_open()
+        refs, nnc = _parse_bai(ctx.build_index())
+        assert refs == [] and nnc == 10
+    finally:
+        ctx.close()
+    # an unsorted file cannot be indexed (hts_idx_push: "Unsorted positions" / "Chromosome blocks not continuous")
+    import bamwriter as bw
+    bad = bw.bam_bytes([("a", 1000), ("b", 1000)], [bw.record(qname="x", tid=0, pos=500, cigar="4M", seq="ACGT"), bw.record(qname="y", tid=0, pos=100, cigar="4M", seq="ACGT")],
+                       text="@HD\tVN:1.6\n@SQ\tSN:a\tLN:1000\n@SQ\tSN:b\tLN:1000\n")
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(bad); ctx.bgzf_index(); ctx.bam_open()
+        with pytest.raises(duckhts_amd.DhtsError, match="Unsorted"):
+            ctx.build_index()
+    finally:
+        ctx.close()
+
+
 # ---- projection pushdown into the string pass ---------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("cols", [("QNAME", "SEQ"), ("QUAL",), ("CIGAR", "READ_GROUP_ID"), ("FLAG", "POS")])
