@@ -333,6 +333,7 @@ __device__ __forceinline__ void store_n16(uint8_t *d, const uint32_t w[4], uint3
 // One wave owns a 64 KiB span and sweeps it in 1 KiB coalesced pieces (16 B per lane); a lane tests its
 // 16 byte positions for the 4-byte magic with byte-aligns, then the remaining signature bytes on a hit.
 // pass 1 counts per span; pass 2 (after a prefix sum over spans) writes the candidates in file order.
+#define SIG_SLOTS 16u                     /* candidates kept per 64 KiB span by the counting sweep */
 __device__ __forceinline__ bool bgzf_sig_rest(const uint8_t *p) {
     // htslib bgzf.c:896-903 check_header == 0 (ID1 ID2 CM FLG.FEXTRA already matched): XLEN==6, 'B','C', SLEN==2
     return p[10] == 6 && p[11] == 0 && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0;
@@ -357,16 +358,33 @@ __device__ __forceinline__ uint32_t sig_hits16(const uint8_t *d, uint64_t n, uin
     return out;
 }
 extern "C" __global__ void __launch_bounds__(256)
-bgzf_sig_count(const uint8_t *d, uint64_t n, uint32_t *cnt) {
+bgzf_sig_count(const uint8_t *d, uint64_t n, uint32_t *cnt, uint16_t *hits, uint32_t *overflow) {
+    // besides the count, the first SIG_SLOTS candidates of the span are kept (offsets inside the span, file order), so that the
+    // usual case -- a handful of blocks per 64 KiB -- needs no second sweep over the file (bgzf_sig_gather); a span with more
+    // raises `overflow` and the host runs bgzf_sig_write over everything.
     const int lane = threadIdx.x & 63;
     int64_t span = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t b = (uint64_t)span * 65536;
     if (b >= n) return;
-    uint32_t c = 0;
-    for (uint64_t p = b; p < b + 65536 && p < n; p += 1024) c += __popc(sig_hits16(d, n, p + lane * 16, lane));
+    uint32_t w = 0;
+    for (uint64_t p = b; p < b + 65536 && p < n; p += 1024) {
+        uint32_t m = sig_hits16(d, n, p + lane * 16, lane);
+        if (__ballot(m != 0) == 0ull) continue;
+        const uint32_t c = __popc(m); uint32_t inc = c;
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k, 64);
-    if (lane == 0) cnt[span] = c;
+        for (int k = 1; k < 64; k <<= 1) { uint32_t t = __shfl_up(inc, k, 64); if (lane >= k) inc += t; }
+        uint32_t at = w + inc - c;
+        while (m) { const int j = __ffs(m) - 1; m &= m - 1; if (at < SIG_SLOTS) hits[span * SIG_SLOTS + at] = (uint16_t)(p - b + lane * 16 + j); at++; }
+        w += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) { cnt[span] = w; if (w > SIG_SLOTS) atomicOr(overflow, 1u); }
+}
+extern "C" __global__ void __launch_bounds__(256)
+bgzf_sig_gather(const uint32_t *cnt, const uint32_t *base, const uint16_t *hits, int64_t nspans, uint64_t *cand) {
+    const int64_t span = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (span >= nspans) return;
+    const uint32_t c = cnt[span] < SIG_SLOTS ? cnt[span] : SIG_SLOTS, w = base[span];
+    for (uint32_t k = 0; k < c; k++) cand[w + k] = (uint64_t)span * 65536 + hits[span * SIG_SLOTS + k];
 }
 extern "C" __global__ void __launch_bounds__(256)
 bgzf_sig_write(const uint8_t *d, uint64_t n, const uint32_t *base, uint64_t *cand) {

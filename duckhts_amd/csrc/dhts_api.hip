@@ -280,12 +280,13 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
     if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
     const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
     int64_t nspans = (int64_t)((n + 65535) / 65536);
-    DevBuf cnt, base, cand; uint64_t total = 0; int rc = 0;
-    auto cleanup = [&]() { cnt.release(); base.release(); cand.release(); };
-    if (cnt.ensure((size_t)nspans * 4 + 64) || base.ensure((size_t)(nspans + 1) * 4 + 64)) { cleanup(); return fail(c, "hipMalloc failed"); }
+    DevBuf cnt, base, cand, hits; uint64_t total = 0; int rc = 0;
+    auto cleanup = [&]() { cnt.release(); base.release(); cand.release(); hits.release(); };
+    if (cnt.ensure((size_t)nspans * 4 + 64) || base.ensure((size_t)(nspans + 1) * 4 + 64) || hits.ensure((size_t)nspans * SIG_SLOTS * 2 + 64) || c->d_nfixed.ensure(64)) { cleanup(); return fail(c, "hipMalloc failed"); }
+    (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
     {
         KTimer t(c, DHTS_K_SIGSCAN);
-        hipLaunchKernelGGL(bgzf_sig_count, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (uint32_t *)cnt.p);
+        hipLaunchKernelGGL(bgzf_sig_count, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (uint32_t *)cnt.p, (uint16_t *)hits.p, (uint32_t *)c->d_nfixed.p);
     }
     const uint32_t *in[1] = {(const uint32_t *)cnt.p}; uint32_t *o32[1] = {(uint32_t *)base.p};
     rc = run_scan(c, 1, in, o32, nullptr, nspans, &total);
@@ -295,9 +296,12 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
     if (!need_seq) {
         if (cand.ensure((size_t)ncand * 8) || c->coff.ensure((size_t)ncand * 8) || c->clen.ensure((size_t)ncand * 4) || c->isize.ensure((size_t)ncand * 4) ||
             c->d_nfixed.ensure(64)) { cleanup(); return fail(c, "hipMalloc failed"); }
+        uint32_t ovf = 0;
+        if (hipMemcpyAsync(&ovf, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return fail(c, "bgzf index sync failed"); }
         {
             KTimer t(c, DHTS_K_SIGSCAN);
-            hipLaunchKernelGGL(bgzf_sig_write, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint32_t *)base.p, (uint64_t *)c->coff.p);
+            if (ovf) hipLaunchKernelGGL(bgzf_sig_write, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint32_t *)base.p, (uint64_t *)c->coff.p);
+            else hipLaunchKernelGGL(bgzf_sig_gather, dim3((unsigned)((nspans + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)cnt.p, (const uint32_t *)base.p, (const uint16_t *)hits.p, nspans, (uint64_t *)c->coff.p);
         }
         (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
         hipLaunchKernelGGL(bgzf_chain_check, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint64_t *)c->coff.p, ncand,
