@@ -691,6 +691,20 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         DIAG_T(t_a);
         if (tot_adv <= BR_SPAN && tot_lit <= 1024u) {
             DIAG_ADD(0, 1);
+            // ---- far matches: request their bytes now, the literal pass below hides the read-back latency ----
+            // sources below rlo are overwritten in the ring by this batch's own output: they come from HBM (always < flushed;
+            // the block's own output is always readable 40 bytes past a far source: ms + 40 < bend)
+            const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
+            const uint32_t bend = outpos + tot_adv, rlo = bend > BR_R ? bend - BR_R : 0u;
+            const bool farm = mlen > 0 && ms < rlo;
+            uint64_t fv0 = 0, fv1 = 0, fv2 = 0, fv3 = 0;
+            if (farm) {
+                const uint8_t *g = dstp + ms;
+                __builtin_memcpy(&fv0, g, 8);
+                if (mlen > 8u) __builtin_memcpy(&fv1, g + 8, 8);
+                if (mlen > 16u) __builtin_memcpy(&fv2, g + 16, 8);
+                if (mlen > 24u) __builtin_memcpy(&fv3, g + 24, 8);
+            }
             // ---- literals ----
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
             __syncthreads();
@@ -713,24 +727,14 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
             // the batch are already placed).  Destinations/sources are rasterised into 64 cells covering the batch's output
             // span; an exclusive prefix-OR over lanes gives each lane the cells still owed by earlier matches.  The earliest
             // pending match always sees an empty set, so every round makes progress; cell granularity only delays.
-            const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
             uint32_t sh = 4; while ((tot_adv >> sh) > 63u) sh++;
             uint64_t dmask = 0, smask = 0;
-            // sources below rlo are overwritten in the ring by this batch's own output: they come from HBM (always < flushed)
-            const uint32_t bend = outpos + tot_adv, rlo = bend > BR_R ? bend - BR_R : 0u;
-            const bool farm = mlen > 0 && ms < rlo;
             if (farm) {
-                // (the block's own output is always readable 40 bytes past a far source: ms + 40 < bend)
                 const uint8_t *g = dstp + ms;
-                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-                __builtin_memcpy(&v0, g, 8);
-                if (mlen > 8u) __builtin_memcpy(&v1, g + 8, 8);
-                if (mlen > 16u) __builtin_memcpy(&v2, g + 16, 8);
-                if (mlen > 24u) __builtin_memcpy(&v3, g + 24, 8);
-                win_st_n(win, md, v0, mlen);
-                if (mlen > 8u) win_st_n(win, md + 8, v1, mlen - 8u);
-                if (mlen > 16u) win_st_n(win, md + 16, v2, mlen - 16u);
-                if (mlen > 24u) win_st_n(win, md + 24, v3, mlen - 24u);
+                win_st_n(win, md, fv0, mlen);
+                if (mlen > 8u) win_st_n(win, md + 8, fv1, mlen - 8u);
+                if (mlen > 16u) win_st_n(win, md + 16, fv2, mlen - 16u);
+                if (mlen > 24u) win_st_n(win, md + 24, fv3, mlen - 24u);
                 for (uint32_t c = 32; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, g + c, 8); win_st_n(win, md + c, v, mlen - c); }
             }
             if (mlen > 0) {

@@ -50,6 +50,7 @@ struct dhts_ctx {
     std::vector<uint64_t> h_coff, h_uoff; std::vector<uint32_t> h_clen, h_isize;
     // inflate scratch
     DevBuf lit, tok, meta;
+    DevBuf sg_cnt, sg_base, sg_cand, sg_hits;      // block discovery scratch
     // index writer
     std::vector<uint8_t> built_index; DevBuf ix_end; BamStream last_stream;   // last_stream: the inflated buffer of the latest batch
     // interval overlap join
@@ -164,7 +165,7 @@ void dhts_destroy(dhts_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     timing_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf *ovb[] = {&c->ix_end, &c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
+    DevBuf *ovb[] = {&c->sg_cnt, &c->sg_base, &c->sg_cand, &c->sg_hits, &c->ix_end, &c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
     for (auto b : ovb) b->release();
     DevBuf *all[] = {&c->comp, &c->coff, &c->clen, &c->isize, &c->uoff, &c->blk_status, &c->lit, &c->tok, &c->meta, &c->ubuf[0], &c->ubuf[1],
                      &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
@@ -280,8 +281,8 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
     if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
     const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
     int64_t nspans = (int64_t)((n + 65535) / 65536);
-    DevBuf cnt, base, cand, hits; uint64_t total = 0; int rc = 0;
-    auto cleanup = [&]() { cnt.release(); base.release(); cand.release(); hits.release(); };
+    DevBuf &cnt = c->sg_cnt, &base = c->sg_base, &cand = c->sg_cand, &hits = c->sg_hits; uint64_t total = 0; int rc = 0;   // kept across calls
+    auto cleanup = [&]() {};
     if (cnt.ensure((size_t)nspans * 4 + 64) || base.ensure((size_t)(nspans + 1) * 4 + 64) || hits.ensure((size_t)nspans * SIG_SLOTS * 2 + 64) || c->d_nfixed.ensure(64)) { cleanup(); return fail(c, "hipMalloc failed"); }
     (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
     {
