@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--unique-records", type=int, default=4_000_000, help="records in the unique segment")
     ap.add_argument("--target-gb", type=float, default=10.0, help="resident compressed size per GPU (GB)")
-    ap.add_argument("--max-blocks", type=int, default=16384, help="BGZF blocks per batch")
+    ap.add_argument("--max-blocks", type=int, default=24576, help="BGZF blocks per batch (24,576 is the largest that keeps in-batch offsets below 2^32)")
     ap.add_argument("--cpu-sample-records", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU shard layout even at N=1 (testing)")
