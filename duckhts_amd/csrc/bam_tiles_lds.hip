@@ -185,11 +185,11 @@ __device__ __forceinline__ int spec_check_lds(const BamStream &st, const PSrc &l
     return REC_OK;
 }
 
-__device__ __forceinline__ void tile_stage(const BamStream &st, uint64_t tb, uint8_t *buf, LSrc &s, int lane) {
+__device__ __forceinline__ void tile_stage(const BamStream &st, uint64_t tb, uint8_t *buf, LSrc &s, int lane, uint32_t nthr = 64u) {
     uint64_t left = st.ulen - tb;
     uint32_t avail = left < (uint64_t)(TL_TILE + TL_HALO) ? (uint32_t)left : (TL_TILE + TL_HALO);
     uint32_t pad = (avail + 15u) & ~15u;                      // the inflated buffer carries >= 256 bytes of padding
-    for (uint32_t k = (uint32_t)lane * 16u; k < pad; k += 1024u) { uint4 v = *(const uint4 *)(st.u + tb + k); *(uint4 *)(buf + k) = v; }
+    for (uint32_t k = (uint32_t)lane * 16u; k < pad; k += nthr * 16u) { uint4 v = *(const uint4 *)(st.u + tb + k); *(uint4 *)(buf + k) = v; }
     s.g = st.u; s.l = buf; s.base = tb; s.len = avail;
     __syncthreads();
 }
@@ -397,7 +397,10 @@ __device__ __forceinline__ uint32_t ts_qual_chunk(const TsSrc &src, uint64_t qua
     store_n16(d + 16u * k, w, n);
     return fz;
 }
-extern "C" __global__ void __launch_bounds__(64)
+// Two waves per tile: wave 0 owns the rows (offsets, the short per-row fields), both waves share the SEQ/QUAL chunks; the tile is
+// latency-bound, so a second wave on the same LDS image is nearly free occupancy.
+#define TS_THREADS 128
+extern "C" __global__ void __launch_bounds__(TS_THREADS)
 bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowbase, const uint64_t *res, int64_t nrows_all, int64_t nrows,
                  const uint32_t *rec_off, const uint32_t *row_map, BamCols c, BamStrOut s, uint32_t colmask) {
     // colmask: projection pushdown (bit = read_bam column id): heaps of columns that are not projected are not written
@@ -405,7 +408,9 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
     __shared__ uint32_t r_seq[64], r_lseq[64], r_oseq[64], r_oqual[64], r_c0[64], r_nul[64];
     __shared__ uint8_t cmap[TS_MAPN];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t sT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;
     const int64_t t = blockIdx.x;
     if (t >= ntiles || (uint64_t)t > res[3]) return;
     const uint32_t n = out.count[t];
@@ -425,36 +430,42 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
         q.off_qn = s.off_qname[r]; q.off_rg = s.off_rg[r]; q.off_cig = s.off_cigar[r]; q.off_seq = s.off_seq[r]; q.off_qual = s.off_qual[r];
         return q;
     };
-    RowIn ri = row_in(d0 + lane < d1 ? d0 + lane : d0);
-    LSrc ss; tile_stage(st, tb, buf, ss, lane);
+    RowIn ri; memset(&ri, 0, sizeof(ri));
+    if (w0) ri = row_in(d0 + lane < d1 ? d0 + lane : d0);
+    LSrc ss; tile_stage(st, tb, buf, ss, tid, TS_THREADS);
     TsSrc src; src.l = buf; src.g = st.u; src.base = tb; src.len = ss.len;
 
     for (int64_t g0 = d0; g0 < d1; g0 += 64) {
         const int64_t d = g0 + lane;
-        const bool act = d < d1;
-        if (g0 != d0) ri = row_in(act ? d : g0);
-        // ---- one lane per row: offsets, core fields ----
+        const bool act = w0 && d < d1;
+        if (w0 && g0 != d0) ri = row_in(act ? d : g0);
+        // ---- wave 0, one lane per row: offsets, core fields ----
         const uint64_t o = ri.o;
         const uint32_t len_seq = ri.len_seq, len_qn = ri.len_qn, rl = ri.rl, rg_rel = ri.rg_rel, ne = ri.ne, cig_rel = ri.cig_rel;
         const uint32_t off_qn = ri.off_qn, off_rg = ri.off_rg, off_cig = ri.off_cig, off_seq = ri.off_seq, off_qual = ri.off_qual;
         const bool ok = act && len_seq != 0;                       // rows that failed validation reserve nothing
-        const uint32_t x2 = src.u32(o + 12), x3 = src.u32(o + 16);
-        const int32_t l_seq_raw = (int32_t)src.u32(o + 20);
-        const uint32_t l_seq = (ok && l_seq_raw > 0) ? (uint32_t)l_seq_raw : 0u;
-        const uint64_t seq = o + 36 + (x2 & 0xff) + 4ull * (x3 & 0xffff);
-        const uint64_t qual = seq + (((uint64_t)l_seq + 1) >> 1);
-        const bool star = !(l_seq > 0 && (uint8_t)src.u32(qual) != 255);
-        const bool lng = l_seq > TS_LONG;
-        const uint32_t nch = (ok && !lng && (w_seq || w_qual)) ? (l_seq + 15u) >> 4 : 0u;
-        const uint32_t cinc = wave_incl_scan(nch, lane);
-        const uint32_t T = RDLANE(cinc, 63), c0 = cinc - nch;
-        r_seq[lane] = (uint32_t)(seq - tb); r_lseq[lane] = star ? (l_seq | 0x80000000u) : l_seq; r_oseq[lane] = off_seq; r_oqual[lane] = off_qual;
-        r_c0[lane] = c0; r_nul[lane] = 0xffffffffu;
-        for (uint32_t k = 0; k < nch; k++) cmap[c0 + k] = (uint8_t)lane;
+        bool star = true, lng = false; uint32_t l_seq = 0; uint64_t seq = 0;
+        if (w0) {
+            const uint32_t x2 = src.u32(o + 12), x3 = src.u32(o + 16);
+            const int32_t l_seq_raw = (int32_t)src.u32(o + 20);
+            l_seq = (ok && l_seq_raw > 0) ? (uint32_t)l_seq_raw : 0u;
+            seq = o + 36 + (x2 & 0xff) + 4ull * (x3 & 0xffff);
+            const uint64_t qual = seq + (((uint64_t)l_seq + 1) >> 1);
+            star = !(l_seq > 0 && (uint8_t)src.u32(qual) != 255);
+            lng = l_seq > TS_LONG;
+            const uint32_t nch = (ok && !lng && (w_seq || w_qual)) ? (l_seq + 15u) >> 4 : 0u;
+            const uint32_t cinc = wave_incl_scan(nch, lane);
+            const uint32_t c0 = cinc - nch;
+            if (lane == 63) sT = cinc;
+            r_seq[lane] = (uint32_t)(seq - tb); r_lseq[lane] = star ? (l_seq | 0x80000000u) : l_seq; r_oseq[lane] = off_seq; r_oqual[lane] = off_qual;
+            r_c0[lane] = c0; r_nul[lane] = 0xffffffffu;
+            for (uint32_t k = 0; k < nch; k++) cmap[c0 + k] = (uint8_t)lane;
+        }
         __syncthreads();
-        // ---- SEQ / QUAL by chunk ----
-        for (uint32_t cb = 0; cb < T; cb += 64) {
-            const uint32_t ch = cb + lane;
+        const uint32_t T = sT;
+        // ---- SEQ / QUAL by chunk, both waves ----
+        for (uint32_t cb = 0; cb < T; cb += TS_THREADS) {
+            const uint32_t ch = cb + (uint32_t)tid;
             if (ch < T) {
                 const uint32_t j = cmap[ch], k = ch - r_c0[j], ls = r_lseq[j], lq = ls & 0x7fffffffu;
                 const uint64_t sq = tb + r_seq[j];
@@ -465,7 +476,7 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
                 }
             }
         }
-        // ---- per-row pieces ----
+        // ---- per-row pieces (wave 0) ----
         if (ok) {
             if (w_seq && l_seq == 0) s.seq[off_seq] = '*';
             if (w_qual && star) s.qual[off_qual] = '*';
@@ -493,18 +504,20 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
                 p += nd + 1;
             }
         }
-        // ---- long fields: the whole wave streams one row at a time ----
-        uint64_t LM = __ballot(ok && lng && (w_seq || w_qual));
-        while (LM) {
-            const int i = __ffsll((unsigned long long)LM) - 1; LM &= LM - 1;
-            const uint32_t lq = RDLANE(l_seq, i), st_i = RDLANE((uint32_t)star, i), os = RDLANE(off_seq, i), oq = RDLANE(off_qual, i);
-            const uint64_t sq = ((uint64_t)RDLANE((uint32_t)(seq >> 32), i) << 32) | RDLANE((uint32_t)seq, i);
-            uint32_t fzm = 0xffffffffu;
-            for (uint32_t k = lane; k < (lq + 15u) >> 4; k += 64) {
-                if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + os);
-                if (w_qual && !st_i) { const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + oq); fzm = fz < fzm ? fz : fzm; }
+        // ---- long fields: wave 0 streams one row at a time ----
+        if (w0) {
+            uint64_t LM = __ballot(ok && lng && (w_seq || w_qual));
+            while (LM) {
+                const int i = __ffsll((unsigned long long)LM) - 1; LM &= LM - 1;
+                const uint32_t lq = RDLANE(l_seq, i), st_i = RDLANE((uint32_t)star, i), os = RDLANE(off_seq, i), oq = RDLANE(off_qual, i);
+                const uint64_t sq = ((uint64_t)RDLANE((uint32_t)(seq >> 32), i) << 32) | RDLANE((uint32_t)seq, i);
+                uint32_t fzm = 0xffffffffu;
+                for (uint32_t k = lane; k < (lq + 15u) >> 4; k += 64) {
+                    if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + os);
+                    if (w_qual && !st_i) { const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + oq); fzm = fz < fzm ? fz : fzm; }
+                }
+                if (fzm != 0xffffffffu) atomicMin(&r_nul[i], fzm);
             }
-            if (fzm != 0xffffffffu) atomicMin(&r_nul[i], fzm);
         }
         __syncthreads();
         if (ok && w_qual) { const uint32_t fz = r_nul[lane]; s.alen_qual[d] = star ? 1u : (fz != 0xffffffffu ? fz : l_seq); }

@@ -1394,7 +1394,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
             ENSURE(c, c->a_qual, tot[3] + PAD_BYTES); ENSURE(c, c->a_rg, tot[4] + PAD_BYTES);
             so.qname = (uint8_t *)c->a_qname.p; so.cigar = (uint8_t *)c->a_cigar.p; so.seq = (uint8_t *)c->a_seq.p; so.qual = (uint8_t *)c->a_qual.p; so.rg = (uint8_t *)c->a_rg.p;
             KTimer tm(c, DHTS_K_STRINGS);
-            hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
+            hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(TS_THREADS), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
                                nrows_scan, nrows, (const uint32_t *)c->rec_off.p, row_map_s, bc, so, colmask);
         }
         HIPCHK(c, hipGetLastError());
