@@ -41,6 +41,9 @@ struct DevBuf {
 struct dhts_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // phase B of the NEXT batch runs on a second stream while this batch's record stage (latency-bound, mostly idle SIMDs) runs on `stream`
+    hipStream_t stream_b = nullptr; hipEvent_t pf_done = nullptr;
+    struct Prefetch { bool valid = false; int64_t b0 = 0, nb = 0; uint64_t carry = 0; int ucur = 0; } pf;
     std::string err;
     // resident compressed bytes
     DevBuf comp; uint64_t comp_len = 0;
@@ -123,9 +126,9 @@ static hipEvent_t ev_get(dhts_ctx *c) {
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 struct KTimer {
-    dhts_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
-    KTimer(dhts_ctx *c_, int id_) : c(c_), id(id_) { if (c->timing) { a = ev_get(c); b = ev_get(c); (void)hipEventRecord(a, c->stream); } }
-    ~KTimer() { if (c->timing) { (void)hipEventRecord(b, c->stream); c->pending.push_back({id, {a, b}}); } }
+    dhts_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; hipStream_t s;
+    KTimer(dhts_ctx *c_, int id_, hipStream_t s_ = nullptr) : c(c_), id(id_), s(s_ ? s_ : c_->stream) { if (c->timing) { a = ev_get(c); b = ev_get(c); (void)hipEventRecord(a, s); } }
+    ~KTimer() { if (c->timing) { (void)hipEventRecord(b, s); c->pending.push_back({id, {a, b}}); } }
 };
 static void timing_collect(dhts_ctx *c) {
     for (auto &p : c->pending) {
@@ -134,6 +137,10 @@ static void timing_collect(dhts_ctx *c) {
         c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
     }
     c->pending.clear();
+}
+
+static void discard_prefetch(dhts_ctx *c) {
+    if (c->pf.valid) { (void)hipStreamSynchronize(c->stream_b); c->pf.valid = false; }
 }
 
 extern "C" {
@@ -149,6 +156,12 @@ dhts_ctx *dhts_create(int device_id) {
     dhts_ctx *c = new dhts_ctx();
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    // the prefetch stream has the LOWEST priority: the record-stage kernels of the current batch (short, latency-bound) should get wave
+    // slots as soon as they ask, the next batch's phase B fills what is left
+    int pr_lo = 0, pr_hi = 0; (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+    if (hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, pr_lo) != hipSuccess || hipEventCreateWithFlags(&c->pf_done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c; return nullptr;
+    }
     // the LDS-window kernel needs more than the default dynamic LDS limit
     if (hipFuncSetAttribute((const void *)bgzf_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)bgzf_huff_decode, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES) != hipSuccess) {
@@ -162,8 +175,10 @@ dhts_ctx *dhts_create(int device_id) {
 void dhts_destroy(dhts_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream_b);
     (void)hipStreamSynchronize(c->stream);
     timing_collect(c);
+    (void)hipEventDestroy(c->pf_done); (void)hipStreamDestroy(c->stream_b);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     DevBuf *ovb[] = {&c->sg_cnt, &c->sg_base, &c->sg_cand, &c->sg_hits, &c->ix_end, &c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
     for (auto b : ovb) b->release();
@@ -186,6 +201,7 @@ static void reset_file_state(dhts_ctx *c) {
 }
 
 int dhts_open_host(dhts_ctx *c, const void *bytes, uint64_t n) {
+    if (c) discard_prefetch(c);
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     reset_file_state(c);
@@ -198,6 +214,7 @@ int dhts_open_host(dhts_ctx *c, const void *bytes, uint64_t n) {
 }
 
 int dhts_open_tiled(dhts_ctx *c, const void *head, uint64_t n_head, const void *body, uint64_t n_body, int reps, const void *tail, uint64_t n_tail) {
+    if (c) discard_prefetch(c);
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     reset_file_state(c);
@@ -277,6 +294,7 @@ static int run_scan(dhts_ctx *c, int narr, const uint32_t **in, uint32_t **out32
 int64_t dhts_bgzf_index(dhts_ctx *c) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    discard_prefetch(c);
     c->huff_b0 = c->huff_nb = 0;
     if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
     const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
@@ -373,8 +391,19 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb) {
 }
 
 // inflate blocks [b0, b0+nb) into `out` (device) so that block b lands at out + (uoff[b] - out_base)
+static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, hipStream_t s) {
+    BgzfTable t = dev_table(c);
+    {
+        KTimer tm(c, DHTS_K_LZ, s);
+        hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)nb), dim3(64), B_LDS_BYTES, s, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, c->huff_b0, out, out_base, (int32_t *)c->blk_status.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
 static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
     if (nb <= 0) return 0;
+    discard_prefetch(c);                                   // (phase A below may reallocate the scratch a prefetched phase B reads)
     for (int64_t b = b0; b < b0 + nb; b++) if (c->h_isize[b] > 65536u) return fail(c, "BGZF block %lld claims ISIZE %u > 65536", (long long)b, c->h_isize[b]);
     if (!(b0 >= c->huff_b0 && b0 + nb <= c->huff_b0 + c->huff_nb)) {
         static const int64_t env_super = getenv("DHTS_SUPER_BLOCKS") ? atoll(getenv("DHTS_SUPER_BLOCKS")) : 0;   // tuning knob
@@ -394,14 +423,7 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
         if (want < nb) want = nb;
         if (huff_blocks(c, b0, want)) return -1;
     }
-    BgzfTable t = dev_table(c);
-    {
-        KTimer tm(c, DHTS_K_LZ);
-        hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)nb), dim3(64), B_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
-                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, c->huff_b0, out, out_base, (int32_t *)c->blk_status.p);
-    }
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    return launch_lz(c, b0, nb, out, out_base, c->stream);
 }
 
 int64_t dhts_bgzf_inflate_to_host(dhts_ctx *c, int64_t blk0, int64_t nblk, uint8_t *out, uint64_t cap, int32_t *blk_status) {
@@ -803,6 +825,7 @@ int dhts_bcf_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
 
 int dhts_bam_rewind(dhts_ctx *c) {
     if (!c) return -1;
+    discard_prefetch(c);
     c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = c->rg_empty_window; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;            // a new pass redoes phase A (nothing is cached across scans)
     skip_header_blocks(c);
@@ -1206,6 +1229,7 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     if (ulen + PAD_BYTES >= (1ull << 32)) return fail(c, "batch too large");
     DevBuf &ub = c->ubuf[c->ucur];
     if (ub.cap < ulen + PAD_BYTES) {
+        discard_prefetch(c);
         // grow while preserving the carry bytes at the front
         DevBuf nbuf; if (nbuf.ensure(ulen + PAD_BYTES)) return fail(c, "hipMalloc failed");
         if (carry) HIPCHK(c, hipMemcpyAsync(nbuf.p, ub.p, carry, hipMemcpyDeviceToDevice, c->stream));
@@ -1214,8 +1238,14 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     }
     uint8_t *u = (uint8_t *)ub.p;
     const uint64_t out_base = c->h_uoff[b0] - carry;          // absolute stream offset of u[0]
-    if (inflate_blocks(c, b0, nb, u, out_base, c->n_blocks)) return -1;
-    HIPCHK(c, hipMemsetAsync(u + ulen, 0, PAD_BYTES, c->stream));
+    if (c->pf.valid && c->pf.b0 == b0 && c->pf.nb == nb && c->pf.carry == carry && c->pf.ucur == c->ucur) {
+        // this batch's phase B was started during the previous batch's record stage: just order the streams
+        c->pf.valid = false;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->pf_done, 0));
+    } else {
+        if (inflate_blocks(c, b0, nb, u, out_base, c->n_blocks)) return -1;
+        HIPCHK(c, hipMemsetAsync(u + ulen, 0, PAD_BYTES, c->stream));
+    }
     // first bad block (if any) ends the byte stream there (bgzf.c:1241-1291: the read fails)
     int blk_err = 0;
     if (nb > 0) {
@@ -1232,6 +1262,7 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
 static int batch_end(dhts_ctx *c, const Batch &B, uint64_t carry_start, bool rec_err, bool shard_finished, int32_t *status) {
     c->first_batch = false;
     c->next_block = B.b0 + B.nb;
+    if (rec_err || B.blk_err || shard_finished || B.last_of_stream) discard_prefetch(c);
     if (rec_err || B.blk_err) { c->stream_done = true; *status = B.blk_err ? B.blk_err * 100 : -4; }
     else if (shard_finished) { c->stream_done = true; *status = 1; }
     else if (B.last_of_stream) { c->stream_done = true; *status = (c->bgzf_status != 0) ? c->bgzf_status : 1; if (carry_start < B.ulen && *status == 1) *status = -4; }
@@ -1239,8 +1270,11 @@ static int batch_end(dhts_ctx *c, const Batch &B, uint64_t carry_start, bool rec
         // move the incomplete tail to the front of the other buffer
         uint64_t tail = B.ulen - carry_start;
         DevBuf &nx = c->ubuf[c->ucur ^ 1];
-        ENSURE(c, nx, tail + PAD_BYTES);
-        if (tail) HIPCHK(c, hipMemcpyAsync(nx.p, B.u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream));
+        if (c->pf.valid && !(c->pf.carry == tail && c->pf.b0 == B.b0 + B.nb && c->pf.ucur == (c->ucur ^ 1))) discard_prefetch(c);
+        if (!c->pf.valid) {                                   // (a live prefetch has already copied the tail there)
+            ENSURE(c, nx, tail + PAD_BYTES);
+            if (tail) HIPCHK(c, hipMemcpyAsync(nx.p, B.u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream));
+        }
         c->carry_len = tail; c->ucur ^= 1;
         if (B.in_halo && tail == 0) { c->stream_done = true; *status = 1; }
         if (B.b0 + B.nb >= c->shard_b1 && B.sharded_tail && tail == 0) { c->stream_done = true; *status = 1; }
@@ -1302,6 +1336,33 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
 
     // sharding: rows belong to this shard iff their record STARTS before the shard's end in the inflated stream
     uint64_t shard_end_u = sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
+    // ---- phase B of the NEXT batch, concurrent with the rest of this one ----
+    // The carry (where this batch's last complete record ends) is known now, so the next batch's destination is too.  Only the
+    // plain case is prefetched: the stream goes on inside this shard, phase A already covers the blocks, nothing can cut this
+    // batch short from here on except a bad row (then batch_end discards the prefetch).
+    {
+        static const bool no_pf = getenv("DHTS_NO_PREFETCH") != nullptr;
+        int64_t mb = max_blocks <= 0 ? 16384 : (max_blocks > 24576 ? 24576 : max_blocks);
+        const int64_t nb0 = B.b0 + B.nb;
+        int64_t nbn = c->shard_b1 - nb0; if (nbn > mb) nbn = mb;
+        const bool plain = !no_pf && !rec_err && !B.blk_err && !B.last_of_stream && !B.in_halo && nbn > 0 && !(sharded_tail && out_base + ulen > shard_end_u) &&
+                           nb0 >= c->huff_b0 && nb0 + nbn <= c->huff_b0 + c->huff_nb && !c->pf.valid;
+        if (plain) {
+            const uint64_t tail = ulen - carry_start, ulen_n = tail + (c->h_uoff[nb0 + nbn] - c->h_uoff[nb0]);
+            bool ok = ulen_n + PAD_BYTES < (1ull << 32);
+            for (int64_t b = nb0; ok && b < nb0 + nbn; b++) if (c->h_isize[b] > 65536u) ok = false;      // the normal path reports it
+            DevBuf &nx = c->ubuf[c->ucur ^ 1];
+            if (ok && nx.cap < ulen_n + PAD_BYTES && nx.ensure(ulen_n + PAD_BYTES)) ok = false;
+            if (ok) {
+                uint8_t *un = (uint8_t *)nx.p;
+                if (tail) HIPCHK(c, hipMemcpyAsync(un, u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream_b));
+                if (launch_lz(c, nb0, nbn, un, c->h_uoff[nb0] - tail, c->stream_b)) return -1;
+                HIPCHK(c, hipMemsetAsync(un + ulen_n, 0, PAD_BYTES, c->stream_b));
+                HIPCHK(c, hipEventRecord(c->pf_done, c->stream_b));
+                c->pf.valid = true; c->pf.b0 = nb0; c->pf.nb = nbn; c->pf.carry = tail; c->pf.ucur = c->ucur ^ 1;
+            }
+        }
+    }
     bool shard_finished = false;
     (void)first0;
 
