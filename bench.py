@@ -180,8 +180,10 @@ def main():
     # measured on full-size launches of this same workload (profiles/<round>/pmc_traffic_*.json), times the blocks of one step
     traffic, traffic_src = None, None
     try:
-        cand = sorted(f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
-                      [os.path.join(ROOT, "profiles", r_, x) for x in sorted(os.listdir(os.path.join(ROOT, "profiles", r_))) if x.startswith("pmc_traffic_")])
+        import re as _re
+        cand = sorted((f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
+                       [os.path.join(ROOT, "profiles", r_, x) for x in os.listdir(os.path.join(ROOT, "profiles", r_)) if x.startswith("pmc_traffic_")]),
+                      key=lambda f: (os.path.basename(os.path.dirname(f)), [int(t) for t in _re.findall(r"\d+", os.path.basename(f))]))   # latest round, highest version
         if cand:
             pj = json.load(open(cand[-1]))["per_block"]
             per_blk = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in pj.values())
