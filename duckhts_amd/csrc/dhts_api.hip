@@ -1010,6 +1010,7 @@ struct BaiBuild {
 int64_t dhts_bam_build_index(dhts_ctx *c) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->bam_open) return fail(c, "dhts_bam_open not called");
     if (c->rg_active || c->shard_b0 != 0 || c->shard_b1 != c->n_blocks || c->ov_active) return fail(c, "index build needs a whole-file scan (no region, shard or join)");
     if (dhts_bam_rewind(c)) return -1;
     const int64_t nb = c->n_blocks;
@@ -1072,6 +1073,7 @@ int dhts_bam_set_overlap_intervals(dhts_ctx *c, const int32_t *tid, const int64_
     HIPCHK(c, hipSetDevice(c->device));
     c->ov_active = false; c->ov_n = 0;
     if (n <= 0) return 0;
+    if (!c->bam_open) return fail(c, "dhts_bam_open not called");      // the intervals are resolved against the header's reference table
     if (!tid || !beg || !end) return fail(c, "overlap intervals: null array");
     if (n > 0xfffffff0ll) return fail(c, "overlap intervals: too many intervals");
     const int32_t n_ref = (int32_t)c->ref_name.size();
