@@ -349,3 +349,18 @@ def test_overlap_join_matches_reference_build_on_random_intervals():
         ref = ro.cgranges_overlap(lib, names, tid, beg, end, q)
         got = ro.overlap_join(t, tid, beg, end)
         assert all(a.tolist() == b.tolist() for a, b in zip(got, ref))
+
+
+def test_first_row_flag_and_cigar_pins_from_the_udf_tests():
+    """duckhts.test:705-790 apply the (out-of-scope) SAM-flag / CIGAR UDFs to the first row of read_bam('range.bam'): those
+    expectations pin FLAG and CIGAR of that row: paired, mapped, mate mapped, reverse, last segment; not proper pair, not duplicate;
+    CIGAR has an M, no soft clip, positive reference length."""
+    r = orc.bam_read(read_golden("range.bam"))
+    f = int(r["FLAG"][0])
+    assert (f & 1) and not (f & 4) and not (f & 8) and (f & 16) and (f & 128)          # :705-716
+    assert not (f & 2)                                                                # :718-723 is_proper_pair = false
+    assert not (f & 1024)                                                             # :766-776 is_duplicate = false
+    cig = bytes(r["CIGAR"][0])
+    assert b"M" in cig and b"S" not in cig                                            # :753-763
+    import re
+    assert sum(int(n) for n, op in re.findall(rb"(\d+)([MDN=X])", cig)) > 0           # cigar_reference_length > 0
