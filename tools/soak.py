@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""soak.py -- randomized GPU-vs-oracle parity over many seeds (not part of the test suite; a way to spend spare GPU minutes).
+
+For every seed: a BAM of random records (random BGZF payload size / zlib level / batch size) through read_bam, its standard-tag and
+auxiliary-tag views, a random region query, and a BCF of fuzz records (wide or tidy, random payload / batch) through read_bcf --
+each compared column for column with the CPU oracle.  Prints one line per seed and a summary; exit code 1 on any mismatch.
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=60)
+    ap.add_argument("--first", type=int, default=1000)
+    ap.add_argument("--seconds", type=float, default=480.0)
+    args = ap.parse_args()
+    import bamwriter as bw  # noqa: F401
+    import bcf_cases
+    import bcfwriter as W
+    import cases
+    import duckhts_amd
+    import orc
+    import region_oracle as ro
+    import tag_cases
+    t0 = time.time()
+    bad = 0
+    done = 0
+    for seed in range(args.first, args.first + args.seeds):
+        if time.time() - t0 > args.seconds:
+            break
+        rnd = random.Random(seed)
+        msgs = []
+        # ---- BAM core columns ----
+        payload = rnd.choice([61, 300, 777, 4000, 20000, 65280])
+        level = rnd.choice([0, 1, 6, 9])
+        n = rnd.choice([50, 300, 1500])
+        data = cases.case_basic(payload=payload, level=level, seed=seed, n=n)
+        exp = orc.bam_read(data)
+        mb = rnd.choice([0, 1, 2, 5])
+        got = duckhts_amd.read_bam(data, max_blocks=mb)
+        if got["n_rows"] != exp["n_rows"]:
+            msgs.append(f"bam n_rows {got['n_rows']} != {exp['n_rows']}")
+        else:
+            for k in duckhts_amd.BAM_COLUMNS:
+                if list(got[k]) != list(exp[k]):
+                    msgs.append(f"bam column {k}")
+        # region
+        names = [bytes(x).decode() for x in exp["ref_names"]]
+        if names and exp["n_rows"]:
+            nm = rnd.choice(names)
+            b = rnd.randrange(1, 5000)
+            reg = f"{nm}:{b}-{b + rnd.randrange(1, 20000)}" if rnd.random() < 0.7 else nm
+            keep = ro.keep_mask(exp, reg)
+            try:
+                g2 = duckhts_amd.read_bam(data, region=reg, max_blocks=mb)
+                if keep is None or g2["n_rows"] != int(keep.sum()) or g2["QNAME"] != [q for q, k in zip(exp["QNAME"], keep) if k]:
+                    msgs.append(f"bam region {reg}")
+            except duckhts_amd.DhtsError:
+                if keep is not None:
+                    msgs.append(f"bam region {reg} raised")
+        # ---- tags ----
+        tdata = tag_cases.fuzz(seed=seed, n=rnd.choice([200, 1500]), payload=rnd.choice([500, 3000, 30000]))
+        et = orc.bam_read_std_tags(tdata)
+        gt = duckhts_amd.read_bam(tdata, std_tags_cols=list(range(56)), max_blocks=rnd.choice([0, 3]))
+        d = orc.bcf_cols_diff(et, gt["tags"])
+        if d is not None:
+            msgs.append("std tags: " + d)
+        excl = rnd.random() < 0.5
+        ea = orc.bam_read_aux_map(tdata, excl)
+        ga = duckhts_amd.read_bam(tdata, aux_map="exclude_standard" if excl else "all", max_blocks=rnd.choice([0, 4]))
+        d = orc.bcf_cols_diff({"n_rows": ea["n_rows"], "cols": ea["cols"]}, ga["aux"])
+        if d is not None:
+            msgs.append("aux map: " + d)
+        # ---- BCF ----
+        ns = rnd.choice([0, len(bcf_cases.SAMPLES)])
+        hdr = bcf_cases.std_header() if ns else bcf_cases.std_header(samples=())
+        recs = bcf_cases.fuzz_records(seed, rnd.choice([100, 800, 2500]), ns)
+        tidy = rnd.random() < 0.4
+        bdata = W.bcf_bytes(hdr, recs, payload=rnd.choice([777, 4000, 65280]))
+        eb = orc.bcf_read(bdata, tidy=tidy)
+        gb = duckhts_amd.read_bcf(bdata, tidy=tidy, max_blocks=rnd.choice([0, 1, 3]))
+        d = orc.bcf_cols_diff(eb, gb)
+        if d is not None:
+            msgs.append("bcf: " + d)
+        done += 1
+        print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (bam {exp['n_rows']} rows payload {payload} level {level}, bcf {eb['n_rows']} rows{' tidy' if tidy else ''})", flush=True)
+        bad += bool(msgs)
+    print(f"soak: {done} seeds, {bad} with mismatches, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
