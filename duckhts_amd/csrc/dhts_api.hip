@@ -404,7 +404,8 @@ static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t
 static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
     if (nb <= 0) return 0;
     discard_prefetch(c);                                   // (phase A below may reallocate the scratch a prefetched phase B reads)
-    for (int64_t b = b0; b < b0 + nb; b++) if (c->h_isize[b] > 65536u) return fail(c, "BGZF block %lld claims ISIZE %u > 65536", (long long)b, c->h_isize[b]);
+    // (a block whose ISIZE field exceeds 64 KiB is placed as 64 KiB -- uoff is the prefix of min(ISIZE, 65536) -- and fails phase B's
+    //  outlen == ISIZE test like any other block with a wrong ISIZE: the stream ends there, rows before it are kept)
     if (!(b0 >= c->huff_b0 && b0 + nb <= c->huff_b0 + c->huff_nb)) {
         static const int64_t env_super = getenv("DHTS_SUPER_BLOCKS") ? atoll(getenv("DHTS_SUPER_BLOCKS")) : 0;   // tuning knob
         int64_t sb = env_super > 0 ? env_super : c->super_blocks;
@@ -1352,7 +1353,6 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         if (plain) {
             const uint64_t tail = ulen - carry_start, ulen_n = tail + (c->h_uoff[nb0 + nbn] - c->h_uoff[nb0]);
             bool ok = ulen_n + PAD_BYTES < (1ull << 32);
-            for (int64_t b = nb0; ok && b < nb0 + nbn; b++) if (c->h_isize[b] > 65536u) ok = false;      // the normal path reports it
             DevBuf &nx = c->ubuf[c->ucur ^ 1];
             if (ok && nx.cap < ulen_n + PAD_BYTES && nx.ensure(ulen_n + PAD_BYTES)) ok = false;
             if (ok) {

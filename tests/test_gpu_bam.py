@@ -399,6 +399,27 @@ def test_index_writer_and_join_edge_cases():
         ctx.close()
 
 
+# ---- a wrong ISIZE ends the stream at that block (documented deviation: htslib never looks at ISIZE) --------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("bogus", [70000, 5, 0x04000000])
+def test_wrong_isize_is_a_block_error_rows_before_kept(bogus):
+    data = bytearray(cases.case_basic(payload=777, n=200, seed=2))
+    clean = orc.bam_read(bytes(data))
+    # blocks; damage the ISIZE field of one in the middle
+    p, blocks = 0, []
+    while p + 18 <= len(data) and data[p:p + 4] == b"\x1f\x8b\x08\x04":
+        bl = struct.unpack_from("<H", data, p + 16)[0] + 1
+        blocks.append((p, bl)); p += bl
+    k = len(blocks) // 2
+    struct.pack_into("<I", data, blocks[k][0] + blocks[k][1] - 4, bogus)
+    for mb in (0, 3):
+        got = duckhts_amd.read_bam(bytes(data), max_blocks=mb)
+        assert got["status"] < 0 and 0 < got["n_rows"] < clean["n_rows"]
+        n = got["n_rows"]
+        for c in COLS:
+            assert list(got[c]) == list(clean[c][:n]), c
+
+
 # ---- projection pushdown into the string pass ---------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("cols", [("QNAME", "SEQ"), ("QUAL",), ("CIGAR", "READ_GROUP_ID"), ("FLAG", "POS")])

@@ -17,11 +17,32 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+def damage(data, rnd):
+    """flip 1-3 random bits after the first 200 bytes (so that most files still open).  ISIZE fields are left alone: the GPU path
+    trusts ISIZE for placing blocks (that is what lets shards start without decoding their predecessors) and reports a block whose
+    inflated length disagrees as an error, whereas htslib -- and the oracle -- never look at ISIZE (deviation (i))."""
+    import struct
+    b = bytearray(data)
+    isize = set()
+    p = 0
+    while p + 18 <= len(b) and b[p:p + 4] == b"\x1f\x8b\x08\x04":
+        bl = struct.unpack_from("<H", b, p + 16)[0] + 1
+        isize.update(range(p + bl - 4, p + bl))
+        p += bl
+    for _ in range(rnd.randint(1, 3)):
+        i = rnd.randrange(min(200, len(b) - 1), len(b))
+        if i in isize:
+            continue
+        b[i] ^= 1 << rnd.randrange(8)
+    return bytes(b)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=60)
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--seconds", type=float, default=480.0)
+    ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
     args = ap.parse_args()
     import bamwriter as bw  # noqa: F401
     import bcf_cases
@@ -44,9 +65,23 @@ def main():
         level = rnd.choice([0, 1, 6, 9])
         n = rnd.choice([50, 300, 1500])
         data = cases.case_basic(payload=payload, level=level, seed=seed, n=n)
+        if args.corrupt:
+            data = damage(data, rnd)
         exp = orc.bam_read(data)
         mb = rnd.choice([0, 1, 2, 5])
-        got = duckhts_amd.read_bam(data, max_blocks=mb)
+        try:
+            got = duckhts_amd.read_bam(data, max_blocks=mb)
+        except duckhts_amd.DhtsError as e:
+            if not args.corrupt:
+                raise
+            # the header itself is damaged: the oracle must have produced nothing and flagged it
+            got = {"n_rows": 0, "status": exp["status"]}     # (the oracle wrapper reports a header failure through its return code)
+            for k in duckhts_amd.BAM_COLUMNS:
+                got[k] = []
+            if exp["n_rows"] != 0:
+                msgs.append(f"bam open failed on the GPU ({e}) but the oracle read {exp['n_rows']} rows status {exp['status']}")
+        if (got["status"] < 0) != (exp["status"] < 0):
+            msgs.append(f"bam status {got['status']} vs {exp['status']}")
         if got["n_rows"] != exp["n_rows"]:
             msgs.append(f"bam n_rows {got['n_rows']} != {exp['n_rows']}")
         else:
@@ -55,7 +90,7 @@ def main():
                     msgs.append(f"bam column {k}")
         # region
         names = [bytes(x).decode() for x in exp["ref_names"]]
-        if names and exp["n_rows"]:
+        if names and exp["n_rows"] and not args.corrupt:
             nm = rnd.choice(names)
             b = rnd.randrange(1, 5000)
             reg = f"{nm}:{b}-{b + rnd.randrange(1, 20000)}" if rnd.random() < 0.7 else nm
@@ -67,6 +102,28 @@ def main():
             except duckhts_amd.DhtsError:
                 if keep is not None:
                     msgs.append(f"bam region {reg} raised")
+        if args.corrupt:
+            # BCF under damage, then next seed (the tag views add nothing here)
+            ns = rnd.choice([0, len(bcf_cases.SAMPLES)])
+            hdr = bcf_cases.std_header() if ns else bcf_cases.std_header(samples=())
+            bdata = damage(W.bcf_bytes(hdr, bcf_cases.fuzz_records(seed, rnd.choice([100, 800]), ns), payload=rnd.choice([777, 4000, 65280])), rnd)
+            eb = orc.bcf_read(bdata)
+            if eb["status"] <= -100:            # header-level failure
+                eb = None
+            try:
+                gb = duckhts_amd.read_bcf(bdata, max_blocks=rnd.choice([0, 1, 3]))
+            except duckhts_amd.DhtsError:
+                gb = None
+            if (eb is None) != (gb is None):
+                msgs.append(f"bcf open: oracle {'fails' if eb is None else 'ok'}, gpu {'fails' if gb is None else 'ok'}")
+            elif eb is not None:
+                d = orc.bcf_cols_diff(eb, gb)
+                if d is not None:
+                    msgs.append("bcf: " + d)
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (damaged: bam {exp['n_rows']} rows status {exp['status']}, bcf {eb['n_rows'] if eb else 'open fails'})", flush=True)
+            bad += bool(msgs)
+            continue
         # ---- tags ----
         tdata = tag_cases.fuzz(seed=seed, n=rnd.choice([200, 1500]), payload=rnd.choice([500, 3000, 30000]))
         et = orc.bam_read_std_tags(tdata)
