@@ -1224,6 +1224,11 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     int64_t nb = limit - b0; if (nb > max_blocks) nb = max_blocks;
     if (in_halo && nb > 4) nb = 4;
     if (nb < 0) nb = 0;
+    if (c->first_batch && c->shard_rank != 0 && !in_halo) {
+        // a shard that starts mid-stream finds its first record by speculation (candidates validated three records deep): give the
+        // search at least 1 MiB of inflated bytes to validate against, whatever batch size the caller asked for
+        while (b0 + nb < limit && c->h_uoff[b0 + nb] - c->h_uoff[b0] < (1u << 20) && nb < 24576) nb++;
+    }
     B.b0 = b0; B.nb = nb; B.in_halo = in_halo;
     B.last_of_stream = (b0 + nb >= c->n_blocks);
     const uint64_t carry = c->carry_len;

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=60)
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--seconds", type=float, default=480.0)
+    ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
     args = ap.parse_args()
     import bamwriter as bw  # noqa: F401
@@ -60,6 +61,52 @@ def main():
             break
         rnd = random.Random(seed)
         msgs = []
+        if args.scans:
+            import numpy as np
+            from duckhts_amd import synth
+            # ---- shards of a random-record file: the union of the ranks' rows is the file, in order ----
+            data = cases.case_basic(payload=rnd.choice([300, 777, 4000, 20000]), level=rnd.choice([1, 6]), seed=seed, n=rnd.choice([300, 1500]))
+            exp = orc.bam_read(data)
+            world = rnd.randint(2, 6)
+            rows, qn = 0, []
+            for rank in range(world):
+                g = duckhts_amd.read_bam(data, shard=(rank, world), max_blocks=rnd.choice([0, 2]))
+                rows += g["n_rows"]; qn += g["QNAME"]
+            if rows != exp["n_rows"] or qn != exp["QNAME"]:
+                msgs.append(f"{world}-way shards: {rows} rows vs {exp['n_rows']}")
+            # ---- sorted file: BAI writer -> indexed region == oracle predicate; overlap join; projection ----
+            sdata = synth.bam_file(rnd.choice([3000, 20000, 60000]), seed=seed)
+            sexp = orc.bam_read(sdata)
+            names = [bytes(x).decode() for x in sexp["ref_names"]]
+            ctx = duckhts_amd.Context(0)
+            try:
+                ctx.open(sdata); ctx.bgzf_index(); ctx.bam_open()
+                bai = ctx.build_index()
+            finally:
+                ctx.close()
+            for _ in range(2):
+                t = rnd.randrange(len(names)); b = rnd.randrange(1, 50_000_000)
+                reg = ",".join(f"{names[rnd.randrange(len(names))]}:{b}-{b + rnd.choice([1000, 1_000_000, 30_000_000])}" for _ in range(rnd.randint(1, 3)))
+                keep = ro.keep_mask(sexp, reg)
+                try:
+                    g = duckhts_amd.read_bam(sdata, region=reg, index=bai, max_blocks=rnd.choice([0, 3]))
+                    if keep is None or g["n_rows"] != int(keep.sum()) or g["QNAME"] != [q for q, k in zip(sexp["QNAME"], keep) if k]:
+                        msgs.append(f"indexed region {reg}")
+                except duckhts_amd.DhtsError:
+                    if keep is not None and keep.any():
+                        msgs.append(f"indexed region {reg} raised")
+            ni = rnd.choice([10, 2000])
+            tid = np.array([rnd.randrange(len(names)) for _ in range(ni)], np.int32)
+            beg = np.array([rnd.randrange(0, 60_000_000) for _ in range(ni)], np.int64)
+            end = beg + np.array([rnd.choice([0, 1, 500, 100_000, 10_000_000]) for _ in range(ni)], np.int64)
+            eo = ro.overlap_join(sexp, tid, beg, end)
+            go = duckhts_amd.read_bam(sdata, overlap=(tid, beg, end), max_blocks=rnd.choice([0, 4]))
+            if len(go["OVERLAPS"]) != len(eo) or any(np.sort(a).tolist() != b.tolist() for a, b in zip(go["OVERLAPS"], eo)):
+                msgs.append("overlap join")
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (shards {world}-way of {exp['n_rows']} rows; sorted file {sexp['n_rows']} rows, {ni} intervals)", flush=True)
+            bad += bool(msgs)
+            continue
         # ---- BAM core columns ----
         payload = rnd.choice([61, 300, 777, 4000, 20000, 65280])
         level = rnd.choice([0, 1, 6, 9])
