@@ -209,7 +209,7 @@ __device__ __forceinline__ void tile_stage(const BamStream &st, uint64_t tb, uin
 
 // One wave per tile: speculate the first record start (64 candidates per step), walk the chain.
 extern "C" __global__ void __launch_bounds__(64)
-bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16_t *tile_recs, uint64_t *tile_recs_first) {
+bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16_t *tile_recs, uint64_t *tile_recs_first, uint64_t spec_from) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
     __shared__ uint16_t rl[TL_RECS];                          // record starts found by the walk, relative to the tile
     const int lane = threadIdx.x;
@@ -224,10 +224,11 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16
     if (t == 0 && start0 != NONE64) first = start0;
     else {
         const uint64_t lim = (t == 0) ? st.ulen : te;         // a shard that begins mid-stream keeps looking past its first tile
-        for (uint64_t base = tb; base < lim; base += 64) {
+        const uint64_t from = (t == 0) ? spec_from : 0;        // (a retry after a false start resumes behind the failed candidate)
+        for (uint64_t base = (t == 0) ? (from & ~63ull) : tb; base < lim; base += 64) {
             const uint64_t o = base + (uint64_t)lane;
             bool ok = false;
-            if (o < lim) {
+            if (o < lim && o >= from) {
                 RecInfo r; uint32_t bl0 = 0;
                 // the cheap test touches <= 36 + 255 bytes: straight LDS when that lies inside the staged window
                 const bool inw = (o - tb) + 300u <= (uint64_t)s.len;
@@ -631,4 +632,15 @@ bam_index_rows(BamStream st, const uint32_t *rec_off, BamCols c, int64_t nrows, 
     if (!(c.flag[row] & 4)) for (uint32_t j = 0; j < ne; j++) { const uint32_t op = ldu32(cig + 4ull * j); if ((0x3C1A7u >> ((op & 0xf) << 1)) & 2u) rlen += op >> 4; }
     if (rlen == 0) rlen = 1;
     endpos[row] = (c.pos[row] - 1) + rlen;
+}
+
+// full bam_read1 validation of every row of a batch (what bam_tile_unpack checks while it writes): used to tell a false start of a
+// speculated shard from a good one before any column is written
+extern "C" __global__ void __launch_bounds__(256)
+bam_validate_rows(BamStream st, const uint32_t *rec_off, int64_t nrows, unsigned long long *bad_row) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrows) return;
+    GSrc gs; gs.g = st.u;
+    RecInfo r;
+    if (rec_check_t(st, gs, rec_off[row], r, true) != REC_OK) atomicMin(bad_row, (unsigned long long)row);
 }

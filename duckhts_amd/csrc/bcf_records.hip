@@ -65,7 +65,7 @@ __device__ void bcf_tile_walk(const BcfStream &st, uint64_t start, uint64_t tile
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-bcf_tile_scan(BcfStream st, uint64_t start0, int64_t ntiles, TileOut out) {
+bcf_tile_scan(BcfStream st, uint64_t start0, int64_t ntiles, TileOut out, uint64_t spec_from) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO];
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
@@ -80,10 +80,11 @@ bcf_tile_scan(BcfStream st, uint64_t start0, int64_t ntiles, TileOut out) {
     if (t == 0 && start0 != NONE64) first = start0;
     else {
         const uint64_t lim = (t == 0) ? st.ulen : te;
-        for (uint64_t base = tb; base < lim; base += 64) {
+        const uint64_t from = (t == 0) ? spec_from : 0;        // (a retry after a false start resumes behind the failed candidate)
+        for (uint64_t base = (t == 0) ? (from & ~63ull) : tb; base < lim; base += 64) {
             const uint64_t o = base + (uint64_t)lane;
             bool ok = false;
-            if (o < lim) {
+            if (o < lim && o >= from) {
                 uint64_t sz = 0;
                 const bool inw = (o - tb) + 32u <= (uint64_t)s.len;
                 const int rc0 = inw ? bcf_hop(st, ls, o, sz, true) : bcf_hop(st, gs, o, sz, true);

@@ -1318,27 +1318,55 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
     else start0 = 0;                                           // the carry begins on a record boundary
     if (c->first_batch && c->shard_rank == 0 && c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch");
     uint64_t res[4] = {0, 0, 0, 0};
-    {
-        KTimer tm(c, DHTS_K_TILES);
-        hipLaunchKernelGGL(bam_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to, (uint16_t *)c->t_recs.p, (uint64_t *)c->t_recs_first.p);
-        int rounds = 0;
-        for (;;) {
-            (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
-            hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
-            { TileOut tmp = to; to = to2; to2 = tmp; }         // the round's output is the current table
-            uint32_t nfixed = 0;
-            HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
-            if (nfixed == 0) break;
-            if (++rounds > 256) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
-        }
-        hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
-    }
-    HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
     uint64_t first0 = NONE64;
-    HIPCHK(c, hipMemcpyAsync(&first0, c->t_first.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // A shard that starts mid-stream speculates its first record.  If the chain that grows from the candidate breaks inside this
+    // batch, the candidate was a false start (or the file is damaged): resume the search behind it.  The true first record always
+    // survives; when every retry fails as well the damage is real and the first attempt's result stands.
+    const bool speculative = (start0 == NONE64);
+    uint64_t spec_from = 0; int spec_tries = 0; bool restoring = false;
+    for (;;) {
+        to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
+        to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
+        {
+            KTimer tm(c, DHTS_K_TILES);
+            hipLaunchKernelGGL(bam_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to, (uint16_t *)c->t_recs.p, (uint64_t *)c->t_recs_first.p, spec_from);
+            int rounds = 0;
+            for (;;) {
+                (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
+                hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
+                { TileOut tmp = to; to = to2; to2 = tmp; }         // the round's output is the current table
+                uint32_t nfixed = 0;
+                HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
+                if (nfixed == 0) break;
+                if (++rounds > 256) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
+            }
+            hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
+        }
+        HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&first0, to.first, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!speculative || restoring) break;
+        bool false_start = res[2] != 0 && first0 != NONE64;
+        const bool exhausted = spec_tries > 0 && first0 == NONE64;
+        if (!false_start && !exhausted && first0 != NONE64 && (int64_t)res[0] > 0) {
+            // the chain holds: do its "records" also pass bam_read1's full validation?  (only speculated shard starts pay for this pass)
+            const int64_t nr = (int64_t)res[0];
+            unsigned long long bad0 = ~0ull;
+            ENSURE(c, c->rec_off, (size_t)nr * 4 + 16);
+            HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));
+            hipLaunchKernelGGL(bam_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (const uint32_t *)c->t_rowbase.p,
+                               (const uint64_t *)c->d_res.p, (uint32_t *)c->rec_off.p);
+            hipLaunchKernelGGL(bam_validate_rows, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->rec_off.p, nr, (unsigned long long *)((uint64_t *)c->d_res.p + 4));
+            HIPCHK(c, hipMemcpyAsync(&bad0, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            false_start = bad0 < (unsigned long long)nr;
+        }
+        if (!false_start && !exhausted) break;
+        if (exhausted || spec_tries == 16) { spec_from = 0; restoring = true; continue; }
+        spec_from = first0 + 1; spec_tries++;
+    }
     int64_t nrows = (int64_t)res[0]; uint64_t carry_start = res[1]; bool rec_err = res[2] != 0;
     if (carry_start == NONE64) carry_start = ulen;             // nothing recognisable in this batch
 
@@ -1371,7 +1399,6 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
         }
     }
     bool shard_finished = false;
-    (void)first0;
 
     // ---- rows ----
     BamCols bc; memset(&bc, 0, sizeof(bc));
@@ -1640,49 +1667,67 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     else start0 = 0;
     if (c->first_batch && c->shard_rank == 0 && c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch");
     uint64_t res[4] = {0, 0, 0, 0};
-    {
-        KTimer tm(c, DHTS_K_TILES);
-        hipLaunchKernelGGL(bcf_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to);
-        int rounds = 0;
-        for (;;) {
-            (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
-            hipLaunchKernelGGL(bcf_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
-            { TileOut tmp = to; to = to2; to2 = tmp; }
-            uint32_t nfixed = 0;
-            HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] bcf tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
-            if (nfixed == 0) break;
-            if (++rounds > 256) { hipLaunchKernelGGL(bcf_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
-        }
-        hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
-    }
-    HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int64_t nrec = (int64_t)res[0]; uint64_t carry_start = res[1]; bool rec_err = res[2] != 0;
-    if (carry_start == NONE64) carry_start = ulen;
+    // (same false-start retry as in dhts_bam_next_batch: a speculated shard start whose chain breaks inside the batch, or whose
+    //  "records" fail bcf_record_check, is replaced by the next candidate; if every retry fails too, the first attempt stands)
+    const bool speculative = (start0 == NONE64);
+    uint64_t first0 = NONE64, spec_from = 0; int spec_tries = 0; bool restoring = false;
+    int64_t nrec = 0; uint64_t carry_start = 0; bool rec_err = false;
     const uint64_t shard_end_u = B.sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
     bool shard_finished = false;
     const int reps = c->bsch.tidy ? c->bsch.n_samples : 1;
     const int D = 2 + st.n_info_f + st.n_fmt_f;
     uint32_t rec0_off = 0;
-
-    if (nrec > 0) {
-        const size_t n = (size_t)nrec;
-        const uint32_t stride = (uint32_t)((n + 63) & ~(size_t)63);
-        ENSURE(c, c->b_rec_off, n * 4 + 16); ENSURE(c, c->b_dir, (size_t)D * stride * 4 + 16);
-        hipLaunchKernelGGL(bcf_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (const uint32_t *)c->t_rowbase.p,
-                           (const uint64_t *)c->d_res.p, nrec, (uint32_t *)c->b_rec_off.p);
-        HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));
+    unsigned long long bad = ~0ull;
+    uint32_t stride = 64;
+    for (;;) {
+        to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
+        to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
         {
-            KTimer tm(c, DHTS_K_BCF_CHECK);
-            hipLaunchKernelGGL(bcf_rec_check, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->b_rec_off.p, nrec, (uint32_t *)c->b_dir.p, stride,
-                               (unsigned long long *)((uint64_t *)c->d_res.p + 4));
+            KTimer tm(c, DHTS_K_TILES);
+            hipLaunchKernelGGL(bcf_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to, spec_from);
+            int rounds = 0;
+            for (;;) {
+                (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
+                hipLaunchKernelGGL(bcf_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
+                { TileOut tmp = to; to = to2; to2 = tmp; }
+                uint32_t nfixed = 0;
+                HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] bcf tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
+                if (nfixed == 0) break;
+                if (++rounds > 256) { hipLaunchKernelGGL(bcf_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
+            }
+            hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
         }
-        unsigned long long bad = ~0ull;
-        HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&rec0_off, c->b_rec_off.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&first0, to.first, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        nrec = (int64_t)res[0]; carry_start = res[1]; rec_err = res[2] != 0;
+        if (carry_start == NONE64) carry_start = ulen;
+        bad = ~0ull; rec0_off = 0;
+        if (nrec > 0) {
+            const size_t n = (size_t)nrec;
+            stride = (uint32_t)((n + 63) & ~(size_t)63);
+            ENSURE(c, c->b_rec_off, n * 4 + 16); ENSURE(c, c->b_dir, (size_t)D * stride * 4 + 16);
+            hipLaunchKernelGGL(bcf_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (const uint32_t *)c->t_rowbase.p,
+                               (const uint64_t *)c->d_res.p, nrec, (uint32_t *)c->b_rec_off.p);
+            HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));
+            {
+                KTimer tm(c, DHTS_K_BCF_CHECK);
+                hipLaunchKernelGGL(bcf_rec_check, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->b_rec_off.p, nrec, (uint32_t *)c->b_dir.p, stride,
+                                   (unsigned long long *)((uint64_t *)c->d_res.p + 4));
+            }
+            HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&rec0_off, c->b_rec_off.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (!speculative || restoring) break;
+        const bool false_start = first0 != NONE64 && (res[2] != 0 || bad < (unsigned long long)nrec), exhausted = spec_tries > 0 && first0 == NONE64;
+        if (!false_start && !exhausted) break;
+        if (exhausted || spec_tries == 16) { spec_from = 0; restoring = true; continue; }
+        spec_from = first0 + 1; spec_tries++;
+    }
+    if (nrec > 0) {
         if (bad < (unsigned long long)nrec) { nrec = (int64_t)bad; rec_err = true; }    // the first bad record ends the scan (bcf_reader.c:1319-1349)
         if (nrec > 0 && B.sharded_tail && out_base + ulen > shard_end_u) {
             std::vector<uint32_t> ro(nrec);

@@ -103,6 +103,26 @@ def main():
             go = duckhts_amd.read_bam(sdata, overlap=(tid, beg, end), max_blocks=rnd.choice([0, 4]))
             if len(go["OVERLAPS"]) != len(eo) or any(np.sort(a).tolist() != b.tolist() for a, b in zip(go["OVERLAPS"], eo)):
                 msgs.append("overlap join")
+            # ---- BCF block-range shards: hand-off chain + POS column ----
+            ns = len(bcf_cases.SAMPLES)
+            bdata = W.bcf_bytes(bcf_cases.std_header(), bcf_cases.fuzz_records(seed, rnd.choice([300, 2500]), ns), payload=rnd.choice([777, 4000, 30000]))
+            eb = orc.bcf_read(bdata)
+            c2 = duckhts_amd.Context(0); c2.open(bdata); nbb = c2.bgzf_index(); c2.close()
+            w2 = rnd.randint(2, 5)
+            cuts = [nbb * r // w2 for r in range(w2 + 1)]
+            spans, poss = [], []
+            for r in range(w2):
+                if cuts[r] == cuts[r + 1]:
+                    continue
+                g = duckhts_amd.read_bcf(bdata, block_range=(cuts[r], cuts[r + 1], r > 0), max_blocks=rnd.choice([0, 2]), columns=["POS"])
+                if g["n_rows"]:                     # (a shard of empty blocks, e.g. the EOF marker, owns no record)
+                    spans.append((g["first_rec_uoff"], g["end_uoff"], g["n_rows"])); poss.append(g["by_name"]["POS"]["fixed"])
+            try:
+                tot = duckhts_amd.check_handoff(spans)
+            except Exception as e:
+                tot = f"hand-off failed: {e}"
+            if tot != eb["n_rows"] or not np.array_equal(np.concatenate(poss) if poss else np.zeros(0), eb["by_name"]["POS"]["fixed"]):
+                msgs.append(f"bcf {w2}-way shards: {tot} vs {eb['n_rows']}")
             done += 1
             print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (shards {world}-way of {exp['n_rows']} rows; sorted file {sexp['n_rows']} rows, {ni} intervals)", flush=True)
             bad += bool(msgs)
