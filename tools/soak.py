@@ -123,6 +123,21 @@ def main():
                 tot = f"hand-off failed: {e}"
             if tot != eb["n_rows"] or not np.array_equal(np.concatenate(poss) if poss else np.zeros(0), eb["by_name"]["POS"]["fixed"]):
                 msgs.append(f"bcf {w2}-way shards: {tot} vs {eb['n_rows']}")
+            # ---- BCF region := 'a,b' (chained union of single regions), wide or tidy ----
+            tidy = rnd.random() < 0.3
+            ebt = orc.bcf_read(bdata, tidy)
+            c3 = duckhts_amd.Context(0); c3.open(bdata); c3.bgzf_index()
+            contigs = [x.decode() if x else "\x01" for x in duckhts_amd.BcfScan(c3, tidy).contigs]
+            c3.close()
+            pos = eb["by_name"]["POS"]["fixed"].astype(np.int64)
+            pmax = int(pos.max()) if len(pos) else 1000
+            reg = ",".join(f"{rnd.choice(contigs)}:{b}-{b + rnd.choice([0, 10, 1000, pmax])}" for b in [rnd.randrange(1, pmax + 2) for _ in range(rnd.randint(1, 3))])
+            rows_ = ro.bcf_region_rows(ebt, contigs, reg, ebt["n_samples"] if tidy and ebt["n_samples"] else 1)
+            want = orc.bcf_take_rows(ebt, rows_)
+            gotr = duckhts_amd.read_bcf(bdata, tidy=tidy, region=reg, max_blocks=rnd.choice([0, 2]))
+            d = orc.bcf_cols_diff(want, gotr)
+            if d is not None:
+                msgs.append(f"bcf region {reg}: {d}")
             done += 1
             print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (shards {world}-way of {exp['n_rows']} rows; sorted file {sexp['n_rows']} rows, {ni} intervals)", flush=True)
             bad += bool(msgs)
