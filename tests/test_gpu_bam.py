@@ -420,6 +420,30 @@ def test_wrong_isize_is_a_block_error_rows_before_kept(bogus):
             assert list(got[c]) == list(clean[c][:n]), c
 
 
+# ---- next-batch prefetch: a caller that changes the batch size invalidates the prefetched phase B ---------------------------
+@pytest.mark.gpu
+def test_varying_batch_sizes_discard_the_prefetch():
+    data = synth.bam_file(120000, seed=17)
+    exp = orc.bam_read(data)
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(data); ctx.bgzf_index(); hdr = ctx.bam_open()
+        for sizes in ([3, 7, 2, 5, 11, 1], [4], [1, 64]):
+            ctx.rewind()
+            qn, pos, k = [], [], 0
+            while True:
+                b = ctx.next_batch(sizes[k % len(sizes)]); k += 1
+                if b.n_rows:
+                    h = ctx.batch_to_host(b, hdr)
+                    qn += h["QNAME"]; pos += list(h["POS"])
+                if b.status != 0:
+                    assert b.status == 1
+                    break
+            assert qn == exp["QNAME"] and pos == list(exp["POS"])
+    finally:
+        ctx.close()
+
+
 # ---- projection pushdown into the string pass ---------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("cols", [("QNAME", "SEQ"), ("QUAL",), ("CIGAR", "READ_GROUP_ID"), ("FLAG", "POS")])
