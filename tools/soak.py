@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=60)
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--seconds", type=float, default=480.0)
+    ap.add_argument("--surface", action="store_true", help="per seed: the DuckDB table functions through the mini host, random projections, chunk-exact against the oracle")
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
     args = ap.parse_args()
@@ -61,6 +62,31 @@ def main():
             break
         rnd = random.Random(seed)
         msgs = []
+        if args.surface:
+            import tempfile
+            import test_duckdb_surface as sf
+            tmp = tempfile.mkdtemp()
+            try:
+                n = rnd.choice([50, 300, 1500, 5000])
+                data = cases.case_basic(payload=rnd.choice([777, 4000, 65280]), level=rnd.choice([1, 6]), seed=seed, n=n)
+                proj = None if rnd.random() < 0.3 else sorted(rnd.sample(range(13), rnd.randint(1, 6)), key=lambda _: rnd.random())
+                sf.compare(data, proj=proj, tmp_path=tmp)
+                ns = rnd.choice([0, len(bcf_cases.SAMPLES)])
+                hdr = bcf_cases.std_header() if ns else bcf_cases.std_header(samples=())
+                bdata = W.bcf_bytes(hdr, bcf_cases.fuzz_records(seed, rnd.choice([100, 800, 3000]), ns), payload=rnd.choice([777, 4000, 65280]))
+                tidy = rnd.random() < 0.3
+                ncol = len(orc.bcf_read(bdata, tidy)["cols"])
+                bproj = None if rnd.random() < 0.3 else sorted(rnd.sample(range(ncol), rnd.randint(1, min(6, ncol))), key=lambda _: rnd.random())
+                sf.compare_bcf(bdata, tmp, tidy=tidy, proj=bproj)
+            except AssertionError as e:
+                msgs.append("surface: " + str(e)[:300])
+            finally:
+                import shutil
+                shutil.rmtree(tmp, ignore_errors=True)
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (surface: bam {n} rows proj {proj}, bcf proj {bproj}{' tidy' if tidy else ''})", flush=True)
+            bad += bool(msgs)
+            continue
         if args.scans:
             import numpy as np
             from duckhts_amd import synth
