@@ -7,8 +7,8 @@
 //           wave64).  Each lane walks its stream with canonical-code arithmetic (no big
 //           LUTs): the 15 left-justified code limits of BOTH alphabets live in the two 16-bit
 //           halves of 15 VGPRs, the canonical base values in 15 more (telescoped deltas), the
-//           sorted symbol lists in LDS ([entry][lane] layout, 26,880 B per wave => 6 waves per
-//           CU; the tables are built in two passes over the code-length stream so that no
+//           sorted symbol lists in LDS ([entry][lane] layout, 20,480 B per wave => 8 waves per
+//           CU: the 196 shortest literal/length codes, the rest are fetched through L2 when they occur; the tables are built in two passes over the code-length stream so that no
 //           per-symbol length array has to be kept).  One symbol per lane per iteration from whichever alphabet the lane expects.
 //           Output is append-only: literal bytes and one 32-bit token per LZ77 match.  No
 //           loads depend on earlier stores, so lanes never stall on the LZ77 window.
@@ -32,14 +32,19 @@
 #ifndef A_ST
 #define A_ST A_SL                           /* LDS row stride in lanes */
 #endif
-#define A_LSYM_LO 0                        /* u8  [288][SL] sorted literal/length symbols, low 8 bits */
-#define A_LSYM_HI (A_LSYM_LO + 288 * A_ST) /* u32 [9][SL]   bit 8 of the same, one bit per entry */
-#define A_DSYM (A_LSYM_HI + 9 * A_ST * 4)  /* u8  [32][SL]  sorted distance symbols */
+#ifndef A_NLO
+#define A_NLO 196u                         /* sorted literal/length entries kept in LDS; the rest (longest codes) live in HBM */
+#endif
+#define A_LSYM_LO 0                        /* u8  [A_NLO][SL] sorted literal/length symbols, low 8 bits */
+#define A_LSYM_HI (A_LSYM_LO + A_NLO * A_ST) /* u32 [7][SL]  bit 8 of the same, one bit per entry */
+#define A_DSYM (A_LSYM_HI + 7 * A_ST * 4)  /* u8  [32][SL]  sorted distance symbols */
 #define A_WIN (A_DSYM + 32 * A_ST)         /* u32 [16][SL]  64-byte input window; while the tables are built it holds: */
 #define A_CNTL A_WIN                       /* u16 [15][SL]  literal/length count, then running offset, of code lengths 1..15 */
 #define A_CNTD (A_CNTL + 15 * A_ST * 2)    /* u8  [15][SL]  distance ditto */
 #define A_CLSYM (A_CNTD + 15 * A_ST)       /* u8  [19][SL]  sorted code-length-code symbols */
-#define A_LDS_BYTES (A_WIN + 16 * A_ST * 4) /* 26,880 B = 420 B per stream: SIX waves per CU (6 x 26,880 = 161,280 <= 163,840) */
+#define A_LDS_BYTES (A_WIN + 16 * A_ST * 4) /* 20,480 B = 320 B per stream: EIGHT waves per CU (8 x 20,480 = 163,840 = all of the LDS) */
+#define A_FAR_SLOT (DHTS_TOK_STRIDE - 64u) /* the far symbols (u16 [92]) sit in the slack at the end of the stream's own token slot */
+static_assert(288u - A_NLO <= 128u && A_NLO <= 224u, "far table must fit 64 dwords, the bitmap 7 rows");
 
 struct BitR {
     const uint8_t *p;   // stream base (deflate payload start)
@@ -144,6 +149,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
     const uint32_t clen = tab.clen[bi];
     uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
     uint32_t *tok = tok_all + (size_t)s * DHTS_TOK_STRIDE;
+    uint16_t *far_tab = (uint16_t *)(tok + A_FAR_SLOT);
 
     BitR br;
     br.p = comp + tab.coff[bi] + 18;
@@ -286,7 +292,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                 if (left < 0 || (left > 0 && nz_l != 1) || !has_eob) { status = DHTS_BLK_ERR_INFLATE; break; }
                 left = build_limits(dl, cntd, lane, bsd);
                 if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
-                for (int k = 0; k < 9; k++) lsym_hi[k * A_ST + lane] = 0;
+                for (int k = 0; k < 7; k++) lsym_hi[k * A_ST + lane] = 0;
                 br = br0;
             }
             uint32_t idx = 0, prev = 0;
@@ -324,8 +330,11 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                         const uint32_t o = cntl[(val - 1) * A_ST + lane]; cntl[(val - 1) * A_ST + lane] = (uint16_t)(o + 1);
                         if (pass == 0) { nz_l++; has_eob |= (i == 256u); }
                         else {
-                            lsym_lo[(o > 287u ? 287u : o) * A_ST + lane] = (uint8_t)i;
-                            if (i & 256) lsym_hi[((o >> 5) > 8u ? 8u : (o >> 5)) * A_ST + lane] |= 1u << (o & 31);
+                            const uint32_t oc = o > 287u ? 287u : o;
+                            if (oc < A_NLO) {
+                                lsym_lo[oc * A_ST + lane] = (uint8_t)i;
+                                if (i & 256) lsym_hi[(oc >> 5) * A_ST + lane] |= 1u << (oc & 31);
+                            } else far_tab[oc - A_NLO] = (uint16_t)i;          // the longest codes: looked up through L2 when they occur
                         }
                     } else {
                         const uint32_t o = cntd[(val - 1) * A_ST + lane]; cntd[(val - 1) * A_ST + lane] = (uint8_t)(o + 1);
@@ -339,6 +348,9 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
 
 #ifdef DHTS_DIAG
         unsigned long long dA_s0 = clock64();
+#endif
+#ifndef HOSTSIM
+        __threadfence();                                      // the far-table stores are in L2 before the loop may read them
 #endif
         // ---- symbol loop ----
         // ONE Huffman symbol per lane per iteration, from whichever alphabet the lane expects (mode 0 = literal/length,
@@ -377,7 +389,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                 const uint32_t dd_ = (i < 14 ? (bsd[i + 1] - bsd[i + 2]) : bsd[15]) & 0xfffu;
                 DB[i] = ((dl_ << 4) | 1u) | (((dd_ << 4) | 1u) << 16);
             }
-            bool live = true; uint32_t mode = 0, want = 0, bad = 0, nw = 0;
+            bool live = true, pending = false; uint32_t mode = 0, want = 0, bad = 0, nw = 0, pend_sym = 0;
             nw = winA[((br.pos >> 2) & 15u) * A_ST + lane];                   // next unread word, always one ahead
             while (__ballot(live) != 0ull) {
                 // park the granule fetched during the previous period, then fetch the next one if this lane is running low
@@ -410,17 +422,33 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                         const uint32_t accB = pk_add_u16(pk_add_u16(b0, b1), b2);
                         const uint32_t accM = mode ? (accB >> 16) : (accB & 0xffffu);
                         const uint32_t clt = accM & 15u;                                     // #{limits > w}
-                        bad |= (clt == 0) ? 1u : 0u;
+                        // a lane whose previous symbol lives in the far table (sorted index >= A_NLO: the longest literal/length
+                        // codes) spent that iteration fetching it: its code bits are already consumed, this iteration only handles it
+                        const bool pend = pending;
+                        bad |= (!pend && clt == 0) ? 1u : 0u;
                         uint32_t L = 16u - clt; L = L > 15u ? 15u : L;
                         uint32_t o = ((accM >> 4) + (w >> (15u - L))) & 0xfffu;
                         const uint32_t omax = mode ? 31u : 287u;
-                        bad |= (o > omax) ? 1u : 0u;
+                        bad |= (!pend && o > omax) ? 1u : 0u;
                         o = o > omax ? omax : o;
-                        const uint32_t sb = smem[(mode ? A_DSYM : A_LSYM_LO) + o * A_ST + lane];
-                        const uint32_t hw = lsym_hi[(o >> 5) * A_ST + lane];               // both reads in flight together
-                        const uint32_t sym = sb | (((hw >> (o & 31u)) << 8) & (mode ? 0u : 0x100u));
+                        const bool far = !pend && !mode && o >= A_NLO;
+                        const uint32_t ol = (!mode && o >= A_NLO) ? A_NLO - 1u : o;      // (LDS index of a far / pending lane is a dummy)
+                        const uint32_t sb = smem[(mode ? A_DSYM : A_LSYM_LO) + ol * A_ST + lane];
+                        const uint32_t hw = lsym_hi[(ol >> 5) * A_ST + lane];              // both reads in flight together
+                        uint32_t sym = sb | (((hw >> (ol & 31u)) << 8) & (mode ? 0u : 0x100u));
+                        if (pend) { sym = pend_sym; L = 0; pending = false; }
+                        if (far) {
+#ifdef HOSTSIM
+                            pend_sym = far_tab[o - A_NLO];
+#else
+                            pend_sym = __hip_atomic_load(far_tab + (o - A_NLO), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                            pending = true;
+                        }
                         br.buf = shr64_small(br.buf, L); br.cnt -= L;
-                        if (!mode && sym < 256u) {
+                        if (far) {
+                            // symbol handled next iteration
+                        } else if (!mode && sym < 256u) {
                             // literal
                             bad |= (outpos >= 65536u) ? 1u : 0u;
                             PUSH_LIT(sym); outpos++;
