@@ -32,19 +32,29 @@
 #ifndef A_ST
 #define A_ST A_SL                           /* LDS row stride in lanes */
 #endif
-#ifndef A_NLO
-#define A_NLO 196u                         /* sorted literal/length entries kept in LDS; the rest (longest codes) live in HBM */
-#endif
-#define A_LSYM_LO 0                        /* u8  [A_NLO][SL] sorted literal/length symbols, low 8 bits */
-#define A_LSYM_HI (A_LSYM_LO + A_NLO * A_ST) /* u32 [7][SL]  bit 8 of the same, one bit per entry */
-#define A_DSYM (A_LSYM_HI + 7 * A_ST * 4)  /* u8  [32][SL]  sorted distance symbols */
-#define A_WIN (A_DSYM + 32 * A_ST)         /* u32 [16][SL]  64-byte input window; while the tables are built it holds: */
-#define A_CNTL A_WIN                       /* u16 [15][SL]  literal/length count, then running offset, of code lengths 1..15 */
-#define A_CNTD (A_CNTL + 15 * A_ST * 2)    /* u8  [15][SL]  distance ditto */
-#define A_CLSYM (A_CNTD + 15 * A_ST)       /* u8  [19][SL]  sorted code-length-code symbols */
-#define A_LDS_BYTES (A_WIN + 16 * A_ST * 4) /* 20,480 B = 320 B per stream: EIGHT waves per CU (8 x 20,480 = 163,840 = all of the LDS) */
+// LDS of one wave, [row][lane] (row stride A_ST lanes), for `nlo` sorted literal/length entries kept in LDS:
+//   u8  [nlo]          sorted literal/length symbols, low 8 bits           offset 0
+//   u32 [(nlo+31)/32]  bit 8 of the same, one bit per entry                A_OFF_HI(nlo)
+//   u8  [32]           sorted distance symbols                             A_OFF_DSYM(nlo)
+//   u32 [16]           64-byte input window                                A_OFF_WIN(nlo); while the tables are built it holds
+//                      u16 [15] literal/length counts -> running offsets of code lengths 1..15, u8 [15] distance ditto, u8 [19] CL symbols
+// Two layouts are launched (kernel argument `nlo`):
+//   A_NLO_ALL  288: every sorted symbol in LDS, 26,880 B = 420 B per stream, SIX waves per CU.  For launches that fit the machine
+//                   at six waves per CU (<= 98,304 blocks): nothing leaves LDS, nothing waits on L2.
+//   A_NLO_FAR  196: 20,480 B = 320 B per stream, EIGHT waves per CU (all 160 KB): the longest codes' symbols sit in the slack of
+//                   the stream's own token slot in HBM; a lane that decodes one fetches it and handles it one iteration later.
+//                   Worth 5-6 % on long launches (two waves per SIMD hide the fetch); on a lone wave the fetch latency is exposed
+//                   (a 1 GB BCF became 25 % slower), hence the first layout for small launches.
+#define A_NLO_ALL 288u
+#define A_NLO_FAR 196u
+#define A_HI_ROWS(nlo) (((nlo) + 31u) >> 5)
+#define A_OFF_HI(nlo) ((nlo) * A_ST)
+#define A_OFF_DSYM(nlo) (A_OFF_HI(nlo) + A_HI_ROWS(nlo) * A_ST * 4u)
+#define A_OFF_WIN(nlo) (A_OFF_DSYM(nlo) + 32u * A_ST)
+#define A_LDS_BYTES_FOR(nlo) (A_OFF_WIN(nlo) + 16u * A_ST * 4u)
+#define A_LDS_BYTES A_LDS_BYTES_FOR(A_NLO_ALL)       /* the larger of the two: what the kernel attribute must allow */
 #define A_FAR_SLOT (DHTS_TOK_STRIDE - 64u) /* the far symbols (u16 [92]) sit in the slack at the end of the stream's own token slot */
-static_assert(288u - A_NLO <= 128u && A_NLO <= 224u, "far table must fit 64 dwords, the bitmap 7 rows");
+static_assert(288u - A_NLO_FAR <= 128u, "far table must fit 64 dwords");
 
 struct BitR {
     const uint8_t *p;   // stream base (deflate payload start)
@@ -131,16 +141,19 @@ __device__ __forceinline__ int build_limits(Limits &lm, T *cnt, int lane, uint32
 #ifdef DHTS_DIAG
 __device__ unsigned long long g_diagA[8];
 #endif
-extern "C" __global__ void __launch_bounds__(64)
-bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
-                 uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *lsym_lo = smem + A_LSYM_LO;
-    uint32_t *lsym_hi = (uint32_t *)(smem + A_LSYM_HI);
-    uint8_t *dsym = smem + A_DSYM;
-    uint16_t *cntl = (uint16_t *)(smem + A_CNTL);
-    uint8_t *cntd = smem + A_CNTD;
-    uint8_t *clsym = smem + A_CLSYM;
+// The body is instantiated twice (see the two LDS layouts above): FAR = false keeps every sorted symbol in LDS and compiles the
+// far-symbol path away; FAR = true is the eight-waves-per-CU layout.
+template <bool FAR>
+__device__ __forceinline__ void huff_decode_body(uint8_t *smem, const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                                                 uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta) {
+    constexpr uint32_t A_NLO = FAR ? A_NLO_FAR : A_NLO_ALL;
+    constexpr uint32_t off_dsym = A_OFF_DSYM(A_NLO), off_win = A_OFF_WIN(A_NLO), hi_rows = A_HI_ROWS(A_NLO);
+    uint8_t *lsym_lo = smem;
+    uint32_t *lsym_hi = (uint32_t *)(smem + A_OFF_HI(A_NLO));
+    uint8_t *dsym = smem + off_dsym;
+    uint16_t *cntl = (uint16_t *)(smem + off_win);
+    uint8_t *cntd = smem + off_win + 15 * A_ST * 2;
+    uint8_t *clsym = smem + off_win + 15 * A_ST * 2 + 15 * A_ST;
 
     const int lane = threadIdx.x;
     const int64_t s = (int64_t)blockIdx.x * A_SL + lane;
@@ -292,7 +305,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                 if (left < 0 || (left > 0 && nz_l != 1) || !has_eob) { status = DHTS_BLK_ERR_INFLATE; break; }
                 left = build_limits(dl, cntd, lane, bsd);
                 if (left < 0 || (left > 0 && nz_d > 1)) { status = DHTS_BLK_ERR_INFLATE; break; }
-                for (int k = 0; k < 7; k++) lsym_hi[k * A_ST + lane] = 0;
+                for (uint32_t k = 0; k < hi_rows; k++) lsym_hi[k * A_ST + lane] = 0;
                 br = br0;
             }
             uint32_t idx = 0, prev = 0;
@@ -361,7 +374,7 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
         // Input: per-lane 64-byte LDS ring of four 16-byte granules, topped up one granule per period of 4 symbols (<= 28 bits per
         // symbol, so a lane moves <= 14 bytes per period): every compressed byte is requested from memory once.
         {
-            uint32_t *winA = (uint32_t *)(smem + A_WIN);
+            uint32_t *winA = (uint32_t *)(smem + off_win);
             const uint8_t *sp = br.p;
             // Input ring: granule G = stream bytes [16G, 16G+16) lives in window words 4(G&3)..4(G&3)+3.  Primed with four granules;
             // afterwards a lane fetches ONE granule (16 bytes) per period, and only while it has less than 40 bytes ahead of its read
@@ -424,16 +437,16 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
                         const uint32_t clt = accM & 15u;                                     // #{limits > w}
                         // a lane whose previous symbol lives in the far table (sorted index >= A_NLO: the longest literal/length
                         // codes) spent that iteration fetching it: its code bits are already consumed, this iteration only handles it
-                        const bool pend = pending;
+                        const bool pend = FAR && pending;
                         bad |= (!pend && clt == 0) ? 1u : 0u;
                         uint32_t L = 16u - clt; L = L > 15u ? 15u : L;
                         uint32_t o = ((accM >> 4) + (w >> (15u - L))) & 0xfffu;
                         const uint32_t omax = mode ? 31u : 287u;
                         bad |= (!pend && o > omax) ? 1u : 0u;
                         o = o > omax ? omax : o;
-                        const bool far = !pend && !mode && o >= A_NLO;
-                        const uint32_t ol = (!mode && o >= A_NLO) ? A_NLO - 1u : o;      // (LDS index of a far / pending lane is a dummy)
-                        const uint32_t sb = smem[(mode ? A_DSYM : A_LSYM_LO) + ol * A_ST + lane];
+                        const bool far = FAR && !pend && !mode && o >= A_NLO;
+                        const uint32_t ol = (FAR && !mode && o >= A_NLO) ? A_NLO - 1u : o;      // (LDS index of a far / pending lane is a dummy)
+                        const uint32_t sb = smem[(mode ? off_dsym : 0u) + ol * A_ST + lane];
                         const uint32_t hw = lsym_hi[(ol >> 5) * A_ST + lane];              // both reads in flight together
                         uint32_t sym = sb | (((hw >> (ol & 31u)) << 8) & (mode ? 0u : 0x100u));
                         if (pend) { sym = pend_sym; L = 0; pending = false; }
@@ -503,6 +516,14 @@ bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, 
 #undef PUSH_LIT
 #undef PUSH_TOK
 #undef A_ST16
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+bgzf_huff_decode(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                 uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta, uint32_t nlo) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (nlo == A_NLO_ALL) huff_decode_body<false>(smem, comp, tab, blk0, nblk, lit_all, tok_all, meta);
+    else huff_decode_body<true>(smem, comp, tab, blk0, nblk, lit_all, tok_all, meta);
 }
 
 // ------------------------------------------------------------------------------------

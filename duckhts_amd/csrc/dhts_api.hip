@@ -382,8 +382,11 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb) {
     BgzfTable t = dev_table(c);
     {
         KTimer tm(c, DHTS_K_HUFF);
-        hipLaunchKernelGGL(bgzf_huff_decode, dim3((unsigned)((nb + A_SL - 1) / A_SL)), dim3(64), A_LDS_BYTES, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
-                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p);
+        // a launch that six waves per CU can hold at once keeps every symbol in LDS; a longer one runs eight waves per CU
+        static const int64_t env_nlo = getenv("DHTS_PHASE_A_NLO") ? atoll(getenv("DHTS_PHASE_A_NLO")) : 0;     // tuning knob: 196 or 288
+        const uint32_t nlo = env_nlo == 196 ? A_NLO_FAR : env_nlo == 288 ? A_NLO_ALL : (nb > 98304 ? A_NLO_FAR : A_NLO_ALL);
+        hipLaunchKernelGGL(bgzf_huff_decode, dim3((unsigned)((nb + A_SL - 1) / A_SL)), dim3(64), A_LDS_BYTES_FOR(nlo), c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p, nlo);
     }
     HIPCHK(c, hipGetLastError());
     c->huff_b0 = b0; c->huff_nb = nb;

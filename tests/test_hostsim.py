@@ -16,4 +16,4 @@ def test_phase_a_kernel_text_is_sanitizer_clean():
     r = subprocess.run([os.path.join(ROOT, "tools", "hostsim", "run.sh")] + files, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("blocks")]
-    assert len(lines) == 2 and all("failed 0 mismatching 0" in l for l in lines), r.stdout
+    assert len(lines) == 4 and all("failed 0 mismatching 0" in l for l in lines), r.stdout      # two files x two LDS layouts

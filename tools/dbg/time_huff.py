@@ -22,7 +22,7 @@ for lib in sys.argv[1:] or [os.path.join(ROOT, "duckhts_amd", "libduckhts_amd.so
     h = L.dhts_create(0)
     L.dhts_open_tiled(C.c_void_p(h), head.ctypes.data, head.nbytes, body.ctypes.data, body.nbytes, 8, tail.ctypes.data, tail.nbytes)
     nb = L.dhts_bgzf_index(C.c_void_p(h))
-    for nblk in (131072, 147456):
+    for nblk in (4096, 32768, 98304, 131072):
         if nblk + 1 > nb:
             continue
         ms = L.dhts_debug_time_huff(C.c_void_p(h), 1, nblk, 2)

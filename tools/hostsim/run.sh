@@ -12,4 +12,4 @@ b=$(grep -n '^// phase B$' "$src" | head -1 | cut -d: -f1)
 sed -n "$((a + 2)),$((b - 2))p" "$src" \
   | sed 's/extern __shared__ __attribute__((aligned(16))) uint8_t smem\[\];/uint8_t *smem = g_smem;/' > "$gen/phaseA_extract.inc"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -I"$gen" -o "$gen/sim_huff" "$here/sim_huff.cpp"
-for f in "$@"; do "$gen/sim_huff" "$f"; done
+for f in "$@"; do NLO=196 "$gen/sim_huff" "$f"; NLO=288 "$gen/sim_huff" "$f"; done

@@ -44,21 +44,22 @@ int main(int argc, char **argv) {
     int64_t nb = coff.size();
     BgzfTable t{coff.data(), clen.data(), isz.data(), uoff.data(), nb};
     std::vector<uint8_t> lit((size_t)nb * DHTS_LIT_STRIDE + 8192); std::vector<uint32_t> tok((size_t)nb * DHTS_TOK_STRIDE + 64); std::vector<InflateMeta> meta(nb);
+    const uint32_t nlo = getenv("NLO") ? (uint32_t)atoi(getenv("NLO")) : A_NLO_FAR;      // both LDS layouts are run by run.sh
     int bad = 0;
     for (int64_t wg = 0; wg * A_SL < nb; wg++) {
-        std::vector<uint8_t> smem(A_LDS_BYTES, (uint8_t)(getenv("FILL") ? atoi(getenv("FILL")) : 0));  // exact size: ASAN catches any overrun
+        std::vector<uint8_t> smem(A_LDS_BYTES_FOR(nlo), (uint8_t)(getenv("FILL") ? atoi(getenv("FILL")) : 0));  // exact size: ASAN catches any overrun
         g_smem = smem.data();
 #ifdef SIM_THREADS
         std::vector<std::thread> th;
         for (int lane = 0; lane < A_SL; lane++) th.emplace_back([&, lane]() {
             blockIdx.x = (unsigned)wg; threadIdx.x = (unsigned)lane;
-            bgzf_huff_decode(d.data(), t, 0, (int32_t)nb, lit.data(), tok.data(), meta.data());
+            bgzf_huff_decode(d.data(), t, 0, (int32_t)nb, lit.data(), tok.data(), meta.data(), nlo);
         });
         for (auto &x : th) x.join();
 #else
         for (int lane = 0; lane < A_SL; lane++) {
             blockIdx.x = (unsigned)wg; threadIdx.x = (unsigned)lane;
-            bgzf_huff_decode(d.data(), t, 0, (int32_t)nb, lit.data(), tok.data(), meta.data());
+            bgzf_huff_decode(d.data(), t, 0, (int32_t)nb, lit.data(), tok.data(), meta.data(), nlo);
         }
 #endif
     }
@@ -87,6 +88,6 @@ int main(int argc, char **argv) {
         const uint32_t want_crc = tr[0] | (tr[1] << 8) | (tr[2] << 16) | ((uint32_t)tr[3] << 24), want_len = tr[4] | (tr[5] << 8) | (tr[6] << 16) | ((uint32_t)tr[7] << 24);
         if (out.size() != want_len || out.size() != meta[b].outlen || c != want_crc) mism++;
     }
-    printf("blocks %lld failed %d mismatching %d (SL=%d LDS=%d)\n", (long long)nb, bad, mism, A_SL, (int)A_LDS_BYTES);
+    printf("blocks %lld failed %d mismatching %d (SL=%d LDS=%d)\n", (long long)nb, bad, mism, A_SL, (int)A_LDS_BYTES_FOR(nlo));
     return (bad || mism) ? 1 : 0;
 }
