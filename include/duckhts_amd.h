@@ -182,6 +182,10 @@ int dhts_bam_index_bytes(dhts_ctx *, uint8_t *out, uint64_t cap);
  * beg_i < read_end && read_beg < end_i on the read's contig (read interval = [pos, bam_endpos)), i.e. cr_overlap's answer as
  * a set.  n = 0 switches the join off.  Host pointers; copied.                                                              */
 int dhts_bam_set_overlap_intervals(dhts_ctx *, const int32_t *tid, const int64_t *beg, const int64_t *end, int64_t n);
+/* Next batch of rows (<= max_blocks BGZF blocks of input; 0 = default 16,384, at most 24,576).  colmask = projection pushdown, bit i
+ * = read_bam core column i (DHTS_BAM_*): the fixed-width columns are always produced; the string heaps (QNAME, CIGAR, SEQ, QUAL,
+ * READ_GROUP_ID) of columns that are not projected are not written, and with none of them projected the string pass is skipped
+ * (what the reference does per column in its writer switch, src/bam_reader.c:783-918).                                            */
 int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 
 /* ---- read_bcf ------------------------------------------------------------------------------
