@@ -66,6 +66,30 @@ template <class S> __device__ __forceinline__ uint64_t aux_skip_t(const S &s, ui
     return p + sz;
 }
 
+// aux_skip_t for a field whose type byte (and the byte after it) have already been read
+template <class S> __device__ __forceinline__ uint64_t aux_skip_known(const S &s, uint64_t p, uint64_t end, uint8_t t, uint8_t nxt) {
+    if (p >= end) return end;
+    ++p;
+    if (t == 'Z' || t == 'H') {
+        p = find_nul_t(s, p, end);
+        return p < end ? p + 1 : end;
+    }
+    if (t == 'B') {
+        if (end - p < 5) return NONE64;
+        const uint8_t sub = nxt;
+        int sz = aux_size(sub); if (sub == 'Z' || sub == 'H' || sub == 'B') sz = sub;
+        ++p;
+        uint64_t n = s.u32(p); p += 4;
+        if (sz == 0 || end - p < (uint64_t)sz * n) return NONE64;
+        return p + (uint64_t)sz * n;
+    }
+    int sz = aux_size(t);
+    if (sz == 0) return NONE64;
+    if (end - p < (uint64_t)sz) return NONE64;
+    return p + sz;
+}
+
+// (one 4-byte read per field: tag, type and the byte after the type -- the walk is a chain of dependent LDS reads)
 template <class S> __device__ __forceinline__ uint64_t aux_find_t(const S &s, uint64_t aux, uint64_t end, uint8_t t0, uint8_t t1, bool *bad, uint64_t skip_beg, uint64_t skip_end) {
     *bad = false;
     uint64_t eff_len = (end - aux) - (skip_end - skip_beg);
@@ -74,14 +98,15 @@ template <class S> __device__ __forceinline__ uint64_t aux_find_t(const S &s, ui
     if (p == skip_beg) p = skip_end;
     p += 2;
     for (;;) {
-        if (s.u8(p - 2) == t0 && s.u8(p - 1) == t1) {
-            uint64_t e = aux_skip_t(s, p, end);
+        const uint32_t x = s.u32(p - 2);                      // tag[0] tag[1] type next   (reads <= 1 byte past `end`: buffers are padded)
+        const uint8_t ty = (uint8_t)(x >> 16);
+        const uint64_t e = aux_skip_known(s, p, end, ty, (uint8_t)(x >> 24));
+        if ((uint8_t)x == t0 && (uint8_t)(x >> 8) == t1) {
             if (e == NONE64) { *bad = true; return NONE64; }
-            uint8_t ty = s.u8(p);
             if ((ty == 'Z' || ty == 'H') && s.u8(e - 1) != 0) { *bad = true; return NONE64; }
             return p;
         }
-        uint64_t nx = aux_skip_t(s, p, end);
+        uint64_t nx = e;
         if (nx == NONE64) { *bad = true; return NONE64; }
         if (nx == skip_beg) nx = skip_end;
         if (end - nx <= 2) return NONE64;
