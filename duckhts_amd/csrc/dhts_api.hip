@@ -664,18 +664,20 @@ int dhts_bam_set_regions(dhts_ctx *c, const char *regions) {
     if (!regions || !*regions) return dhts_bam_rewind(c);
     const size_t n_ref = c->ref_name.size();
     std::vector<std::vector<std::pair<int64_t, int64_t>>> per(n_ref);
-    int usable = 0;
+    int usable = 0, ntok = 0;
     std::string all(regions); size_t p = 0;
     while (p <= all.size()) {
         size_t q = all.find(',', p); if (q == std::string::npos) q = all.size();
         std::string tok = all.substr(p, q - p); p = q + 1;
         if (tok.empty()) continue;
+        ntok++;
         if (tok == ".") { c->rg_all = true; usable++; continue; }
         if (tok == "*") { c->rg_nocoor = true; usable++; continue; }
         int tid; int64_t b, e;
         if (!parse_region_token(c->ref_name, tok, tid, b, e)) continue;
         per[tid].push_back({b, e}); usable++;
     }
+    if (ntok == 0) return dhts_bam_rewind(c);               // a string of commas only: the reference's strtok split yields no region at all (bam_reader.c:319-345) => plain scan
     if (!usable) return 1;
     c->rg_tid_first.assign(n_ref + 1, 0);
     for (size_t t = 0; t < n_ref; t++) {

@@ -97,7 +97,9 @@ static void bam_read_bind(duckdb_bind_info info) {
     BamBind *b = new BamBind();
     b->path = file_path;
     std::string idx = index_path ? index_path : "";
-    bool has_region = region && strlen(region) > 0;
+    // parse_regions (bam_reader.c:319-345) splits with strtok: a string without a non-empty token ('' or ',,') is no region at all
+    bool has_region = false;
+    for (const char *q = region; q && *q; q++) if (*q != ',') { has_region = true; break; }
     std::string region_copy = has_region ? region : "";
     dfree(file_path); if (region) dfree(region); if (index_path) dfree(index_path); if (reference) dfree(reference);
 

@@ -128,8 +128,12 @@ def endpos(pos0, flag, cigar):
 
 
 def keep_mask(table, region_string):
-    """table = orc.bam_read(...) result -> boolean numpy mask of the rows read_bam(region := ...) returns (file order)."""
+    """table = orc.bam_read(...) result -> boolean numpy mask of the rows read_bam(region := ...) returns (file order).
+    A string without any non-empty token ('' or ',,') is no region at all: parse_regions' strtok split yields n_regions = 0 and the
+    reader does a plain scan (src/bam_reader.c:319-345, 571).  None = tokens were given but none names a known reference."""
     names = [bytes(x).decode() for x in table["ref_names"]]
+    if not any(region_string.split(",")):
+        return np.ones(table["n_rows"], bool)
     rl = reglist(names, region_string)
     if rl is None:
         return None

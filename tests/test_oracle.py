@@ -259,6 +259,8 @@ def test_region_oracle_pins():
     assert cnt("CHROMOSOME_I") == 18 and cnt("CHROMOSOME_I:1-1000") == 2 and cnt("CHROMOSOME_I:1-1000,CHROMOSOME_I:1-1000") == 2
     assert cnt(".") == 112 and cnt("*") == 0
     assert region_oracle.keep_mask(t, "nosuch") is None
+    # parse_regions' strtok split (src/bam_reader.c:319-345): no non-empty token = no region at all = plain scan
+    assert int(region_oracle.keep_mask(t, "").sum()) == 112 and int(region_oracle.keep_mask(t, ",,").sum()) == 112
     names = ["chr1", "chr1:100-200", "a:b"]
     assert region_oracle.parse_region(names, "chr1:1,000-2k") == (0, 999, 2000)
     assert region_oracle.parse_region(names, "{chr1:100-200}") == (1, 0, region_oracle.POS_MAX)

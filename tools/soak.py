@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=60)
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--seconds", type=float, default=480.0)
+    ap.add_argument("--regions", action="store_true", help="random (mostly malformed) region strings against the restatement of hts_parse_region / sam_itr_regarray")
     ap.add_argument("--surface", action="store_true", help="per seed: the DuckDB table functions through the mini host, random projections, chunk-exact against the oracle")
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
@@ -62,6 +63,44 @@ def main():
             break
         rnd = random.Random(seed)
         msgs = []
+        if args.regions:
+            if seed == args.first:
+                rdata = cases.case_basic(payload=4000, level=6, seed=5, n=1500)
+                rexp = orc.bam_read(rdata)
+                rnames = [bytes(x).decode() for x in rexp["ref_names"]]
+                main.cache = (rdata, rexp, rnames)
+            rdata, rexp, rnames = main.cache
+            for _ in range(20):
+                toks = []
+                for _t in range(rnd.randint(1, 3)):
+                    kind = rnd.random()
+                    nm = rnd.choice(rnames + ["nosuch", "", "*", ".", "{" + rnd.choice(rnames) + "}", rnd.choice(rnames) + ":1"])
+                    if kind < 0.3:
+                        toks.append(nm)
+                    elif kind < 0.7:
+                        a = rnd.choice(["", "1", "1,000", "2k", "5K", "1m", "0", "-5", "1e3", "12x", "99999999999", str(rnd.randrange(1, 30000))])
+                        b = rnd.choice(["", "1", "3,500", "20k", "1M", "0", "abc", str(rnd.randrange(1, 60000))])
+                        toks.append(f"{nm}:{a}-{b}" if rnd.random() < 0.8 else f"{nm}:{a}")
+                    else:
+                        toks.append("".join(rnd.choice("chr1:-,{}*.0123456789kKmMeE ") for _c in range(rnd.randint(1, 12))))
+                reg = ",".join(toks)
+                try:
+                    keep = ro.keep_mask(rexp, reg)
+                except Exception as e:
+                    msgs.append(f"oracle raised on {reg!r}: {e}"); continue
+                try:
+                    g = duckhts_amd.read_bam(rdata, region=reg)
+                    if keep is None:
+                        msgs.append(f"region {reg!r}: gpu {g['n_rows']} rows, oracle: no known reference")
+                    elif g["n_rows"] != int(keep.sum()) or g["QNAME"] != [q for q, k in zip(rexp["QNAME"], keep) if k]:
+                        msgs.append(f"region {reg!r}: {g['n_rows']} rows vs {int(keep.sum())}")
+                except duckhts_amd.DhtsError as e:
+                    if keep is not None:
+                        msgs.append(f"region {reg!r}: gpu raised ({e}), oracle keeps {int(keep.sum())}")
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs[:3])}", flush=True)
+            bad += bool(msgs)
+            continue
         if args.surface:
             import tempfile
             import test_duckdb_surface as sf
