@@ -535,7 +535,7 @@ def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=
             sc.set_block_range(*block_range)
         parts, status, first, end = [], 0, None, None
         # region := 'a,b': chained union of single-region scans in the given order (src/bcf_reader.c:1327-1345)
-        passes = [None] if region is None else [r for r in region.split(",") if r]
+        passes = [None] if region is None else ([r for r in region.split(",") if r] or [None])     # no non-empty token = no region
         for rg in passes:
             if rg is not None and not sc.set_region(rg):
                 continue
