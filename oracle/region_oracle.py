@@ -160,6 +160,8 @@ def bcf_region_rows(table, contigs, region_string, tidy_reps=1):
     table = orc.bcf_read(...) result (its "rec" arrays); -> list of ROW indices in output order."""
     rec = table["rec"]
     out = []
+    if not any(region_string.split(",")):            # parse_regions_duckdb (bcf_reader.c:286-328): no non-empty token = no region = plain scan
+        return list(range(len(rec["rid"]) * tidy_reps))
     for tok in region_string.split(","):
         if tok == "":
             continue

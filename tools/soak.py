@@ -97,6 +97,33 @@ def main():
                 except duckhts_amd.DhtsError as e:
                     if keep is not None:
                         msgs.append(f"region {reg!r}: gpu raised ({e}), oracle keeps {int(keep.sum())}")
+            # the same strings as read_bcf regions (chained single-region scans; unknown ones are skipped)
+            if seed == args.first:
+                import numpy as np
+                bd = W.bcf_bytes(bcf_cases.std_header(), bcf_cases.fuzz_records(7, 1200, len(bcf_cases.SAMPLES)), payload=4000)
+                be = orc.bcf_read(bd)
+                c3 = duckhts_amd.Context(0); c3.open(bd); c3.bgzf_index()
+                bcont = [x.decode() if x else "\x01" for x in duckhts_amd.BcfScan(c3, False).contigs]
+                c3.close()
+                main.bcache = (bd, be, bcont)
+            bd, be, bcont = main.bcache
+            for _ in range(6):
+                toks = []
+                for _t in range(rnd.randint(1, 3)):
+                    nm = rnd.choice(bcont + ["nosuch", ".", "{" + rnd.choice(bcont) + "}"])
+                    a = rnd.choice(["", "1", "1,000", "2k", "0", "-5", "1e3", "12x", str(rnd.randrange(1, 3000))])
+                    b = rnd.choice(["", "1", "3,500", "20k", "abc", str(rnd.randrange(1, 9000))])
+                    toks.append(rnd.choice([nm, f"{nm}:{a}-{b}", f"{nm}:{a}", "".join(rnd.choice("12:-,{}.kK ") for _c in range(rnd.randint(1, 8)))]))
+                reg = ",".join(toks)
+                try:
+                    rows_ = ro.bcf_region_rows(be, bcont, reg, 1)
+                    want = orc.bcf_take_rows(be, rows_)
+                    gotr = duckhts_amd.read_bcf(bd, region=reg)
+                    d = orc.bcf_cols_diff(want, gotr)
+                    if d is not None:
+                        msgs.append(f"bcf region {reg!r}: {d}")
+                except Exception as e:
+                    msgs.append(f"bcf region {reg!r}: {type(e).__name__} {e}")
             done += 1
             print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs[:3])}", flush=True)
             bad += bool(msgs)
