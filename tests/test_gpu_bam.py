@@ -444,6 +444,28 @@ def test_varying_batch_sizes_discard_the_prefetch():
         ctx.close()
 
 
+# ---- both LDS layouts of the Huffman kernel ---------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlo", ["196", "288"])
+def test_phase_a_layouts_forced(nlo):
+    """launches of > 98,304 blocks use the far-table layout (196 sorted symbols in LDS), smaller ones keep all 288 in LDS: force
+    each on a file small enough for the oracle (the knob is read once per process, hence the child process)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import duckhts_amd, orc, cases\n"
+        "from duckhts_amd import synth\n"
+        "for data in (synth.bam_file(60000, seed=31), cases.ALL_CASES['fixed_huffman'](), cases.ALL_CASES['basic_stored'](), cases.ALL_CASES['basic_level9']()):\n"
+        "    exp = orc.bam_read(data); got = duckhts_amd.read_bam(data, max_blocks=700)\n"
+        "    assert got['n_rows'] == exp['n_rows'] and got['status'] == 1\n"
+        "    for k in duckhts_amd.BAM_COLUMNS: assert list(got[k]) == list(exp[k]), k\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, DHTS_PHASE_A_NLO=nlo)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 # ---- projection pushdown into the string pass ---------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("cols", [("QNAME", "SEQ"), ("QUAL",), ("CIGAR", "READ_GROUP_ID"), ("FLAG", "POS")])
