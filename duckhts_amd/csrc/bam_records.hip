@@ -403,6 +403,11 @@ bgzf_sig_write(const uint8_t *d, uint64_t n, const uint32_t *base, uint64_t *can
         w += __shfl(inc, 63, 64);
     }
 }
+// The ISIZE trailer field as the block table keeps it.  A BGZF block inflates to at most 65,536 bytes, so a larger claim can never be
+// met: it is recorded as 65,537, which (a) still fails phase B's `outlen == ISIZE` test -- the stream ends at that block like for
+// any other wrong ISIZE -- and (b) keeps uoff, the prefix sum of these values, monotone and far from 32-bit wrap-around whatever
+// bytes a damaged or hostile file carries there (a raw 0xFFFFxxxx used to wrap the u32 partial sums and misplace its neighbours).
+__device__ __forceinline__ uint32_t isize_placed(uint32_t raw) { return raw > 65536u ? 65537u : raw; }
 // Sequential restatement of the htslib chain walk (bgzf.c:1155-1236); used only when the parallel proof fails
 // (corrupt or unusual files).  res[0] = number of good blocks, res[1] = status (0 clean end, -1 bad header, -2 short block).
 extern "C" __global__ void bgzf_chain_walk_seq(const uint8_t *d, uint64_t n, uint64_t *coff, uint32_t *clen, uint32_t *isize,
@@ -416,7 +421,7 @@ extern "C" __global__ void bgzf_chain_walk_seq(const uint8_t *d, uint64_t n, uin
         uint32_t bl = ((uint32_t)p[16] | ((uint32_t)p[17] << 8)) + 1;
         if (bl < 18) { status = -1; break; }
         if (o + bl > n) { status = -2; break; }
-        coff[k] = o; clen[k] = bl; isize[k] = bl >= 26 ? ldu32(p + bl - 4) : 0;
+        coff[k] = o; clen[k] = bl; isize[k] = bl >= 26 ? isize_placed(ldu32(p + bl - 4)) : 0;
         k++; o += bl;
     }
     res[0] = k; res[1] = status;
@@ -434,6 +439,6 @@ bgzf_chain_check(const uint8_t *d, uint64_t n, const uint64_t *cand, int64_t nca
     if (o + bl > n || bl < 26) ok = false;
     if (ok) { if (i + 1 < ncand) ok = (cand[i + 1] == o + bl); else ok = (o + bl == n); }
     clen[i] = bl;
-    isize[i] = ok ? ldu32(d + o + bl - 4) : 0;
+    isize[i] = ok ? isize_placed(ldu32(d + o + bl - 4)) : 0;
     if (!ok) atomicAdd(bad, 1u);
 }

@@ -25,8 +25,14 @@
 #define TILE_BYTES TL_TILE               /* record-stage tile = what bam_tiles_lds.hip stages per wave */
 #define PAD_BYTES 256u
 
+// Owning device allocation: freed by its destructor, so deleting a context returns every byte of HBM it held.
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
     int ensure(size_t n) {
         if (n <= cap) return 0;
         if (p) (void)hipFree(p);
@@ -112,6 +118,8 @@ struct dhts_ctx {
     std::vector<hipEvent_t> ev_pool;
 };
 
+static const bool g_debug = getenv("DHTS_DEBUG") != nullptr;      // read once, not per repair round
+
 static int fail(dhts_ctx *c, const char *fmt, ...) {
     char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     if (c) c->err = buf;
@@ -180,16 +188,8 @@ void dhts_destroy(dhts_ctx *c) {
     timing_collect(c);
     (void)hipEventDestroy(c->pf_done); (void)hipStreamDestroy(c->stream_b);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf *ovb[] = {&c->sg_cnt, &c->sg_base, &c->sg_cand, &c->sg_hits, &c->ix_end, &c->t_recs, &c->t_recs_first, &c->ov_beg, &c->ov_end, &c->ov_pmax, &c->ov_bmax, &c->ov_id, &c->ov_first, &c->ov_cnt, &c->ov_off, &c->ov_ids};
-    for (auto b : ovb) b->release();
-    DevBuf *all[] = {&c->comp, &c->coff, &c->clen, &c->isize, &c->uoff, &c->blk_status, &c->lit, &c->tok, &c->meta, &c->ubuf[0], &c->ubuf[1],
-                     &c->t_first, &c->t_end, &c->t_count, &c->t_err, &c->t_rowbase, &c->d_res, &c->d_nfixed, &c->rec_off, &c->c_flag, &c->c_pos,
-                     &c->c_mapq, &c->c_pnext, &c->c_tlen, &c->c_tid, &c->c_mtid, &c->c_rgidx, &c->c_rgvalid, &c->l_qname, &c->l_cigar, &c->l_seq,
-                     &c->l_qual, &c->l_rg, &c->cig_rel, &c->ncig_eff, &c->rg_rel, &c->alen_qual, &c->o_qname, &c->o_cigar, &c->o_seq, &c->o_qual,
-                     &c->o_rg, &c->scan_partial, &c->scan_total, &c->a_qname, &c->a_cigar, &c->a_seq, &c->a_qual, &c->a_rg, &c->d_rg_off, &c->d_rg_bytes, &c->c_rgflag, &c->t2_first, &c->t2_end, &c->t2_count, &c->t2_err};
-    for (auto b : all) b->release();
     (void)hipStreamDestroy(c->stream);
-    delete c;
+    delete c;                                               // every DevBuf member frees its allocation (device `c->device` is current)
 }
 
 const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no context (no MI355X device or code object)"; }
@@ -340,7 +340,7 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
         c->n_blocks = res[0]; c->bgzf_status = (int)res[1];
     }
     cleanup();
-    // uoff = exclusive prefix of min(isize, 65536)
+    // uoff = exclusive prefix of the recorded ISIZE values (each <= 65,537: isize_placed)
     const int64_t nb = c->n_blocks;
     ENSURE(c, c->uoff, (size_t)(nb + 1) * 8 + 64);
     ENSURE(c, c->blk_status, (size_t)(nb + 1) * 4);
@@ -407,8 +407,8 @@ static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t
 static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
     if (nb <= 0) return 0;
     discard_prefetch(c);                                   // (phase A below may reallocate the scratch a prefetched phase B reads)
-    // (a block whose ISIZE field exceeds 64 KiB is placed as 64 KiB -- uoff is the prefix of min(ISIZE, 65536) -- and fails phase B's
-    //  outlen == ISIZE test like any other block with a wrong ISIZE: the stream ends there, rows before it are kept)
+    // (a block whose ISIZE field exceeds 64 KiB is recorded and placed as 65,537 bytes -- isize_placed in bam_records.hip -- and fails
+    //  phase B's outlen == ISIZE test like any other block with a wrong ISIZE: the stream ends there, rows before it are kept)
     if (!(b0 >= c->huff_b0 && b0 + nb <= c->huff_b0 + c->huff_nb)) {
         static const int64_t env_super = getenv("DHTS_SUPER_BLOCKS") ? atoll(getenv("DHTS_SUPER_BLOCKS")) : 0;   // tuning knob
         int64_t sb = env_super > 0 ? env_super : c->super_blocks;
@@ -1247,7 +1247,7 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
         DevBuf nbuf; if (nbuf.ensure(ulen + PAD_BYTES)) return fail(c, "hipMalloc failed");
         if (carry) HIPCHK(c, hipMemcpyAsync(nbuf.p, ub.p, carry, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        ub.release(); ub = nbuf;
+        ub.swap(nbuf);                                          // nbuf's destructor frees the old buffer
     }
     uint8_t *u = (uint8_t *)ub.p;
     const uint64_t out_base = c->h_uoff[b0] - carry;          // absolute stream offset of u[0]
@@ -1343,7 +1343,7 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
                 uint32_t nfixed = 0;
                 HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
+                if (g_debug) fprintf(stderr, "[dhts] tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
                 if (nfixed == 0) break;
                 if (++rounds > 256) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
             }
@@ -1698,7 +1698,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                 uint32_t nfixed = 0;
                 HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (getenv("DHTS_DEBUG")) fprintf(stderr, "[dhts] bcf tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
+                if (g_debug) fprintf(stderr, "[dhts] bcf tiles=%lld round=%d nfixed=%u\n", (long long)ntiles, rounds, nfixed);
                 if (nfixed == 0) break;
                 if (++rounds > 256) { hipLaunchKernelGGL(bcf_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
             }

@@ -8,8 +8,8 @@
 // ---- BGZF block table (device, SoA) ---------------------------------------
 // coff[i]  : byte offset of block i's 18-byte header in the compressed buffer
 // clen[i]  : total block length BSIZE+1 (header 18 + deflate payload + trailer 8)
-// isize[i] : ISIZE from the trailer (claimed inflated length, <= 65536)
-// uoff[i]  : exclusive prefix sum of isize = offset of block i in the inflated stream
+// isize[i] : ISIZE from the trailer (claimed inflated length); claims above 65536 are stored as 65537 (never met: isize_placed)
+// uoff[i]  : exclusive prefix sum of isize[] = offset of block i in the inflated stream (u64)
 struct BgzfTable {
     const uint64_t *coff;
     const uint32_t *clen;

@@ -9,9 +9,15 @@
 // The htslib calls underneath are replaced by include/duckhts_amd.h (HIP kernels); DuckDB is reached only
 // through the function-pointer table returned by access->get_api(info, "v1.2.0").
 //
-// Scan mode: the reference's sequential mode (i): one scan thread, all records in file
-// order including unplaced reads, full 2048-row chunks except the last.  region / tag columns / CRAM / SAM are
-// not on the GPU path yet and are rejected at bind time with an explicit message.
+// Scan mode: the reference's sequential mode (i): all records in file order including
+// unplaced reads, full 2048-row chunks except the last.  region, standard_tags and auxiliary_tags are served by
+// the GPU path; CRAM / SAM text input fails at bind with the reference's header error.
+//
+// Linkage (src/duckhts.c:13-16,54-55): register_read_bam_function / register_read_bcf_function have external
+// linkage and read the DuckDB API through the global `duckdb_ext_api`, exactly like the reference's readers
+// (DUCKDB_EXTENSION_EXTERN, duckdb_extension.h:1161), so a reference-built src/duckhts.c links against them
+// unchanged.  This file also carries a weak definition of that global and a weak duckhts_init_c_api, which
+// are what a stand-alone libduckhts_amd.so uses; strong definitions from src/duckhts.c win at link time.
 #include "../../include/duckhts_amd.h"
 #include "../../include/duckhts_extension.h"
 
@@ -21,9 +27,16 @@
 #include <string>
 #include <vector>
 
-static const void *const *g_api = nullptr;   // duckdb_ext_api_v1 viewed as an array of function pointers
+// duckdb_ext_api_v1 viewed as an array of function pointers (slot numbers: include/duckdb_abi_slots.h).  Weak: the definition
+// DUCKDB_EXTENSION_GLOBAL emits in a reference-built src/duckhts.c (duckdb_extension.h:1151) replaces it.
+extern "C" __attribute__((visibility("default"), weak)) const void *duckdb_ext_api[DUCKDB_ABI_V120_NSLOTS] = {nullptr};
 
-#define API(ret, name, ...) ((ret(*)(__VA_ARGS__))g_api[SLOT_##name])
+#define API(ret, name, ...) ((ret(*)(__VA_ARGS__))duckdb_ext_api[SLOT_##name])
+
+// what DUCKDB_EXTENSION_API_INIT does (`duckdb_ext_api = *res`, duckdb_extension.h:1153-1158), for hosts that hold the table
+extern "C" __attribute__((visibility("default"))) void dhts_set_duckdb_api(const void *api_table) {
+    if (api_table) memcpy((void *)duckdb_ext_api, api_table, sizeof(void *) * DUCKDB_ABI_V120_NSLOTS);
+}
 
 static inline void set_null(duckdb_vector vec, idx_t row) {           // src/bam_reader.c:38-42
     API(void, duckdb_vector_ensure_validity_writable, duckdb_vector)(vec);
@@ -110,14 +123,14 @@ static void bam_read_bind(duckdb_bind_info info) {
     }
     int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
     b->ctx = dhts_create(dev);
-    if (!b->ctx) { set_error(info, "read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); delete b; return; }
+    if (!b->ctx) { set_error(info, "read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); destroy_bind(b); return; }
     if (dhts_open_path(b->ctx, b->path.c_str()) != 0) {
         snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());
-        set_error(info, err); delete b; return;
+        set_error(info, err); destroy_bind(b); return;
     }
     if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bam_open(b->ctx) != 0 || dhts_bam_header_get(b->ctx, &b->hdr) != 0) {
         set_error(info, "Failed to read SAM/BAM/CRAM header");                    // bam_reader.c:461 (also what SAM/CRAM input gets here)
-        delete b; return;
+        destroy_bind(b); return;
     }
     // index lookup order of sam_index_load3 (hts.c:4720-4790): explicit path, <file>.csi, <file>.bai, <file minus .bam>.bai/.csi
     {
@@ -377,7 +390,7 @@ static void bam_read_function(duckdb_function_info info, duckdb_data_chunk outpu
     set_size(output, row_count);
 }
 
-static void register_read_bam_function(duckdb_connection connection) {                      // bam_reader.c:1044-1068
+extern "C" __attribute__((visibility("default"))) void register_read_bam_function(duckdb_connection connection) {                      // bam_reader.c:1044-1068
     duckdb_table_function tf = API(duckdb_table_function, duckdb_create_table_function, void)();
     API(void, duckdb_table_function_set_name, duckdb_table_function, const char *)(tf, "read_bam");
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
@@ -403,7 +416,7 @@ static void register_read_bam_function(duckdb_connection connection) {          
 // =====================================================================================================================
 // read_bcf -- mirrors register_read_bcf_function src/bcf_reader.c:2055-2080, bcf_read_bind 452-880 (schema 540-760),
 // global/local init 886-1150 (projection ids, region error), bcf_read_function 1155-2049 (<= vector_size rows per call).
-// Sequential mode; tidy_format supported; region / VCF text / VEP columns are rejected with explicit messages.
+// Sequential mode; tidy_format and region supported; VCF text input is rejected with the reference's header error.
 // =====================================================================================================================
 struct BcfBind {
     std::string path, region;
@@ -470,15 +483,15 @@ static void bcf_read_bind(duckdb_bind_info info) {
     }
     int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
     b->ctx = dhts_create(dev);
-    if (!b->ctx) { set_error(info, "read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); delete b; return; }
+    if (!b->ctx) { set_error(info, "read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); destroy_bcf_bind(b); return; }
     if (dhts_open_path(b->ctx, b->path.c_str()) != 0) {
         snprintf(err, sizeof(err), "Failed to open BCF/VCF file: %s", b->path.c_str());
-        set_error(info, err); delete b; return;
+        set_error(info, err); destroy_bcf_bind(b); return;
     }
     if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bcf_open(b->ctx, tidy) != 0 || dhts_bcf_info_get(b->ctx, &b->inf) != 0) {
         const char *m = dhts_error(b->ctx);
         set_error(info, (m && strstr(m, "VEP")) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505
-        delete b; return;
+        destroy_bcf_bind(b); return;
     }
     for (const std::string &f : {idx, b->path + ".csi", b->path + ".tbi"}) if (!f.empty() && file_exists(f)) { b->index_file = f; break; }
     b->has_index = !b->index_file.empty();
@@ -638,7 +651,7 @@ static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk outpu
     set_size(output, row_count);
 }
 
-static void register_read_bcf_function(duckdb_connection connection) {                       // bcf_reader.c:2055-2080
+extern "C" __attribute__((visibility("default"))) void register_read_bcf_function(duckdb_connection connection) {                       // bcf_reader.c:2055-2080
     duckdb_table_function tf = API(duckdb_table_function, duckdb_create_table_function, void)();
     API(void, duckdb_table_function_set_name, duckdb_table_function, const char *)(tf, "read_bcf");
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
@@ -660,11 +673,11 @@ static void register_read_bcf_function(duckdb_connection connection) {          
     API(void, duckdb_destroy_table_function, duckdb_table_function *)(&tf);
 }
 
-extern "C" __attribute__((visibility("default"))) bool duckhts_init_c_api(duckdb_extension_info info, struct duckdb_extension_access *access) {
+extern "C" __attribute__((visibility("default"), weak)) bool duckhts_init_c_api(duckdb_extension_info info, struct duckdb_extension_access *access) {
     // duckdb_extension.h:1151-1158,1182-1194: fetch the API table, connect, register, disconnect
     const void *api = access->get_api(info, DUCKHTS_API_VERSION);
     if (!api) return false;
-    g_api = (const void *const *)api;
+    dhts_set_duckdb_api(api);
     duckdb_database *db = access->get_database(info);
     duckdb_connection conn = nullptr;
     if (API(duckdb_state, duckdb_connect, duckdb_database, duckdb_connection *)(*db, &conn) == DuckDBError) {

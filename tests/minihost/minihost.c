@@ -8,7 +8,10 @@
  *   masked), then the payload: fixed width = n x width bytes (invalid rows zeroed); VARCHAR = per row u32 len
  *   (0xFFFFFFFF for NULL) + bytes; LIST = n x (u64 offset, u64 length) exactly as written, u64 child size, u32 child type,
  *   then the child payload in the scalar encoding (child validity is not used by the readers: children are always valid).
- * usage: minihost <ext.so> <function> <path> [-n name=value]... [-p 0,3,5] [-o out.bin]
+ * usage: minihost [--direct] <ext.so> <function> <path> [-n name=value]... [-p 0,3,5] [-o out.bin]
+ * --direct plays a reference-built src/duckhts.c (src/duckhts.c:13-16,48-55): it fills the extension's `duckdb_ext_api`
+ * global the way DUCKDB_EXTENSION_API_INIT does and calls register_read_bcf_function / register_read_bam_function
+ * itself, never touching duckhts_init_c_api.
  */
 #include <dlfcn.h>
 #include <stdbool.h>
@@ -131,6 +134,8 @@ static duckdb_database *get_database(duckdb_extension_info info) { (void)info; r
 static void set_error(duckdb_extension_info info, const char *e) { (void)info; fprintf(stderr, "extension error: %s\n", e); }
 
 int main(int argc, char **argv) {
+    int direct = 0;
+    if (argc > 1 && !strcmp(argv[1], "--direct")) { direct = 1; argv++; argc--; }
     if (argc < 4) { fprintf(stderr, "usage: minihost ext.so function path [-n k=v] [-p cols] [-o out]\n"); return 2; }
 #define SET(name, fn) g_api[SLOT_##name] = (void *)(fn)
     SET(duckdb_malloc, h_malloc); SET(duckdb_free, h_free); SET(duckdb_vector_size, h_vector_size); SET(duckdb_connect, h_connect); SET(duckdb_disconnect, h_disconnect);
@@ -154,10 +159,29 @@ int main(int argc, char **argv) {
 
     void *so = dlopen(argv[1], RTLD_NOW);
     if (!so) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
-    bool (*entry)(duckdb_extension_info, struct duckdb_extension_access *) = dlsym(so, "duckhts_init_c_api");
-    if (!entry) { fprintf(stderr, "no duckhts_init_c_api\n"); return 2; }
     struct duckdb_extension_access acc = { set_error, get_database, get_api };
-    if (!entry((void *)0x3, &acc)) { fprintf(stderr, "entrypoint returned false\n"); return 2; }
+    if (direct) {
+        void **tab = dlsym(so, "duckdb_ext_api");
+        void (*reg_bcf)(duckdb_connection) = dlsym(so, "register_read_bcf_function");
+        void (*reg_bam)(duckdb_connection) = dlsym(so, "register_read_bam_function");
+        if (!tab || !reg_bcf || !reg_bam) { fprintf(stderr, "missing duckdb_ext_api / register_read_*_function\n"); return 2; }
+        memcpy(tab, g_api, sizeof(g_api));                 /* duckdb_ext_api = *res */
+        duckdb_connection conn = NULL; h_connect(g_db, &conn);
+        reg_bcf(conn); reg_bam(conn);                      /* src/duckhts.c:54-55 */
+        h_disconnect(&conn);
+    } else {
+        bool (*entry)(duckdb_extension_info, struct duckdb_extension_access *) = dlsym(so, "duckhts_init_c_api");
+        if (!entry) { fprintf(stderr, "no duckhts_init_c_api\n"); return 2; }
+        if (!entry((void *)0x3, &acc)) { fprintf(stderr, "entrypoint returned false\n"); return 2; }
+    }
+    if (!strcmp(argv[2], "--catalog")) {                   /* list what got registered, no scan */
+        for (int i = 0; i < g_ntf; i++) {
+            printf("TF %s pushdown=%d bind=%d init=%d local_init=%d func=%d named=", g_tfs[i].name, g_tfs[i].pushdown, g_tfs[i].bind != NULL, g_tfs[i].init != NULL, g_tfs[i].local_init != NULL, g_tfs[i].func != NULL);
+            for (int k = 0; k < g_tfs[i].n_named; k++) printf("%s%s:%d", k ? "," : "", g_tfs[i].named[k], g_tfs[i].named_type[k]);
+            printf("\n");
+        }
+        return 0;
+    }
     TF *tf = NULL;
     for (int i = 0; i < g_ntf; i++) if (!strcmp(g_tfs[i].name, argv[2])) tf = &g_tfs[i];
     if (!tf) { printf("ERROR catalog: table function %s not registered\n", argv[2]); return 3; }

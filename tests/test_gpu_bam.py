@@ -401,7 +401,7 @@ def test_index_writer_and_join_edge_cases():
 
 # ---- a wrong ISIZE ends the stream at that block (documented deviation: htslib never looks at ISIZE) --------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("bogus", [70000, 5, 0x04000000])
+@pytest.mark.parametrize("bogus", [70000, 5, 0x04000000, 0x80000010, 0xFFFFFFFF, -1])
 def test_wrong_isize_is_a_block_error_rows_before_kept(bogus):
     data = bytearray(cases.case_basic(payload=777, n=200, seed=2))
     clean = orc.bam_read(bytes(data))
@@ -411,7 +411,10 @@ def test_wrong_isize_is_a_block_error_rows_before_kept(bogus):
         bl = struct.unpack_from("<H", data, p + 16)[0] + 1
         blocks.append((p, bl)); p += bl
     k = len(blocks) // 2
-    struct.pack_into("<I", data, blocks[k][0] + blocks[k][1] - 4, bogus)
+    at = blocks[k][0] + blocks[k][1] - 4
+    if bogus == -1:                                          # 0xFFFF0000 + true length: used to wrap the 32-bit partial sums of the uoff scan
+        bogus = 0xFFFF0000 + struct.unpack_from("<I", data, at)[0]
+    struct.pack_into("<I", data, at, bogus)
     for mb in (0, 3):
         got = duckhts_amd.read_bam(bytes(data), max_blocks=mb)
         assert got["status"] < 0 and 0 < got["n_rows"] < clean["n_rows"]

@@ -160,3 +160,30 @@ def test_region_synthetic():
     data = synth.bcf_file(40000, seed=9)
     for region in ("chr1:1,000,000-30,000,000", "chr2,chrX:1-50000000", "chr21:1-1000"):
         _region_check(data, region, max_blocks=16)
+
+
+# ---- a context returns every byte of HBM when it is destroyed (DevBuf is RAII now) -------------------------
+@pytest.mark.gpu
+def test_no_hbm_leak_over_200_queries():
+    import torch
+    import duckhts_amd
+    import tag_cases
+    data = _gold("vcf_file.bcf")
+    bam = _gold("range.bam")
+    tags = tag_cases.fuzz(seed=3, n=200, payload=3000)
+
+    def cycle(i):
+        duckhts_amd.read_bcf(data, tidy=bool(i & 1))
+        if i % 4 == 0:
+            duckhts_amd.read_bam(bam, region="CHROMOSOME_I:1-5000")
+            duckhts_amd.read_bam(tags, std_tags_cols=list(range(56)), aux_map="all")
+
+    for i in range(8):                      # warm up: code objects, runtime pools
+        cycle(i)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for i in range(200):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 10} KiB of HBM lost over 200 create -> scan -> destroy cycles"

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--regions", action="store_true", help="random (mostly malformed) region strings against the restatement of hts_parse_region / sam_itr_regarray")
     ap.add_argument("--surface", action="store_true", help="per seed: the DuckDB table functions through the mini host, random projections, chunk-exact against the oracle")
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
+    ap.add_argument("--isize", action="store_true", help="per seed: hostile ISIZE trailer values (bit flips, 0xFFFFxxxx, > 64 KiB) on random blocks: the scan must end at that block with the rows before it intact")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
     args = ap.parse_args()
     import bamwriter as bw  # noqa: F401
@@ -63,6 +64,42 @@ def main():
             break
         rnd = random.Random(seed)
         msgs = []
+        if args.isize:
+            import struct
+            payload = rnd.choice([61, 777, 4000, 65280]); n = rnd.choice([50, 300, 1500])
+            data = bytearray(cases.case_basic(payload=payload, level=rnd.choice([0, 1, 6]), seed=seed, n=n))
+            clean = orc.bam_read(bytes(data))
+            p, blocks = 0, []
+            while p + 18 <= len(data) and data[p:p + 4] == b"\x1f\x8b\x08\x04":
+                bl = struct.unpack_from("<H", data, p + 16)[0] + 1
+                blocks.append((p, bl)); p += bl
+            hit = []
+            for _ in range(rnd.randint(1, 3)):
+                k = rnd.randrange(1, len(blocks))
+                at = blocks[k][0] + blocks[k][1] - 4
+                old = struct.unpack_from("<I", data, at)[0]
+                new = rnd.choice([old ^ (1 << rnd.randrange(32)), 0xFFFF0000 + old, 0xFFFFFFFF, 0x80000000 | old, 65537, 65536, old + 1, rnd.getrandbits(32)])
+                struct.pack_into("<I", data, at, new & 0xFFFFFFFF)
+                if (new & 0xFFFFFFFF) != old:
+                    hit.append(k)
+            mb = rnd.choice([0, 1, 2, 5])
+            got = {}
+            try:
+                got = duckhts_amd.read_bam(bytes(data), max_blocks=mb)
+                if hit:
+                    if not (got["status"] < 0 and got["n_rows"] <= clean["n_rows"]):
+                        msgs.append(f"isize damage in block {min(hit)} of {len(blocks)} not reported: status {got['status']} rows {got['n_rows']}/{clean['n_rows']}")
+                elif got["status"] < 0 or got["n_rows"] != clean["n_rows"]:
+                    msgs.append("undamaged file differs")
+                for kk in duckhts_amd.BAM_COLUMNS:
+                    if list(got[kk]) != list(clean[kk][:got["n_rows"]]):
+                        msgs.append(f"column {kk} is not a prefix of the clean scan")
+            except duckhts_amd.DhtsError as e:
+                msgs.append(f"raised {e}")
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (isize: {len(blocks)} blocks, damaged {sorted(set(hit))}, rows {got['n_rows'] if 'n_rows' in got else '?'} of {clean['n_rows']})", flush=True)
+            bad += bool(msgs)
+            continue
         if args.regions:
             if seed == args.first:
                 rdata = cases.case_basic(payload=4000, level=6, seed=5, n=1500)
