@@ -3,6 +3,7 @@
 // Single translation unit with the kernels (no -fgpu-rdc needed).
 #include "../../include/duckhts_amd.h"
 #include "bgzf_inflate.hip"
+#include "bgzf_huff_wave.hip"
 #include "bam_records.hip"
 #include "bam_tiles_lds.hip"
 #include "bcf_records.hip"
@@ -375,16 +376,29 @@ static BgzfTable dev_table(dhts_ctx *c) {
 }
 
 // phase A over [b0, b0+nb): tokens + literals into the scratch
-static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb) {
+static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {      // force: -1 default choice, 0 / 1 lane kernel (all symbols in LDS / far table), 2 wave kernel
     ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 8192);
     ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
     ENSURE(c, c->meta, (size_t)nb * sizeof(InflateMeta));
     BgzfTable t = dev_table(c);
-    {
+    // Two interchangeable kernels fill the scratch (same format, cross-checked by the tests):
+    //   wave: one WAVE per BGZF block, table-driven (bgzf_huff_wave.hip): a block takes well under a millisecond, so short launches --
+    //         index windows, small files, a 1 GB BCF -- no longer pay one lane's serial decode of a whole block (13-15 ms);
+    //   lane: one LANE per block, canonical arithmetic (bgzf_inflate.hip): fewer instructions per symbol once a launch is long enough
+    //         to keep every SIMD backfilled (measured on MI355X: 65,536 blocks 12.9 ms against 20.8 ms).
+    // DHTS_PHASE_A = wave | lane forces one of them; the default switches at DHTS_WAVE_MAX_BLOCKS (40,000: where the two meet).
+    static const char *env_a = getenv("DHTS_PHASE_A");
+    static const int64_t wave_max = getenv("DHTS_WAVE_MAX_BLOCKS") ? atoll(getenv("DHTS_WAVE_MAX_BLOCKS")) : 40000;
+    const bool env_lane = force >= 0 ? force != 2 : env_a ? !strcmp(env_a, "lane") : (nb > wave_max);
+    if (!env_lane) {
+        KTimer tm(c, DHTS_K_HUFF);
+        hipLaunchKernelGGL(bgzf_huff_decode_wave, dim3((unsigned)nb), dim3(64), 0, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p);
+    } else {
         KTimer tm(c, DHTS_K_HUFF);
         // a launch that six waves per CU can hold at once keeps every symbol in LDS; a longer one runs eight waves per CU
         static const int64_t env_nlo = getenv("DHTS_PHASE_A_NLO") ? atoll(getenv("DHTS_PHASE_A_NLO")) : 0;     // tuning knob: 196 or 288
-        const uint32_t nlo = env_nlo == 196 ? A_NLO_FAR : env_nlo == 288 ? A_NLO_ALL : (nb > 98304 ? A_NLO_FAR : A_NLO_ALL);
+        const uint32_t nlo = force == 0 ? A_NLO_ALL : force == 1 ? A_NLO_FAR : env_nlo == 196 ? A_NLO_FAR : env_nlo == 288 ? A_NLO_ALL : (nb > 98304 ? A_NLO_FAR : A_NLO_ALL);
         hipLaunchKernelGGL(bgzf_huff_decode, dim3((unsigned)((nb + A_SL - 1) / A_SL)), dim3(64), A_LDS_BYTES_FOR(nlo), c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
                            (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p, nlo);
     }
@@ -1256,7 +1270,9 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
         c->pf.valid = false;
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->pf_done, 0));
     } else {
-        if (inflate_blocks(c, b0, nb, u, out_base, c->n_blocks)) return -1;
+        // phase A may run ahead of this batch, but not beyond what the scan can reach: the shard (or index window) plus its halo
+        const int64_t ahead = c->shard_b1 + 8 < c->n_blocks ? c->shard_b1 + 8 : c->n_blocks;
+        if (inflate_blocks(c, b0, nb, u, out_base, ahead)) return -1;
         HIPCHK(c, hipMemsetAsync(u + ulen, 0, PAD_BYTES, c->stream));
     }
     // first bad block (if any) ends the byte stream there (bgzf.c:1241-1291: the read fails)
@@ -1859,6 +1875,15 @@ int dhts_debug_diag(dhts_ctx *c, unsigned long long *out8) {
     return 0;
 }
 #endif
+#ifdef HW_DIAG
+extern "C" int dhts_debug_hw_diag(dhts_ctx *c, unsigned long long *out16, int reset) {
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_hw_diag), 128));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_hw_diag), z, 128)); }
+    return 0;
+}
+#endif
 // debugging aid (not part of the public header): phase-A metadata of scratch slot s
 // kernel experiments (tools/dbg): phase A alone over blocks [b0, b0+nb), `reps` launches; returns ms per launch
 extern "C" double dhts_debug_time_huff(dhts_ctx *c, int64_t b0, int64_t nb, int reps) {
@@ -1872,6 +1897,25 @@ extern "C" double dhts_debug_time_huff(dhts_ctx *c, int64_t b0, int64_t nb, int 
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / reps;
+}
+// cross-check aid for the tests (not part of the public header): run ONE phase-A kernel over blocks [b0, b0+nb) (kernel: 0 / 1 = lane
+// per block with all symbols in LDS / with the far table, 2 = wave per block), then read a scratch slot back
+extern "C" int dhts_debug_huff_run(dhts_ctx *c, int64_t b0, int64_t nb, int kernel) {
+    if (!c || b0 < 0 || nb <= 0 || b0 + nb > c->n_blocks || kernel < 0 || kernel > 2) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    discard_prefetch(c);
+    if (huff_blocks(c, b0, nb, kernel)) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int dhts_debug_scratch_get(dhts_ctx *c, int64_t s, uint32_t *meta4, uint8_t *lit, uint32_t *tok) {
+    if (!c || s < 0 || s >= c->huff_nb) return -1;
+    HIPCHK(c, hipMemcpy(meta4, (InflateMeta *)c->meta.p + s, 16, hipMemcpyDeviceToHost));
+    if (meta4[3] != 0u) return 0;                                     // failed block: the scratch content is unspecified
+    if (meta4[1] > DHTS_LIT_STRIDE || meta4[0] > DHTS_TOK_STRIDE) return fail(c, "scratch counts out of range");
+    if (lit && meta4[1]) HIPCHK(c, hipMemcpy(lit, (uint8_t *)c->lit.p + (size_t)s * DHTS_LIT_STRIDE, meta4[1], hipMemcpyDeviceToHost));
+    if (tok && meta4[0]) HIPCHK(c, hipMemcpy(tok, (uint32_t *)c->tok.p + (size_t)s * DHTS_TOK_STRIDE, (size_t)meta4[0] * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 int dhts_debug_meta(dhts_ctx *c, int64_t s, uint32_t *out4) {
     if (!c || s < 0 || s >= c->huff_nb) return -1;

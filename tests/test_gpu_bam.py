@@ -592,3 +592,57 @@ def test_auxiliary_tags_map(which, excl):
     if which == "sam_equiv" and excl:
         k, v = (orc.bcf_col_py(c) for c in got["aux"]["cols"])
         assert k == [[b"XZ"]] and v == [[b"foo"]]
+
+
+# ---- the two phase-A kernels produce the same scratch, word for word ---------------------------------------------------------
+def _huff_scratch(ctx, nb, kernel):
+    import ctypes as C
+    L = ctx.L
+    L.dhts_debug_huff_run.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    L.dhts_debug_scratch_get.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.dhts_debug_huff_run(C.c_void_p(ctx.h), 0, nb, kernel) == 0, L.dhts_error(ctx.h)
+    out = []
+    meta = (C.c_uint32 * 4)(); lit = (C.c_uint8 * 65536)(); tok = (C.c_uint32 * 22528)()
+    for s in range(nb):
+        assert L.dhts_debug_scratch_get(C.c_void_p(ctx.h), s, meta, lit, tok) == 0, L.dhts_error(ctx.h)
+        m = list(meta)
+        if m[3] != 0:
+            out.append(("failed",))
+        else:
+            out.append((m[0], m[1], m[2], bytes(bytearray(lit)[:m[1]]), bytes(bytearray(tok)[:4 * m[0]])))
+    return out
+
+
+@pytest.mark.gpu
+def test_wave_and_lane_huffman_kernels_agree():
+    """bgzf_huff_decode_wave (one wave per block, lookup tables, self-synchronising bit ranges) against bgzf_huff_decode (one lane
+    per block, canonical arithmetic), both LDS layouts: literal stream, token stream and meta of every block, incl. damaged blocks"""
+    import random
+    files = [read_golden("range.bam"), read_golden("vcf_file.bcf"), read_golden("bgzf_boundaries3.bam"), synth.bam_file(40000, seed=5)]
+    files += [cases.ALL_CASES[k]() for k in ("fixed_huffman", "basic_stored", "basic_level1", "basic_level9", "basic_tiny_blocks", "bad_deflate", "long_record")]
+    import bamwriter as bw
+    for name, raw in sorted(_lz_payloads().items()):
+        files.append(bw.bgzf_file(raw, payload=65280, level=6))
+    rnd = random.Random(9)
+    dam = bytearray(synth.bam_file(20000, seed=6))
+    for _ in range(60):                                    # payload damage: both kernels must fail the same blocks
+        i = rnd.randrange(2000, len(dam) - 2000)
+        dam[i] ^= 1 << rnd.randrange(8)
+    files.append(bytes(dam))
+    for data in files:
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(data)
+            try:
+                nb = ctx.bgzf_index()
+            except duckhts_amd.DhtsError:
+                continue
+            if nb <= 0:
+                continue
+            ref = _huff_scratch(ctx, nb, 0)
+            for kernel in (1, 2):
+                got = _huff_scratch(ctx, nb, kernel)
+                for b, (x, y) in enumerate(zip(ref, got)):
+                    assert x == y, f"block {b} differs between kernel 0 and kernel {kernel}"
+        finally:
+            ctx.close()
