@@ -76,7 +76,9 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
            "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_set_overlap_intervals", "dhts_bam_build_index", "dhts_bam_index_bytes", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
-           "dhts_bcf_rewind", "dhts_bcf_next_batch"]
+           "dhts_bcf_rewind", "dhts_bcf_next_batch",
+           "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
+           "dhts_host_alloc", "dhts_host_free", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
 
 
 def lib():

@@ -428,17 +428,26 @@ extern "C" __global__ void bgzf_chain_walk_seq(const uint8_t *d, uint64_t n, uin
 }
 // chain proof: candidate i must start exactly where candidate i-1 ends; fills the block table.
 // bad[0] counts violations (then the host falls back to a sequential chain walk).
+// partial_tail: the resident bytes are a window that stops short of the end of the file, so the last block may be cut off.  Candidates
+// whose block runs past the end of the buffer are then counted in bad[1] instead ("cut"), and must be the last ones.
 extern "C" __global__ void __launch_bounds__(256)
-bgzf_chain_check(const uint8_t *d, uint64_t n, const uint64_t *cand, int64_t ncand, uint32_t *clen, uint32_t *isize, uint32_t *bad) {
+bgzf_chain_check(const uint8_t *d, uint64_t n, const uint64_t *cand, int64_t ncand, uint32_t *clen, uint32_t *isize, uint32_t *bad, int partial_tail) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncand) return;
     uint64_t o = cand[i];
     uint32_t bl = ((uint32_t)d[o + 16] | ((uint32_t)d[o + 17] << 8)) + 1;
-    bool ok = true;
+    bool ok = true, cut = false;
     if (i == 0 && o != 0) ok = false;
-    if (o + bl > n || bl < 26) ok = false;
-    if (ok) { if (i + 1 < ncand) ok = (cand[i + 1] == o + bl); else ok = (o + bl == n); }
+    if (bl < 26) ok = false;
+    if (o + bl > n) { if (partial_tail) cut = true; else ok = false; }
+    if (ok && !cut) { if (i + 1 < ncand) ok = (cand[i + 1] == o + bl); else ok = partial_tail ? true : (o + bl == n); }
+    if (ok && cut && i + 1 < ncand) {
+        // everything behind a cut block must be cut as well (a candidate inside the cut block's span)
+        const uint64_t o2 = cand[i + 1]; const uint32_t bl2 = ((uint32_t)d[o2 + 16] | ((uint32_t)d[o2 + 17] << 8)) + 1;
+        if (o2 + bl2 <= n) ok = false;
+    }
     clen[i] = bl;
-    isize[i] = ok ? isize_placed(ldu32(d + o + bl - 4)) : 0;
+    isize[i] = (ok && !cut) ? isize_placed(ldu32(d + o + bl - 4)) : 0;
     if (!ok) atomicAdd(bad, 1u);
+    else if (cut) atomicAdd(bad + 1, 1u);
 }

@@ -22,6 +22,9 @@
 #include <map>
 #include <algorithm>
 #include <limits.h>
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 #define TILE_BYTES TL_TILE               /* record-stage tile = what bam_tiles_lds.hip stages per wave */
 #define PAD_BYTES 256u
@@ -53,7 +56,9 @@ struct dhts_ctx {
     struct Prefetch { bool valid = false; int64_t b0 = 0, nb = 0; uint64_t carry = 0; int ucur = 0; } pf;
     std::string err;
     // resident compressed bytes
-    DevBuf comp; uint64_t comp_len = 0;
+    DevBuf comp; uint64_t comp_len = 0; uint64_t file_off = 0, file_size = 0;   // resident bytes = file bytes [file_off, file_off + comp_len)
+    // dhts_open_path_shard: resident bytes = file[0, seg_split) ++ file[seg_file_off, ...): the header blocks, then this rank's window
+    uint64_t seg_split = 0, seg_file_off = 0; bool partial_tail = false; uint64_t hdr_bytes_known = 0;
     // block table
     int64_t n_blocks = 0; int bgzf_status = 0;
     DevBuf coff, clen, isize, uoff, blk_status;
@@ -196,7 +201,7 @@ void dhts_destroy(dhts_ctx *c) {
 const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no context (no MI355X device or code object)"; }
 
 static void reset_file_state(dhts_ctx *c) {
-    c->huff_b0 = c->huff_nb = 0;
+    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false;
     c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
     c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
 }
@@ -234,37 +239,92 @@ int dhts_open_tiled(dhts_ctx *c, const void *head, uint64_t n_head, const void *
     return 0;
 }
 
-int dhts_open_path(dhts_ctx *c, const char *path) {
+// ---- pinned host memory, pooled for the life of the process ---------------------------------------------------------------------
+// Page-locking is slow (a few GB/s), so staging and read-back buffers are kept and handed out again: a long-lived host (DuckDB)
+// pays for them once, not per query.  Portable: usable from every device.
+namespace {
+struct PinBuf { void *p; size_t cap; bool busy; };
+std::mutex g_pin_mu;
+std::vector<PinBuf> g_pin;
+}
+extern "C" void *dhts_host_alloc(uint64_t n) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pin.size(); i++) if (!g_pin[i].busy && g_pin[i].cap >= n && (best < 0 || g_pin[i].cap < g_pin[best].cap)) best = (int)i;
+    if (best >= 0) { g_pin[best].busy = true; return g_pin[best].p; }
+    void *p = nullptr; size_t want = (size_t)n + (size_t)n / 8 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
+    // drop idle buffers that are too small to matter any more (keeps the pool from growing without bound)
+    for (size_t i = 0; i < g_pin.size();) { if (!g_pin[i].busy && g_pin[i].cap * 2 <= want && g_pin.size() > 16) { (void)hipHostFree(g_pin[i].p); g_pin.erase(g_pin.begin() + i); } else i++; }
+    g_pin.push_back({p, want, true});
+    return p;
+}
+extern "C" void dhts_host_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto &b : g_pin) if (b.p == p) { b.busy = false; return; }
+}
+
+// file bytes [off, off+len) -> comp[0, len): reader threads pread 8 MiB pieces into their own pair of pinned buffers and queue the
+// H2D copies on their own streams, so the page-cache copy (one core moves ~5-10 GB/s) and the PCIe transfer overlap and scale.
+static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uint8_t *dst) {
+    const size_t CH = 8u << 20;
+    const uint64_t npieces = (len + CH - 1) / CH;
+    static const int env_thr = getenv("DHTS_READ_THREADS") ? atoi(getenv("DHTS_READ_THREADS")) : 0;
+    int nthr = env_thr > 0 ? env_thr : 4; if ((uint64_t)nthr > npieces) nthr = (int)npieces; if (nthr < 1) nthr = 1;
+    std::atomic<uint64_t> next(0); std::atomic<int> rc(0);
+    const int dev = c->device;
+    auto worker = [&]() {
+        if (hipSetDevice(dev) != hipSuccess) { rc = -1; return; }
+        hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; void *pin[2] = {dhts_host_alloc(CH), dhts_host_alloc(CH)}; bool used[2] = {false, false};
+        if (!pin[0] || !pin[1] || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = -2;
+        int k = 0;
+        while (rc == 0) {
+            const uint64_t pi = next.fetch_add(1);
+            if (pi >= npieces) break;
+            const uint64_t o = pi * CH; const size_t want = (size_t)(len - o < CH ? len - o : CH);
+            if (used[k]) (void)hipEventSynchronize(ev[k]);
+            size_t got = 0;
+            while (got < want) { ssize_t r = pread(fd, (char *)pin[k] + got, want - got, (off_t)(off + o + got)); if (r <= 0) { rc = -3; break; } got += (size_t)r; }
+            if (rc != 0) break;
+            if (hipMemcpyAsync(dst + o, pin[k], want, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { rc = -4; break; }
+            used[k] = true; k ^= 1;
+        }
+        if (st) (void)hipStreamSynchronize(st);
+        for (int q = 0; q < 2; q++) { if (ev[q]) (void)hipEventDestroy(ev[q]); dhts_host_free(pin[q]); }
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return rc.load();
+}
+
+// htslib hts_open + the reads underneath bgzf_read_block, for a BYTE RANGE of the file: [off, off+len) (len = 0: to the end of the
+// file) becomes the context's resident bytes.  A rank of a multi-GPU scan stages only its own block range plus the halo.
+int dhts_open_path_range(dhts_ctx *c, const char *path, uint64_t off, uint64_t len) {
     if (!c) return -1;
+    discard_prefetch(c);
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(c, "cannot open %s", path);
     struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
-    uint64_t n = (uint64_t)sb.st_size;
-    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    if (off > fsize) off = fsize;
+    uint64_t n = fsize - off; if (len != 0 && len < n) n = len;
+    if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
     reset_file_state(c);
-    if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc failed"); }
-    const size_t CH = 64u << 20;
-    void *pin[2] = {nullptr, nullptr};
-    if (hipHostMalloc(&pin[0], CH) != hipSuccess || hipHostMalloc(&pin[1], CH) != hipSuccess) { close(fd); return fail(c, "hipHostMalloc failed"); }
-    hipEvent_t done[2]; (void)hipEventCreate(&done[0]); (void)hipEventCreate(&done[1]);
-    uint64_t off = 0; int k = 0; bool used[2] = {false, false}; int rc = 0;
-    while (off < n) {
-        if (used[k]) (void)hipEventSynchronize(done[k]);
-        size_t want = (size_t)((n - off) < CH ? (n - off) : CH), got = 0;
-        while (got < want) { ssize_t r = pread(fd, (char *)pin[k] + got, want - got, (off_t)(off + got)); if (r <= 0) { rc = -1; break; } got += (size_t)r; }
-        if (rc) break;
-        if (hipMemcpyAsync((uint8_t *)c->comp.p + off, pin[k], want, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = -1; break; }
-        (void)hipEventRecord(done[k], c->stream); used[k] = true;
-        off += want; k ^= 1;
-    }
-    (void)hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]);
-    (void)hipHostFree(pin[0]); (void)hipHostFree(pin[1]); close(fd);
-    if (rc) return fail(c, "read error on %s", path);
-    c->comp_len = n;
+    if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc of %llu bytes failed", (unsigned long long)(n + PAD_BYTES)); }
+    int rc = n ? stage_file_range(c, fd, off, n, (uint8_t *)c->comp.p) : 0;
+    close(fd);
+    if (rc) return fail(c, rc == -3 ? "read error on %s" : "staging %s failed", path);
+    HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->comp_len = n; c->file_off = off; c->file_size = fsize;
     return 0;
 }
+int dhts_open_path(dhts_ctx *c, const char *path) { return dhts_open_path_range(c, path, 0, 0); }
 
 uint64_t dhts_resident_bytes(const dhts_ctx *c) { return c ? c->comp_len : 0; }
 
@@ -323,13 +383,13 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
             if (ovf) hipLaunchKernelGGL(bgzf_sig_write, dim3((unsigned)((nspans * 64 + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint32_t *)base.p, (uint64_t *)c->coff.p);
             else hipLaunchKernelGGL(bgzf_sig_gather, dim3((unsigned)((nspans + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)cnt.p, (const uint32_t *)base.p, (const uint16_t *)hits.p, nspans, (uint64_t *)c->coff.p);
         }
-        (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
+        (void)hipMemsetAsync(c->d_nfixed.p, 0, 8, c->stream);
         hipLaunchKernelGGL(bgzf_chain_check, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, c->stream, d, n, (const uint64_t *)c->coff.p, ncand,
-                           (uint32_t *)c->clen.p, (uint32_t *)c->isize.p, (uint32_t *)c->d_nfixed.p);
-        uint32_t bad = 0;
-        if (hipMemcpyAsync(&bad, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return fail(c, "bgzf index sync failed"); }
-        need_seq = bad != 0;
-        c->n_blocks = ncand; c->bgzf_status = 0;
+                           (uint32_t *)c->clen.p, (uint32_t *)c->isize.p, (uint32_t *)c->d_nfixed.p, c->partial_tail ? 1 : 0);
+        uint32_t bad[2] = {0, 0};
+        if (hipMemcpyAsync(bad, c->d_nfixed.p, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return fail(c, "bgzf index sync failed"); }
+        need_seq = bad[0] != 0;
+        c->n_blocks = ncand - (int64_t)bad[1]; c->bgzf_status = 0;       // (cut candidates are the last ones: chain proof)
     }
     if (need_seq) {
         // unusual / corrupt container: restate htslib's sequential walk on the device
@@ -339,6 +399,7 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
         int64_t res[2] = {0, 0};
         if (hipMemcpyAsync(res, c->d_res.p, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return fail(c, "bgzf index sync failed"); }
         c->n_blocks = res[0]; c->bgzf_status = (int)res[1];
+        if (c->partial_tail && c->bgzf_status == -2) c->bgzf_status = 0;      // the window ends inside a block: expected, the block belongs to the next window
     }
     cleanup();
     // uoff = exclusive prefix of the recorded ISIZE values (each <= 65,537: isize_placed)
@@ -587,6 +648,109 @@ int dhts_bam_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculativ
     c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = speculative_start ? 1 : 0; c->shard_world = (b1 < c->n_blocks || speculative_start) ? 2 : 1;
     c->scan_first_uoff = c->first_rec_uoff;
     return dhts_bam_rewind(c);
+}
+
+// ---- one file, several GPUs: every rank stages only its own byte window --------------------------------------------------------------
+// Cut points: t_0 = 0, t_r = H + (size - H) * r / world for r >= 1 (H = bytes of the header blocks), so rank 0 always owns the header
+// and the first records; a block belongs to the rank whose [t_r, t_r+1) holds its first byte -- the rule of dhts_shard_cut applied to
+// file offsets.  Rank r > 0 finds the first block start at or behind t_r on the host (BGZF signature + three chained hops), and its
+// resident bytes become  file[0, H) ++ file[start_r, t_r+1 + halo) : the header blocks (every rank needs the dictionaries) followed
+// by its window and a halo in which the last record of the window completes.
+#define DHTS_SHARD_HALO (4u << 20)
+static uint64_t shard_target(uint64_t fsize, uint64_t hdr, int r, int world) {
+    if (r <= 0) return 0;
+    if (r >= world) return fsize;
+    if (hdr > fsize) hdr = fsize;
+    return hdr + (uint64_t)((__uint128_t)(fsize - hdr) * (unsigned)r / (unsigned)world);
+}
+static bool host_is_bgzf_header(const uint8_t *p) {
+    return p[0] == 31 && p[1] == 139 && p[2] == 8 && (p[3] & 4) && p[10] == 6 && p[11] == 0 && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0;
+}
+int dhts_open_path_shard(dhts_ctx *c, const char *path, int rank, int world, uint64_t header_bytes) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return -1;
+    discard_prefetch(c);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(c, "cannot open %s", path);
+    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    if (header_bytes > fsize) header_bytes = fsize;
+    const uint64_t t0 = shard_target(fsize, header_bytes, rank, world), t1 = shard_target(fsize, header_bytes, rank + 1, world);
+    uint64_t wend = t1 + DHTS_SHARD_HALO; if (wend > fsize || rank == world - 1) wend = fsize;
+    uint64_t wbeg = 0;
+    if (rank > 0) {
+        // first block start in [t0, ...): probe on the host
+        wbeg = fsize;
+        const size_t PROBE = 1u << 20;
+        std::vector<uint8_t> buf(PROBE + 32);
+        for (uint64_t base = t0; base < fsize && wbeg == fsize; base += PROBE - 65536 - 18) {
+            const size_t want = (size_t)(fsize - base < PROBE ? fsize - base : PROBE);
+            size_t got = 0;
+            while (got < want) { ssize_t r = pread(fd, buf.data() + got, want - got, (off_t)(base + got)); if (r <= 0) break; got += (size_t)r; }
+            if (got < 18) break;
+            for (size_t q = 0; q + 18 <= got && q < PROBE - 65536 - 18; q++) {
+                if (!host_is_bgzf_header(buf.data() + q)) continue;
+                // three hops must land on headers (or exactly on the end of the file)
+                size_t o = q; int hops = 0; bool ok = true;
+                while (hops < 3) {
+                    const size_t bl = ((size_t)buf[o + 16] | ((size_t)buf[o + 17] << 8)) + 1;
+                    if (bl < 26) { ok = false; break; }
+                    o += bl;
+                    if (base + o == fsize) break;
+                    if (o + 18 > got) { ok = (base + o < fsize) && hops >= 1; break; }      // ran out of probe bytes: accept after at least one verified hop
+                    if (!host_is_bgzf_header(buf.data() + o)) { ok = false; break; }
+                    hops++;
+                }
+                if (ok) { wbeg = base + q; break; }
+            }
+            if (got < want) break;
+        }
+        if (wbeg >= wend) wbeg = wend = fsize > 0 ? fsize : 0;          // no block starts in this rank's range: it scans nothing
+    }
+    if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
+    reset_file_state(c);
+    const uint64_t n_hdr = rank > 0 ? header_bytes : 0, n_win = wend > wbeg ? wend - wbeg : 0, n = n_hdr + n_win;
+    if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc of %llu bytes failed", (unsigned long long)(n + PAD_BYTES)); }
+    int rc = 0;
+    if (n_hdr) rc = stage_file_range(c, fd, 0, n_hdr, (uint8_t *)c->comp.p);
+    if (rc == 0 && n_win) rc = stage_file_range(c, fd, wbeg, n_win, (uint8_t *)c->comp.p + n_hdr);
+    close(fd);
+    if (rc) return fail(c, rc == -3 ? "read error on %s" : "staging %s failed", path);
+    HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->comp_len = n; c->file_off = 0; c->file_size = fsize;
+    c->seg_split = n_hdr; c->seg_file_off = rank > 0 ? wbeg : 0; c->partial_tail = wend < fsize; c->hdr_bytes_known = header_bytes;
+    return 0;
+}
+// file offset of resident block i (the two-segment layout of dhts_open_path_shard; identity otherwise)
+static uint64_t block_file_off(const dhts_ctx *c, int64_t i) {
+    const uint64_t o = i < c->n_blocks ? c->h_coff[i] : c->comp_len;
+    return (c->seg_split && o >= c->seg_split) ? o - c->seg_split + c->seg_file_off : o + c->file_off;
+}
+int dhts_bam_set_file_shard(dhts_ctx *c, int rank, int world) {
+    if (!c || !c->bam_open || world < 1 || rank < 0 || rank >= world) return -1;
+    const uint64_t t1 = shard_target(c->file_size, c->hdr_bytes_known, rank + 1, world);
+    int64_t b0 = 0;
+    if (rank > 0) { while (b0 < c->n_blocks && c->h_coff[b0] < c->seg_split) b0++; }      // behind the header blocks
+    int64_t lo = b0, hi = c->n_blocks;
+    if (rank == world - 1) lo = c->n_blocks;
+    else while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (block_file_off(c, mid) < t1) lo = mid + 1; else hi = mid; }
+    return dhts_bam_set_block_range(c, b0, lo, rank > 0);
+}
+// compressed bytes of the blocks that hold the header: what every rank of a multi-GPU scan stages in front of its window
+uint64_t dhts_bam_header_bytes(const dhts_ctx *c) {
+    if (!c || !c->bam_open || c->n_blocks <= 0) return 0;
+    int64_t k = 0;
+    while (k + 1 < c->n_blocks && c->h_uoff[k + 1] < c->first_rec_uoff) k++;
+    return c->h_coff[k] + c->h_clen[k];
+}
+// BGZF virtual offset (file offset of the block << 16 | offset inside its inflated payload; htslib bgzf.h bgzf_tell) of a position of
+// the inflated stream as this context numbers it: what adjacent ranks compare at a shard boundary (their uoff numbering differs)
+uint64_t dhts_voffset(const dhts_ctx *c, uint64_t uoff) {
+    if (!c || c->n_blocks <= 0) return 0;
+    int64_t lo = 0, hi = c->n_blocks;                       // smallest i with h_uoff[i + 1] > uoff
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (c->h_uoff[mid + 1] > uoff) hi = mid; else lo = mid + 1; }
+    if (lo >= c->n_blocks) return block_file_off(c, c->n_blocks) << 16;
+    return (block_file_off(c, lo) << 16) | (uoff - c->h_uoff[lo]);
 }
 
 int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
@@ -1920,6 +2084,62 @@ extern "C" int dhts_debug_scratch_get(dhts_ctx *c, int64_t s, uint32_t *meta4, u
 int dhts_debug_meta(dhts_ctx *c, int64_t s, uint32_t *out4) {
     if (!c || s < 0 || s >= c->huff_nb) return -1;
     HIPCHK(c, hipMemcpy(out4, (InflateMeta *)c->meta.p + s, 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- one batch -> one host arena --------------------------------------------------------------------------------------------------
+// The projected core columns of a batch are laid out back to back (64-byte aligned pieces) in caller memory -- pinned memory from
+// dhts_host_alloc makes the copies true DMA -- with every copy queued before the single wait, instead of one synchronous copy per
+// column array.  `out` is `b` with HOST pointers (tag columns, the auxiliary map and the overlap lists stay device pointers).
+static inline uint64_t al64(uint64_t v) { return (v + 63u) & ~(uint64_t)63; }
+uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t m) {
+    if (!b || b->n_rows <= 0) return 0;
+    const uint64_t n = (uint64_t)b->n_rows; uint64_t t = 0;
+    if (m & (1u << DHTS_BAM_FLAG)) t += al64(n * 2);
+    if (m & (1u << DHTS_BAM_POS)) t += al64(n * 8);
+    if (m & (1u << DHTS_BAM_MAPQ)) t += al64(n * 4);
+    if (m & (1u << DHTS_BAM_PNEXT)) t += al64(n * 8);
+    if (m & (1u << DHTS_BAM_TLEN)) t += al64(n * 8);
+    if (m & (1u << DHTS_BAM_RNAME)) t += al64(n * 4);
+    if (m & (1u << DHTS_BAM_RNEXT)) t += al64(n * 4);
+    if (m & (1u << DHTS_BAM_SAMPLE_ID)) t += al64(n * 4);
+    if (m & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) t += al64(((n + 63) / 64) * 8);
+    const dhts_strcol *sc[5] = {&b->qname, &b->cigar, &b->seq, &b->qual, &b->rg};
+    const int bit[5] = {DHTS_BAM_QNAME, DHTS_BAM_CIGAR, DHTS_BAM_SEQ, DHTS_BAM_QUAL, DHTS_BAM_READ_GROUP_ID};
+    for (int k = 0; k < 5; k++) if (m & (1u << bit[k])) t += al64((n + 1) * 4) + al64(n * 4) + al64(sc[k]->nbytes + 1);
+    return t;
+}
+int dhts_bam_batch_fetch(dhts_ctx *c, const dhts_bam_batch *b, uint32_t m, void *dst, uint64_t cap, dhts_bam_batch *out) {
+    if (!c || !b || !out) return -1;
+    *out = *b;
+    if (b->n_rows <= 0) return 0;
+    if (!dst || dhts_bam_batch_host_bytes(b, m) > cap) return fail(c, "host arena too small for the batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = (uint64_t)b->n_rows; uint8_t *h = (uint8_t *)dst; uint64_t at = 0;
+    auto put = [&](const void *src, uint64_t bytes) -> const void * {
+        void *d = h + at; at += al64(bytes);
+        if (bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return nullptr;
+        return d;
+    };
+#define DHTS_FETCH(field, type, bitno, bytes) do { if (m & (1u << (bitno))) { out->field = (const type *)put(b->field, (bytes)); if (!out->field) return fail(c, "hipMemcpyAsync failed"); } else out->field = nullptr; } while (0)
+    DHTS_FETCH(flag, uint16_t, DHTS_BAM_FLAG, n * 2); DHTS_FETCH(pos, int64_t, DHTS_BAM_POS, n * 8); DHTS_FETCH(mapq, int32_t, DHTS_BAM_MAPQ, n * 4);
+    DHTS_FETCH(pnext, int64_t, DHTS_BAM_PNEXT, n * 8); DHTS_FETCH(tlen, int64_t, DHTS_BAM_TLEN, n * 8); DHTS_FETCH(tid, int32_t, DHTS_BAM_RNAME, n * 4);
+    DHTS_FETCH(mtid, int32_t, DHTS_BAM_RNEXT, n * 4); DHTS_FETCH(rg_idx, int32_t, DHTS_BAM_SAMPLE_ID, n * 4);
+#undef DHTS_FETCH
+    if (m & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) { out->rg_valid = (const uint64_t *)put(b->rg_valid, ((n + 63) / 64) * 8); if (!out->rg_valid) return fail(c, "hipMemcpyAsync failed"); }
+    else out->rg_valid = nullptr;
+    const dhts_strcol *sc[5] = {&b->qname, &b->cigar, &b->seq, &b->qual, &b->rg};
+    dhts_strcol *oc[5] = {&out->qname, &out->cigar, &out->seq, &out->qual, &out->rg};
+    const int bit[5] = {DHTS_BAM_QNAME, DHTS_BAM_CIGAR, DHTS_BAM_SEQ, DHTS_BAM_QUAL, DHTS_BAM_READ_GROUP_ID};
+    for (int k = 0; k < 5; k++) {
+        if (!(m & (1u << bit[k]))) { oc[k]->off = oc[k]->len = nullptr; oc[k]->bytes = nullptr; oc[k]->nbytes = 0; continue; }
+        oc[k]->off = (const uint32_t *)put(sc[k]->off, (n + 1) * 4); oc[k]->len = (const uint32_t *)put(sc[k]->len, n * 4);
+        const uint64_t at0 = at;
+        oc[k]->bytes = (const uint8_t *)put(sc[k]->bytes, sc[k]->nbytes);
+        at = at0 + al64(sc[k]->nbytes + 1);                             // (one readable byte behind the heap, as in the size formula)
+        if (!oc[k]->off || !oc[k]->len || !oc[k]->bytes) return fail(c, "hipMemcpyAsync failed");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -24,7 +24,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // duckdb_ext_api_v1 viewed as an array of function pointers (slot numbers: include/duckdb_abi_slots.h).  Weak: the definition
@@ -46,35 +50,66 @@ static inline void set_null(duckdb_vector vec, idx_t row) {           // src/bam
 
 struct BamBind {
     std::string path, region, index_file;
-    dhts_ctx *ctx = nullptr;          // resident file + header, reused by the scan (one GPU)
+    dhts_ctx *ctx = nullptr;          // bind-time context: holds only the head of the file (header + dictionaries)
     dhts_bam_header hdr;
+    uint64_t header_bytes = 0;        // compressed bytes [0, header_bytes) cover the header blocks
     int has_index = 0;
     int standard_tags = 0, auxiliary_tags = 0;
     idx_t aux_col_idx = (idx_t)-1;
+    std::vector<duckdb_string_t> ref_inl; std::vector<char> ref_is_inl;      // RNAME / RNEXT values of <= 12 bytes, ready to store
+    duckdb_string_t star_inl;
 };
 
-struct HostStr { std::vector<uint32_t> off, len; std::vector<uint8_t> bytes; };
-struct BamLocal {
-    std::vector<idx_t> column_ids;
-    uint32_t colmask = 0;
-    bool done = false;
-    // current batch, host side
-    int64_t n = 0, cur = 0;
-    int status = 0;
-    std::vector<uint16_t> flag; std::vector<int64_t> pos, pnext, tlen; std::vector<int32_t> mapq, tid, mtid, rgidx; std::vector<uint64_t> rgvalid;
-    HostStr qname, cigar, seq, qual, rg;
-    std::vector<int32_t> tag_ids;        // standard-tag ids requested by the projection
-    std::vector<int> tag_slot;           // output vector -> index into tags (-1 = not a tag column)
-    struct HostTag { std::vector<uint8_t> valid, bytes; std::vector<int64_t> fixed; std::vector<uint32_t> off; std::vector<int64_t> child; };
+// ---- scan pipeline: GPU producer thread(s) -> pinned host batches -> scan callbacks ------------------------------------------------
+// The reference's callback reads one record at a time from its htsFile (src/bam_reader.c:747-1035).  Here a producer thread per GPU
+// owns a scan context and turns the file into batches: stage (reader threads -> pinned -> HBM), inflate + unpack on the device, then
+// ONE queued read-back of the projected columns into a pinned arena (dhts_bam_batch_fetch).  The scan callbacks only copy from
+// those arenas into DataChunk vectors, so the device works on batch k+1 while the engine's threads fill chunks from batch k.
+//   DHTS_THREADS = 1 (default): the reference's sequential mode (i) -- one worker, rows in file order, full 2048-row chunks.
+//   DHTS_THREADS = k > 1: k workers claim 2048-row slices of the ready batches, the row ORDER across workers is unspecified,
+//                  exactly like the reference's own parallel mode (contig-parallel, src/bam_reader.c:577-585, 689-716).
+//   DHTS_DEVICES = 0,1,...: one producer per listed GPU, each staging and scanning its own BGZF block range of the file.
+struct HostTag { std::vector<uint8_t> valid, bytes; std::vector<int64_t> fixed; std::vector<uint32_t> off; std::vector<int64_t> child; };
+struct HostBatch {
+    void *arena = nullptr; uint64_t cap = 0;
+    dhts_bam_batch b;                 // HOST pointers for the core columns
+    int64_t n = 0; int status = 0;
     std::vector<HostTag> tags;
-    // AUXILIARY_TAGS of the current batch: list offsets + rendered key / value strings
-    bool want_aux = false;
     std::vector<uint8_t> aux_valid; std::vector<uint32_t> aux_off; std::vector<std::string> aux_key, aux_val;
+    // parallel mode
+    int64_t next = 0; int readers = 0; bool retired = false;
+};
+struct Producer {
+    int device = 0, rank = 0, world = 1;
+    std::thread th;
+    std::deque<HostBatch *> ready; std::vector<HostBatch *> free_slots; std::vector<HostBatch *> all;
+    bool done = false;
+    // where this rank's rows begin and end in the file, as BGZF virtual offsets: adjacent ranks must meet exactly (SURVEY 8(e) hand-off)
+    bool has_rows = false, clean_end = false; uint64_t first_v = 0, end_v = 0;
+};
+struct BamScan {
+    BamBind *bind = nullptr;
+    std::vector<idx_t> column_ids; uint32_t colmask = 0;
+    std::vector<int32_t> tag_ids; std::vector<int> tag_slot; bool want_aux = false;
+    int n_workers = 1;
+    std::mutex mu; std::condition_variable cv_ready, cv_free;
+    std::vector<Producer *> prod; size_t cur_prod = 0;
+    std::string error; bool cancel = false, handoff_checked = false;
+    std::vector<uint8_t> index_bytes;
+    ~BamScan() {
+        { std::lock_guard<std::mutex> lk(mu); cancel = true; }
+        cv_free.notify_all(); cv_ready.notify_all();
+        for (auto p : prod) { if (p->th.joinable()) p->th.join(); for (auto hb : p->all) { dhts_host_free(hb->arena); delete hb; } delete p; }
+    }
+};
+struct BamLocal {
+    bool done = false;
+    HostBatch *cur = nullptr; Producer *cur_owner = nullptr; int64_t pos = 0, end = 0;     // rows [pos, end) of `cur` are this worker's
 };
 
 static void destroy_bind(void *p) { BamBind *b = (BamBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
 static void destroy_local(void *p) { delete (BamLocal *)p; }
-static void destroy_global(void *p) { free(p); }
+static void destroy_global(void *p) { delete (BamScan *)p; }
 
 static char *get_named_varchar(duckdb_bind_info info, const char *name) {
     duckdb_value v = API(duckdb_value, duckdb_bind_get_named_parameter, duckdb_bind_info, const char *)(info, name);
@@ -91,6 +126,18 @@ static int get_named_bool(duckdb_bind_info info, const char *name) {
     return r;
 }
 static bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+static std::vector<int> device_list() {
+    std::vector<int> d;
+    if (const char *e = getenv("DHTS_DEVICES")) { for (const char *q = e; *q;) { char *end; long v = strtol(q, &end, 10); if (end == q) break; d.push_back((int)v); q = *end ? end + 1 : end; } }
+    if (d.empty()) d.push_back(getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0);
+    return d;
+}
+// a string of <= 12 bytes is stored inside duckdb_string_t itself (duckdb.h:377-391: length, then the bytes, zero padded): no heap, no call
+static inline bool inl_string(duckdb_string_t *d, const char *s, size_t len) {
+    if (len > 12) return false;
+    memset(d, 0, sizeof(*d)); d->value.inlined.length = (uint32_t)len; memcpy(d->value.inlined.inlined, s, len);
+    return true;
+}
 
 static void bam_read_bind(duckdb_bind_info info) {
     auto set_error = API(void, duckdb_bind_set_error, duckdb_bind_info, const char *);
@@ -121,17 +168,27 @@ static void bam_read_bind(duckdb_bind_info info) {
         snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());   // bam_reader.c:446
         set_error(info, err); delete b; return;
     }
-    int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
-    b->ctx = dhts_create(dev);
+    b->ctx = dhts_create(device_list()[0]);
     if (!b->ctx) { set_error(info, "read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); destroy_bind(b); return; }
-    if (dhts_open_path(b->ctx, b->path.c_str()) != 0) {
-        snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());
-        set_error(info, err); destroy_bind(b); return;
+    // like the reference, bind reads the header only (sam_open + sam_hdr_read, bam_reader.c:441-461): the head of the file is staged,
+    // four times more whenever the header turns out to be longer.  The scan stages the file itself (bam_read_global_init).
+    bool hdr_ok = false;
+    for (uint64_t head = 1u << 20;; head *= 4) {
+        if (dhts_open_path_range(b->ctx, b->path.c_str(), 0, head) != 0) {
+            snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());
+            set_error(info, err); destroy_bind(b); return;
+        }
+        const bool whole = dhts_resident_bytes(b->ctx) < head;
+        if (dhts_bgzf_index(b->ctx) > 0 && dhts_bam_open(b->ctx) == 0 && dhts_bam_header_get(b->ctx, &b->hdr) == 0) { hdr_ok = true; break; }
+        if (whole || head >= (1ull << 34)) break;
     }
-    if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bam_open(b->ctx) != 0 || dhts_bam_header_get(b->ctx, &b->hdr) != 0) {
+    if (!hdr_ok) {
         set_error(info, "Failed to read SAM/BAM/CRAM header");                    // bam_reader.c:461 (also what SAM/CRAM input gets here)
         destroy_bind(b); return;
     }
+    b->header_bytes = dhts_bam_header_bytes(b->ctx);
+    for (int32_t i = 0; i < b->hdr.n_ref; i++) { duckdb_string_t t; b->ref_is_inl.push_back(inl_string(&t, b->hdr.ref_name[i], strlen(b->hdr.ref_name[i])) ? 1 : 0); b->ref_inl.push_back(t); }
+    inl_string(&b->star_inl, "*", 1);
     // index lookup order of sam_index_load3 (hts.c:4720-4790): explicit path, <file>.csi, <file>.bai, <file minus .bam>.bai/.csi
     {
         std::string stem = b->path.size() > 4 && b->path.compare(b->path.size() - 4, 4, ".bam") == 0 ? b->path.substr(0, b->path.size() - 4) : std::string();
@@ -170,95 +227,23 @@ static void bam_read_bind(duckdb_bind_info info) {
     API(void, duckdb_bind_set_bind_data, duckdb_bind_info, void *, duckdb_delete_callback_t)(info, b, destroy_bind);
 }
 
-static void bam_read_global_init(duckdb_init_info info) {
-    // sequential mode: one scan thread (bam_reader.c:582-585).  The GPU supplies the parallelism.
-    API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, 1);
-    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, calloc(1, 16), destroy_global);
-}
-
-static void bam_read_local_init(duckdb_init_info info) {
-    BamBind *bind = (BamBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
-    BamLocal *l = new BamLocal();
-    idx_t n = API(idx_t, duckdb_init_get_column_count, duckdb_init_info)(info);               // bam_reader.c:676-679
-    for (idx_t i = 0; i < n; i++) {
-        idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
-        l->column_ids.push_back(id);
-        if (id < DHTS_BAM_CORE_COUNT) l->colmask |= 1u << id;
-        int sl = -1;
-        if (bind->standard_tags && id >= DHTS_BAM_CORE_COUNT && id < (idx_t)(DHTS_BAM_CORE_COUNT + dhts_bam_std_tag_count())) {
-            const int32_t tid_ = (int32_t)(id - DHTS_BAM_CORE_COUNT);
-            for (size_t k = 0; k < l->tag_ids.size(); k++) if (l->tag_ids[k] == tid_) sl = (int)k;
-            if (sl < 0) { sl = (int)l->tag_ids.size(); l->tag_ids.push_back(tid_); }
-        }
-        l->tag_slot.push_back(sl);
-    }
-    l->tags.resize(l->tag_ids.size());
-    dhts_bam_set_tag_columns(bind->ctx, l->tag_ids.data(), (int32_t)l->tag_ids.size());
-    for (idx_t id : l->column_ids) if (bind->auxiliary_tags && id == bind->aux_col_idx) l->want_aux = true;
-    dhts_bam_set_aux_map(bind->ctx, l->want_aux ? 1 : 0, bind->standard_tags);
-    auto init_error = API(void, duckdb_init_set_error, duckdb_init_info, const char *);
-    if (!bind->region.empty()) {
-        // bam_reader.c:639-668: a region needs an index; sam_itr_regarray failing reports "No reads found"
-        if (!bind->has_index) { init_error(info, "Region query requires an index (.bai/.csi/.crai)"); delete l; return; }
-        int rc = dhts_bam_set_regions(bind->ctx, bind->region.c_str());
-        if (rc != 0) {
-            char err[640]; snprintf(err, sizeof(err), "No reads found for region(s): %s", bind->region.c_str());
-            init_error(info, rc == 1 ? err : dhts_error(bind->ctx)); delete l; return;
-        }
-        // the index (BAI or CSI) narrows the scan window; the device predicate decides the rows
-        FILE *f = fopen(bind->index_file.c_str(), "rb");
-        if (f) {
-            std::vector<uint8_t> ib; uint8_t tmp[65536]; size_t k;
-            while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) ib.insert(ib.end(), tmp, tmp + k);
-            fclose(f);
-            const bool known = ib.size() >= 4 && (memcmp(ib.data(), "BAI\1", 4) == 0 || memcmp(ib.data(), "CSI\1", 4) == 0 || (ib[0] == 0x1f && ib[1] == 0x8b));
-            if (known && dhts_bam_load_index(bind->ctx, ib.data(), ib.size()) != 0) { init_error(info, dhts_error(bind->ctx)); delete l; return; }
-        }
-    } else if (dhts_bam_set_regions(bind->ctx, nullptr) != 0) { init_error(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
-    if (bind->region.empty() && dhts_bam_rewind(bind->ctx) != 0) { init_error(info, "Failed to open SAM/BAM/CRAM file"); delete l; return; }
-    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, l, destroy_local);
-}
-
-static int fetch_str(dhts_ctx *c, const dhts_strcol &d, int64_t n, HostStr &h, bool want) {
-    if (!want) return 0;
-    h.off.resize(n + 1); h.len.resize(n); h.bytes.resize(d.nbytes + 1);
-    if (dhts_memcpy_d2h(c, h.off.data(), d.off, (n + 1) * 4) || dhts_memcpy_d2h(c, h.len.data(), d.len, n * 4) || dhts_memcpy_d2h(c, h.bytes.data(), d.bytes, d.nbytes)) return -1;
-    return 0;
-}
-
-// pulls the next GPU batch and copies only the projected columns to the host
-static int next_host_batch(BamBind *bind, BamLocal *l) {
-    dhts_bam_batch b;
-    for (;;) {
-        if (dhts_bam_next_batch(bind->ctx, 0, l->colmask, &b) != 0) return -1;
-        l->status = b.status;
-        if (b.n_rows > 0 || b.status != 0) break;
-    }
-    int64_t n = b.n_rows; l->n = n; l->cur = 0;
-    if (n == 0) return 0;
-    dhts_ctx *c = bind->ctx; uint32_t m = l->colmask;
-#define FETCH(vec, ptr, bit) do { if (m & (1u << (bit))) { (vec).resize(n); if (dhts_memcpy_d2h(c, (vec).data(), ptr, n * sizeof((vec)[0]))) return -1; } } while (0)
-    FETCH(l->flag, b.flag, DHTS_BAM_FLAG); FETCH(l->pos, b.pos, DHTS_BAM_POS); FETCH(l->mapq, b.mapq, DHTS_BAM_MAPQ);
-    FETCH(l->pnext, b.pnext, DHTS_BAM_PNEXT); FETCH(l->tlen, b.tlen, DHTS_BAM_TLEN); FETCH(l->tid, b.tid, DHTS_BAM_RNAME); FETCH(l->mtid, b.mtid, DHTS_BAM_RNEXT);
-    FETCH(l->rgidx, b.rg_idx, DHTS_BAM_SAMPLE_ID);
-    if (m & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) { l->rgvalid.resize((n + 63) / 64); if (dhts_memcpy_d2h(c, l->rgvalid.data(), b.rg_valid, l->rgvalid.size() * 8)) return -1; }
-    if (fetch_str(c, b.qname, n, l->qname, m & (1u << DHTS_BAM_QNAME)) || fetch_str(c, b.cigar, n, l->cigar, m & (1u << DHTS_BAM_CIGAR)) ||
-        fetch_str(c, b.seq, n, l->seq, m & (1u << DHTS_BAM_SEQ)) || fetch_str(c, b.qual, n, l->qual, m & (1u << DHTS_BAM_QUAL)) ||
-        fetch_str(c, b.rg, n, l->rg, m & (1u << DHTS_BAM_READ_GROUP_ID))) return -1;
-    if (l->want_aux && b.aux_map) {
+// copies the standard-tag columns and the auxiliary map of a device batch to pageable host memory (optional columns, off by default)
+static int fetch_optional(dhts_ctx *c, BamScan *g, const dhts_bam_batch &b, HostBatch *hb) {
+    const int64_t n = b.n_rows;
+    if (g->want_aux && b.aux_map) {
         // typed entries -> value text, bam_aux_to_string (bam_reader.c:140-183); assigned through the NUL-terminated API
         const dhts_aux_map &am = *b.aux_map; const size_t ne = (size_t)am.n_ent;
         std::vector<uint16_t> key(ne + 1); std::vector<uint8_t> kind(ne + 1), sub(ne + 1), pay(am.payload_bytes + 8); std::vector<uint32_t> po(ne + 2);
-        l->aux_valid.resize(n); l->aux_off.resize(n + 1);
-        if (dhts_memcpy_d2h(c, l->aux_valid.data(), am.valid, n) || dhts_memcpy_d2h(c, l->aux_off.data(), am.off, (n + 1) * 4)) return -1;
+        hb->aux_valid.resize(n); hb->aux_off.resize(n + 1);
+        if (dhts_memcpy_d2h(c, hb->aux_valid.data(), am.valid, n) || dhts_memcpy_d2h(c, hb->aux_off.data(), am.off, (n + 1) * 4)) return -1;
         if (ne && (dhts_memcpy_d2h(c, key.data(), am.key, ne * 2) || dhts_memcpy_d2h(c, kind.data(), am.kind, ne) || dhts_memcpy_d2h(c, sub.data(), am.sub, ne))) return -1;
         if (dhts_memcpy_d2h(c, po.data(), am.pay_off, (ne + 1) * 4)) return -1;
         if (am.payload_bytes && dhts_memcpy_d2h(c, pay.data(), am.payload, am.payload_bytes)) return -1;
-        l->aux_key.assign(ne, std::string()); l->aux_val.assign(ne, std::string());
+        hb->aux_key.assign(ne, std::string()); hb->aux_val.assign(ne, std::string());
         char tmp[64];
         for (size_t i = 0; i < ne; i++) {
             char kb[3] = {(char)(key[i] & 0xff), (char)(key[i] >> 8), 0};
-            l->aux_key[i] = kb;
+            hb->aux_key[i] = kb;
             const uint8_t *p = pay.data() + po[i]; const size_t pl = po[i + 1] - po[i];
             std::string v;
             int64_t iv; double dv;
@@ -270,11 +255,12 @@ static int next_host_batch(BamBind *bind, BamLocal *l) {
             case 5: v.push_back((char)sub[i]); for (size_t q = 0; q < pl / 8; q++) { memcpy(&dv, p + 8 * q, 8); snprintf(tmp, sizeof tmp, ",%g", dv); v += tmp; } break;
             default: break;
             }
-            l->aux_val[i] = v.c_str();                              // C-string semantics: cut at the first NUL
+            hb->aux_val[i] = v.c_str();                              // C-string semantics: cut at the first NUL
         }
     }
+    hb->tags.resize(b.n_tag_cols);
     for (int i = 0; i < b.n_tag_cols; i++) {
-        const dhts_col &d = b.tag_cols[i]; BamLocal::HostTag &h = l->tags[i];
+        const dhts_col &d = b.tag_cols[i]; HostTag &h = hb->tags[i];
         h.valid.resize(n); if (dhts_memcpy_d2h(c, h.valid.data(), d.valid, n)) return -1;
         if (d.fixed) { h.fixed.resize(n); if (dhts_memcpy_d2h(c, h.fixed.data(), d.fixed, n * 8)) return -1; }
         if (d.off) { h.off.resize(n + 1); if (dhts_memcpy_d2h(c, h.off.data(), d.off, (n + 1) * 4)) return -1; }
@@ -284,82 +270,273 @@ static int next_host_batch(BamBind *bind, BamLocal *l) {
     return 0;
 }
 
+// producer thread: one GPU, one scan context, one block range of the file
+static void producer_main(BamScan *g, Producer *p) {
+    BamBind *bind = g->bind;
+    auto fail_with = [&](const std::string &msg) {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->error.empty()) g->error = msg;
+        p->done = true; g->cv_ready.notify_all();
+    };
+    dhts_ctx *c = dhts_create(p->device);
+    if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
+    int rc;
+    if (p->world > 1) rc = dhts_open_path_shard(c, bind->path.c_str(), p->rank, p->world, bind->header_bytes);
+    else rc = dhts_open_path(c, bind->path.c_str());
+    if (rc == 0 && dhts_bgzf_index(c) <= 0) rc = -1;
+    if (rc == 0 && dhts_bam_open(c) != 0) rc = -1;
+    if (rc != 0) { std::string m = std::string("Failed to open SAM/BAM/CRAM file: ") + bind->path; dhts_destroy(c); fail_with(m); return; }
+    dhts_bam_set_tag_columns(c, g->tag_ids.data(), (int32_t)g->tag_ids.size());
+    dhts_bam_set_aux_map(c, g->want_aux ? 1 : 0, bind->standard_tags);
+    if (!bind->region.empty()) {
+        rc = dhts_bam_set_regions(c, bind->region.c_str());
+        if (rc == 0 && !g->index_bytes.empty()) rc = dhts_bam_load_index(c, g->index_bytes.data(), g->index_bytes.size());
+    } else rc = dhts_bam_set_regions(c, nullptr);
+    if (rc == 0 && p->world > 1) rc = dhts_bam_set_file_shard(c, p->rank, p->world);
+    else if (rc == 0 && bind->region.empty()) rc = dhts_bam_rewind(c);
+    if (rc != 0) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
+    static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
+    const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;       // ~270 MB of inflated stream per batch: the engine gets its first chunk early and the stages overlap
+    for (;;) {
+        dhts_bam_batch b;
+        if (dhts_bam_next_batch(c, max_blocks, g->colmask, &b) != 0) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
+        if (b.n_rows > 0) {
+            HostBatch *hb = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(g->mu);
+                g->cv_free.wait(lk, [&] { return g->cancel || !p->free_slots.empty(); });
+                if (g->cancel) break;
+                hb = p->free_slots.back(); p->free_slots.pop_back();
+            }
+            const uint64_t need = dhts_bam_batch_host_bytes(&b, g->colmask);
+            if (need > hb->cap) { dhts_host_free(hb->arena); hb->arena = dhts_host_alloc(need); hb->cap = hb->arena ? need : 0; }
+            if ((need && !hb->arena) || dhts_bam_batch_fetch(c, &b, g->colmask, hb->arena, hb->cap, &hb->b) != 0 || fetch_optional(c, g, b, hb) != 0) {
+                std::string m = hb->arena || !need ? dhts_error(c) : "read_bam: out of pinned host memory"; dhts_destroy(c); fail_with(m); return;
+            }
+            hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false;
+            if (!p->has_rows) { p->has_rows = true; p->first_v = dhts_voffset(c, b.first_rec_uoff); }
+            p->end_v = dhts_voffset(c, b.end_uoff);
+            { std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
+            g->cv_ready.notify_all();
+        }
+        if (b.status != 0) { p->clean_end = b.status == 1; break; }       // end of the stream, or the silent stop at the first bad block / record (bam_reader.c:754-766)
+        { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
+    }
+    dhts_destroy(c);
+    { std::lock_guard<std::mutex> lk(g->mu); p->done = true; }
+    g->cv_ready.notify_all();
+}
+
+static void bam_read_global_init(duckdb_init_info info) {
+    BamBind *bind = (BamBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
+    auto init_error = API(void, duckdb_init_set_error, duckdb_init_info, const char *);
+    BamScan *g = new BamScan();
+    g->bind = bind;
+    idx_t n = API(idx_t, duckdb_init_get_column_count, duckdb_init_info)(info);               // bam_reader.c:676-679
+    for (idx_t i = 0; i < n; i++) {
+        idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
+        g->column_ids.push_back(id);
+        if (id < DHTS_BAM_CORE_COUNT) g->colmask |= 1u << id;
+        int sl = -1;
+        if (bind->standard_tags && id >= DHTS_BAM_CORE_COUNT && id < (idx_t)(DHTS_BAM_CORE_COUNT + dhts_bam_std_tag_count())) {
+            const int32_t tid_ = (int32_t)(id - DHTS_BAM_CORE_COUNT);
+            for (size_t k = 0; k < g->tag_ids.size(); k++) if (g->tag_ids[k] == tid_) sl = (int)k;
+            if (sl < 0) { sl = (int)g->tag_ids.size(); g->tag_ids.push_back(tid_); }
+        }
+        g->tag_slot.push_back(sl);
+        if (bind->auxiliary_tags && id == bind->aux_col_idx) g->want_aux = true;
+    }
+    if (!bind->region.empty()) {
+        // bam_reader.c:639-668: a region needs an index; sam_itr_regarray failing reports "No reads found"
+        if (!bind->has_index) { init_error(info, "Region query requires an index (.bai/.csi/.crai)"); delete g; return; }
+        int rc = dhts_bam_set_regions(bind->ctx, bind->region.c_str());          // (validated on the bind context: it holds the header)
+        if (rc != 0) {
+            char err[640]; snprintf(err, sizeof(err), "No reads found for region(s): %s", bind->region.c_str());
+            init_error(info, rc == 1 ? err : dhts_error(bind->ctx)); delete g; return;
+        }
+        // the index (BAI or CSI) narrows the scan window; the device predicate decides the rows
+        FILE *f = fopen(bind->index_file.c_str(), "rb");
+        if (f) {
+            std::vector<uint8_t> ib; uint8_t tmp[65536]; size_t k;
+            while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) ib.insert(ib.end(), tmp, tmp + k);
+            fclose(f);
+            const bool known = ib.size() >= 4 && (memcmp(ib.data(), "BAI\1", 4) == 0 || memcmp(ib.data(), "CSI\1", 4) == 0 || (ib[0] == 0x1f && ib[1] == 0x8b));
+            if (known) g->index_bytes.swap(ib);
+        }
+    }
+    // sequential mode unless the user asks for parallel fill (bam_reader.c:577-585: the reference goes parallel only with an index)
+    int thr = getenv("DHTS_THREADS") ? atoi(getenv("DHTS_THREADS")) : 1; if (thr < 1) thr = 1; if (thr > 64) thr = 64;
+    g->n_workers = thr;
+    std::vector<int> devs = device_list();
+    if (!bind->region.empty()) devs.resize(1);          // an index window is one short scan: a single device serves it
+    for (size_t k = 0; k < devs.size(); k++) {
+        Producer *p = new Producer(); p->device = devs[k]; p->rank = (int)k; p->world = (int)devs.size();
+        for (int q = 0; q < 3; q++) { HostBatch *hb = new HostBatch(); p->free_slots.push_back(hb); p->all.push_back(hb); }
+        g->prod.push_back(p);
+    }
+    for (auto p : g->prod) p->th = std::thread(producer_main, g, p);
+    API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, (idx_t)thr);
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, g, destroy_global);
+}
+
+static void bam_read_local_init(duckdb_init_info info) {
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, new BamLocal(), destroy_local);
+}
+
+// hands the calling worker its next run of rows: the rest of the current batch (sequential mode) or a 2048-row slice of a ready batch.
+// Returns false at the end of the scan (or on a producer error: g->error).
+static bool next_rows(BamScan *g, BamLocal *l, idx_t want) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    // give back what the worker holds
+    if (l->cur) {
+        HostBatch *hb = l->cur; Producer *own = l->cur_owner;
+        hb->readers--;
+        const bool finished = g->n_workers == 1 ? true : (hb->retired && hb->readers == 0);
+        if (finished) { own->free_slots.push_back(hb); g->cv_free.notify_all(); }
+        l->cur = nullptr;
+    }
+    for (;;) {
+        if (!g->error.empty()) return false;
+        // ordered mode drains the producers one after the other (file order); parallel mode takes whatever is ready
+        for (size_t k = 0; k < g->prod.size(); k++) {
+            Producer *p = g->prod[g->n_workers == 1 ? g->cur_prod : (g->cur_prod + k) % g->prod.size()];
+            while (!p->ready.empty()) {
+                HostBatch *hb = p->ready.front();
+                if (g->n_workers == 1) {
+                    p->ready.pop_front(); hb->readers = 1;
+                    l->cur = hb; l->cur_owner = p; l->pos = 0; l->end = hb->n;
+                    return true;
+                }
+                if (hb->next >= hb->n) {            // every row is claimed: the last reader returns the slot
+                    p->ready.pop_front(); hb->retired = true;
+                    if (hb->readers == 0) { p->free_slots.push_back(hb); g->cv_free.notify_all(); }
+                    continue;
+                }
+                l->cur = hb; l->cur_owner = p; l->pos = hb->next; l->end = hb->next + (int64_t)want < hb->n ? hb->next + (int64_t)want : hb->n;
+                hb->next = l->end; hb->readers++;
+                return true;
+            }
+            if (g->n_workers == 1) {
+                if (p->done && p->ready.empty()) {
+                    if (!p->clean_end) return false;      // the stream ended on an error inside this rank: the scan ends here, silently (bam_reader.c:754-766)
+                    if (g->cur_prod + 1 < g->prod.size()) { g->cur_prod++; k = (size_t)-1; continue; }
+                }
+                break;
+            }
+        }
+        bool all_done = true;
+        for (auto p : g->prod) if (!p->done || !p->ready.empty()) all_done = false;
+        if (all_done) {
+            // several GPUs on one file: every rank's last record must end exactly where the next rank's first record begins
+            if (g->prod.size() > 1 && !g->handoff_checked) {
+                g->handoff_checked = true;
+                const Producer *prev = nullptr;
+                if (g->n_workers > 1) for (auto p : g->prod) if (!p->clean_end && g->error.empty())
+                    g->error = "read_bam: the stream ended on an error inside one GPU's block range; rerun with DHTS_THREADS=1 for the reference's rows-before-the-error result";
+                for (auto p : g->prod) {
+                    if (prev && p->has_rows && prev->clean_end && prev->end_v != p->first_v && g->error.empty()) {
+                        char m[256]; snprintf(m, sizeof(m), "read_bam: GPU shard hand-off mismatch between ranks %d and %d (%llx vs %llx)", prev->rank, p->rank, (unsigned long long)prev->end_v, (unsigned long long)p->first_v);
+                        g->error = m;
+                    }
+                    if (p->has_rows) prev = p;
+                    if (!p->clean_end) break;                 // the stream ended on an error inside this rank: later ranks' rows are not reachable sequentially
+                }
+                if (!g->error.empty()) return false;
+            }
+            return false;
+        }
+        g->cv_ready.wait(lk);
+    }
+}
+
 static void bam_read_function(duckdb_function_info info, duckdb_data_chunk output) {
     BamBind *bind = (BamBind *)API(void *, duckdb_function_get_bind_data, duckdb_function_info)(info);
+    BamScan *g = (BamScan *)API(void *, duckdb_function_get_init_data, duckdb_function_info)(info);
     BamLocal *l = (BamLocal *)API(void *, duckdb_function_get_local_init_data, duckdb_function_info)(info);
     auto set_size = API(void, duckdb_data_chunk_set_size, duckdb_data_chunk, idx_t);
-    if (!l || l->done) { set_size(output, 0); return; }                                      // bam_reader.c:730-733
+    if (!l || !g || l->done) { set_size(output, 0); return; }                                // bam_reader.c:730-733
     const idx_t vector_size = API(idx_t, duckdb_vector_size, void)();
     auto get_vec = API(duckdb_vector, duckdb_data_chunk_get_vector, duckdb_data_chunk, idx_t);
     auto get_data = API(void *, duckdb_vector_get_data, duckdb_vector);
     auto assign_len = API(void, duckdb_vector_assign_string_element_len, duckdb_vector, idx_t, const char *, idx_t);
     idx_t row_count = 0;
     while (row_count < vector_size) {
-        if (l->cur >= l->n) {
-            if (l->status != 0) { l->done = true; break; }          // end of stream or silent stop on error (bam_reader.c:754-766)
-            if (next_host_batch(bind, l) != 0) {
-                API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, dhts_error(bind->ctx));
-                l->done = true; set_size(output, 0); return;
+        if (!l->cur || l->pos >= l->end) {
+            if (g->n_workers > 1 && row_count > 0) break;           // parallel mode: one slice per chunk
+            if (!next_rows(g, l, vector_size)) {
+                l->done = true;
+                if (!g->error.empty()) { API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, g->error.c_str()); set_size(output, 0); return; }
+                break;
             }
-            if (l->n == 0) { l->done = true; break; }
         }
-        idx_t take = (idx_t)(l->n - l->cur); if (take > vector_size - row_count) take = vector_size - row_count;
-        const int64_t s = l->cur;
-        for (size_t ci = 0; ci < l->column_ids.size(); ci++) {
+        const HostBatch *hb = l->cur; const dhts_bam_batch &b = hb->b;
+        idx_t take = (idx_t)(l->end - l->pos); if (take > vector_size - row_count) take = vector_size - row_count;
+        const int64_t s = l->pos;
+        for (size_t ci = 0; ci < g->column_ids.size(); ci++) {
             duckdb_vector vec = get_vec(output, ci);
-            auto put_str = [&](const HostStr &h) { for (idx_t r = 0; r < take; r++) assign_len(vec, row_count + r, (const char *)h.bytes.data() + h.off[s + r], h.len[s + r]); };
-            auto put_name = [&](const std::vector<int32_t> &ids) {
-                for (idx_t r = 0; r < take; r++) { int32_t t = ids[s + r]; const char *nm = t >= 0 ? bind->hdr.ref_name[t] : "*"; assign_len(vec, row_count + r, nm, strlen(nm)); } };
-            switch (l->column_ids[ci]) {
-            case DHTS_BAM_QNAME: put_str(l->qname); break;
-            case DHTS_BAM_FLAG: memcpy((uint16_t *)get_data(vec) + row_count, l->flag.data() + s, take * 2); break;
-            case DHTS_BAM_RNAME: put_name(l->tid); break;
-            case DHTS_BAM_POS: memcpy((int64_t *)get_data(vec) + row_count, l->pos.data() + s, take * 8); break;
-            case DHTS_BAM_MAPQ: memcpy((int32_t *)get_data(vec) + row_count, l->mapq.data() + s, take * 4); break;
-            case DHTS_BAM_CIGAR: put_str(l->cigar); break;
-            case DHTS_BAM_RNEXT: put_name(l->mtid); break;
-            case DHTS_BAM_PNEXT: memcpy((int64_t *)get_data(vec) + row_count, l->pnext.data() + s, take * 8); break;
-            case DHTS_BAM_TLEN: memcpy((int64_t *)get_data(vec) + row_count, l->tlen.data() + s, take * 8); break;
-            case DHTS_BAM_SEQ: put_str(l->seq); break;
-            case DHTS_BAM_QUAL: put_str(l->qual); break;
-            case DHTS_BAM_READ_GROUP_ID:
+            // strings of <= 12 bytes are written in place (no call, no heap); longer ones are copied into the vector's heap by the engine
+            auto put_str = [&](const dhts_strcol &h) {
+                duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;
+                for (idx_t r = 0; r < take; r++) { const char *p = (const char *)h.bytes + h.off[s + r]; const uint32_t n = h.len[s + r]; if (!inl_string(d + r, p, n)) assign_len(vec, row_count + r, p, n); } };
+            auto put_name = [&](const int32_t *ids) {
+                duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;
                 for (idx_t r = 0; r < take; r++) {
-                    int64_t g = s + (int64_t)r;
-                    if ((l->rgvalid[g >> 6] >> (g & 63)) & 1) assign_len(vec, row_count + r, (const char *)l->rg.bytes.data() + l->rg.off[g], l->rg.len[g]);
+                    const int32_t t = ids[s + r];
+                    if (t < 0) d[r] = bind->star_inl; else if (bind->ref_is_inl[t]) d[r] = bind->ref_inl[t];
+                    else { const char *nm = bind->hdr.ref_name[t]; assign_len(vec, row_count + r, nm, strlen(nm)); }
+                } };
+            switch (g->column_ids[ci]) {
+            case DHTS_BAM_QNAME: put_str(b.qname); break;
+            case DHTS_BAM_FLAG: memcpy((uint16_t *)get_data(vec) + row_count, b.flag + s, take * 2); break;
+            case DHTS_BAM_RNAME: put_name(b.tid); break;
+            case DHTS_BAM_POS: memcpy((int64_t *)get_data(vec) + row_count, b.pos + s, take * 8); break;
+            case DHTS_BAM_MAPQ: memcpy((int32_t *)get_data(vec) + row_count, b.mapq + s, take * 4); break;
+            case DHTS_BAM_CIGAR: put_str(b.cigar); break;
+            case DHTS_BAM_RNEXT: put_name(b.mtid); break;
+            case DHTS_BAM_PNEXT: memcpy((int64_t *)get_data(vec) + row_count, b.pnext + s, take * 8); break;
+            case DHTS_BAM_TLEN: memcpy((int64_t *)get_data(vec) + row_count, b.tlen + s, take * 8); break;
+            case DHTS_BAM_SEQ: put_str(b.seq); break;
+            case DHTS_BAM_QUAL: put_str(b.qual); break;
+            case DHTS_BAM_READ_GROUP_ID: {
+                duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;
+                for (idx_t r = 0; r < take; r++) {
+                    int64_t q = s + (int64_t)r;
+                    if ((b.rg_valid[q >> 6] >> (q & 63)) & 1) { const char *p = (const char *)b.rg.bytes + b.rg.off[q]; const uint32_t n = b.rg.len[q]; if (!inl_string(d + r, p, n)) assign_len(vec, row_count + r, p, n); }
                     else set_null(vec, row_count + r);
                 }
                 break;
+            }
             case DHTS_BAM_SAMPLE_ID:
                 for (idx_t r = 0; r < take; r++) {
-                    int64_t g = s + (int64_t)r; int32_t k = l->rgidx[g];
-                    const char *sm = (((l->rgvalid[g >> 6] >> (g & 63)) & 1) && k >= 0) ? bind->hdr.rg_sm[k] : nullptr;
+                    int64_t q = s + (int64_t)r; int32_t k = b.rg_idx[q];
+                    const char *sm = (((b.rg_valid[q >> 6] >> (q & 63)) & 1) && k >= 0) ? bind->hdr.rg_sm[k] : nullptr;
                     if (sm) assign_len(vec, row_count + r, sm, strlen(sm)); else set_null(vec, row_count + r);
                 }
                 break;
             default: {
-                if (l->want_aux && l->column_ids[ci] == bind->aux_col_idx) {               // bam_reader.c:967-1027
+                if (g->want_aux && g->column_ids[ci] == bind->aux_col_idx) {               // bam_reader.c:967-1027
                     auto list_size = API(idx_t, duckdb_list_vector_get_size, duckdb_vector);
                     duckdb_list_entry *le = (duckdb_list_entry *)get_data(vec);
                     idx_t base = list_size(vec);
-                    const uint32_t c0 = l->aux_off[s], c1 = l->aux_off[s + take];
+                    const uint32_t c0 = hb->aux_off[s], c1 = hb->aux_off[s + take];
                     if (c1 > c0) { API(duckdb_state, duckdb_list_vector_reserve, duckdb_vector, idx_t)(vec, base + (c1 - c0)); API(duckdb_state, duckdb_list_vector_set_size, duckdb_vector, idx_t)(vec, base + (c1 - c0)); }
                     duckdb_vector child = API(duckdb_vector, duckdb_list_vector_get_child, duckdb_vector)(vec);
                     duckdb_vector kvec = API(duckdb_vector, duckdb_struct_vector_get_child, duckdb_vector, idx_t)(child, 0);
                     duckdb_vector vvec = API(duckdb_vector, duckdb_struct_vector_get_child, duckdb_vector, idx_t)(child, 1);
                     for (idx_t r = 0; r < take; r++) {
-                        le[row_count + r].offset = base + (l->aux_off[s + r] - c0); le[row_count + r].length = l->aux_off[s + r + 1] - l->aux_off[s + r];
-                        if (!l->aux_valid[s + r]) set_null(vec, row_count + r);            // no tags: NULL, entry {size, 0}
+                        le[row_count + r].offset = base + (hb->aux_off[s + r] - c0); le[row_count + r].length = hb->aux_off[s + r + 1] - hb->aux_off[s + r];
+                        if (!hb->aux_valid[s + r]) set_null(vec, row_count + r);            // no tags: NULL, entry {size, 0}
                     }
                     for (uint32_t k = c0; k < c1; k++) {
-                        assign_len(kvec, base + (k - c0), l->aux_key[k].data(), l->aux_key[k].size());
-                        assign_len(vvec, base + (k - c0), l->aux_val[k].data(), l->aux_val[k].size());
+                        assign_len(kvec, base + (k - c0), hb->aux_key[k].data(), hb->aux_key[k].size());
+                        assign_len(vvec, base + (k - c0), hb->aux_val[k].data(), hb->aux_val[k].size());
                     }
                     break;
                 }
-                const int sl = l->tag_slot[ci];
+                const int sl = g->tag_slot[ci];
                 if (sl < 0) break;                                 // unknown ids (e.g. a row-id pseudo column) write nothing, like the reference's default arm
-                const BamLocal::HostTag &h = l->tags[sl];
-                char nm[3], ty, sub; dhts_bam_std_tag_info(l->tag_ids[sl], nm, &ty, &sub);
+                const HostTag &h = hb->tags[sl];
+                char nm[3], ty, sub; dhts_bam_std_tag_info(g->tag_ids[sl], nm, &ty, &sub);
                 if (ty == 'i') {                                    // bam_reader.c:946-950
                     memcpy((int64_t *)get_data(vec) + row_count, h.fixed.data() + s, take * 8);
                     for (idx_t r = 0; r < take; r++) if (!h.valid[s + r]) set_null(vec, row_count + r);
@@ -385,7 +562,7 @@ static void bam_read_function(duckdb_function_info info, duckdb_data_chunk outpu
             }
             }
         }
-        row_count += take; l->cur += (int64_t)take;
+        row_count += take; l->pos += (int64_t)take;
     }
     set_size(output, row_count);
 }

@@ -135,7 +135,20 @@ void dhts_destroy(dhts_ctx *);
 const char *dhts_error(const dhts_ctx *);          /* last error message ("" if none) */
 
 /* ---- input: compressed bytes become resident in HBM -------------------------------------- */
-int dhts_open_path(dhts_ctx *, const char *path);                  /* pread -> pinned -> HBM */
+int dhts_open_path(dhts_ctx *, const char *path);                  /* pread (reader threads) -> pinned -> HBM, whole file */
+/* bytes [off, off+len) of the file (len = 0: to its end) become the resident bytes: a rank of a multi-GPU scan stages only its
+ * own block range plus a halo; a bind that only needs the header stages the first megabytes (hts_open + the reads under
+ * bgzf_read_block, htslib/bgzf.c:1004-1239, restricted to a window of the file) */
+int dhts_open_path_range(dhts_ctx *, const char *path, uint64_t off, uint64_t len);
+/* one rank's share of ONE file: resident bytes = the header blocks file[0, header_bytes) followed by the rank's own
+ * window of whole BGZF blocks plus a 4 MiB halo; cut points t_r = header_bytes + (size - header_bytes) * r / world.  Follow with
+ * dhts_bgzf_index, dhts_bam_open and dhts_bam_set_file_shard(rank, world).  header_bytes: dhts_bam_header_bytes of a context that has
+ * opened (the head of) the file.  dhts_voffset turns a position of the inflated stream into a BGZF virtual offset (bgzf_tell,
+ * htslib/bgzf.h): adjacent ranks hand off end == first-record as virtual offsets. */
+int dhts_open_path_shard(dhts_ctx *, const char *path, int rank, int world, uint64_t header_bytes);
+int dhts_bam_set_file_shard(dhts_ctx *, int rank, int world);
+uint64_t dhts_bam_header_bytes(const dhts_ctx *);
+uint64_t dhts_voffset(const dhts_ctx *, uint64_t uoff);
 int dhts_open_host(dhts_ctx *, const void *bytes, uint64_t n);     /* copy host bytes -> HBM */
 int dhts_open_tiled(dhts_ctx *, const void *head, uint64_t n_head, const void *body, uint64_t n_body, int reps,
                     const void *tail, uint64_t n_tail);            /* HBM = head + body x reps + tail (benchmark helper) */
@@ -240,6 +253,17 @@ int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative
 int dhts_bcf_set_region(dhts_ctx *, const char *region);
 int dhts_bcf_rewind(dhts_ctx *);
 int dhts_bcf_next_batch(dhts_ctx *, int64_t max_blocks, dhts_bcf_batch *out);
+
+/* ---- batches in host memory ---------------------------------------------------------------------
+ * dhts_host_alloc: pinned (page-locked, portable) host memory from a process-wide pool; dhts_host_free returns it to the pool.
+ * dhts_bam_batch_fetch copies the projected core columns (colmask as in dhts_bam_next_batch) of `b` into `dst` -- every copy
+ * queued, one wait -- and fills `out` = `b` with HOST pointers for those columns (NULL for unprojected ones); tag columns, the
+ * auxiliary map and the overlap lists keep their device pointers.  dhts_bam_batch_host_bytes = the room `dst` needs.
+ * This is the seam a DuckDB scan callback fills DataChunks from (src/bam_reader.c:783-918 reads the same values out of bam1_t). */
+void *dhts_host_alloc(uint64_t nbytes);
+void dhts_host_free(void *p);
+uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
+int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);
 
 /* ---- utilities ------------------------------------------------------------------------------ */
 int dhts_memcpy_d2h(dhts_ctx *, void *dst, const void *src_dev, uint64_t n);

@@ -14,6 +14,8 @@
  * itself, never touching duckhts_init_c_api.
  */
 #include <dlfcn.h>
+#include <pthread.h>
+#include <time.h>
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -26,7 +28,7 @@
 
 typedef struct LType { int id; struct LType *child; } LType;
 typedef struct Value { int is_null; int is_bool; int b; char *s; } Value;
-typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap; int child_type; struct Vec *child; idx_t list_size, list_cap; struct Vec *kids[2]; } Vec;
+typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap, heap_used, heap_cap; int child_type; struct Vec *child; idx_t list_size, list_cap; struct Vec *kids[2]; } Vec;
 typedef struct Chunk { Vec *vecs; size_t ncol; idx_t size; } Chunk;
 typedef struct TF {
     char name[64]; duckdb_table_function_bind_t bind; duckdb_table_function_init_t init, local_init; duckdb_table_function_t func;
@@ -101,7 +103,15 @@ static void h_assign_len(duckdb_vector v, idx_t row, const char *s, idx_t len) {
     memset(d, 0, sizeof(*d));
     d->value.inlined.length = (uint32_t)len;
     if (len <= 12) memcpy(d->value.inlined.inlined, s, len);
-    else { char *h = malloc(len); memcpy(h, s, len); x->heap = realloc(x->heap, (x->nheap + 1) * sizeof(char *)); x->heap[x->nheap++] = h; memcpy(d->value.pointer.prefix, s, 4); d->value.pointer.ptr = h; }
+    else {
+        /* the vector's string heap is an arena (slabs of 256 KiB), like the engine's StringHeap: one bump allocation + one copy per string */
+        if (x->nheap == 0 || x->heap_used + len > x->heap_cap) {
+            size_t cap = len > (256u << 10) ? len : (256u << 10);
+            x->heap = realloc(x->heap, (x->nheap + 1) * sizeof(char *)); x->heap[x->nheap++] = malloc(cap); x->heap_used = 0; x->heap_cap = cap;
+        }
+        char *h = x->heap[x->nheap - 1] + x->heap_used; x->heap_used += len;
+        memcpy(h, s, len); memcpy(d->value.pointer.prefix, s, 4); d->value.pointer.ptr = h;
+    }
 }
 static void h_assign(duckdb_vector v, idx_t row, const char *s) { h_assign_len(v, row, s, strlen(s)); }
 
@@ -132,6 +142,88 @@ static const void *get_api(duckdb_extension_info info, const char *version) { (v
 static duckdb_database g_db = (void *)0x2;
 static duckdb_database *get_database(duckdb_extension_info info) { (void)info; return &g_db; }
 static void set_error(duckdb_extension_info info, const char *e) { (void)info; fprintf(stderr, "extension error: %s\n", e); }
+
+/* ---- scan workers: what DuckDB's task scheduler does with a parallel table function: every worker runs local_init once, then calls
+ * the scan function until it returns a 0-row chunk.  Chunks are serialised under a lock in arrival order. ---- */
+typedef struct Worker { Bind *b; Init *g; TF *tf; FILE *fo; Init l; uint64_t rows, chunks; int failed; char err[1024]; } Worker;
+static pthread_mutex_t g_out_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void write_chunk(FILE *fo, Chunk *cp, uint64_t n) {
+    Chunk c = *cp;
+    fwrite(&n, 8, 1, fo);
+    for (size_t k = 0; k < c.ncol; k++) {
+        Vec *v = &c.vecs[k]; uint32_t t = (uint32_t)v->type; fwrite(&t, 4, 1, fo);
+        uint64_t words = (n + 63) / 64;
+        for (uint64_t w = 0; w < words; w++) { uint64_t m = v->validity ? v->validity[w] : ~0ull; if (w == words - 1 && (n % 64)) m &= (1ull << (n % 64)) - 1; fwrite(&m, 8, 1, fo); }
+        if (v->type == DUCKDB_TYPE_MAP) {                 /* entries, child size, then keys and values in the VARCHAR child encoding */
+            fwrite(v->data, 16, n, fo);
+            uint64_t cn = v->list_size; fwrite(&cn, 8, 1, fo);
+            for (int q = 0; q < 2; q++) for (uint64_t r = 0; r < cn; r++) {
+                duckdb_string_t *d = (duckdb_string_t *)v->child->kids[q]->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo);
+                fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo);
+            }
+            continue;
+        }
+        if (v->type == DUCKDB_TYPE_LIST) {
+            fwrite(v->data, 16, n, fo);
+            uint64_t cn = v->list_size; uint32_t ct = (uint32_t)v->child->type; fwrite(&cn, 8, 1, fo); fwrite(&ct, 4, 1, fo);
+            for (uint64_t r = 0; r < cn; r++) {
+                if (ct == DUCKDB_TYPE_VARCHAR) { duckdb_string_t *d = (duckdb_string_t *)v->child->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo); fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo); }
+                else fwrite((char *)v->child->data + r * type_width((int)ct), 1, (size_t)type_width((int)ct), fo);
+            }
+            continue;
+        }
+        for (uint64_t r = 0; r < n; r++) {
+            int valid = v->validity ? (int)((v->validity[r / 64] >> (r % 64)) & 1) : 1;
+            if (v->type == DUCKDB_TYPE_VARCHAR) {
+                duckdb_string_t *d = (duckdb_string_t *)v->data + r; uint32_t len = valid ? d->value.inlined.length : 0xFFFFFFFFu; fwrite(&len, 4, 1, fo);
+                if (valid) fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo);
+            } else { int w = type_width(v->type); static const char zero[16] = {0}; fwrite(valid ? (char *)v->data + r * w : zero, 1, (size_t)w, fo); }
+        }
+    }
+}
+
+static void vec_release(Vec *v) { for (size_t h = 0; h < v->nheap; h++) free(v->heap[h]); free(v->heap); v->heap = NULL; v->nheap = 0; v->heap_used = v->heap_cap = 0; }
+
+static void *worker_main(void *arg) {
+    Worker *w = arg; Bind *b = w->b; Init *g = w->g; TF *tf = w->tf;
+    memset(&w->l, 0, sizeof(w->l)); w->l.b = b; memcpy(w->l.proj, g->proj, sizeof(g->proj)); w->l.nproj = g->nproj;
+    if (tf->local_init) tf->local_init(&w->l);
+    if (w->l.has_err) { w->failed = 1; snprintf(w->err, sizeof(w->err), "%s", w->l.err); return NULL; }
+    Func fi; memset(&fi, 0, sizeof(fi)); fi.b = b; fi.g = g; fi.l = &w->l;
+    /* the DataChunk is allocated once and reset between calls, as the engine does */
+    Chunk c; c.ncol = g->nproj; c.size = 0; c.vecs = calloc(c.ncol, sizeof(Vec));
+    for (size_t k = 0; k < c.ncol; k++) { int t = g->proj[k] < (idx_t)b->ncol ? b->coltype[g->proj[k]] : DUCKDB_TYPE_BIGINT; c.vecs[k].type = t; c.vecs[k].data = calloc(VSIZE, (size_t)type_width(t));
+        if (t == DUCKDB_TYPE_LIST) { Vec *ch = calloc(1, sizeof(Vec)); ch->type = b->colchild[g->proj[k]]; c.vecs[k].child = ch; c.vecs[k].child_type = ch->type; list_grow(&c.vecs[k], VSIZE); }
+        if (t == DUCKDB_TYPE_MAP) {
+            Vec *ch = calloc(1, sizeof(Vec)); ch->type = DUCKDB_TYPE_STRUCT;
+            for (int q = 0; q < 2; q++) { ch->kids[q] = calloc(1, sizeof(Vec)); ch->kids[q]->type = DUCKDB_TYPE_VARCHAR; }
+            c.vecs[k].child = ch; c.vecs[k].child_type = DUCKDB_TYPE_STRUCT; list_grow(&c.vecs[k], VSIZE);
+        } }
+    for (;;) {
+        c.size = 0;
+        tf->func(&fi, &c);
+        if (fi.has_err) { w->failed = 2; snprintf(w->err, sizeof(w->err), "%s", fi.err); break; }
+        uint64_t n = c.size;
+        if (w->fo && n) { pthread_mutex_lock(&g_out_mu); write_chunk(w->fo, &c, n); pthread_mutex_unlock(&g_out_mu); }
+        /* reset: validity masks dropped, string heaps released, lists emptied */
+        for (size_t k = 0; k < c.ncol; k++) {
+            Vec *v = &c.vecs[k];
+            free(v->validity); v->validity = NULL; vec_release(v);
+            if (v->type == DUCKDB_TYPE_LIST || v->type == DUCKDB_TYPE_MAP) memset(v->data, 0, (size_t)VSIZE * 16);    /* entries of NULL rows are left untouched by the readers: keep the dump deterministic */
+            if (v->child) { v->list_size = 0; if (v->child->type == DUCKDB_TYPE_STRUCT) { for (int q = 0; q < 2; q++) vec_release(v->child->kids[q]); } else vec_release(v->child); }
+        }
+        if (n == 0) break;
+        w->rows += n; w->chunks++;
+    }
+    for (size_t k = 0; k < c.ncol; k++) {
+        Vec *ch = c.vecs[k].child;
+        if (ch && ch->type == DUCKDB_TYPE_STRUCT) { for (int q = 0; q < 2; q++) { Vec *kv = ch->kids[q]; vec_release(kv); free(kv->data); free(kv); } free(ch); ch = NULL; }
+        if (ch) { vec_release(ch); free(ch->data); free(ch); }
+        vec_release(&c.vecs[k]); free(c.vecs[k].data); free(c.vecs[k].validity); }
+    free(c.vecs);
+    return NULL;
+}
 
 int main(int argc, char **argv) {
     int direct = 0;
@@ -186,95 +278,53 @@ int main(int argc, char **argv) {
     for (int i = 0; i < g_ntf; i++) if (!strcmp(g_tfs[i].name, argv[2])) tf = &g_tfs[i];
     if (!tf) { printf("ERROR catalog: table function %s not registered\n", argv[2]); return 3; }
 
-    static Bind b; memset(&b, 0, sizeof(b)); b.tf = tf; b.path = argv[3];
     const char *proj = NULL, *out = NULL;
+    int threads = 0, repeat = 1;
+    static char names[16][32], vals[16][512]; int n_named = 0;
     for (int i = 4; i < argc; i++) {
         if (!strcmp(argv[i], "-n") && i + 1 < argc) {
             char *eq = strchr(argv[++i], '='); if (!eq) continue;
             int known = 0; *eq = 0;
             for (int k = 0; k < tf->n_named; k++) if (!strcmp(tf->named[k], argv[i])) known = 1;
             if (!known) { printf("ERROR binder: unknown named parameter %s\n", argv[i]); return 3; }
-            snprintf(b.names[b.n_named], 32, "%s", argv[i]); snprintf(b.vals[b.n_named++], 512, "%s", eq + 1);
+            snprintf(names[n_named], 32, "%s", argv[i]); snprintf(vals[n_named++], 512, "%s", eq + 1);
         } else if (!strcmp(argv[i], "-p") && i + 1 < argc) proj = argv[++i];
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+        else if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);       /* worker threads offered to the scan (<= max_threads it asks for) */
+        else if (!strcmp(argv[i], "-r") && i + 1 < argc) repeat = atoi(argv[++i]);        /* run the query this many times in one process (warm runs) */
     }
-    tf->bind(&b);
-    if (b.has_err) { printf("ERROR bind: %s\n", b.err); return 3; }
-    static Init g, l; memset(&g, 0, sizeof(g)); memset(&l, 0, sizeof(l)); g.b = &b; l.b = &b;
-    if (proj) { char *dup = strdup(proj); for (char *t = strtok(dup, ","); t; t = strtok(NULL, ",")) g.proj[g.nproj++] = (idx_t)strtoull(t, NULL, 10); }
-    else for (int i = 0; i < b.ncol; i++) g.proj[g.nproj++] = (idx_t)i;
-    memcpy(l.proj, g.proj, sizeof(g.proj)); l.nproj = g.nproj;
-    if (tf->init) tf->init(&g);
-    if (g.has_err) { printf("ERROR init: %s\n", g.err); return 3; }
-    if (tf->local_init) tf->local_init(&l);
-    if (l.has_err) { printf("ERROR init: %s\n", l.err); return 3; }
-
-    FILE *fo = out ? fopen(out, "wb") : NULL;
-    /* schema record */
-    if (fo) { uint32_t nc = (uint32_t)b.ncol; fwrite(&nc, 4, 1, fo); for (int i = 0; i < b.ncol; i++) { uint32_t t = (uint32_t)b.coltype[i]; fwrite(&t, 4, 1, fo); uint32_t ct = (uint32_t)b.colchild[i]; fwrite(&ct, 4, 1, fo); fwrite(b.colname[i], 1, 256, fo); } uint32_t np = (uint32_t)g.nproj; fwrite(&np, 4, 1, fo); }
-    Func fi = { &b, &g, &l, {0}, 0 };
-    uint64_t total = 0, chunks = 0;
-    for (;;) {
-        Chunk c; c.ncol = g.nproj; c.size = 0; c.vecs = calloc(c.ncol, sizeof(Vec));
-        for (size_t k = 0; k < c.ncol; k++) { int t = g.proj[k] < (idx_t)b.ncol ? b.coltype[g.proj[k]] : DUCKDB_TYPE_BIGINT; c.vecs[k].type = t; c.vecs[k].data = calloc(VSIZE, (size_t)type_width(t));
-            if (t == DUCKDB_TYPE_LIST) { Vec *ch = calloc(1, sizeof(Vec)); ch->type = b.colchild[g.proj[k]]; c.vecs[k].child = ch; c.vecs[k].child_type = ch->type; list_grow(&c.vecs[k], VSIZE); }
-            if (t == DUCKDB_TYPE_MAP) {
-                Vec *ch = calloc(1, sizeof(Vec)); ch->type = DUCKDB_TYPE_STRUCT;
-                for (int q = 0; q < 2; q++) { ch->kids[q] = calloc(1, sizeof(Vec)); ch->kids[q]->type = DUCKDB_TYPE_VARCHAR; }
-                c.vecs[k].child = ch; c.vecs[k].child_type = DUCKDB_TYPE_STRUCT; list_grow(&c.vecs[k], VSIZE);
-            } }
-        tf->func(&fi, &c);
-        if (fi.has_err) { printf("ERROR scan: %s\n", fi.err); return 3; }
-        uint64_t n = c.size;
-        if (fo && n) {
-            fwrite(&n, 8, 1, fo);
-            for (size_t k = 0; k < c.ncol; k++) {
-                Vec *v = &c.vecs[k]; uint32_t t = (uint32_t)v->type; fwrite(&t, 4, 1, fo);
-                uint64_t words = (n + 63) / 64;
-                for (uint64_t w = 0; w < words; w++) { uint64_t m = v->validity ? v->validity[w] : ~0ull; if (w == words - 1 && (n % 64)) m &= (1ull << (n % 64)) - 1; fwrite(&m, 8, 1, fo); }
-                if (v->type == DUCKDB_TYPE_MAP) {                 /* entries, child size, then keys and values in the VARCHAR child encoding */
-                    fwrite(v->data, 16, n, fo);
-                    uint64_t cn = v->list_size; fwrite(&cn, 8, 1, fo);
-                    for (int q = 0; q < 2; q++) for (uint64_t r = 0; r < cn; r++) {
-                        duckdb_string_t *d = (duckdb_string_t *)v->child->kids[q]->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo);
-                        fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo);
-                    }
-                    continue;
-                }
-                if (v->type == DUCKDB_TYPE_LIST) {
-                    fwrite(v->data, 16, n, fo);
-                    uint64_t cn = v->list_size; uint32_t ct = (uint32_t)v->child->type; fwrite(&cn, 8, 1, fo); fwrite(&ct, 4, 1, fo);
-                    for (uint64_t r = 0; r < cn; r++) {
-                        if (ct == DUCKDB_TYPE_VARCHAR) { duckdb_string_t *d = (duckdb_string_t *)v->child->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo); fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo); }
-                        else fwrite((char *)v->child->data + r * type_width((int)ct), 1, (size_t)type_width((int)ct), fo);
-                    }
-                    continue;
-                }
-                for (uint64_t r = 0; r < n; r++) {
-                    int valid = v->validity ? (int)((v->validity[r / 64] >> (r % 64)) & 1) : 1;
-                    if (v->type == DUCKDB_TYPE_VARCHAR) {
-                        duckdb_string_t *d = (duckdb_string_t *)v->data + r; uint32_t len = valid ? d->value.inlined.length : 0xFFFFFFFFu; fwrite(&len, 4, 1, fo);
-                        if (valid) fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo);
-                    } else { int w = type_width(v->type); static const char zero[16] = {0}; fwrite(valid ? (char *)v->data + r * w : zero, 1, (size_t)w, fo); }
-                }
-            }
-        }
-        for (size_t k = 0; k < c.ncol; k++) {
-            Vec *ch = c.vecs[k].child;
-            if (ch && ch->type == DUCKDB_TYPE_STRUCT) {
-                for (int q = 0; q < 2; q++) { Vec *kv = ch->kids[q]; for (size_t h = 0; h < kv->nheap; h++) free(kv->heap[h]); free(kv->heap); free(kv->data); free(kv); }
-                free(ch); ch = NULL;
-            }
-            if (ch) { for (size_t h = 0; h < ch->nheap; h++) free(ch->heap[h]); free(ch->heap); free(ch->data); free(ch); }
-            for (size_t h = 0; h < c.vecs[k].nheap; h++) free(c.vecs[k].heap[h]); free(c.vecs[k].heap); free(c.vecs[k].data); free(c.vecs[k].validity); }
-        free(c.vecs);
-        if (n == 0) break;
-        total += n; chunks++;
+    for (int rep = 0; rep < repeat; rep++) {
+        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+        static Bind b; memset(&b, 0, sizeof(b)); b.tf = tf; b.path = argv[3];
+        memcpy(b.names, names, sizeof(names)); memcpy(b.vals, vals, sizeof(vals)); b.n_named = n_named;
+        tf->bind(&b);
+        if (b.has_err) { printf("ERROR bind: %s\n", b.err); return 3; }
+        static Init g; memset(&g, 0, sizeof(g)); g.b = &b;
+        if (proj) { char *dup = strdup(proj); for (char *t = strtok(dup, ","); t; t = strtok(NULL, ",")) g.proj[g.nproj++] = (idx_t)strtoull(t, NULL, 10); free(dup); }
+        else for (int i = 0; i < b.ncol; i++) g.proj[g.nproj++] = (idx_t)i;
+        if (tf->init) tf->init(&g);
+        if (g.has_err) { printf("ERROR init: %s\n", g.err); if (b.bind_del) b.bind_del(b.bind_data); return 3; }
+        int nthr = threads > 0 ? threads : 1; if ((idx_t)nthr > g.max_threads && g.max_threads > 0) nthr = (int)g.max_threads;
+        FILE *fo = (out && rep == 0) ? fopen(out, "wb") : NULL;
+        /* schema record */
+        if (fo) { uint32_t nc = (uint32_t)b.ncol; fwrite(&nc, 4, 1, fo); for (int i = 0; i < b.ncol; i++) { uint32_t t = (uint32_t)b.coltype[i]; fwrite(&t, 4, 1, fo); uint32_t ct = (uint32_t)b.colchild[i]; fwrite(&ct, 4, 1, fo); fwrite(b.colname[i], 1, 256, fo); } uint32_t np = (uint32_t)g.nproj; fwrite(&np, 4, 1, fo); }
+        static Worker w[64]; memset(w, 0, sizeof(w));
+        pthread_t th[64];
+        for (int k = 0; k < nthr; k++) { w[k].b = &b; w[k].g = &g; w[k].tf = tf; w[k].fo = fo; }
+        for (int k = 1; k < nthr; k++) pthread_create(&th[k], NULL, worker_main, &w[k]);
+        worker_main(&w[0]);
+        for (int k = 1; k < nthr; k++) pthread_join(th[k], NULL);
+        uint64_t total = 0, chunks = 0; int failed = 0;
+        for (int k = 0; k < nthr; k++) { total += w[k].rows; chunks += w[k].chunks; if (w[k].failed) { if (!failed) printf("ERROR %s: %s\n", w[k].failed == 1 ? "init" : "scan", w[k].err); failed = 1; } }
+        if (fo) fclose(fo);
+        for (int k = 0; k < nthr; k++) if (w[k].l.del) w[k].l.del(w[k].l.data);
+        if (g.del) g.del(g.data);
+        if (b.bind_del) b.bind_del(b.bind_data);
+        if (failed) return 3;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (repeat > 1) printf("RUN %d seconds=%.6f rows=%llu threads=%d\n", rep, sec, (unsigned long long)total, nthr);
+        if (rep == repeat - 1) printf("OK rows=%llu chunks=%llu columns=%d max_threads=%llu\n", (unsigned long long)total, (unsigned long long)chunks, b.ncol, (unsigned long long)g.max_threads);
     }
-    if (fo) fclose(fo);
-    if (l.del) l.del(l.data);
-    if (g.del) g.del(g.data);
-    if (b.bind_del) b.bind_del(b.bind_data);
-    printf("OK rows=%llu chunks=%llu columns=%d max_threads=%llu\n", (unsigned long long)total, (unsigned long long)chunks, b.ncol, (unsigned long long)g.max_threads);
     return 0;
 }

@@ -20,15 +20,17 @@ VARCHAR = 17
 LIST = 24
 
 
-def run_host(path, named=(), proj=None, fn="read_bam"):
+def run_host(path, named=(), proj=None, fn="read_bam", threads=None, env=None):
     out = tempfile.NamedTemporaryFile(suffix=".chunks", delete=False).name
     cmd = [HOST, duckhts_amd.LIB_PATH, fn, path]
     for k, v in named:
         cmd += ["-n", f"{k}={v}"]
     if proj is not None:
         cmd += ["-p", ",".join(map(str, proj))]
+    if threads:
+        cmd += ["-t", str(threads)]
     cmd += ["-o", out]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     return r.returncode, r.stdout.strip(), out
 
 
@@ -386,3 +388,72 @@ def test_read_bam_auxiliary_tags_through_the_surface(tmp_path):
     schema, chunks = parse_chunks(dump)
     (t0, v0, rg), (t1, v1, nm), (t2, v2, (ent, keys, vals)) = chunks[0][1]
     assert list(rg) == [b"x1"] and list(nm) == [2] and keys == [b"XZ"] and vals == [b"foo"]
+
+
+# ---- the scan pipeline: parallel fill (DHTS_THREADS) and several producers on one file (DHTS_DEVICES) ---------------------------
+def _rows(chunks, ncol):
+    """flatten the chunks into row tuples (values as Python objects, NULL = None)"""
+    rows = []
+    for n, cols in chunks:
+        cvals = []
+        for t, val, vals in cols:
+            if t == VARCHAR:
+                cvals.append(list(vals))
+            else:
+                cvals.append([int(x) for x in vals])
+        rows += list(zip(*cvals))
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["threads4", "two_ranks_ordered", "three_ranks_threads3"])
+def test_read_bam_pipeline_modes(tmp_path, mode):
+    """DHTS_THREADS=k: k workers fill chunks from 2048-row slices -- the row MULTISET equals the sequential scan (the order across
+    workers is unspecified, like the reference's contig-parallel mode, src/bam_reader.c:577-585, 689-716).
+    DHTS_DEVICES=a,b,..: one producer per entry, each staging only its own byte window of the file (dhts_open_path_shard); with one
+    worker the rows come out in file order, chunk for chunk as in the single-device scan; adjacent ranks hand off on BGZF virtual
+    offsets.  (The same GPU is listed several times here: the ranks are separate contexts either way.)"""
+    from duckhts_amd import synth
+    data = synth.bam_file(250000, seed=23)
+    fn = os.path.join(str(tmp_path), "p.bam")
+    open(fn, "wb").write(data)
+    exp = orc.bam_read(data)
+    env = {"threads4": {"DHTS_THREADS": "4", "DHTS_BATCH_BLOCKS": "97"}, "two_ranks_ordered": {"DHTS_DEVICES": "0,0", "DHTS_BATCH_BLOCKS": "150"},
+           "three_ranks_threads3": {"DHTS_DEVICES": "0,0,0", "DHTS_THREADS": "3", "DHTS_BATCH_BLOCKS": "64"}}[mode]
+    threads = int(env.get("DHTS_THREADS", "1"))
+    rc, out, dump = run_host(fn, threads=threads, env=env)
+    assert rc == 0, out
+    assert f"rows={exp['n_rows']} " in out and f"max_threads={threads}" in out
+    schema, chunks = parse_chunks(dump)
+    assert schema == SCHEMA
+    names = [s[0] for s in SCHEMA]
+    want = list(zip(*[[None if v is None else (bytes(v) if isinstance(v, (bytes, bytearray)) else int(v)) for v in exp[nm]] for nm in names]))
+    got = _rows(chunks, 13)
+    if threads == 1:
+        assert [c[0] for c in chunks] == [min(2048, exp["n_rows"] - i) for i in range(0, exp["n_rows"], 2048)]      # full chunks, file order
+        assert got == want
+    else:
+        assert all(c[0] <= 2048 for c in chunks)
+        assert sorted(got, key=repr) == sorted(want, key=repr)
+
+
+@pytest.mark.gpu
+def test_read_bam_two_ranks_error_in_first_rank_ends_the_scan(tmp_path):
+    """a damaged block inside rank 0's window: with one worker the scan ends there, rows before it only (bam_reader.c:754-766)"""
+    from duckhts_amd import synth
+    data = bytearray(synth.bam_file(120000, seed=24))
+    # damage a block at ~20 % of the file
+    p, blocks = 0, []
+    while p + 18 <= len(data) and data[p:p + 4] == b"\x1f\x8b\x08\x04":
+        bl = struct.unpack_from("<H", data, p + 16)[0] + 1
+        blocks.append((p, bl)); p += bl
+    k = len(blocks) // 5
+    for j in range(30, 60):
+        data[blocks[k][0] + j] ^= 0xA5
+    fn = os.path.join(str(tmp_path), "e.bam")
+    open(fn, "wb").write(bytes(data))
+    exp = orc.bam_read(bytes(data))
+    assert 0 < exp["n_rows"] < 120000
+    for env in ({}, {"DHTS_DEVICES": "0,0"}):
+        rc, out, dump = run_host(fn, proj=[0, 3], env=env)
+        assert rc == 0 and f"rows={exp['n_rows']} " in out, out
