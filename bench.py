@@ -5,19 +5,32 @@ One "step" = one pass of the whole hot path over the resident input: BGZF block 
 inflate (Huffman decode + LZ resolve + CRC-32) -> BAM record boundaries -> 13-column unpack, with the
 compressed bytes already in HBM when the timed region starts and the columns left in HBM.
 
-Workload at N=1: BASELINE.json configs[1], "read_bam full scan of a synthetic 10 GB BGZF BAM on
-1xMI355X".  The 10 GB are `reps` back-to-back copies of one deterministic WGS-shaped segment
-(SURVEY.md 8(d) explicitly allows concatenated segments); the segment is far larger than L2+MALL,
-so replays do not hit cache.  --unique-records / --target-gb change the sizes; N>1 = weak scaling,
-every rank scans its own 10 GB shard (distinct seed), no data-path collective.
+Workload at N=1: BASELINE.json configs[1], "read_bam full scan of a synthetic 10 GB BGZF BAM on 1xMI355X".
+The file is generated in full: `reps` segments of `--unique-records` records each, record i of the whole file drawn
+from (seed, i) -- every segment is different data, coordinate-sorted over the whole file.
+It is written to a scratch file, staged with dhts_open_path, and removed at the end.
+
+Besides `value` (resident input, columns left in HBM) the line carries
+  * `operator`: the same file through the DuckDB table function (mini host): pread + H2D + scan + D2H + DataChunk fill,
+  * `parity_sample`: CRC-32 digests of all 13 columns of one whole segment (>= 1 % of the file) from the resident scan
+    against the oracle's, computed inside this run,
+  * `cpu_baseline`: the oracle port timed on the host in three thread shapes (1 core; 1 scan + 2 inflate threads, the
+    reference's own shape; all cores), with nproc and the CPU model.
+
+N>1 (torchrun): weak scaling, every rank scans its own 10 GB file (own seed), no data-path collective;
+`--strong`: ONE file, every rank stages and scans only its own byte window (dhts_open_path_shard).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,6 +38,109 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def scratch_dir(need_bytes):
+    for d in (os.environ.get("DHTS_BENCH_DIR"), "/dev/shm", tempfile.gettempdir()):
+        if d and os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes * 1.15 + (1 << 30):
+            return d
+    return tempfile.gettempdir()
+
+
+def generate_file(path, synth, seed, n_u, reps, threads):
+    """the whole file, segment by segment; returns (per-segment byte sizes, header bytes, inflated bytes)"""
+    total_n = n_u * reps
+    sizes, raw = [], 0
+    buf = np.empty(n_u * 260 + (1 << 20), np.uint8)
+    with open(path, "wb") as f:
+        head, _ = synth.bam_segment(0, seed=seed, total_n=total_n, with_header=True, with_eof=False, threads=threads)
+        f.write(head.tobytes())
+        for k in range(reps):
+            seg, st = synth.bam_segment(n_u, seed=seed, total_n=total_n, rec0=k * n_u, with_header=False, with_eof=False, threads=threads, out=buf)
+            seg.tofile(f)
+            sizes.append(int(seg.nbytes)); raw += st["raw_bytes"]
+        f.write(EOF_BLOCK)
+    return sizes, int(head.nbytes), raw
+
+
+def crc_str(off, ln, data):
+    """(crc of the u32 lengths, crc of the concatenated string bytes) of a device-layout string column"""
+    ln = np.ascontiguousarray(ln, np.uint32)
+    total = int(ln.sum(dtype=np.uint64))
+    if total == int(off[-1]):                                  # reserved == actual everywhere: the heap is already the concatenation
+        body = data[:total]
+    else:
+        start = off[:-1].astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(ln.astype(np.int64))])[:-1]
+        body = data[np.repeat(start - cum, ln) + np.arange(total, dtype=np.int64)]
+    return zlib.crc32(ln.tobytes()), zlib.crc32(np.ascontiguousarray(body).tobytes())
+
+
+def gpu_digest(ctx, hdr, b0, b1, speculative, max_blocks):
+    """the oracle's digest layout (oracle/dhts_oracle.c orc_bam_digest) over the rows of blocks [b0, b1) of the resident file"""
+    ctx.set_block_range(b0, b1, speculative)
+    cols = {k: [] for k in ("flag", "tid", "pos", "mapq", "mtid", "pnext", "tlen", "rgi", "valid")}
+    strs = {k: ([], []) for k in ("qname", "cigar", "seq", "qual", "rg")}
+    n = 0
+    while True:
+        b = ctx.next_batch(max_blocks)
+        r = int(b.n_rows)
+        if r:
+            cols["flag"].append(ctx.d2h(b.flag, r, np.uint16)); cols["tid"].append(ctx.d2h(b.tid, r, np.int32)); cols["pos"].append(ctx.d2h(b.pos, r, np.int64))
+            cols["mapq"].append(ctx.d2h(b.mapq, r, np.int32)); cols["mtid"].append(ctx.d2h(b.mtid, r, np.int32)); cols["pnext"].append(ctx.d2h(b.pnext, r, np.int64))
+            cols["tlen"].append(ctx.d2h(b.tlen, r, np.int64)); cols["rgi"].append(ctx.d2h(b.rg_idx, r, np.int32))
+            w = ctx.d2h(b.rg_valid, (r + 63) // 64, np.uint64)
+            cols["valid"].append(np.unpackbits(w.view(np.uint8), bitorder="little")[:r])
+            for k, c in (("qname", b.qname), ("cigar", b.cigar), ("seq", b.seq), ("qual", b.qual), ("rg", b.rg)):
+                off = ctx.d2h(c.off, r + 1, np.uint32); ln = ctx.d2h(c.len, r, np.uint32); data = ctx.d2h(c.bytes, int(c.nbytes), np.uint8)
+                total = int(ln.sum(dtype=np.uint64))
+                if total != int(off[-1]):
+                    start = off[:-1].astype(np.int64); cum = np.concatenate([[0], np.cumsum(ln.astype(np.int64))])[:-1]
+                    data = data[np.repeat(start - cum, ln) + np.arange(total, dtype=np.int64)]
+                strs[k][0].append(ln); strs[k][1].append(data[:total])
+            n += r
+        if b.status != 0:
+            st = 0 if b.status == 1 else int(b.status)
+            break
+    cat = {k: (np.concatenate(v) if v else np.zeros(0, np.uint8)) for k, v in cols.items()}
+    out = [0] * 32
+    out[0], out[1] = n, st & 0xffffffff
+    out[2] = zlib.crc32(cat["flag"].tobytes()); out[3] = zlib.crc32(cat["tid"].tobytes()); out[4] = zlib.crc32(cat["pos"].tobytes()); out[5] = zlib.crc32(cat["mapq"].tobytes())
+    out[6] = zlib.crc32(cat["mtid"].tobytes()); out[7] = zlib.crc32(cat["pnext"].tobytes()); out[8] = zlib.crc32(cat["tlen"].tobytes())
+    for i, k in enumerate(("qname", "cigar", "seq", "qual")):
+        ln = np.concatenate(strs[k][0]) if strs[k][0] else np.zeros(0, np.uint32)
+        out[9 + 2 * i] = zlib.crc32(ln.tobytes()); out[10 + 2 * i] = zlib.crc32(b"".join(x.tobytes() for x in strs[k][1]))
+    valid = cat["valid"].astype(np.uint8)
+    ln = (np.concatenate(strs["rg"][0]) if strs["rg"][0] else np.zeros(0, np.uint32)) * valid
+    out[17] = zlib.crc32(valid.tobytes()); out[18] = zlib.crc32(ln.astype(np.uint32).tobytes())
+    # (an absent RG writes no bytes on either side)
+    out[19] = zlib.crc32(b"".join(x.tobytes() for x in strs["rg"][1]))
+    # SAMPLE_ID: @RG index -> SM by the header dictionary (dictionary-coded column), NULL without RG / without SM
+    sm = [x if x is not None else None for x in hdr["rg_sm"]]
+    smlen = np.array([len(x) if x is not None else 0 for x in sm] + [0], np.uint32)
+    has = np.array([1 if x is not None else 0 for x in sm] + [0], np.uint8)
+    idx = np.where(cat["rgi"] >= 0, cat["rgi"], len(sm))
+    sval = valid & has[idx]
+    sl = smlen[idx] * sval
+    flat = np.frombuffer(b"".join(x or b"" for x in sm), np.uint8)
+    starts = np.concatenate([[0], np.cumsum(smlen[:-1])]).astype(np.int64)
+    tot = int(sl.sum(dtype=np.uint64))
+    cum = np.concatenate([[0], np.cumsum(sl.astype(np.int64))])[:-1]
+    body = flat[np.repeat(starts[idx] - cum, sl) + np.arange(tot, dtype=np.int64)] if tot else np.zeros(0, np.uint8)
+    out[20] = zlib.crc32(sval.tobytes()); out[21] = zlib.crc32(sl.astype(np.uint32).tobytes()); out[22] = zlib.crc32(body.tobytes())
+    return out
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), model
 
 
 def main():
@@ -32,17 +148,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--unique-records", type=int, default=4_000_000, help="records in the unique segment")
-    ap.add_argument("--target-gb", type=float, default=10.0, help="resident compressed size per GPU (GB)")
+    ap.add_argument("--unique-records", type=int, default=4_000_000, help="records per generated segment")
+    ap.add_argument("--target-gb", type=float, default=10.0, help="compressed size of the file per GPU (GB)")
     ap.add_argument("--max-blocks", type=int, default=24576, help="BGZF blocks per batch (24,576 is the largest that keeps in-batch offsets below 2^32)")
-    ap.add_argument("--cpu-sample-records", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU shard layout even at N=1 (testing)")
+    ap.add_argument("--no-operator", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="N>1: ONE file, every rank stages and scans its own byte window")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run (one per GPU)")
     dist = None
     if world > 1:
         import torch
@@ -63,169 +182,241 @@ def main():
 
     # ---- workload (untimed) ----
     t0 = time.time()
-    seed = 42 + rank
     n_u = args.unique_records
-    head, _ = synth.bam_segment(0, seed=seed, total_n=n_u, with_header=True, with_eof=False)
-    body, st = synth.bam_segment(n_u, seed=seed, total_n=n_u, with_header=False, with_eof=False)
-    tail = np.frombuffer(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"), dtype=np.uint8)
-    reps = max(1, int(round(args.target_gb * 1e9 / body.nbytes)))
-    gen_s = time.time() - t0
+    probe, _ = synth.bam_segment(200_000, seed=42, total_n=200_000, with_header=False, with_eof=False)
+    reps = max(1, int(round(args.target_gb * 1e9 / (probe.nbytes * (n_u / 200_000)))))
     n_records = n_u * reps
-    ctx = duckhts_amd.Context(local_rank if world > 1 else 0)
-    sharded = world > 1 or args.force_sharded
-    if not sharded:
-        ctx.open_tiled(head, body, reps, tail)
-        file_bytes = head.nbytes + body.nbytes * reps + tail.nbytes
-    else:
-        # Every rank holds ONE SHARD of a conceptual world x 10 GB file: its block range starts in the middle of the
-        # record stream (a BGZF block boundary one third into the segment, where a record straddles), so the rank
-        # speculates its first record and finishes its last record from halo blocks -- the 8(e) protocol, per rank.
-        b16 = body.view(np.uint8)
-        offs, pos = [], 0
-        while pos < body.nbytes:
-            offs.append(pos)
-            pos += (int(b16[pos + 16]) | (int(b16[pos + 17]) << 8)) + 1
-        cut = offs[len(offs) // 3]
-        halo = offs[len(offs) // 3 + 8] - cut
-        ctx.open_tiled(np.concatenate([head, body[cut:]]), body, reps - 1, np.concatenate([body[:cut], body[cut:cut + halo], tail]))
-        file_bytes = body.nbytes * reps
-    raw_bytes = st["raw_bytes"] * reps
+    strong = args.strong and world > 1
+    seed = 42 if strong else 42 + rank
+    ncpu, cpu_model = cpu_info()
+    gen_threads = max(1, min(32, ncpu // (1 if strong else min(world, max(1, ncpu)))))
+    sdir = scratch_dir(args.target_gb * 1e9 * (1 if strong else 1))
+    path = os.path.join(sdir, f"dhts_bench_{os.getpid() if not strong else 'strong'}_{rank if not strong else 0}.bam")
+    sizes = hdr_bytes = raw_bytes = None
+    if not strong or rank == 0:
+        sizes, hdr_bytes, raw_bytes = generate_file(path, synth, seed, n_u, reps, gen_threads)
+    if strong:
+        import torch
+        meta = [sizes, hdr_bytes, raw_bytes, path]
+        dist.broadcast_object_list(meta, src=0)
+        sizes, hdr_bytes, raw_bytes, path = meta
+    gen_s = time.time() - t0
+    file_bytes = hdr_bytes + sum(sizes) + len(EOF_BLOCK)
 
-    def barrier():
-        ctx.L.dhts_sync(ctx.h)
+    ctx = duckhts_amd.Context(local_rank if world > 1 else 0)
+    L = ctx.L
+    try:
+        if strong:
+            import ctypes as C
+            L.dhts_open_path_shard.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64]
+            L.dhts_bam_set_file_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.dhts_voffset.restype = C.c_uint64
+            L.dhts_voffset.argtypes = [C.c_void_p, C.c_uint64]
+            L.dhts_resident_bytes.restype = C.c_uint64
+            ctx._chk(L.dhts_open_path_shard(ctx.h, os.fsencode(path), rank, world, hdr_bytes))
+        else:
+            ctx.open(path)
+        staged_bytes = int(L.dhts_resident_bytes(ctx.h))
+        spans = {}
+
+        def barrier():
+            L.dhts_sync(ctx.h)
+            if dist is not None:
+                import torch
+                torch.cuda.synchronize()
+                dist.barrier()
+
+        def step():
+            nb = ctx.bgzf_index()
+            if strong:
+                ctx._chk(L.dhts_bam_set_file_shard(ctx.h, rank, world))
+            else:
+                ctx.rewind()
+            rows, out_bytes, first = 0, 0, None
+            while True:
+                b = ctx.next_batch(args.max_blocks)
+                if b.n_rows and first is None:
+                    first = b.first_rec_uoff
+                if b.n_rows:
+                    spans["first"], spans["end"] = first, b.end_uoff
+                rows += b.n_rows
+                out_bytes += b.n_rows * (2 + 8 + 4 + 8 + 8 + 4 + 4 + 4 + 5 * 8) + b.qname.nbytes + b.cigar.nbytes + b.seq.nbytes + b.qual.nbytes + b.rg.nbytes
+                if b.status != 0:
+                    if b.status < 0:
+                        raise RuntimeError(f"scan ended with error status {b.status}")
+                    break
+            return rows, nb, out_bytes
+
+        nb = ctx.bgzf_index()
+        hdr = ctx.bam_open()
+        for _ in range(args.warmup):
+            rows, nb, out_bytes = step()
+            if not strong:
+                assert rows == n_records, (rows, n_records)
+        ctx.set_timing(True)
+        ctx.reset_times()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rows, nb, out_bytes = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if not strong:
+            assert rows == n_records, (rows, n_records)
+        ktimes = ctx.kernel_times()
+        ctx.set_timing(False)
+
+        # ---- multi-rank bookkeeping ----
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    def step():
-        nb = ctx.bgzf_index()
-        rows = 0
-        if sharded:
-            ctx.set_block_range(1, 1 + n_body_blocks * reps, True)     # header block excluded; speculative first record
+            if strong:
+                # hand-off: every rank's last record ends where the next rank's first record begins (BGZF virtual offsets), and
+                # the ranks' rows add up to the file's
+                v = torch.tensor([int(L.dhts_voffset(ctx.h, spans.get("first", 0))) if rows else -1, int(L.dhts_voffset(ctx.h, spans.get("end", 0))) if rows else -1, rows, staged_bytes],
+                                 dtype=torch.int64, device=tdev)
+                allv = [torch.zeros_like(v) for _ in range(world)]
+                dist.all_gather(allv, v)
+                have = [a for a in allv if int(a[2]) > 0]
+                assert sum(int(a[2]) for a in allv) == n_records, [a.tolist() for a in allv]
+                assert all(int(have[i][1]) == int(have[i + 1][0]) for i in range(len(have) - 1)), [a.tolist() for a in allv]
+                staged_total = sum(int(a[3]) for a in allv)
+            else:
+                sp = torch.tensor([rows, n_records], dtype=torch.int64, device=tdev)
+                allsp = [torch.zeros_like(sp) for _ in range(world)]
+                dist.all_gather(allsp, sp)
+                assert all(int(a[0]) == int(a[1]) for a in allsp), [a.tolist() for a in allsp]
+            tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+            if strong:
+                total_records, total_file_bytes = float(n_records), float(file_bytes)
+            else:
+                tot = torch.tensor([float(n_records), float(file_bytes)], dtype=torch.float64, device=tdev)
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                total_records, total_file_bytes = float(tot[0].item()), float(tot[1].item())
         else:
-            ctx.rewind()
-        out_bytes = 0
-        first = None
-        while True:
-            b = ctx.next_batch(args.max_blocks)
-            if b.n_rows and first is None:
-                first = b.first_rec_uoff
-            if b.n_rows:
-                spans["first"], spans["end"] = first, b.end_uoff
-            rows += b.n_rows
-            out_bytes += b.n_rows * (2 + 8 + 4 + 8 + 8 + 4 + 4 + 4 + 5 * 8) + b.qname.nbytes + b.cigar.nbytes + b.seq.nbytes + b.qual.nbytes + b.rg.nbytes
-            if b.status != 0:
-                if b.status < 0:
-                    raise RuntimeError(f"scan ended with error status {b.status}")
-                break
-        return rows, nb, out_bytes
+            total_records, total_file_bytes = float(n_records), float(file_bytes)
 
-    nb = ctx.bgzf_index()
-    ctx.bam_open()
-    spans = {}
-    if sharded:
-        n_body_blocks = len(offs)
-    for _ in range(args.warmup):
-        rows, nb, out_bytes = step()
-        assert rows == n_records, (rows, n_records)
-    ctx.set_timing(True)
-    ctx.reset_times()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rows, nb, out_bytes = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    assert rows == n_records, (rows, n_records)
-    ktimes = ctx.kernel_times()
-    ctx.set_timing(False)
+        if rank != 0:
+            if dist is not None:
+                dist.barrier()                      # rank 0 is still using the file (strong mode)
+                dist.destroy_process_group()
+            return
 
-    if sharded:
-        # hand-off proof: the shard covers exactly `reps` segments of the record stream, starting and ending mid-block
-        assert spans["end"] - spans["first"] == raw_bytes - 0, (spans, raw_bytes)
-    if dist is not None:
-        import torch
-        # every rank's shard must span exactly its own `reps` segments and yield its own record count (seeds differ per rank)
-        sp = torch.tensor([spans["end"] - spans["first"], raw_bytes, rows, n_records], dtype=torch.int64, device=tdev)
-        allsp = [torch.zeros_like(sp) for _ in range(world)]
-        dist.all_gather(allsp, sp)
-        assert all(int(a[0]) == int(a[1]) and int(a[2]) == int(a[3]) for a in allsp), [a.tolist() for a in allsp]
-        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        tot = torch.tensor([float(n_records), float(file_bytes)], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_records, total_file_bytes = float(tot[0].item()), float(tot[1].item())
-    else:
-        total_records, total_file_bytes = float(n_records), float(file_bytes)
+        sec_per_step = dt / args.steps
+        value = total_records / sec_per_step
+        C_ = file_bytes / n_records
+        U = raw_bytes / n_records
+        O = out_bytes / max(rows, 1)
+        kt = {k: {"ms_total": round(v[0], 3), "launches": v[1], "ms_per_launch": round(v[0] / v[1], 4) if v[1] else None} for k, v in ktimes.items()}
+        inflate_ms_step = (ktimes["huff_decode"][0] + ktimes["lz_resolve"][0]) / args.steps
+        frac_of_file = 1.0 if not strong else staged_bytes / file_bytes
+        bytes_per_step = (file_bytes + raw_bytes) * frac_of_file
+        achieved = bytes_per_step / (inflate_ms_step * 1e-3) / 1e9 if inflate_ms_step > 0 else 0.0
+        lz_n = max(ktimes["lz_resolve"][1], 1)
+        # HBM traffic of the inflate stage from the committed PMC passes (rocprofv3 cannot wrap itself): bytes per BGZF block
+        # measured on full-size launches of this same workload (profiles/<round>/pmc_traffic_*.json), times the blocks of one step
+        traffic, traffic_src = None, None
+        try:
+            import re as _re
+            cand = sorted((f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
+                           [os.path.join(ROOT, "profiles", r_, x) for x in os.listdir(os.path.join(ROOT, "profiles", r_)) if x.startswith("pmc_traffic_")]),
+                          key=lambda f: (os.path.basename(os.path.dirname(f)), [int(t) for t in _re.findall(r"\d+", os.path.basename(f))]))   # latest round, highest version
+            if cand:
+                pj = json.load(open(cand[-1]))["per_block"]
+                per_blk = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in pj.values())
+                traffic = int(per_blk * nb)
+                traffic_src = os.path.relpath(cand[-1], ROOT)
+        except Exception:
+            traffic = None
+        roof = {"bound": "hbm", "kernel": "bgzf_huff_decode+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src,
+                "ms_per_step": round(inflate_ms_step, 3), "bytes_per_step": int(bytes_per_step),
+                "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
+                "path_frac": round(value * (C_ + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5)}
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    sec_per_step = dt / args.steps
-    value = total_records / sec_per_step
-    C = file_bytes / n_records
-    U = raw_bytes / n_records
-    O = out_bytes / n_records
-    # dominant kernel pair = the inflate stage; algorithmic bytes per launch = (C + U) x records per launch
-    kt = {k: {"ms_total": round(v[0], 3), "launches": v[1], "ms_per_launch": round(v[0] / v[1], 4) if v[1] else None} for k, v in ktimes.items()}
-    inflate_ms_step = (ktimes["huff_decode"][0] + ktimes["lz_resolve"][0]) / args.steps
-    bytes_per_step = file_bytes + raw_bytes
-    achieved = bytes_per_step / (inflate_ms_step * 1e-3) / 1e9 if inflate_ms_step > 0 else 0.0
-    lz_n = max(ktimes["lz_resolve"][1], 1)
-    # HBM traffic of the inflate stage from the committed PMC passes (rocprofv3 cannot wrap itself): bytes per BGZF block
-    # measured on full-size launches of this same workload (profiles/<round>/pmc_traffic_*.json), times the blocks of one step
-    traffic, traffic_src = None, None
-    try:
-        import re as _re
-        cand = sorted((f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
-                       [os.path.join(ROOT, "profiles", r_, x) for x in os.listdir(os.path.join(ROOT, "profiles", r_)) if x.startswith("pmc_traffic_")]),
-                      key=lambda f: (os.path.basename(os.path.dirname(f)), [int(t) for t in _re.findall(r"\d+", os.path.basename(f))]))   # latest round, highest version
-        if cand:
-            pj = json.load(open(cand[-1]))["per_block"]
-            per_blk = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in pj.values())
-            traffic = int(per_blk * nb)
-            traffic_src = os.path.relpath(cand[-1], ROOT)
-    except Exception:
-        traffic = None
-    roof = {"bound": "hbm", "kernel": "bgzf_huff_decode+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src,
-            "ms_per_step": round(inflate_ms_step, 3), "bytes_per_step": int(bytes_per_step),
-            "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
-            "path_frac": round(value * (C + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5)}
-
-    cpu = None
-    if not args.no_cpu_baseline:
+        # ---- parity sample + CPU baseline on one whole segment (>= 1 % of the file), inside this run ----
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orc
-        n_s = min(args.cpu_sample_records, n_u)
-        sample, _ = synth.bam_segment(n_s, seed=seed, total_n=n_u)
-        sb = sample.tobytes()
-        zl = orc.use_system_zlib(True)
-        t1 = time.perf_counter()
-        got, stt = orc.bam_scan_count(sb)
-        cdt = time.perf_counter() - t1
-        orc.use_system_zlib(False)
-        assert got == n_s and stt == 0
-        cpu = {"value": round(n_s / cdt, 1), "unit": "records/s", "cores": 1, "kind": "port",
-               "sample": f"first {n_s} records ({len(sb)} compressed bytes) of the same synthetic BAM, all 13 columns materialised, "
-                         f"inflate+crc32 via {'system zlib (the reference dependency)' if zl else 'the RFC 1951 restatement'}, {cdt:.1f} s"}
+        parity, cpu = None, None
+        k_s = reps // 2
+        seg_off = hdr_bytes + sum(sizes[:k_s])
+        if (not args.no_parity_sample or not args.no_cpu_baseline) and world == 1:
+            import orc
+            with open(path, "rb") as f:
+                head_b = f.read(hdr_bytes)
+                f.seek(seg_off)
+                sample = head_b + f.read(sizes[k_s]) + EOF_BLOCK
+            if not args.no_parity_sample:
+                coff, _, _, _ = ctx.bgzf_table(int(nb))
+                b0 = int(np.searchsorted(coff, seg_off)); b1 = int(np.searchsorted(coff, seg_off + sizes[k_s]))
+                t1 = time.perf_counter()
+                got = gpu_digest(ctx, hdr, b0, b1, True, 4096)
+                want = orc.bam_digest(sample)
+                names = ["n_rows", "status", "FLAG", "RNAME(id)", "POS", "MAPQ", "RNEXT(id)", "PNEXT", "TLEN", "QNAME.len", "QNAME", "CIGAR.len", "CIGAR", "SEQ.len", "SEQ", "QUAL.len", "QUAL",
+                         "RG.valid", "RG.len", "READ_GROUP_ID", "SM.valid", "SM.len", "SAMPLE_ID"]
+                bad = [names[i] for i in range(23) if got[i] != want[i]]
+                assert not bad, f"parity sample: digests differ in {bad}: gpu {got[:23]} oracle {want[:23]}"
+                parity = {"rows": got[0], "fraction_of_file": round(got[0] / n_records, 4), "columns": 13, "digest": "CRC-32 of each column's values (lengths + bytes for strings, validity for nullable ones)",
+                          "segment": k_s, "equal": True, "seconds": round(time.perf_counter() - t1, 1),
+                          "how": "rows of the segment's block range from the resident 10 GB scan (speculative start, halo) vs the oracle on header + that segment"}
+            if not args.no_cpu_baseline:
+                zl = orc.use_system_zlib(True)
+                modes = {}
+                for name, thr in (("1_core", 0), ("1_scan_plus_2_inflate_threads", 2), ("all_cores", max(1, ncpu - 1))):
+                    t1 = time.perf_counter()
+                    got_n, stt = orc.bam_scan_count(sample) if thr == 0 else orc.bam_scan_count_mt(sample, thr)
+                    cdt = time.perf_counter() - t1
+                    assert got_n == n_u and stt == 0, (name, got_n, stt)
+                    modes[name] = {"records_per_s": round(n_u / cdt, 1), "threads": 1 if thr == 0 else thr + 1, "seconds": round(cdt, 2)}
+                orc.use_system_zlib(False)
+                ref = modes["1_scan_plus_2_inflate_threads"]
+                cpu = {"value": ref["records_per_s"], "unit": "records/s", "cores": 3, "kind": "port",
+                       "sample": f"segment {k_s} of the same file ({n_u} records, {len(sample)} compressed bytes), all 13 columns materialised, inflate+crc32 via "
+                                 f"{'system zlib (the reference dependency)' if zl else 'the RFC 1951 restatement'}; value = the reference's own thread shape "
+                                 f"(1 scan thread + hts_set_threads(fp, 2), src/bam_reader.c:584,625)",
+                       "modes": modes, "nproc": ncpu, "cpu_model": cpu_model}
+    finally:
+        ctx.close()
+
+    # ---- the operator: the same file through the DuckDB table function (pread + H2D + scan + D2H + DataChunk fill) ----
+    operator = None
+    if not args.no_operator and world == 1:
+        host = os.path.join(ROOT, "tests", "minihost", "minihost")
+        thr = max(1, min(8, ncpu - 2))
+        env = dict(os.environ, DHTS_THREADS=str(thr))
+        r = subprocess.run([host, duckhts_amd.LIB_PATH, "read_bam", path, "-t", str(thr), "-r", "2"], capture_output=True, text=True, env=env)
+        if r.returncode == 0:
+            runs = [float(l.split("seconds=")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("RUN ")]
+            orow = int(r.stdout.split("OK rows=")[1].split()[0])
+            assert orow == n_records, (orow, n_records)
+            operator = {"records_per_s": round(n_records / runs[-1], 1), "bgzf_GBps": round(file_bytes / runs[-1] / 1e9, 3), "seconds": round(runs[-1], 3),
+                        "first_query_seconds": round(runs[0], 3), "includes": "pread+H2D+scan+D2H+fill", "columns": 13, "DHTS_THREADS": thr,
+                        "how": "read_bam(path) through duckhts_init_c_api driven by the mini DuckDB host (tests/minihost), second query of one process"}
+        else:
+            operator = {"error": (r.stdout + r.stderr)[-300:]}
+
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+    if dist is not None:
+        dist.barrier()
 
     line = {
         "metric": "read_bam_records_per_sec", "value": round(value, 1), "unit": "records/s", "n_gpus": args.gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"read_bam full scan, synthetic {file_bytes / 1e9:.2f} GB BGZF BAM per GPU ({reps} x {n_u}-record WGS-shaped segment, "
-                               f"150 bp paired, zlib-6, records straddle blocks), 13 core columns, inputs resident in HBM",
-                   "records_per_gpu": n_records, "bgzf_blocks": int(nb), "compressed_bytes_per_record": round(C, 2),
+        "config": {"workload": f"read_bam full scan, synthetic {file_bytes / 1e9:.2f} GB BGZF BAM {'shared by all GPUs' if strong else 'per GPU'} ({n_records} distinct records generated as {reps} segments, "
+                               f"150 bp paired, coordinate-sorted, zlib-6, records straddle blocks), 13 core columns, inputs resident in HBM",
+                   "records_per_gpu": n_records if not strong else n_records // world, "bgzf_blocks": int(nb), "compressed_bytes_per_record": round(C_, 2),
                    "inflated_bytes_per_record": round(U, 2), "column_bytes_per_record": round(O, 2), "batch_blocks": args.max_blocks,
-                   "parallelism": f"bgzf-block-range shards x{world}"},
+                   "parallelism": f"bgzf-block-range shards x{world}" + (" of one file, byte-window staging" if strong else "")},
         "bgzf_GBps": round(total_file_bytes / sec_per_step / 1e9, 3),
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kt, "gen_seconds": round(gen_s, 1),
+        "roofline": roof, "operator": operator, "parity_sample": parity, "cpu_baseline": cpu, "kernels": kt, "gen_seconds": round(gen_s, 1),
     }
+    if strong:
+        line["staged_bytes_total"] = staged_total
+        line["staged_over_file"] = round(staged_total / file_bytes, 4)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -2113,7 +2113,8 @@ int dhts_bam_batch_fetch(dhts_ctx *c, const dhts_bam_batch *b, uint32_t m, void 
     if (!c || !b || !out) return -1;
     *out = *b;
     if (b->n_rows <= 0) return 0;
-    if (!dst || dhts_bam_batch_host_bytes(b, m) > cap) return fail(c, "host arena too small for the batch");
+    const uint64_t need = dhts_bam_batch_host_bytes(b, m);
+    if (need > cap || (need && !dst)) return fail(c, "host arena too small for the batch");
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t n = (uint64_t)b->n_rows; uint8_t *h = (uint8_t *)dst; uint64_t at = 0;
     auto put = [&](const void *src, uint64_t bytes) -> const void * {

@@ -699,7 +699,7 @@ static void bcf_read_global_init(duckdb_init_info info) {
         return;
     }
     API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, 1);
-    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, calloc(1, 16), destroy_global);
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, calloc(1, 16), free);
 }
 
 static void bcf_read_local_init(duckdb_init_info info) {

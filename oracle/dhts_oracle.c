@@ -428,6 +428,7 @@ static const char NT16[] = "=ACMGRSVTWYHKDBN";           /* htslib/hts.c:260 seq
 static void (*g_aux_hook)(const uint8_t *aux, const uint8_t *end, void *ud) = NULL;
 static void *g_aux_ud = NULL;
 
+static void (*g_avail_wait)(size_t need) = NULL;    /* set only by orc_bam_scan_count_mt */
 static int bam_decode_stream(const uint8_t *u, size_t ulen, orc_bam_t *b) {
     size_t p = 0;
     /* ---- header: htslib/sam.c:229-342 bam_hdr_read ---- */
@@ -462,6 +463,9 @@ static int bam_decode_stream(const uint8_t *u, size_t ulen, orc_bam_t *b) {
 
     /* ---- record loop: src/bam_reader.c:747-1035 over htslib/sam.c:779-855 bam_read1 ---- */
     for (;;) {
+        if (g_avail_wait) {                                           /* timing leg only: the bytes are being inflated by other threads */
+            if (p + 4 <= ulen) { g_avail_wait(p + 4); size_t e_ = p + 4 + (size_t)(le32(u + p) & 0x7fffffffu); g_avail_wait(e_ < ulen ? e_ : ulen); }
+        }
         if (p == ulen) { status = 0; break; }                        /* ret == -1: normal EOF */
         if (ulen - p < 4) { status = -2; break; }                    /* truncated */
         int32_t block_len = (int32_t)le32(u + p);
@@ -626,6 +630,122 @@ int64_t orc_bam_scan_count(const uint8_t *file, size_t flen, int *status) {
     return n;
 }
 
+
+/* Column digests of a scan (bench.py's in-run parity sample): CRC-32 (RFC 1952) of each column's canonical bytes, so that a multi-
+ * million-row sample can be compared without materialising Python objects.  Layout of out[32]:
+ *   0 n_rows, 1 status, 2 FLAG u16[], 3 tid i32[] (RNAME ids), 4 POS i64[], 5 MAPQ i32[], 6 mtid i32[] (RNEXT ids), 7 PNEXT i64[],
+ *   8 TLEN i64[]; string columns as (lengths u32[], bytes): 9,10 QNAME  11,12 CIGAR  13,14 SEQ  15,16 QUAL;
+ *   17,18,19 READ_GROUP_ID validity u8[], lengths, bytes;  20,21,22 SAMPLE_ID likewise. */
+static uint32_t dg_crc(const void *p, size_t n) {
+    uint32_t c = 0; const uint8_t *q = (const uint8_t *)p;
+    while (n) { size_t k = n > (1u << 30) ? (1u << 30) : n; c = orc_crc32(c, q, k); q += k; n -= k; }
+    return c;
+}
+static void dg_str(const orc_strcol_t *c, size_t n, uint32_t *len_crc, uint32_t *byte_crc, uint32_t *valid_crc) {
+    uint32_t *l = (uint32_t *)malloc((n ? n : 1) * 4);
+    for (size_t i = 0; i < n; i++) l[i] = (uint32_t)(c->off[i + 1] - c->off[i]);
+    *len_crc = dg_crc(l, n * 4); *byte_crc = dg_crc(c->bytes, (size_t)c->off[n]);
+    if (valid_crc) *valid_crc = dg_crc(c->valid, n);
+    free(l);
+}
+int orc_bam_digest(const uint8_t *file, size_t flen, uint32_t *out) {
+    orc_bam_t b; orc_bam_read(file, flen, &b);
+    size_t n = (size_t)b.n_rows;
+    memset(out, 0, 32 * 4);
+    out[0] = (uint32_t)n; out[1] = (uint32_t)b.status;
+    out[2] = dg_crc(b.flag, n * 2); out[3] = dg_crc(b.tid, n * 4); out[4] = dg_crc(b.pos, n * 8); out[5] = dg_crc(b.mapq, n * 4);
+    out[6] = dg_crc(b.mtid, n * 4); out[7] = dg_crc(b.pnext, n * 8); out[8] = dg_crc(b.tlen, n * 8);
+    dg_str(&b.qname, n, &out[9], &out[10], NULL); dg_str(&b.cigar, n, &out[11], &out[12], NULL);
+    dg_str(&b.seq, n, &out[13], &out[14], NULL); dg_str(&b.qual, n, &out[15], &out[16], NULL);
+    dg_str(&b.rg, n, &out[18], &out[19], &out[17]); dg_str(&b.sample, n, &out[21], &out[22], &out[20]);
+    int st = b.status;
+    orc_bam_free(&b);
+    return st;
+}
+
+/* ------------------------------------------------------------------------
+ * Timing leg only (bench.py cpu_baseline): the same scan with the BGZF blocks inflated by `n_threads` worker threads while ONE thread
+ * decodes records and materialises the columns -- the shape of the reference's read path, which opens its file with
+ * hts_set_threads(fp, 2) (src/bam_reader.c:625 -> hts.c:1922-1932 -> bgzf_mt, bgzf.c:1781-1800) and scans on one DuckDB thread when
+ * there is no index (bam_reader.c:582-585).  Blocks are placed by their ISIZE fields; if any block disagrees (or fails) the routine
+ * falls back to the sequential restatement, so the result is always the oracle's.
+ * ------------------------------------------------------------------------ */
+#include <pthread.h>
+#include <sched.h>
+typedef struct {
+    const uint8_t *file; const size_t *coff; const uint32_t *clen; const uint64_t *uoff; size_t nb; uint8_t *out;
+    size_t ngroups; volatile int *done; volatile long next; volatile int failed;
+} mt_job_t;
+#define MT_GROUP 16
+static mt_job_t *g_mt = NULL; static size_t g_mt_front_group = 0; static size_t g_mt_avail = 0;
+static void *mt_worker(void *arg) {
+    mt_job_t *j = (mt_job_t *)arg;
+    for (;;) {
+        long g = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if ((size_t)g >= j->ngroups || j->failed) break;
+        size_t b0 = (size_t)g * MT_GROUP, b1 = b0 + MT_GROUP < j->nb ? b0 + MT_GROUP : j->nb;
+        for (size_t b = b0; b < b1; b++) {
+            size_t want = (size_t)(j->uoff[b + 1] - j->uoff[b]), dlen = 0;
+            const uint8_t *blk = j->file + j->coff[b];
+            int r = use_zlib ? zlib_inflate_raw(blk + 18, (size_t)j->clen[b] - 18, j->out + j->uoff[b], want, &dlen)
+                             : orc_inflate_raw(blk + 18, (size_t)j->clen[b] - 18, j->out + j->uoff[b], want, &dlen);
+            const uint8_t *t = blk + j->clen[b] - 8;
+            uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            uint32_t have = use_zlib ? (uint32_t)z_crc32(z_crc32(0, NULL, 0), j->out + j->uoff[b], (unsigned)dlen) : orc_crc32(0, j->out + j->uoff[b], dlen);
+            if (r < 0 || dlen != want || have != crc) { j->failed = 1; break; }
+        }
+        __atomic_store_n(&j->done[g], 1, __ATOMIC_RELEASE);
+    }
+    return NULL;
+}
+static void mt_wait(size_t need) {
+    mt_job_t *j = g_mt;
+    while (g_mt_avail < need && g_mt_front_group < j->ngroups && !j->failed) {
+        if (__atomic_load_n(&j->done[g_mt_front_group], __ATOMIC_ACQUIRE)) {
+            size_t b1 = (g_mt_front_group + 1) * MT_GROUP < j->nb ? (g_mt_front_group + 1) * MT_GROUP : j->nb;
+            g_mt_avail = (size_t)j->uoff[b1]; g_mt_front_group++;
+        } else sched_yield();
+    }
+}
+int64_t orc_bam_scan_count_mt(const uint8_t *file, size_t flen, int n_threads, int *status) {
+    if (n_threads < 1) return orc_bam_scan_count(file, flen, status);
+    /* BSIZE chain (bgzf.c:1155-1236) */
+    size_t cap = 1024, nb = 0, pos = 0; int clean = 1;
+    size_t *coff = (size_t *)malloc(cap * sizeof(size_t)); uint32_t *clen = (uint32_t *)malloc(cap * 4); uint64_t *uoff = (uint64_t *)malloc((cap + 1) * 8);
+    uoff[0] = 0;
+    while (pos < flen) {
+        if (flen - pos < 18 || bgzf_check_header(file + pos) != 0) { clean = 0; break; }
+        size_t bl = (size_t)(file[pos + 16] | (file[pos + 17] << 8)) + 1;
+        if (bl < 26 || pos + bl > flen) { clean = 0; break; }
+        if (nb == cap) { cap *= 2; coff = (size_t *)realloc(coff, cap * sizeof(size_t)); clen = (uint32_t *)realloc(clen, cap * 4); uoff = (uint64_t *)realloc(uoff, (cap + 1) * 8); }
+        const uint8_t *t = file + pos + bl - 4;
+        uint32_t isz = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isz > 65536) { clean = 0; break; }
+        coff[nb] = pos; clen[nb] = (uint32_t)bl; uoff[nb + 1] = uoff[nb] + isz; nb++;
+        pos += bl;
+    }
+    int64_t n = -1;
+    if (clean && nb > 0) {
+        mt_job_t j; memset(&j, 0, sizeof(j));
+        j.file = file; j.coff = coff; j.clen = clen; j.uoff = uoff; j.nb = nb; j.out = (uint8_t *)malloc((size_t)uoff[nb] + 64);
+        j.ngroups = (nb + MT_GROUP - 1) / MT_GROUP; j.done = (volatile int *)calloc(j.ngroups, sizeof(int));
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+        for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, mt_worker, &j);
+        g_mt = &j; g_mt_front_group = 0; g_mt_avail = 0;
+        mt_wait((size_t)uoff[nb] < (1u << 20) ? (size_t)uoff[nb] : (1u << 20));       /* the header (bench files: a few KB) */
+        orc_bam_t b; memset(&b, 0, sizeof(b));
+        g_avail_wait = mt_wait;
+        int st = bam_decode_stream(j.out, (size_t)uoff[nb], &b);
+        g_avail_wait = NULL;
+        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+        if (!j.failed) { n = b.n_rows; if (status) *status = st == 0 ? b.status : st; }
+        orc_bam_free(&b);
+        free(th); free((void *)j.done); free(j.out); g_mt = NULL;
+    }
+    free(coff); free(clen); free(uoff);
+    if (n < 0) return orc_bam_scan_count(file, flen, status);
+    return n;
+}
 
 /* ========================================================================
  * standard_tags := true  (src/bam_reader.c:54-70 table, 88-104 types, 920-966 writers over bam_aux_get sam.c:4834-4855,

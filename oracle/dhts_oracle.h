@@ -80,6 +80,10 @@ void orc_bam_free(orc_bam_t *b);
 /* timing helper for bench.py's cpu_baseline ("port"): decodes the whole file
  * (inflate + crc + record decode + 13-column materialisation), returns rows. */
 int64_t orc_bam_scan_count(const uint8_t *file, size_t flen, int *status);
+/* CRC-32 digests of the 13 columns of a whole-file scan (layout: dhts_oracle.c), out[32] */
+int orc_bam_digest(const uint8_t *file, size_t flen, uint32_t *out);
+/* timing leg only: n_threads BGZF inflate workers + one scan thread (the reference opens with hts_set_threads(fp, 2), src/bam_reader.c:625) */
+int64_t orc_bam_scan_count_mt(const uint8_t *file, size_t flen, int n_threads, int *status);
 /* timing leg only: inflate + crc32 through system zlib (the reference's own dependency) instead of the RFC restatement */
 int orc_use_system_zlib(int on);
 

@@ -127,6 +127,25 @@ def bam_scan_count(file_bytes: bytes):
     return n, st.value
 
 
+def bam_digest(file_bytes):
+    """CRC-32 digests of the oracle's 13 columns (layout: oracle/dhts_oracle.c orc_bam_digest) -> uint32[32]"""
+    out = (C.c_uint32 * 32)()
+    L = lib()
+    L.orc_bam_digest.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    L.orc_bam_digest(file_bytes, len(file_bytes), out)
+    return [int(x) for x in out]
+
+
+def bam_scan_count_mt(file_bytes, n_threads: int):
+    """timing leg only (bench.py cpu_baseline): n_threads inflate workers + one scan thread, the shape of the reference's read path"""
+    st = C.c_int(0)
+    L = lib()
+    L.orc_bam_scan_count_mt.restype = C.c_int64
+    L.orc_bam_scan_count_mt.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+    n = L.orc_bam_scan_count_mt(file_bytes, len(file_bytes), n_threads, C.byref(st))
+    return n, st.value
+
+
 def use_system_zlib(on: bool) -> bool:
     """timing leg only (bench.py cpu_baseline): route inflate/crc32 through libz.so.1 like the reference does"""
     return bool(lib().orc_use_system_zlib(int(on)))
