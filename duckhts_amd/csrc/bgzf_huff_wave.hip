@@ -23,7 +23,8 @@
 //     decodes the ranges once more, storing literals and tokens (same token format as the lane-per-block kernel: a literal run
 //     that crosses lane boundaries is carried into the lane that holds the next match).
 // A block costs ~2.2 decodes of each symbol at ~45 instructions per 64 symbols, a fraction of the canonical-arithmetic loop, and
-// its latency is microseconds.  LDS per wave: 11.5 KB, so 13 waves share a CU.
+// its latency is microseconds.  LDS per wave: 8 KB, so 20 waves share a CU (five per SIMD): the loop is a chain of dependent
+// operations with two LDS lookups in it, and what hides that latency is the number of resident waves.
 #ifndef BGZF_HUFF_WAVE_HIP
 #define BGZF_HUFF_WAVE_HIP
 #ifndef HOSTSIM_W
@@ -66,8 +67,12 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 #endif
 
 // ---- geometry --------------------------------------------------------------------------------------------------------------------
-#define HW_RLL 12u                 /* root bits of the literal/length table (u16 entries: 8 KB) */
-#define HW_RD 9u                   /* root bits of the distance table (u32 entries: 2 KB) */
+#ifndef HW_RLL
+#define HW_RLL 11u                 /* root bits of the literal/length table (u16 entries: 4 KB) */
+#endif
+#ifndef HW_RD
+#define HW_RD 8u                   /* root bits of the distance table (u32 entries: 1 KB) */
+#endif
 #ifndef HW_SYNC_W
 #define HW_SYNC_W 768u             /* bits decoded ahead of a range boundary to propose the neighbour's start */
 #endif
@@ -76,13 +81,13 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 // LDS image of one wave
 #define HW_OFF_LL 0u                                     /* u16 [4096] */
 #define HW_OFF_D (HW_OFF_LL + (2u << HW_RLL))            /* u32 [512]  */
-#define HW_OFF_STAGE (HW_OFF_D + (4u << HW_RD))          /* u8 [1024 + 8] header bytes */
-#define HW_OFF_LENS (HW_OFF_STAGE + HW_STAGE + 8u)       /* u8 [320] code lengths: literal/length then distance */
+#define HW_OFF_STAGE (HW_OFF_D + (4u << HW_RD))          /* u8 [1024 + 8] header bytes; the lane exchange arrays reuse this space once the header is read */
+#define HW_OFF_LENS (HW_OFF_STAGE + 6u * 256u)           /* u8 [320] code lengths: literal/length then distance */
 #define HW_OFF_SLL (HW_OFF_LENS + 320u)                  /* u16 [288] literal/length entries (without the code length) in canonical order */
 #define HW_OFF_SD (HW_OFF_SLL + 576u)                    /* u32 [32]  distance entries in canonical order */
 #define HW_OFF_TAB (HW_OFF_SD + 128u)                    /* u32 [2][3][16]: per alphabet limit15 / first / offs by code length */
-#define HW_OFF_X (HW_OFF_TAB + 384u)                     /* u32 [6][64] lane exchange arrays */
-#define HW_LDS_BYTES (HW_OFF_X + 6u * 256u)
+#define HW_OFF_X HW_OFF_STAGE                            /* u32 [6][64] lane exchange arrays */
+#define HW_LDS_BYTES (HW_OFF_TAB + 384u)
 // exchange arrays
 #define HX_START 0
 #define HX_END 1
@@ -91,20 +96,22 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 #define HX_B 4
 #define HX_C 5
 
-// literal/length entry (u16): [3:0] code length (0 = no symbol: bit 4 set -> code longer than the root, else invalid);
-//   bit 15 = 0: bit 12 = end of block, else literal byte in [11:4];   bit 15 = 1: length code, base-3 in [11:4], extra bits in [14:12]
+// literal/length entry (u16): [3:0] code length (0 = no symbol: bit 4 set -> code longer than the root, else invalid), [6:4] extra bits,
+//   bit 7 = length code, [15:8] literal byte or length base - 3; end of block = length code with extra-bit count 7 (0x00F0)
 // distance entry (u32): [3:0] code length (0 as above), [7:4] extra bits, [31:16] base
+// (the two formats share the positions of the code length and of the extra-bit count, so one extraction serves both alphabets)
 #define HW_LONG 0x10u
+#define HW_EOB 0x00F0u
 W_DEV uint32_t hw_ll_entry(uint32_t sym) {
-    if (sym < 256u) return sym << 4;
-    if (sym == 256u) return 0x1000u;
+    if (sym < 256u) return sym << 8;
+    if (sym == 256u) return HW_EOB;
     const uint32_t j = sym - 257u;
     if (j >= 29u) return 0xffffffffu;                      // 286, 287: never valid in a stream (RFC 1951 3.2.6)
-    if (j == 28u) return 0x8000u | (255u << 4);            // length 258, no extra bits
-    if (j < 8u) return 0x8000u | (j << 4);
+    if (j == 28u) return 0x80u | (255u << 8);              // length 258, no extra bits
+    if (j < 8u) return 0x80u | (j << 8);
     const uint32_t x = (j >> 2) - 1u;
     const uint32_t base = 3u + ((4u | (j & 3u)) << x);
-    return 0x8000u | (x << 12) | ((base - 3u) << 4);
+    return 0x80u | (x << 4) | ((base - 3u) << 8);
 }
 W_DEV uint32_t hw_d_entry(uint32_t sym) {
     if (sym >= 30u) return 0xffffffffu;                    // 30, 31: never valid
@@ -137,88 +144,139 @@ struct HwLane {
 #define HWF_EOB 1u
 #define HWF_BAD 2u
 
-struct HwBits { uint64_t buf; uint32_t cnt, widx, nw; };
+// (hi:lo) >> n for n < 32
+#ifdef HOSTSIM_W
+static inline uint32_t hw_shr64lo(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> n); }
+#else
+__device__ __forceinline__ uint32_t hw_shr64lo(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
+#endif
 
-W_DEV void hw_bits_init(HwBits &b, const uint32_t *in32, uint32_t pos) {
-    const uint32_t w = pos >> 5, o = pos & 31u;
-    b.buf = (uint64_t)(in32[w] >> o); b.cnt = 32u - o; b.nw = in32[w + 1]; b.widx = w + 2;
+// code longer than the table's root (or no code at all): canonical arithmetic on the left-justified 15-bit prefix; 0 = invalid
+W_DEV uint32_t hw_long_code(const uint8_t *smem, uint32_t bits, uint32_t mode, uint32_t root) {
+    const uint32_t *tab = (const uint32_t *)(smem + HW_OFF_TAB) + 48u * mode;
+    const uint32_t w15 = w_brev32(bits) >> 17;
+    uint32_t L = root + 1u;
+    while (L <= 15u && w15 >= tab[L]) L++;
+    if (L > 15u) return 0u;
+    const uint32_t si = tab[32 + L] + ((w15 >> (15u - L)) - tab[16 + L]);
+    if (mode) { const uint32_t v = si < 32u ? ((const uint32_t *)(smem + HW_OFF_SD))[si] : 0xffffffffu; return v == 0xffffffffu ? 0u : (v | L); }
+    const uint32_t v = si < 288u ? ((const uint16_t *)(smem + HW_OFF_SLL))[si] : 0xffffu;
+    return v == 0xffffu ? 0u : (v | L);
 }
 
-// One lane decodes the units that START in [start, stop) with the tables in LDS.
+// the four literal/length code lengths above the root (HW_RLL + 1 .. 15 when HW_RLL is 11): limits, first codes and offsets, wave-uniform
+struct HwLong { uint32_t l0, l1, l2, l3, f0, f1, f2, f3, o0, o1, o2, o3; };
+W_DEV uint32_t hw_long_ll(const uint8_t *smem, uint32_t bits, const HwLong q) {
+    const uint32_t w15 = w_brev32(bits) >> 17;
+    const uint32_t c0 = w15 >= q.l0, c1 = w15 >= q.l1, c2 = w15 >= q.l2;
+    if (w15 >= q.l3) return 0u;
+    const uint32_t L = HW_RLL + 1u + c0 + c1 + c2;
+    const uint32_t f = c2 ? q.f3 : c1 ? q.f2 : c0 ? q.f1 : q.f0;
+    const uint32_t o = c2 ? q.o3 : c1 ? q.o2 : c0 ? q.o1 : q.o0;
+    const uint32_t si = o + ((w15 >> (15u - L)) - f);
+    const uint32_t v = si < 288u ? ((const uint16_t *)(smem + HW_OFF_SLL))[si] : 0xffffu;
+    return v == 0xffffu ? 0u : (v | L);
+}
+
+// One lane decodes the units that START in [start, stop) with the tables in LDS: ONE Huffman symbol of either alphabet per iteration
+// (a wave always holds lanes in both states), written as straight-line selects: the only branches are the refill of the bit buffer,
+// the rare long code, and -- in the emitting pass -- the stores.
 // PASS 0: nothing is counted (proposal of the neighbour's start);  PASS 1: counts;  PASS 2: emits literals and tokens.
 template <int PASS>
-W_DEV void hw_span(const uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t stop, uint32_t limit_bits, uint32_t mask_ll, uint32_t mask_d, uint32_t rll, uint32_t rd,
+W_DEV void hw_span(const uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t stop, uint32_t limit_bits, uint32_t mask_ll, uint32_t mask_d, uint32_t rll, uint32_t rd, const HwLong lq,
                    HwLane &r, uint8_t *lit, uint32_t *tok, uint32_t lit_at, uint32_t tok_at, uint32_t out_at, uint32_t run_in, int32_t &status) {
     const uint16_t *lut_ll = (const uint16_t *)(smem + HW_OFF_LL);
     const uint32_t *lut_d = (const uint32_t *)(smem + HW_OFF_D);
-    const uint16_t *sll = (const uint16_t *)(smem + HW_OFF_SLL);
-    const uint32_t *sd = (const uint32_t *)(smem + HW_OFF_SD);
-    const uint32_t *tab = (const uint32_t *)(smem + HW_OFF_TAB);
-    HwBits b; hw_bits_init(b, in32, start);
+    // input: the lane reads its range 16 bytes at a time (each 64-byte line is fetched by four loads instead of sixteen), one chunk
+    // ahead of the chunk it is consuming, so a load has four refills (~16 symbols) to arrive before anything waits for it
+    uint32_t lo, hi = 0, cnt, q0, q1, q2, left;
+    uint4 nx;                                                 // the chunk in flight
+    const uint32_t *qp;
+    {
+        const uint32_t w = start >> 5, o = start & 31u;
+        uint4 c0; __builtin_memcpy(&c0, in32 + w, 16);
+        lo = c0.x >> o; cnt = 32u - o; q0 = c0.y; q1 = c0.z; q2 = c0.w; left = 3;
+        qp = in32 + w + 4; __builtin_memcpy(&nx, qp, 16);
+    }
     uint32_t pos = start, mode = 0, want = 0, flags = 0;
     uint32_t nlit = 0, nmatch = 0, lead = 0, run = (PASS == 2) ? run_in : 0u, pint = 0, outb = 0;
-    uint32_t litw = 0;                                       // PASS 2: literal bytes not yet stored (low (nlit & 3) bytes)
-    while (true) {
-        if (mode == 0u && pos >= stop) break;
-        if (b.cnt < 32u) { b.buf |= (uint64_t)b.nw << b.cnt; b.cnt += 32u; b.nw = in32[b.widx++]; }
-        const uint32_t bits = (uint32_t)b.buf;
-        uint32_t e, use;
-        if (mode == 0u) {
-            e = lut_ll[bits & mask_ll];
-            if ((e & 15u) == 0u && (e & HW_LONG)) {
-                // code longer than the root: canonical arithmetic on the left-justified 15-bit prefix
-                const uint32_t w15 = w_brev32(bits) >> 17;
-                uint32_t L = rll + 1u;
-                while (L <= 15u && w15 >= tab[L]) L++;
-                e = 0;
-                if (L <= 15u) { const uint32_t si = tab[32 + L] + ((w15 >> (15u - L)) - tab[16 + L]); e = (si < 288u ? sll[si] : 0u); if (e != 0xffffu) e |= L; else e = 0; }
-            }
-            use = e & 15u;
-            if (use == 0u) { flags |= HWF_BAD; break; }
-            if (e & 0x8000u) {
-                const uint32_t x = (e >> 12) & 7u;
-                want = ((e >> 4) & 255u) + 3u + ((bits >> use) & ((1u << x) - 1u));
-                use += x; mode = 1u;
-            } else if (e & 0x1000u) {
-                pos += use; flags |= HWF_EOB; break;
-            } else {
-                if (PASS == 1) { nlit++; run++; outb++; }
-                if (PASS == 2) {
-                    litw |= ((e >> 4) & 255u) << (8u * (nlit & 3u)); nlit++; run++; outb++;
-                    if ((nlit & 3u) == 0u) { __builtin_memcpy(lit + lit_at + nlit - 4u, &litw, 4); litw = 0; }
+    uint32_t litw = 0, l0 = 0, l1 = 0, l2 = 0;               // PASS 2: literal bytes not yet stored: (nlit >> 2) & 3 whole words, then the low (nlit & 3) bytes of litw
+    uint32_t ntk = 0, t0 = 0, t1 = 0, t2 = 0;                // PASS 2: tokens of this lane so far; the last ntk & 3 are not yet stored
+    bool live = pos < stop;
+    while (live) {
+        if (cnt < 32u) {
+            if (left == 0u) { q0 = nx.x; q1 = nx.y; q2 = nx.z; const uint32_t q3 = nx.w; qp += 4; __builtin_memcpy(&nx, qp, 16); lo |= q0 << cnt; hi |= (q0 >> 1) >> (31u - cnt); q0 = q1; q1 = q2; q2 = q3; left = 3; }
+            else { lo |= q0 << cnt; hi |= (q0 >> 1) >> (31u - cnt); q0 = q1; q1 = q2; left--; }
+            cnt += 32u;
+        }
+        const uint32_t bits = lo;
+        const uint32_t e0 = lut_ll[bits & mask_ll], e1 = lut_d[bits & mask_d];
+        uint32_t e = mode ? e1 : e0;
+        if ((e & 15u) == 0u) {
+            // (a literal/length code above the root can only exist when the root is HW_RLL: four lengths, limits in registers)
+            e = !(e & HW_LONG) ? 0u : mode ? hw_long_code(smem, bits, 1u, rd) : (HW_RLL == 11u && rll == HW_RLL) ? hw_long_ll(smem, bits, lq) : hw_long_code(smem, bits, 0u, rll);
+            if ((e & 15u) == 0u) { flags |= HWF_BAD; e = 0x0001u; }
+        }
+        const uint32_t L = e & 15u;
+        const uint32_t islen = mode ? 0u : (e >> 7) & 1u;
+        const uint32_t xr = (e >> 4) & (mode ? 15u : 7u);
+        const uint32_t iseob = (islen && xr == 7u) ? 1u : 0u;
+        const uint32_t x = iseob ? 0u : xr;
+        const uint32_t val = (mode ? (e >> 16) : ((e >> 8) & 255u) + 3u) + ((bits >> L) & ((1u << x) - 1u));
+        const uint32_t use = L + x;
+        const uint32_t islit = (mode | islen) ^ 1u;
+        if (PASS == 2) {
+            // literals and tokens leave the lane 16 bytes at a time (one store per 16 literals / 4 matches: stores are counted by the
+            // same vmcnt as the input loads, and a scattered 4-byte store per lane costs the memory pipeline a transaction per lane)
+            if (islit) {
+                litw |= ((e >> 8) & 255u) << (8u * (nlit & 3u));
+                if ((nlit & 3u) == 3u) {
+                    const uint32_t qd = (nlit >> 2) & 3u;
+                    if (qd == 0u) l0 = litw; else if (qd == 1u) l1 = litw; else if (qd == 2u) l2 = litw;
+                    else { const uint4 v16 = make_uint4(l0, l1, l2, litw); __builtin_memcpy(lit + lit_at + nlit - 15u, &v16, 16); }
+                    litw = 0;
                 }
             }
-        } else {
-            e = lut_d[bits & mask_d];
-            if ((e & 15u) == 0u && (e & HW_LONG)) {
-                const uint32_t w15 = w_brev32(bits) >> 17;
-                uint32_t L = rd + 1u;
-                while (L <= 15u && w15 >= tab[48 + L]) L++;
-                e = 0;
-                if (L <= 15u) { const uint32_t si = tab[80 + L] + ((w15 >> (15u - L)) - tab[64 + L]); e = (si < 32u ? sd[si] : 0u); if (e != 0xffffffffu) e |= L; else e = 0; }
-            }
-            use = e & 15u;
-            if (use == 0u) { flags |= HWF_BAD; break; }
-            const uint32_t x = (e >> 4) & 15u;
-            const uint32_t dist = (e >> 16) + ((bits >> use) & ((1u << x) - 1u));
-            use += x; mode = 0u;
-            if (PASS == 1) {
-                if (nmatch == 0u) lead = run; else pint += run / DHTS_TOK_PURE;
-                nmatch++; run = 0; outb += want;
-            }
-            if (PASS == 2) {
+            if (mode) {
                 // the stream position of this match is out_at + outb: a distance may not reach before the start of the block
-                if (dist > out_at + outb) { status = DHTS_BLK_ERR_INFLATE; flags |= HWF_BAD; break; }
-                while (run >= DHTS_TOK_PURE) { tok[tok_at++] = DHTS_TOK_PURE << 23; run -= DHTS_TOK_PURE; }
-                tok[tok_at++] = (run << 23) | ((want - 3u) << 15) | (dist - 1u);
-                nmatch++; run = 0; outb += want;
+                if (val > out_at + outb) { status = DHTS_BLK_ERR_INFLATE; flags |= HWF_BAD; }
+                else {
+                    uint32_t tv = DHTS_TOK_PURE << 23;
+                    for (;;) {
+                        const bool pure = run >= DHTS_TOK_PURE;
+                        if (!pure) tv = (run << 23) | ((want - 3u) << 15) | (val - 1u); else run -= DHTS_TOK_PURE;
+                        const uint32_t qd = ntk & 3u;
+                        if (qd == 0u) t0 = tv; else if (qd == 1u) t1 = tv; else if (qd == 2u) t2 = tv;
+                        else { const uint4 v16 = make_uint4(t0, t1, t2, tv); __builtin_memcpy(tok + tok_at + ntk - 3u, &v16, 16); }
+                        ntk++;
+                        if (!pure) break;
+                    }
+                }
             }
         }
-        b.buf >>= use; b.cnt -= use; pos += use;
-        if (pos > limit_bits + 64u) { flags |= HWF_BAD; break; }       // ran off the payload (a true stream never does)
+        if (PASS != 0) {
+            if (PASS == 1 && mode && nmatch && run >= DHTS_TOK_PURE) pint += run / DHTS_TOK_PURE;
+            lead = (mode && nmatch == 0u) ? run : lead;
+            nlit += islit; outb += mode ? want : islit;
+            nmatch += mode; run = mode ? 0u : run + islit;
+        }
+        want = islen ? val : want;
+        mode = islen & (iseob ^ 1u);
+        lo = hw_shr64lo(hi, lo, use); hi >>= use; cnt -= use; pos += use;
+        flags |= iseob ? HWF_EOB : 0u;
+        flags |= (pos > limit_bits + 64u) ? HWF_BAD : 0u;            // ran off the payload (a true stream never does)
+        live = flags == 0u && (mode != 0u || pos < stop);
     }
     if (PASS == 2) {
+        const uint32_t wq = (nlit >> 2) & 3u, base = lit_at + (nlit & ~15u);
+        if (wq > 0u) __builtin_memcpy(lit + base, &l0, 4);
+        if (wq > 1u) __builtin_memcpy(lit + base + 4u, &l1, 4);
+        if (wq > 2u) __builtin_memcpy(lit + base + 8u, &l2, 4);
         for (uint32_t k = nlit & ~3u; k < nlit; k++) lit[lit_at + k] = (uint8_t)(litw >> (8u * (k & 3u)));
+        const uint32_t tq = ntk & 3u, tb_ = tok_at + (ntk & ~3u);
+        if (tq > 0u) tok[tb_] = t0;
+        if (tq > 1u) tok[tb_ + 1u] = t1;
+        if (tq > 2u) tok[tb_ + 2u] = t2;
     }
     r.end = pos; r.flags = flags;
     if (PASS == 1) { r.nlit = nlit; r.nmatch = nmatch; r.lead = nmatch ? lead : nlit; r.tail = nmatch ? run : 0u; r.pint = pint; r.outb = outb; }
@@ -456,6 +514,13 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
         }
         if (status != 0) break;
         const uint32_t mask_ll = (1u << rll) - 1u, mask_d = (1u << rd) - 1u;
+        HwLong lq;
+        {
+            const uint32_t a0 = HW_RLL + 1u < 15u ? HW_RLL + 1u : 15u, a1 = HW_RLL + 2u < 15u ? HW_RLL + 2u : 15u, a2 = HW_RLL + 3u < 15u ? HW_RLL + 3u : 15u;
+            lq.l0 = W_UNI(tb[a0]); lq.l1 = W_UNI(tb[a1]); lq.l2 = W_UNI(tb[a2]); lq.l3 = W_UNI(tb[15]);
+            lq.f0 = W_UNI(tb[16 + a0]); lq.f1 = W_UNI(tb[16 + a1]); lq.f2 = W_UNI(tb[16 + a2]); lq.f3 = W_UNI(tb[16 + 15]);
+            lq.o0 = W_UNI(tb[32 + a0]); lq.o1 = W_UNI(tb[32 + a1]); lq.o2 = W_UNI(tb[32 + a2]); lq.o3 = W_UNI(tb[32 + 15]);
+        }
         HWD_T(t_h2); HWD_ADD(1, t_h1, t_h2);
 
         // ---- symbols: segments of up to 64 bit ranges until the end-of-block symbol ----
@@ -482,7 +547,7 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                     const uint32_t bnd = p0 + ((uint32_t)lane + 1u) * S;
                     const uint32_t from = bnd - p0 > HW_SYNC_W + (uint32_t)lane * S ? bnd - HW_SYNC_W : p0 + (uint32_t)lane * S;
                     HwLane tmp; int32_t st_ = 0;
-                    hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, tmp, nullptr, nullptr, 0, 0, 0, 0, st_);
+                    hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, tmp, nullptr, nullptr, 0, 0, 0, 0, st_);
                     if (tmp.flags == 0u) xch[HX_START * 64 + lane + 1] = tmp.end;
                 }
             }
@@ -501,7 +566,7 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                     if ((dirty >> lane) & 1ull) {
                         int32_t st_ = 0;
                         const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? p0 + ((uint32_t)lane + 1u) * S : 0xffffffffu;   // the last lane runs to the end-of-block symbol
-                        hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, PL(ln), nullptr, nullptr, 0, 0, 0, 0, st_);
+                        hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, PL(ln), nullptr, nullptr, 0, 0, 0, 0, st_);
                         // a range whose first unit starts at or beyond its boundary holds nothing: it ends where it starts
                     }
                     xch[HX_END * 64 + lane] = PL(ln).end; xch[HX_FLAG * 64 + lane] = PL(ln).flags;
@@ -559,7 +624,7 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                 if ((uint32_t)lane < n_ok) {
                     HwLane chk; int32_t st_ = 0;
                     const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? p0 + ((uint32_t)lane + 1u) * S : 0xffffffffu;
-                    hw_span<2>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, chk, lit, tok, nlit_tot + PL(o_lit), ntok_tot + PL(o_tok), outpos + PL(o_out), PL(carry), st_);
+                    hw_span<2>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, chk, lit, tok, nlit_tot + PL(o_lit), ntok_tot + PL(o_tok), outpos + PL(o_out), PL(carry), st_);
                     xch[HX_FLAG * 64 + lane] = (st_ != 0 || chk.end != PL(ln).end) ? 1u : 0u;
                 } else xch[HX_FLAG * 64 + lane] = 0u;
             }

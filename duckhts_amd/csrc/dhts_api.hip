@@ -446,10 +446,11 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {   
     //   wave: one WAVE per BGZF block, table-driven (bgzf_huff_wave.hip): a block takes well under a millisecond, so short launches --
     //         index windows, small files, a 1 GB BCF -- no longer pay one lane's serial decode of a whole block (13-15 ms);
     //   lane: one LANE per block, canonical arithmetic (bgzf_inflate.hip): fewer instructions per symbol once a launch is long enough
-    //         to keep every SIMD backfilled (measured on MI355X: 65,536 blocks 12.9 ms against 20.8 ms).
-    // DHTS_PHASE_A = wave | lane forces one of them; the default switches at DHTS_WAVE_MAX_BLOCKS (40,000: where the two meet).
+    //         to keep every SIMD backfilled (measured on MI355X per 65,536 blocks: 13.0 ms against 16.3 ms in launches of 131,072;
+    //         launches of 32,768 take 17.6 ms -- one lane's serial decode -- against 8.5 ms).
+    // DHTS_PHASE_A = wave | lane forces one of them; the default switches at DHTS_WAVE_MAX_BLOCKS (65,536: where the two meet).
     static const char *env_a = getenv("DHTS_PHASE_A");
-    static const int64_t wave_max = getenv("DHTS_WAVE_MAX_BLOCKS") ? atoll(getenv("DHTS_WAVE_MAX_BLOCKS")) : 40000;
+    static const int64_t wave_max = getenv("DHTS_WAVE_MAX_BLOCKS") ? atoll(getenv("DHTS_WAVE_MAX_BLOCKS")) : 65536;
     const bool env_lane = force >= 0 ? force != 2 : env_a ? !strcmp(env_a, "lane") : (nb > wave_max);
     if (!env_lane) {
         KTimer tm(c, DHTS_K_HUFF);
