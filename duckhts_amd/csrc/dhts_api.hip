@@ -23,13 +23,45 @@
 #include <algorithm>
 #include <limits.h>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
 #define TILE_BYTES TL_TILE               /* record-stage tile = what bam_tiles_lds.hip stages per wave */
 #define PAD_BYTES 256u
 
-// Owning device allocation: freed by its destructor, so deleting a context returns every byte of HBM it held.
+// Device memory is pooled for the life of the process, like the pinned host buffers: a scan context allocates ~100 buffers, some of
+// them gigabytes (the phase-A scratch), and hipMalloc / hipFree of those costs up to hundreds of milliseconds and synchronises the
+// device.  A long-lived host (DuckDB) creates one context per query, so buffers go back to a per-device free list when a context is
+// destroyed and the next one picks them up.  The list is bounded (DHTS_POOL_GB, default 96 GB per process); beyond it memory is freed.
+namespace {
+struct PoolBuf { void *p; size_t cap; int dev; };
+std::mutex g_pool_mu;
+std::vector<PoolBuf> g_pool;
+size_t g_pool_bytes = 0;
+size_t pool_limit() { static const size_t lim = (size_t)(getenv("DHTS_POOL_GB") ? atof(getenv("DHTS_POOL_GB")) : 96.0) * (size_t)(1u << 30); return lim; }
+void *pool_take(size_t n, size_t *cap_out) {
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i].dev == dev && g_pool[i].cap >= n && g_pool[i].cap / 4 <= n + 65536 && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = (int)i;
+    if (best < 0) return nullptr;
+    void *p = g_pool[best].p; *cap_out = g_pool[best].cap; g_pool_bytes -= g_pool[best].cap;
+    g_pool[best] = g_pool.back(); g_pool.pop_back();
+    return p;
+}
+void pool_give(void *p, size_t cap) {
+    int dev = 0; hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device; else (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_bytes + cap <= pool_limit() && g_pool.size() < 4096) { g_pool.push_back({p, cap, dev}); g_pool_bytes += cap; return; }
+    }
+    (void)hipFree(p);
+}
+}
+// Owning device allocation: returned to the pool by its destructor, so deleting a context gives back every byte of HBM it held.
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     DevBuf() = default;
@@ -39,15 +71,33 @@ struct DevBuf {
     void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
     int ensure(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = n + n / 8 + 4096;
-        if (hipMalloc(&p, want) != hipSuccess) return -1;
+        release();
+        size_t want = n + n / 8 + 4096, got = 0;
+        if (void *q = pool_take(want, &got)) { p = q; cap = got; return 0; }
+        if (hipMalloc(&p, want) != hipSuccess) {
+            // out of memory: drop what the pool holds on to and try once more
+            { std::lock_guard<std::mutex> lk(g_pool_mu); for (auto &b : g_pool) (void)hipFree(b.p); g_pool.clear(); g_pool_bytes = 0; }
+            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        }
         cap = want; return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) pool_give(p, cap); p = nullptr; cap = 0; }
 };
 
+// progress of a staging run: `frontier` = contiguous bytes of the range that are in HBM (their copies have completed)
+struct StageProg {
+    std::mutex mu; std::condition_variable cv;
+    std::vector<uint8_t> piece_done; uint64_t next_piece = 0, frontier = 0, len = 0; bool finished = false; int rc = 0;
+    void mark(uint64_t pi, uint64_t ch) {
+        std::lock_guard<std::mutex> lk(mu);
+        piece_done[pi] = 1;
+        while (next_piece < piece_done.size() && piece_done[next_piece]) next_piece++;
+        const uint64_t f = next_piece * ch; frontier = f < len ? f : len;
+        cv.notify_all();
+    }
+};
+struct dhts_ctx;
+static void stop_stager(dhts_ctx *c);
 struct dhts_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -59,6 +109,8 @@ struct dhts_ctx {
     DevBuf comp; uint64_t comp_len = 0; uint64_t file_off = 0, file_size = 0;   // resident bytes = file bytes [file_off, file_off + comp_len)
     // dhts_open_path_shard: resident bytes = file[0, seg_split) ++ file[seg_file_off, ...): the header blocks, then this rank's window
     uint64_t seg_split = 0, seg_file_off = 0; bool partial_tail = false; uint64_t hdr_bytes_known = 0;
+    // dhts_open_path_async: the file is still arriving; the block table covers the staged prefix and grows (dhts_bgzf_index_staged)
+    std::thread stager; StageProg *prog = nullptr; bool growing = false; uint64_t stage_total = 0;
     // block table
     int64_t n_blocks = 0; int bgzf_status = 0;
     DevBuf coff, clen, isize, uoff, blk_status;
@@ -189,6 +241,7 @@ dhts_ctx *dhts_create(int device_id) {
 void dhts_destroy(dhts_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    stop_stager(c);
     (void)hipStreamSynchronize(c->stream_b);
     (void)hipStreamSynchronize(c->stream);
     timing_collect(c);
@@ -200,7 +253,12 @@ void dhts_destroy(dhts_ctx *c) {
 
 const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no context (no MI355X device or code object)"; }
 
+static void stop_stager(dhts_ctx *c) {
+    if (c->stager.joinable()) c->stager.join();            // (a staging run always terminates: it only reads a file)
+    delete c->prog; c->prog = nullptr; c->growing = false;
+}
 static void reset_file_state(dhts_ctx *c) {
+    stop_stager(c);
     c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false;
     c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
     c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
@@ -259,24 +317,32 @@ extern "C" void *dhts_host_alloc(uint64_t n) {
     g_pin.push_back({p, want, true});
     return p;
 }
+// gives the idle pooled buffers (device and pinned host) back to the driver; buffers in use are untouched
+extern "C" void dhts_release_pools(void) {
+    { std::lock_guard<std::mutex> lk(g_pool_mu); for (auto &b : g_pool) (void)hipFree(b.p); g_pool.clear(); g_pool_bytes = 0; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pin.size();) { if (!g_pin[i].busy) { (void)hipHostFree(g_pin[i].p); g_pin.erase(g_pin.begin() + i); } else i++; }
+}
 extern "C" void dhts_host_free(void *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (auto &b : g_pin) if (b.p == p) { b.busy = false; return; }
 }
 
-// file bytes [off, off+len) -> comp[0, len): reader threads pread 8 MiB pieces into their own pair of pinned buffers and queue the
+// file bytes [off, off+len) -> dst[0, len): reader threads pread 8 MiB pieces into their own pair of pinned buffers and queue the
 // H2D copies on their own streams, so the page-cache copy (one core moves ~5-10 GB/s) and the PCIe transfer overlap and scale.
-static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uint8_t *dst) {
+static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uint8_t *dst, StageProg *prog = nullptr) {
     const size_t CH = 8u << 20;
     const uint64_t npieces = (len + CH - 1) / CH;
     static const int env_thr = getenv("DHTS_READ_THREADS") ? atoi(getenv("DHTS_READ_THREADS")) : 0;
-    int nthr = env_thr > 0 ? env_thr : 4; if ((uint64_t)nthr > npieces) nthr = (int)npieces; if (nthr < 1) nthr = 1;
+    int nthr = env_thr > 0 ? env_thr : 8; if ((uint64_t)nthr > npieces) nthr = (int)npieces; if (nthr < 1) nthr = 1;
     std::atomic<uint64_t> next(0); std::atomic<int> rc(0);
     const int dev = c->device;
+    if (prog) { std::lock_guard<std::mutex> lk(prog->mu); prog->piece_done.assign(npieces, 0); prog->next_piece = 0; prog->frontier = 0; prog->len = len; }
     auto worker = [&]() {
         if (hipSetDevice(dev) != hipSuccess) { rc = -1; return; }
         hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; void *pin[2] = {dhts_host_alloc(CH), dhts_host_alloc(CH)}; bool used[2] = {false, false};
+        uint64_t piece_of[2] = {0, 0};
         if (!pin[0] || !pin[1] || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = -2;
         int k = 0;
@@ -284,15 +350,17 @@ static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uin
             const uint64_t pi = next.fetch_add(1);
             if (pi >= npieces) break;
             const uint64_t o = pi * CH; const size_t want = (size_t)(len - o < CH ? len - o : CH);
-            if (used[k]) (void)hipEventSynchronize(ev[k]);
+            if (used[k]) { (void)hipEventSynchronize(ev[k]); if (prog) prog->mark(piece_of[k], CH); used[k] = false; }
             size_t got = 0;
             while (got < want) { ssize_t r = pread(fd, (char *)pin[k] + got, want - got, (off_t)(off + o + got)); if (r <= 0) { rc = -3; break; } got += (size_t)r; }
             if (rc != 0) break;
             if (hipMemcpyAsync(dst + o, pin[k], want, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { rc = -4; break; }
-            used[k] = true; k ^= 1;
+            used[k] = true; piece_of[k] = pi; k ^= 1;
+            // the other buffer's copy was queued a whole pread ago: it has usually landed, report it now rather than a piece later
+            if (prog && used[k] && hipEventQuery(ev[k]) == hipSuccess) { prog->mark(piece_of[k], CH); used[k] = false; }
         }
         if (st) (void)hipStreamSynchronize(st);
-        for (int q = 0; q < 2; q++) { if (ev[q]) (void)hipEventDestroy(ev[q]); dhts_host_free(pin[q]); }
+        for (int q = 0; q < 2; q++) { if (used[q] && prog && rc == 0) prog->mark(piece_of[q], CH); if (ev[q]) (void)hipEventDestroy(ev[q]); dhts_host_free(pin[q]); }
         if (st) (void)hipStreamDestroy(st);
     };
     std::vector<std::thread> th;
@@ -326,6 +394,51 @@ int dhts_open_path_range(dhts_ctx *c, const char *path, uint64_t off, uint64_t l
 }
 int dhts_open_path(dhts_ctx *c, const char *path) { return dhts_open_path_range(c, path, 0, 0); }
 
+// The same for a scan that starts before the file has arrived: staging runs on background threads, dhts_stage_wait reports how many
+// contiguous bytes are resident, dhts_bgzf_index_staged (re)builds the block table over that prefix, and dhts_bam_next_batch serves the
+// blocks known so far (the stream is not "at its end" while bytes are still arriving).
+int dhts_open_path_async(dhts_ctx *c, const char *path) {
+    if (!c) return -1;
+    discard_prefetch(c);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(c, "cannot open %s", path);
+    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
+    const uint64_t n = (uint64_t)sb.st_size;
+    if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
+    reset_file_state(c);
+    if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc of %llu bytes failed", (unsigned long long)(n + PAD_BYTES)); }
+    HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->prog = new StageProg(); c->prog->len = n; c->stage_total = n; c->file_off = 0; c->file_size = n; c->comp_len = 0; c->growing = true;
+    StageProg *pg = c->prog; uint8_t *dst = (uint8_t *)c->comp.p;
+    c->stager = std::thread([c, fd, n, dst, pg]() {
+        int rc = n ? stage_file_range(c, fd, 0, n, dst, pg) : 0;
+        close(fd);
+        std::lock_guard<std::mutex> lk(pg->mu); pg->rc = rc; pg->finished = true; if (rc == 0) pg->frontier = n; pg->cv.notify_all();
+    });
+    return 0;
+}
+int64_t dhts_stage_wait(dhts_ctx *c, uint64_t min_bytes, int *done) {
+    if (!c || !c->prog) { if (done) *done = 1; return c ? (int64_t)c->comp_len : -1; }
+    StageProg *pg = c->prog;
+    std::unique_lock<std::mutex> lk(pg->mu);
+    pg->cv.wait(lk, [&] { return pg->finished || pg->frontier >= min_bytes; });
+    if (pg->finished && pg->rc != 0) { lk.unlock(); return fail(c, "staging failed (read error)"); }
+    if (done) *done = pg->finished ? 1 : 0;
+    return (int64_t)pg->frontier;
+}
+static int64_t index_impl(dhts_ctx *c, bool extend);
+int64_t dhts_bgzf_index_staged(dhts_ctx *c) {
+    if (!c) return -1;
+    if (!c->prog) return dhts_bgzf_index(c);
+    int done = 0; const int64_t f = dhts_stage_wait(c, 0, &done);
+    if (f < 0) return -1;
+    const bool extend = c->comp_len > 0 && c->n_blocks > 0;
+    c->comp_len = (uint64_t)f; c->partial_tail = !done; c->growing = !done;
+    return index_impl(c, extend);
+}
+int64_t dhts_blocks_ahead(const dhts_ctx *c) { return c ? c->n_blocks - c->next_block : 0; }
+
 uint64_t dhts_resident_bytes(const dhts_ctx *c) { return c ? c->comp_len : 0; }
 
 // ---- scans --------------------------------------------------------------------------------
@@ -352,11 +465,14 @@ static int run_scan(dhts_ctx *c, int narr, const uint32_t **in, uint32_t **out32
 }
 
 // ---- BGZF index -------------------------------------------------------------------------------
-int64_t dhts_bgzf_index(dhts_ctx *c) {
-    if (!c) return -1;
+int64_t dhts_bgzf_index(dhts_ctx *c) { return c ? index_impl(c, false) : -1; }
+// extend: the resident bytes have grown since the last call (a file that is still being staged): the table is rebuilt over the longer
+// prefix -- the blocks known before keep their numbers, offsets and scratch -- and the scan position is left alone
+static int64_t index_impl(dhts_ctx *c, bool extend) {
     HIPCHK(c, hipSetDevice(c->device));
     discard_prefetch(c);
-    c->huff_b0 = c->huff_nb = 0;
+    const int64_t old_nb = c->n_blocks;
+    if (!extend) c->huff_b0 = c->huff_nb = 0;
     if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
     const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
     int64_t nspans = (int64_t)((n + 65535) / 65536);
@@ -418,6 +534,11 @@ int64_t dhts_bgzf_index(dhts_ctx *c) {
         HIPCHK(c, hipMemcpy(c->h_isize.data(), c->isize.p, nb * 4, hipMemcpyDeviceToHost));
     }
     HIPCHK(c, hipMemcpy(c->h_uoff.data(), c->uoff.p, (nb + 1) * 8, hipMemcpyDeviceToHost));
+    if (extend) {
+        if (nb < old_nb) return fail(c, "internal: the block table shrank while the file was being staged");
+        if (c->shard_b1 == old_nb) c->shard_b1 = nb;            // a whole-file scan follows the table
+        return nb;
+    }
     c->shard_b0 = 0; c->shard_b1 = nb; c->shard_rank = 0; c->shard_world = 1;
     return nb;
 }
@@ -493,7 +614,8 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
                 const double per_block = ((double)DHTS_LIT_STRIDE + (double)DHTS_TOK_STRIDE * 4 + sizeof(InflateMeta)) * 1.125;
-                const int64_t fit = (int64_t)(0.45 * ((double)fr + (double)c->lit.cap + (double)c->tok.cap) / per_block);
+                size_t pooled = 0; { std::lock_guard<std::mutex> lk(g_pool_mu); pooled = g_pool_bytes; }       // (idle buffers of earlier contexts can be taken back)
+                const int64_t fit = (int64_t)(0.45 * ((double)fr + (double)pooled + (double)c->lit.cap + (double)c->tok.cap) / per_block);
                 if (sb > fit) sb = fit;
             }
             if (sb < 16384) sb = 16384;
@@ -1414,7 +1536,7 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
         while (b0 + nb < limit && c->h_uoff[b0 + nb] - c->h_uoff[b0] < (1u << 20) && nb < 24576) nb++;
     }
     B.b0 = b0; B.nb = nb; B.in_halo = in_halo;
-    B.last_of_stream = (b0 + nb >= c->n_blocks);
+    B.last_of_stream = (b0 + nb >= c->n_blocks) && !c->growing;        // (more blocks may still arrive: dhts_open_path_async)
     const uint64_t carry = c->carry_len;
     const uint64_t inflated = c->h_uoff[b0 + nb] - c->h_uoff[b0];
     uint64_t ulen = carry + inflated;

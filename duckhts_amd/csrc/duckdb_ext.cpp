@@ -22,6 +22,7 @@
 #include "../../include/duckhts_extension.h"
 
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <condition_variable>
@@ -271,8 +272,11 @@ static int fetch_optional(dhts_ctx *c, BamScan *g, const dhts_bam_batch &b, Host
 }
 
 // producer thread: one GPU, one scan context, one block range of the file
+static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void producer_main(BamScan *g, Producer *p) {
     BamBind *bind = g->bind;
+    static const bool trace = getenv("DHTS_TRACE") != nullptr;       // stage timings of every producer on stderr
+    const double t_start = now_s(); double t_open = 0, t_gpu = 0, t_fetch = 0, t_slot = 0, t_wait = 0, t_index = 0; int64_t n_batches = 0, n_rows = 0, n_index = 0;
     auto fail_with = [&](const std::string &msg) {
         std::lock_guard<std::mutex> lk(g->mu);
         if (g->error.empty()) g->error = msg;
@@ -281,11 +285,28 @@ static void producer_main(BamScan *g, Producer *p) {
     dhts_ctx *c = dhts_create(p->device);
     if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     int rc;
+    // a plain whole-file scan on one device starts decoding while the file is still being staged: the block table is built over the
+    // resident prefix and extended as more bytes arrive (DHTS_STREAM=0 stages the whole file first)
+    static const bool env_nostream = getenv("DHTS_STREAM") && atoi(getenv("DHTS_STREAM")) == 0;
+    const bool streaming = p->world == 1 && bind->region.empty() && !env_nostream;
+    int staged_all = 1;
     if (p->world > 1) rc = dhts_open_path_shard(c, bind->path.c_str(), p->rank, p->world, bind->header_bytes);
+    else if (streaming) rc = dhts_open_path_async(c, bind->path.c_str());
     else rc = dhts_open_path(c, bind->path.c_str());
-    if (rc == 0 && dhts_bgzf_index(c) <= 0) rc = -1;
-    if (rc == 0 && dhts_bam_open(c) != 0) rc = -1;
+    if (rc == 0 && !streaming) { if (dhts_bgzf_index(c) <= 0 || dhts_bam_open(c) != 0) rc = -1; }
+    if (rc == 0 && streaming) {
+        // the header needs the first blocks only: start with what the bind saw, four times more whenever that is not enough
+        uint64_t want = bind->header_bytes + (32u << 20);
+        for (;;) {
+            const int64_t f = dhts_stage_wait(c, want, &staged_all);
+            if (f < 0) { rc = -1; break; }
+            if (dhts_bgzf_index_staged(c) > 0 && dhts_bam_open(c) == 0) break;
+            if (staged_all) { rc = -1; break; }
+            want *= 4;
+        }
+    }
     if (rc != 0) { std::string m = std::string("Failed to open SAM/BAM/CRAM file: ") + bind->path; dhts_destroy(c); fail_with(m); return; }
+    t_open = now_s() - t_start;
     dhts_bam_set_tag_columns(c, g->tag_ids.data(), (int32_t)g->tag_ids.size());
     dhts_bam_set_aux_map(c, g->want_aux ? 1 : 0, bind->standard_tags);
     if (!bind->region.empty()) {
@@ -299,7 +320,18 @@ static void producer_main(BamScan *g, Producer *p) {
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;       // ~270 MB of inflated stream per batch: the engine gets its first chunk early and the stages overlap
     for (;;) {
         dhts_bam_batch b;
+        if (streaming && !staged_all && dhts_blocks_ahead(c) < max_blocks) {
+            // not enough known blocks for a full batch: wait for (at least) another 128 MiB of the file, then extend the block table
+            const double tw0 = now_s();
+            int64_t f = dhts_stage_wait(c, 0, &staged_all);
+            if (f >= 0 && !staged_all) f = dhts_stage_wait(c, (uint64_t)f + (128u << 20), &staged_all);
+            const double tw1 = now_s(); t_wait += tw1 - tw0;
+            if (f < 0 || dhts_bgzf_index_staged(c) < 0) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
+            t_index += now_s() - tw1; n_index++;
+        }
+        const double tb0 = now_s();
         if (dhts_bam_next_batch(c, max_blocks, g->colmask, &b) != 0) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
+        const double tb1 = now_s(); t_gpu += tb1 - tb0; n_batches++; n_rows += b.n_rows;
         if (b.n_rows > 0) {
             HostBatch *hb = nullptr;
             {
@@ -308,11 +340,13 @@ static void producer_main(BamScan *g, Producer *p) {
                 if (g->cancel) break;
                 hb = p->free_slots.back(); p->free_slots.pop_back();
             }
+            const double tb2 = now_s(); t_slot += tb2 - tb1;
             const uint64_t need = dhts_bam_batch_host_bytes(&b, g->colmask);
             if (need > hb->cap) { dhts_host_free(hb->arena); hb->arena = dhts_host_alloc(need); hb->cap = hb->arena ? need : 0; }
             if ((need && !hb->arena) || dhts_bam_batch_fetch(c, &b, g->colmask, hb->arena, hb->cap, &hb->b) != 0 || fetch_optional(c, g, b, hb) != 0) {
                 std::string m = hb->arena || !need ? dhts_error(c) : "read_bam: out of pinned host memory"; dhts_destroy(c); fail_with(m); return;
             }
+            t_fetch += now_s() - tb2;
             hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false;
             if (!p->has_rows) { p->has_rows = true; p->first_v = dhts_voffset(c, b.first_rec_uoff); }
             p->end_v = dhts_voffset(c, b.end_uoff);
@@ -323,6 +357,8 @@ static void producer_main(BamScan *g, Producer *p) {
         { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
     }
     dhts_destroy(c);
+    if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: open+index+header %.3f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
+                       p->rank, p->world, p->device, t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
     { std::lock_guard<std::mutex> lk(g->mu); p->done = true; }
     g->cv_ready.notify_all();
 }

@@ -140,6 +140,15 @@ int dhts_open_path(dhts_ctx *, const char *path);                  /* pread (rea
  * own block range plus a halo; a bind that only needs the header stages the first megabytes (hts_open + the reads under
  * bgzf_read_block, htslib/bgzf.c:1004-1239, restricted to a window of the file) */
 int dhts_open_path_range(dhts_ctx *, const char *path, uint64_t off, uint64_t len);
+/* Staging that overlaps the scan (the analogue of bgzf_mt_reader running ahead of the consumer, htslib/bgzf.c:1598-1738):
+ * dhts_open_path_async starts reader threads and returns; dhts_stage_wait blocks until at least min_bytes contiguous bytes of the file
+ * are resident (or staging has finished: *done) and returns that count; dhts_bgzf_index_staged builds -- later extends -- the block table
+ * over the resident prefix; dhts_bam_next_batch then serves the blocks known so far and reports status 0 ("more may follow") until the
+ * table covers the whole file; dhts_blocks_ahead = blocks in the table that the scan has not consumed yet. */
+int dhts_open_path_async(dhts_ctx *, const char *path);
+int64_t dhts_stage_wait(dhts_ctx *, uint64_t min_bytes, int *done);
+int64_t dhts_bgzf_index_staged(dhts_ctx *);
+int64_t dhts_blocks_ahead(const dhts_ctx *);
 /* one rank's share of ONE file: resident bytes = the header blocks file[0, header_bytes) followed by the rank's own
  * window of whole BGZF blocks plus a 4 MiB halo; cut points t_r = header_bytes + (size - header_bytes) * r / world.  Follow with
  * dhts_bgzf_index, dhts_bam_open and dhts_bam_set_file_shard(rank, world).  header_bytes: dhts_bam_header_bytes of a context that has
@@ -262,6 +271,9 @@ int dhts_bcf_next_batch(dhts_ctx *, int64_t max_blocks, dhts_bcf_batch *out);
  * This is the seam a DuckDB scan callback fills DataChunks from (src/bam_reader.c:783-918 reads the same values out of bam1_t). */
 void *dhts_host_alloc(uint64_t nbytes);
 void dhts_host_free(void *p);
+/* Device buffers of destroyed contexts and freed pinned buffers are kept in process-wide pools (a context per query would otherwise pay
+ * hipMalloc / hipHostMalloc of gigabytes each time); this returns every idle pooled buffer to the driver. */
+void dhts_release_pools(void);
 uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
 int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);
 

@@ -178,12 +178,20 @@ def test_no_hbm_leak_over_200_queries():
             duckhts_amd.read_bam(bam, region="CHROMOSOME_I:1-5000")
             duckhts_amd.read_bam(tags, std_tags_cols=list(range(56)), aux_map="all")
 
+    L = duckhts_amd.lib()
     for i in range(8):                      # warm up: code objects, runtime pools
         cycle(i)
+    L.dhts_release_pools()                  # buffers of destroyed contexts are pooled for the next query: hand the idle ones back
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info(0)
+    held = []
     for i in range(200):
         cycle(i)
+        if i % 50 == 49:
+            torch.cuda.synchronize()
+            held.append(free0 - torch.cuda.mem_get_info(0)[0])
+    assert max(held) - min(held) < (64 << 20), f"the pool keeps growing: {held}"        # steady state, not a leak with a pool in front
+    L.dhts_release_pools()
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(0)
     assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 10} KiB of HBM lost over 200 create -> scan -> destroy cycles"
