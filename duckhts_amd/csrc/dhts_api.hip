@@ -335,7 +335,8 @@ static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uin
     const size_t CH = 8u << 20;
     const uint64_t npieces = (len + CH - 1) / CH;
     static const int env_thr = getenv("DHTS_READ_THREADS") ? atoi(getenv("DHTS_READ_THREADS")) : 0;
-    int nthr = env_thr > 0 ? env_thr : 4;          // (measured on the MI355X host: 4 readers 75 ms per 0.85 GB query, 8: 80, 16: 120, 32: 180) if ((uint64_t)nthr > npieces) nthr = (int)npieces; if (nthr < 1) nthr = 1;
+    // (measured on the MI355X host, per 0.85 GB query: 4 readers 75 ms, 8: 80, 16: 120, 32: 180)
+    int nthr = env_thr > 0 ? env_thr : 4; if ((uint64_t)nthr > npieces) nthr = (int)npieces; if (nthr < 1) nthr = 1;
     std::atomic<uint64_t> next(0); std::atomic<int> rc(0);
     const int dev = c->device;
     if (prog) { std::lock_guard<std::mutex> lk(prog->mu); prog->piece_done.assign(npieces, 0); prog->next_piece = 0; prog->frontier = 0; prog->len = len; }
