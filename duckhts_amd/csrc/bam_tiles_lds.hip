@@ -581,14 +581,15 @@ bam_pack_validity(const uint8_t *flag, int64_t nrows, uint64_t *words) {
 struct RegionDev { const int64_t *beg, *end; const uint32_t *tid_first; int32_t n_ref, all, nocoor, pad; };
 
 extern "C" __global__ void __launch_bounds__(256)
-bam_region_keep(BamStream st, RegionDev rg, const uint32_t *rec_off, int64_t nrows, uint32_t *keep) {
+bam_region_keep(BamStream st, RegionDev rg, const uint32_t *rec_off, int64_t nrows, uint32_t *keep, uint64_t end_rel) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= nrows) return;
     GSrc gs; gs.g = st.u;
     const uint64_t o = rec_off[row];
     RecInfo r;
     uint32_t k = 0;
-    if (rec_check_t(st, gs, o, r, true) == REC_OK) {
+    // end_rel: where the current index window ends in this buffer; a record that starts there or later belongs to the next window
+    if (o < end_rel && rec_check_t(st, gs, o, r, true) == REC_OK) {
         if (rg.all) k = 1;
         else if (r.tid < 0) k = rg.nocoor ? 1u : 0u;
         else if (r.tid < rg.n_ref) {

@@ -154,6 +154,10 @@ struct dhts_ctx {
     std::vector<int64_t> rg_beg, rg_end; std::vector<uint32_t> rg_tid_first;
     DevBuf d_rg_beg, d_rg_end, d_rg_first, c_keep, c_rowmap;
     bool rg_empty_window = false;          // the index shows no chunk for the regions: the scan yields nothing
+    // the chunk list of a region query (hts_itr_multi_bam / reg2intervals, hts.c:3597-3739, 3299-3354) as disjoint scan windows in file
+    // order; the scan walks them one after the other.  scan_end_uoff: rows whose record starts at or behind it belong to a later window.
+    struct ScanWin { int64_t b0, b1; uint64_t first_uoff, end_uoff; };
+    std::vector<ScanWin> wins; size_t win_cur = 0; uint64_t scan_end_uoff = ~0ull;
     uint64_t scan_first_uoff = 0;          // inflated offset of the first record of a non-speculative scan (header end, or an index chunk start)
     // read_bcf
     bool bcf_open = false; bool bcf_tidy_req = false;
@@ -769,6 +773,7 @@ int dhts_shard_cut(const uint64_t *coff, int64_t n_blocks, uint64_t comp_len, in
 
 int dhts_bam_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculative_start) {
     if (!c || b0 < 0 || b1 < b0 || b1 > c->n_blocks) return -1;
+    c->wins.clear(); c->scan_end_uoff = ~0ull;
     c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = speculative_start ? 1 : 0; c->shard_world = (b1 < c->n_blocks || speculative_start) ? 2 : 1;
     c->scan_first_uoff = c->first_rec_uoff;
     return dhts_bam_rewind(c);
@@ -962,6 +967,7 @@ int dhts_bam_set_regions(dhts_ctx *c, const char *regions) {
     if (!c || !c->bam_open) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     c->rg_active = false; c->rg_all = false; c->rg_nocoor = false; c->rg_empty_window = false; c->rg_beg.clear(); c->rg_end.clear(); c->rg_tid_first.clear();
+    c->wins.clear(); c->win_cur = 0; c->scan_end_uoff = ~0ull;
     c->scan_first_uoff = c->first_rec_uoff; c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1;
     if (!regions || !*regions) return dhts_bam_rewind(c);
     const size_t n_ref = c->ref_name.size();
@@ -1005,7 +1011,7 @@ int dhts_bam_set_regions(dhts_ctx *c, const char *regions) {
 // the bins the intervals touch (reg2bins hts.c:3142-3213, generalised to min_shift / depth), pruned by the BAI linear index
 // (hts.c:3556-3563).  It is a superset of the iterator's chunk list; the device predicate decides the rows, so results are exact.
 struct QIv { int32_t tid; int64_t beg, end; };
-struct IdxWindow { bool any = false; uint64_t vmin = ~0ull, vmax = 0, last_end = 0; };
+struct IdxWindow { bool any = false; uint64_t vmin = ~0ull, vmax = 0, last_end = 0; std::vector<std::pair<uint64_t, uint64_t>> chunks; };   // chunks: (begin, end) virtual offsets of every bin chunk the query touches
 
 static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::vector<QIv> &q, bool whole, IdxWindow &w) {
     std::vector<uint8_t> inflated;
@@ -1079,13 +1085,14 @@ static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::ve
             w.any = true;
             if (ch.u < w.vmin) w.vmin = ch.u;
             if (ch.v > w.vmax) w.vmax = ch.v;
+            w.chunks.push_back({ch.u > min_off ? ch.u : min_off, ch.v});      // (the linear index: nothing below min_off can overlap, hts.c:3540-3560)
         }
     }
     return 0;
 }
 
 // turns a window into the context's scan range; nocoor = also everything after the last mapped chunk ("*")
-static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor) {
+static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor, bool multi = false) {
     int64_t b0 = 0, b1 = c->n_blocks; uint64_t first_uoff = c->first_rec_uoff;
     auto block_of = [&](uint64_t coffset) -> int64_t {
         int64_t lo = 0, hi = c->n_blocks;
@@ -1093,12 +1100,39 @@ static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor
         return lo;
     };
     c->rg_empty_window = false;
+    c->wins.clear(); c->win_cur = 0; c->scan_end_uoff = ~0ull;
     if (!whole && !nocoor) {
         if (!w.any) { c->rg_empty_window = true; return 0; }
         b0 = block_of(w.vmin >> 16); b1 = block_of(w.vmax >> 16) + 1; if (b1 > c->n_blocks) b1 = c->n_blocks;
         if (b0 >= c->n_blocks || c->h_coff[b0] != (w.vmin >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(w.vmin >> 16));
         first_uoff = c->h_uoff[b0] + (w.vmin & 0xffff);
         if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
+        if (multi && w.chunks.size() > 1) {
+            // Disjoint windows: the chunks sorted by their start, neighbours merged while the gap between them is cheaper to scan than a
+            // window is to start (a window costs a batch: ~1.5 ms of launches and hand-shakes, i.e. tens of MB at scan speed).  Rows are
+            // decided by the overlap predicate, so merging never changes the result; the windows only bound what is inflated.
+            const uint64_t gap_bytes = (uint64_t)(getenv("DHTS_WINDOW_GAP_MB") ? atof(getenv("DHTS_WINDOW_GAP_MB")) : 32.0) * (1u << 20);
+            std::vector<std::pair<uint64_t, uint64_t>> ch = w.chunks;
+            std::sort(ch.begin(), ch.end());
+            std::vector<std::pair<uint64_t, uint64_t>> mg;
+            for (auto &x : ch) {
+                if (!mg.empty() && (x.first >> 16) <= (mg.back().second >> 16) + gap_bytes) { if (x.second > mg.back().second) mg.back().second = x.second; }
+                else mg.push_back(x);
+            }
+            if (mg.size() > 1) {
+                for (auto &x : mg) {
+                    dhts_ctx::ScanWin sw;
+                    sw.b0 = block_of(x.first >> 16);
+                    if (sw.b0 >= c->n_blocks || c->h_coff[sw.b0] != (x.first >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(x.first >> 16));
+                    int64_t be = block_of(x.second >> 16); if (be >= c->n_blocks) be = c->n_blocks - 1;
+                    sw.b1 = be + 1;
+                    sw.first_uoff = c->h_uoff[sw.b0] + (x.first & 0xffff); if (sw.first_uoff < c->first_rec_uoff) sw.first_uoff = c->first_rec_uoff;
+                    sw.end_uoff = (c->h_coff[be] == (x.second >> 16)) ? c->h_uoff[be] + (x.second & 0xffff) : c->h_uoff[be + 1];
+                    c->wins.push_back(sw);
+                }
+                b0 = c->wins[0].b0; b1 = c->wins[0].b1; first_uoff = c->wins[0].first_uoff; c->scan_end_uoff = c->wins[0].end_uoff;
+            }
+        }
     } else if (!whole && nocoor) {
         const uint64_t s0 = w.any ? w.vmin : w.last_end;
         b0 = block_of(s0 >> 16); if (b0 >= c->n_blocks) b0 = c->n_blocks > 0 ? c->n_blocks - 1 : 0;
@@ -1109,6 +1143,16 @@ static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor
     return 0;
 }
 
+// how much of the file the current scan range covers: windows (1 without an index) and BGZF blocks
+int dhts_scan_window_stats(const dhts_ctx *c, int64_t *n_windows, int64_t *n_blocks) {
+    if (!c) return -1;
+    int64_t w = 1, b = c->shard_b1 - c->shard_b0;
+    if (!c->wins.empty()) { w = (int64_t)c->wins.size(); b = 0; for (auto &x : c->wins) b += x.b1 - x.b0; }
+    if (c->rg_empty_window) { w = 0; b = 0; }
+    if (n_windows) *n_windows = w;
+    if (n_blocks) *n_blocks = b;
+    return 0;
+}
 int dhts_bam_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     if (!c || !c->bam_open) return -1;
     std::vector<QIv> q;
@@ -1116,7 +1160,7 @@ int dhts_bam_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     const bool whole = !c->rg_active || c->rg_all;
     IdxWindow w;
     if (index_window(c, (const uint8_t *)bytes, n, q, whole, w)) return -1;
-    if (apply_window(c, w, whole, c->rg_nocoor)) return -1;
+    if (apply_window(c, w, whole, c->rg_nocoor, true)) return -1;
     return dhts_bam_rewind(c);
 }
 
@@ -1131,9 +1175,16 @@ int dhts_bcf_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     return dhts_bcf_rewind(c);
 }
 
+// the scan range becomes window k of a multi-window region query
+static void enter_window(dhts_ctx *c, size_t k) {
+    const dhts_ctx::ScanWin &w = c->wins[k];
+    c->win_cur = k; c->shard_b0 = w.b0; c->shard_b1 = w.b1; c->shard_rank = 0; c->shard_world = (w.b1 < c->n_blocks) ? 2 : 1;
+    c->scan_first_uoff = w.first_uoff; c->scan_end_uoff = w.end_uoff;
+}
 int dhts_bam_rewind(dhts_ctx *c) {
     if (!c) return -1;
     discard_prefetch(c);
+    if (!c->wins.empty()) enter_window(c, 0);
     c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = c->rg_empty_window; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;            // a new pass redoes phase A (nothing is cached across scans)
     skip_header_blocks(c);
@@ -1601,7 +1652,23 @@ static int batch_end(dhts_ctx *c, const Batch &B, uint64_t carry_start, bool rec
     return 0;
 }
 
+static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out) {
+    if (!c || !out) return -1;
+    for (;;) {
+        if (bam_next_batch_one(c, max_blocks, colmask, out)) return -1;
+        // a region query with several index windows: the end of one window is the start of the next, not the end of the scan
+        if (out->status == 1 && c->win_cur + 1 < c->wins.size()) {
+            enter_window(c, c->win_cur + 1);
+            discard_prefetch(c);
+            c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+            out->status = 0;
+            if (out->n_rows == 0) continue;
+        }
+        return 0;
+    }
+}
+static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out) {
     if (!c || !out) return -1;
     memset(out, 0, sizeof(*out));
     if (!c->bam_open) return fail(c, "dhts_bam_open not called");
@@ -1739,7 +1806,8 @@ int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_
                 KTimer tm(c, DHTS_K_CORE);
                 hipLaunchKernelGGL(bam_tile_offsets, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, (const uint32_t *)c->t_rowbase.p,
                                    (const uint64_t *)c->d_res.p, (uint32_t *)c->rec_off.p);
-                hipLaunchKernelGGL(bam_region_keep, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, rg, (const uint32_t *)c->rec_off.p, nrows, (uint32_t *)c->c_keep.p);
+                const uint64_t end_rel = c->scan_end_uoff == ~0ull ? ~0ull : (c->scan_end_uoff > out_base ? c->scan_end_uoff - out_base : 0ull);
+                hipLaunchKernelGGL(bam_region_keep, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, st, rg, (const uint32_t *)c->rec_off.p, nrows, (uint32_t *)c->c_keep.p, end_rel);
             }
             const uint32_t *kin[1] = {(const uint32_t *)c->c_keep.p}; uint32_t *kout[1] = {(uint32_t *)c->c_rowmap.p};
             { KTimer tm(c, DHTS_K_SCAN); if (run_scan(c, 1, kin, kout, nullptr, nrows, &kept_total)) return -1; }

@@ -184,6 +184,9 @@ int dhts_bam_set_regions(dhts_ctx *, const char *regions);
  * the chunks of the bins the regions touch (reg2bins hts.c:3142-3213 + BAI linear index); optional for exactness, call after
  * dhts_bam_set_regions / dhts_bcf_set_region.                                                                                    */
 int dhts_bam_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
+/* the scan range the regions + index produced: number of disjoint windows (the merged chunk list of hts_itr_multi_bam, hts.c:3597-3739;
+ * chunks closer than DHTS_WINDOW_GAP_MB, default 32, are scanned as one window) and the BGZF blocks they cover */
+int dhts_scan_window_stats(const dhts_ctx *, int64_t *n_windows, int64_t *n_blocks);
 int dhts_bcf_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
 /* standard_tags := true (src/bam_reader.c:54-70, 920-966): the reference's 56-entry tag table, in its order */
 int dhts_bam_std_tag_count(void);

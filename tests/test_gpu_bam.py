@@ -646,3 +646,39 @@ def test_wave_and_lane_huffman_kernels_agree():
                     assert x == y, f"block {b} differs between kernel 0 and kernel {kernel}"
         finally:
             ctx.close()
+
+
+# ---- region queries through several disjoint index windows ---------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("gap_mb", ["0", "0.05", "32"])
+def test_region_query_disjoint_index_windows(gap_mb):
+    """the chunk list of a multi-region query (hts_itr_multi_bam / reg2intervals, hts.c:3597-3739, 3299-3354) as disjoint scan windows:
+    DHTS_WINDOW_GAP_MB=0 keeps every merged chunk a window of its own, 32 (the default) merges everything in a file this small.
+    The rows must be those of the unindexed predicate -- and of the region oracle -- whatever the windows, in file order, no duplicates."""
+    import region_oracle
+    data = synth.bam_file(300000, seed=29)
+    exp = orc.bam_read(data)
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(data); ctx.bgzf_index(); ctx.bam_open()
+        bai = ctx.build_index()
+    finally:
+        ctx.close()
+    regions = ["chr1:1,000,000-1,200,000,chr5:40000000-41000000,chrX:1-3,000,000,chr1:200,000,000-201,000,000",
+               "chr2:5000000-5100000,chr2:5,050,000-5,300,000,chr20,chr3:100-200",
+               ",".join(f"chr{1 + k % 22}:{1_000_000 * (1 + 7 * k % 40)}-{1_000_000 * (1 + 7 * k % 40) + 150_000}" for k in range(60))]
+    old = os.environ.get("DHTS_WINDOW_GAP_MB")
+    os.environ["DHTS_WINDOW_GAP_MB"] = gap_mb
+    try:
+        for region in regions:
+            keep = region_oracle.keep_mask(exp, region)
+            want = [q for q, k in zip(exp["QNAME"], keep) if k]
+            for mb in (0, 5):
+                a = duckhts_amd.read_bam(data, region=region, index=bai, max_blocks=mb)
+                assert a["status"] == 1 and a["n_rows"] == len(want) and a["QNAME"] == want, (region[:40], gap_mb, mb, a["n_rows"], len(want))
+                assert list(a["POS"]) == [int(p) for p, k in zip(exp["POS"], keep) if k]
+    finally:
+        if old is None:
+            del os.environ["DHTS_WINDOW_GAP_MB"]
+        else:
+            os.environ["DHTS_WINDOW_GAP_MB"] = old

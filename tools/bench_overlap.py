@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--intervals", type=int, default=1_000_000)
     ap.add_argument("--regions", type=int, default=10_000)
     ap.add_argument("--indexed-records", type=int, default=8_000_000, help="records of the (single-segment, coordinate-sorted) file of the indexed queries")
-    ap.add_argument("--queries", default="region,overlap,both,indexed1,unindexed1")
+    ap.add_argument("--queries", default="region,overlap,both,indexed1,unindexed1,indexed10k,unindexed10k,indexed100")
     args = ap.parse_args()
     import duckhts_amd
     from duckhts_amd import synth
@@ -35,10 +35,10 @@ def main():
     tail = np.frombuffer(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"), dtype=np.uint8)
     reps = max(1, int(round(args.target_gb * 1e9 / body.nbytes)))
     n_records = n_u * reps
-    rng = np.random.default_rng(7)
     for q in args.queries.split(","):
+        rng = np.random.default_rng(7)                 # every query draws the same regions / intervals
         ctx = duckhts_amd.Context(0)
-        if q in ("indexed1", "unindexed1"):        # an index needs a coordinate-sorted file: one segment, not the tiled one
+        if q in ("indexed1", "unindexed1", "indexed10k", "unindexed10k", "indexed100"):        # an index needs a coordinate-sorted file: one segment, not the tiled one
             sorted_file = synth.bam_file(args.indexed_records, seed=42)
             ctx.open(sorted_file)
             n_q, bytes_q = args.indexed_records, len(sorted_file)
@@ -50,6 +50,17 @@ def main():
         names = [x.decode() for x in hdr["ref_names"]]
         lens = np.array(hdr["ref_len"], np.int64)
         build_s = None
+        if q in ("indexed10k", "unindexed10k", "indexed100"):
+            # BASELINE config 5: a self-built BAI and seeded regions with log-uniform widths 100 bp .. 1 Mb
+            nreg = 100 if q == "indexed100" else args.regions
+            if q != "unindexed10k":
+                t1 = time.perf_counter(); bai = ctx.build_index(); build_s = time.perf_counter() - t1
+            t = rng.choice(len(names), nreg, p=lens / lens.sum())
+            w = np.exp(rng.uniform(np.log(100), np.log(1_000_000), nreg)).astype(np.int64)
+            b = (rng.random(nreg) * np.maximum(lens[t] - w, 1)).astype(np.int64) + 1
+            ctx.set_regions(",".join(f"{names[a]}:{s}-{s + d}" for a, s, d in zip(t, b, w)))
+            if q != "unindexed10k":
+                ctx.load_index(bai)
         if q in ("indexed1", "unindexed1"):
             # one 1 Mb region; "indexed1" first builds a BAI for the file (dhts_bam_build_index) and lets it narrow the scan window
             if q == "indexed1":
@@ -69,7 +80,7 @@ def main():
             ctx.set_overlap_intervals(t, b, e)
 
         def step():
-            if q not in ("indexed1", "unindexed1"):       # (re-indexing the BGZF container would reset the index window)
+            if q in ("region", "overlap", "both"):       # (re-indexing the BGZF container would reset the index window)
                 ctx.bgzf_index()
             ctx.rewind()
             rows = pairs = 0
@@ -90,8 +101,11 @@ def main():
             rows, pairs = step()
         ctx.L.dhts_sync(ctx.h)
         dt = (time.perf_counter() - t0) / args.steps
+        import ctypes as C
+        nw, nbk = C.c_int64(0), C.c_int64(0)
+        ctx.L.dhts_scan_window_stats(C.c_void_p(ctx.h), C.byref(nw), C.byref(nbk))
         print(json.dumps({"metric": "read_bam_records_per_sec", "query": q, "value": round(n_q / dt, 1), "unit": "records/s (records scanned)",
-                          "ms_per_step": round(dt * 1e3, 2), "index_build_s": None if build_s is None else round(build_s, 2), "rows_out": int(rows), "pairs_out": int(pairs), "pairs_per_s": round(pairs / dt, 1),
+                          "ms_per_step": round(dt * 1e3, 2), "index_windows": nw.value, "blocks_scanned": nbk.value, "index_build_s": None if build_s is None else round(build_s, 2), "rows_out": int(rows), "pairs_out": int(pairs), "pairs_per_s": round(pairs / dt, 1),
                           "config": {"workload": f"read_bam {q}: synthetic {bytes_q:,} B BGZF BAM, {n_q} records, {nb} blocks; "
                                                  f"{args.regions if q != 'overlap' else 0} regions, {args.intervals if q != 'region' else 0} intervals",
                                      "inputs": "resident in HBM", "outputs": "13 core columns + pair lists in HBM"}}), flush=True)
