@@ -115,9 +115,10 @@ int register_line(BcfHeader &h, const HeaderLine &r) {
         h.ctg[idx] = *id; h.ctg_present[idx] = 1;
         return 1;
     }
-    const std::string *id = nullptr; int type = -1, var = -1, num = -1, idx = -1;
+    const std::string *id = nullptr, *desc = nullptr; int type = -1, var = -1, num = -1, idx = -1;
     for (auto &p : r.kv) {
         if (p.first == "ID") id = &p.second;
+        else if (p.first == "Description") { if (!desc) desc = &p.second; }
         else if (p.first == "IDX") { if (!parse_idx(p.second, idx)) return 0; }
         else if (p.first == "Type") {
             const std::string &v = p.second;
@@ -145,6 +146,7 @@ int register_line(BcfHeader &h, const HeaderLine &r) {
         h.ids[k].present = true; h.ids[k].key = *id;
     } else if (h.ids[k].has[hl]) return 0;
     h.ids[k].has[hl] = true; h.ids[k].type[hl] = type & 0xf; h.ids[k].vl[hl] = var & 0xf;
+    if (hl == BCF_HL_INFO && desc) h.ids[k].info_desc = *desc;
     return 1;
 }
 
@@ -176,6 +178,16 @@ bool list_after_correction(const Spec *tab, const std::string &name, int vl) {
 }
 
 int duck_of(int ht) { return ht == BCF_HT_FLAG ? DT_BOOLEAN : ht == BCF_HT_INT ? DT_INTEGER : ht == BCF_HT_REAL ? DT_FLOAT : DT_VARCHAR; }
+
+// bcftools split-vep type inference as the reference restates it (src/vep_parser.c:70-92)
+int vep_infer_type(const std::string &n) {
+    auto has = [&](const char *x) { return n.find(x) != std::string::npos; };
+    if (n == "DISTANCE" || n == "STRAND" || n == "TSL" || n == "GENE_PHENO" || n == "HGVS_OFFSET" || n.compare(0, 9, "MOTIF_POS") == 0) return BCF_HT_INT;
+    if (n == "Consequence" || n == "FLAGS" || n == "CLIN_SIG") return BCF_HT_STR;
+    if (has("_AF") || has("AF_") || has("AFR_AF") || has("AMR_AF") || has("EAS_AF") || has("EUR_AF") || has("SAS_AF") || has("MAX_AF") || has("MOTIF_SCORE_CHANGE") ||
+        n.compare(0, 17, "SpliceAI_pred_DS_") == 0) return BCF_HT_REAL;
+    return BCF_HT_STR;
+}
 
 }  // namespace
 
@@ -228,7 +240,7 @@ bool bcf_parse_header(const char *text, BcfHeader &h, std::string *err) {
             b = e + 1;
         }
     }
-    static const char *vep[] = {"CSQ", "BCSQ", "ANN", "vep", "VEP"};
+    static const char *vep[] = {"CSQ", "BCSQ", "ANN", "VEP", "vep"};
     for (const char *t : vep) { int id = h.find_id(t); if (id >= 0 && h.ids[id].has[BCF_HL_INFO]) h.has_vep_tag = true; }
     return true;
 }
@@ -245,7 +257,35 @@ void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s) {
     add("CHROM", BK_CHROM, DT_VARCHAR, false); add("POS", BK_POS, DT_BIGINT, false); add("ID", BK_ID, DT_VARCHAR, false);
     add("REF", BK_REF, DT_VARCHAR, false); add("ALT", BK_ALT, DT_VARCHAR, true); add("QUAL", BK_QUAL, DT_DOUBLE, false);
     add("FILTER", BK_FILTER, DT_VARCHAR, true);
+    // VEP / BCSQ / ANN: the first of CSQ, BCSQ, ANN, VEP, vep that is an INFO tag (vep_detect_tag, vep_parser.c:100-118); its Description
+    // carries "Format: a|b|c" up to the closing quote (parse_format_string / split_format_fields :33-68); every field becomes a
+    // VEP_<name> LIST column right behind FILTER (bcf_reader.c:582-603)
+    int vep_id = -1;
+    {
+        static const char *tags[] = {"CSQ", "BCSQ", "ANN", "VEP", "vep"};
+        for (const char *t : tags) { int id = h.find_id(t); if (id >= 0 && h.ids[id].has[BCF_HL_INFO]) { vep_id = id; s.vep_tag = t; break; } }
+        if (vep_id >= 0) {
+            const std::string &d = h.ids[vep_id].info_desc;
+            size_t f = d.find("Format: ");
+            int nf = 0;
+            if (f != std::string::npos) {
+                f += 8;
+                size_t e = d.find('"', f); if (e == std::string::npos) e = d.size();
+                nf = 1; for (size_t k = f; k < e; k++) if (d[k] == '|') nf++;
+                if (nf <= 256) {
+                    size_t st = f;
+                    for (size_t k = f;; k++) {
+                        if (k == e || d[k] == '|') { VepField vf; vf.name = d.substr(st, k - st); vf.htype = vep_infer_type(vf.name); s.vep_fields.push_back(vf); if (k == e) break; st = k + 1; }
+                    }
+                }
+            }
+            if (s.vep_fields.empty()) { vep_id = -1; s.vep_tag.clear(); }
+            for (size_t v = 0; v < s.vep_fields.size(); v++) add("VEP_" + s.vep_fields[v].name, BK_VEP, duck_of(s.vep_fields[v].htype), true, (int)v);
+        }
+    }
+    int vep_info_field = -1;
     for (size_t i = 0; i < h.ids.size(); i++) if (h.ids[i].present && h.ids[i].has[BCF_HL_INFO]) {
+        if ((int)i == vep_id) vep_info_field = (int)s.info_fields.size();
         BcfField f; f.name = h.ids[i].key; f.id = (int)i; f.htype = h.ids[i].type[BCF_HL_INFO];
         f.is_list = list_after_correction(kInfoSpec, f.name, h.ids[i].vl[BCF_HL_INFO]);
         s.info_fields.push_back(f);
@@ -266,6 +306,11 @@ void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s) {
             for (int sm = 0; sm < s.n_samples; sm++) for (size_t f = 0; f < s.format_fields.size(); f++)
                 add("FORMAT_" + s.format_fields[f].name + "_" + h.samples[sm], BK_FORMAT, duck_of(s.format_fields[f].htype), s.format_fields[f].is_list, (int)f, sm);
         }
+    }
+    if (vep_id >= 0 && vep_info_field >= 0) {
+        // hidden: the tag's whole INFO string as one VARCHAR per record (bcf_get_info_string in vep_record_parse_bcf, vep_parser.c:286-296)
+        s.vep_raw_col = (int)s.cols.size();
+        add("", BK_INFO, DT_VARCHAR, false, vep_info_field);
     }
 }
 

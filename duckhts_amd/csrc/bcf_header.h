@@ -21,6 +21,7 @@ struct BcfDictEntry {
     bool has[3] = {false, false, false};  // FILTER / INFO / FORMAT definition present
     int type[3] = {0, 0, 0};              // BCF_HT_*
     int vl[3] = {0, 0, 0};                // BCF_VL_* (only FIXED vs not matters to the schema)
+    std::string info_desc;                // Description of the INFO definition (the VEP field list lives there)
 };
 
 struct BcfHeader {
@@ -29,7 +30,7 @@ struct BcfHeader {
     std::vector<char> ctg_present;
     std::vector<std::string> samples;
     int version = 0;                      // major*1000000 + minor*1000, e.g. 4002000 (vcf.c:139-186)
-    bool has_vep_tag = false;             // CSQ / BCSQ / ANN / vep / VEP INFO tag (vep_parser.c:100-118)
+    bool has_vep_tag = false;             // CSQ / BCSQ / ANN / VEP / vep INFO tag (vep_parser.c:100-118)
     int find_id(const std::string &k) const;
 };
 
@@ -40,7 +41,10 @@ bool bcf_parse_header(const char *text, BcfHeader &h, std::string *err);
 enum { DT_BOOLEAN = 1, DT_INTEGER = 4, DT_BIGINT = 5, DT_FLOAT = 10, DT_DOUBLE = 11, DT_VARCHAR = 17 };
 
 // kinds of output column
-enum { BK_CHROM = 0, BK_POS, BK_ID, BK_REF, BK_ALT, BK_QUAL, BK_FILTER, BK_INFO, BK_SAMPLE_ID, BK_FORMAT };
+enum { BK_CHROM = 0, BK_POS, BK_ID, BK_REF, BK_ALT, BK_QUAL, BK_FILTER, BK_INFO, BK_SAMPLE_ID, BK_FORMAT,
+       BK_VEP };       // VEP_<field>: LIST per transcript, split on the host from the annotation tag's raw INFO string (field = index into vep_fields)
+
+struct VepField { std::string name; int htype = BCF_HT_STR; };
 
 struct BcfField { std::string name; int id = -1; int htype = BCF_HT_STR; bool is_list = false; };
 
@@ -60,6 +64,10 @@ struct BcfSchema {
     int n_samples = 0;
     bool gt_string_ok = false;            // header has FORMAT/GT declared String: the GT getter works (vcf.c:6183-6187)
     int gt_id = -1;                       // dictionary id of "GT" (any class), -1 if absent: updatephasing key (vcf.c:2063-2067)
+    // VEP / BCSQ / ANN annotation (src/vep_parser.c:100-182, src/bcf_reader.c:582-603): the tag, its '|'-separated fields, and the hidden
+    // column (last entry of `cols`, never shown to the engine) that carries the tag's raw INFO string to the host
+    std::string vep_tag; std::vector<VepField> vep_fields; int vep_raw_col = -1;
+    int n_visible() const { return (int)cols.size() - (vep_raw_col >= 0 ? 1 : 0); }
 };
 
 void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s);
