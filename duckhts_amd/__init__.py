@@ -59,7 +59,7 @@ class BcfInfo(C.Structure):
 
 class BcfCol(C.Structure):
     _fields_ = [("col", C.c_int32), ("reserved", C.c_int32), ("valid", C.c_void_p), ("fixed", C.c_void_p), ("off", C.c_void_p),
-                ("bytes", C.c_void_p), ("nbytes", C.c_uint64), ("child_fixed", C.c_void_p), ("child_off", C.c_void_p), ("child_n", C.c_uint64)]
+                ("bytes", C.c_void_p), ("nbytes", C.c_uint64), ("child_fixed", C.c_void_p), ("child_off", C.c_void_p), ("child_n", C.c_uint64), ("child_valid", C.c_void_p)]
 
 
 class BcfBatch(C.Structure):
@@ -69,7 +69,7 @@ class BcfBatch(C.Structure):
 
 # DUCKDB_TYPE_* element codes -> the canonical type tags of the test oracle's column blob
 _CANON_TYPE = {17: 1, 5: 2, 11: 3, 1: 4, 4: 5, 10: 6}
-ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE = 0, 1, 2, 3
+ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE, ENC_FLOAT_TEXT = 0, 1, 2, 3, 4
 
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
@@ -78,7 +78,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
-           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
+           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
 
 
 def lib():
@@ -477,7 +477,15 @@ class BcfScan:
                 c["loff"], c["llen"] = off[:-1].copy(), off[1:] - off[:-1]
                 cn = int(dc.child_n)
                 c["child_n"] = cn
-                if enc != ENC_PLAIN:
+                if dc.child_valid:
+                    c["cvalid"] = d2h(dc.child_valid, cn, np.uint8)
+                if enc == ENC_FLOAT_TEXT:                 # LIST(FLOAT) delivered as text: (float)strtod per element, NaN unless the whole text converts
+                    co = d2h(dc.child_off, cn + 1, np.uint32) if n else np.zeros(1, np.uint32)
+                    raw = d2h(dc.bytes, int(dc.nbytes), np.uint8).tobytes()
+                    cv = c.get("cvalid", np.ones(cn, np.uint8))
+                    vals = np.array([c_strtof(raw[int(co[k]):int(co[k + 1])]) if cv[k] else 0.0 for k in range(cn)], np.float32)
+                    c["cfixed"] = vals.view(np.uint32).astype(np.uint64)
+                elif enc != ENC_PLAIN:
                     ids = d2h(dc.child_fixed, cn, np.int32).astype(np.int64)
                     c["csoff"], c["csbytes"] = _gather_strings(ids, names)
                 elif sc["type"] == 17:
@@ -487,6 +495,27 @@ class BcfScan:
                     c["cfixed"] = d2h(dc.child_fixed, cn, np.uint32).astype(np.uint64)
             cols.append(c)
         return {"n_rows": n, "status": int(b.status), "cols": cols}
+
+
+def c_strtof(tok: bytes):
+    """(float)strtod(tok, &end) in the C locale: NaN unless the whole token converts (vep_parse_float, src/vep_parser.c:222-235)"""
+    global _LIBC
+    try:
+        _LIBC
+    except NameError:
+        _LIBC = C.CDLL(None)
+        _LIBC.strtod.restype = C.c_double
+        _LIBC.strtod.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+    if not tok or b"\0" in tok:
+        return float("nan")
+    buf = C.create_string_buffer(tok)
+    end = C.c_char_p()
+    v = _LIBC.strtod(buf, C.byref(end))
+    consumed = C.cast(end, C.c_void_p).value - C.addressof(buf)
+    if consumed != len(tok):
+        return float("nan")
+    with np.errstate(over="ignore"):
+        return float(np.float32(v))
 
 
 def _concat_tables(parts, schema_cols):
@@ -515,6 +544,8 @@ def _concat_tables(parts, schema_cols):
                 lo.append(x["loff"] + np.uint64(base))
                 base += x["child_n"]
             c["loff"], c["llen"], c["child_n"] = np.concatenate(lo), np.concatenate([x["llen"] for x in cs]), base
+            if "cvalid" in cs[0]:
+                c["cvalid"] = np.concatenate([x["cvalid"] for x in cs])
             if "cfixed" in cs[0]:
                 c["cfixed"] = np.concatenate([x["cfixed"] for x in cs])
             else:

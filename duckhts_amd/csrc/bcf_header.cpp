@@ -280,12 +280,11 @@ void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s) {
                 }
             }
             if (s.vep_fields.empty()) { vep_id = -1; s.vep_tag.clear(); }
-            for (size_t v = 0; v < s.vep_fields.size(); v++) add("VEP_" + s.vep_fields[v].name, BK_VEP, duck_of(s.vep_fields[v].htype), true, (int)v);
+            for (size_t v = 0; v < s.vep_fields.size(); v++) add(("VEP_" + s.vep_fields[v].name).substr(0, 255), BK_VEP, duck_of(s.vep_fields[v].htype), true, (int)v);
         }
     }
-    int vep_info_field = -1;
     for (size_t i = 0; i < h.ids.size(); i++) if (h.ids[i].present && h.ids[i].has[BCF_HL_INFO]) {
-        if ((int)i == vep_id) vep_info_field = (int)s.info_fields.size();
+        if ((int)i == vep_id) s.vep_info_field = (int)s.info_fields.size();
         BcfField f; f.name = h.ids[i].key; f.id = (int)i; f.htype = h.ids[i].type[BCF_HL_INFO];
         f.is_list = list_after_correction(kInfoSpec, f.name, h.ids[i].vl[BCF_HL_INFO]);
         s.info_fields.push_back(f);
@@ -306,11 +305,6 @@ void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s) {
             for (int sm = 0; sm < s.n_samples; sm++) for (size_t f = 0; f < s.format_fields.size(); f++)
                 add("FORMAT_" + s.format_fields[f].name + "_" + h.samples[sm], BK_FORMAT, duck_of(s.format_fields[f].htype), s.format_fields[f].is_list, (int)f, sm);
         }
-    }
-    if (vep_id >= 0 && vep_info_field >= 0) {
-        // hidden: the tag's whole INFO string as one VARCHAR per record (bcf_get_info_string in vep_record_parse_bcf, vep_parser.c:286-296)
-        s.vep_raw_col = (int)s.cols.size();
-        add("", BK_INFO, DT_VARCHAR, false, vep_info_field);
     }
 }
 

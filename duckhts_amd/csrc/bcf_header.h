@@ -42,7 +42,7 @@ enum { DT_BOOLEAN = 1, DT_INTEGER = 4, DT_BIGINT = 5, DT_FLOAT = 10, DT_DOUBLE =
 
 // kinds of output column
 enum { BK_CHROM = 0, BK_POS, BK_ID, BK_REF, BK_ALT, BK_QUAL, BK_FILTER, BK_INFO, BK_SAMPLE_ID, BK_FORMAT,
-       BK_VEP };       // VEP_<field>: LIST per transcript, split on the host from the annotation tag's raw INFO string (field = index into vep_fields)
+       BK_VEP };       // VEP_<field>: LIST per transcript out of the annotation tag's INFO string (field = index of the field inside a transcript)
 
 struct VepField { std::string name; int htype = BCF_HT_STR; };
 
@@ -64,10 +64,9 @@ struct BcfSchema {
     int n_samples = 0;
     bool gt_string_ok = false;            // header has FORMAT/GT declared String: the GT getter works (vcf.c:6183-6187)
     int gt_id = -1;                       // dictionary id of "GT" (any class), -1 if absent: updatephasing key (vcf.c:2063-2067)
-    // VEP / BCSQ / ANN annotation (src/vep_parser.c:100-182, src/bcf_reader.c:582-603): the tag, its '|'-separated fields, and the hidden
-    // column (last entry of `cols`, never shown to the engine) that carries the tag's raw INFO string to the host
-    std::string vep_tag; std::vector<VepField> vep_fields; int vep_raw_col = -1;
-    int n_visible() const { return (int)cols.size() - (vep_raw_col >= 0 ? 1 : 0); }
+    // VEP / BCSQ / ANN annotation (src/vep_parser.c:100-182, src/bcf_reader.c:582-603): the tag, its '|'-separated fields, and the
+    // entry of info_fields that is the tag itself (the cells kernel reads the tag's INFO string through that slot)
+    std::string vep_tag; std::vector<VepField> vep_fields; int vep_info_field = -1;
 };
 
 void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s);

@@ -281,7 +281,7 @@ bcf_rec_check(BcfStream st, const uint32_t *rec_off, int64_t nrec, uint32_t *dir
 }
 
 // ---- cells -------------------------------------------------------------------------------------------------------------------
-enum { BK_CHROM = 0, BK_POS, BK_ID, BK_REF, BK_ALT, BK_QUAL, BK_FILTER, BK_INFO, BK_SAMPLE_ID, BK_FORMAT };
+enum { BK_CHROM = 0, BK_POS, BK_ID, BK_REF, BK_ALT, BK_QUAL, BK_FILTER, BK_INFO, BK_SAMPLE_ID, BK_FORMAT, BK_VEP };
 enum { BF_NULL_ALWAYS = 1, BF_GT = 2, BF_GT_FIX = 4 };
 
 struct BcfColDev {
@@ -292,6 +292,8 @@ struct BcfColDev {
     uint8_t *bytes;               // VARCHAR bytes (scalar) or child bytes (list of VARCHAR)
     uint32_t *child_off;          // list of VARCHAR: child_n + 1 byte offsets
     uint32_t *child_fixed;        // list of 4-byte words (INTEGER, FLOAT bits, dictionary ids)
+    uint8_t *child_valid;         // BK_VEP: one byte per child, 0 = NULL element (a missing field of a transcript)
+    int32_t vep_field, pad_;      // BK_VEP: index of the field inside a transcript
 };
 
 struct BcfCellArgs {
@@ -361,6 +363,7 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
         cnt++; nbytes += l;
     };
     auto put_child_w = [&](uint32_t w) { if (WRITE) cd.child_fixed[cbase + cnt] = w; cnt++; };
+    auto c_isspace = [](uint8_t ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };
     const uint8_t dot = '.';
 
     switch (cd.kind) {
@@ -395,6 +398,52 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
             uint64_t p = o + a.dir[(size_t)a.stride + rec]; int n, t; bcf_dec_size(u, p, n, t);
             if (n <= 0) put_child_w(0xffffffffu);                              // no filters => literal "PASS" (bcf_reader.c:1443-1447)
             else for (int i = 0; i < n; i++) put_child_w((uint32_t)(t == 1 ? (int32_t)(int8_t)u[p + i] : t == 2 ? b_i16(u + p + 2 * i) : (int32_t)ldu32(u + p + 4 * i)));
+        } break;
+    case BK_VEP: {
+            // One field of every transcript of the annotation tag (CSQ / BCSQ / ANN / ...).  vep_record_parse_bcf (src/vep_parser.c:317-326)
+            // takes the tag through bcf_get_info_string -- nothing unless the tag is declared String, present and non-empty (vcf.c:6056-6081);
+            // vep_record_parse (:286-315) walks the non-empty ','-separated pieces (strtok_r), parse_single_transcript (:243-284) the
+            // '|'-separated fields of a piece: white space trimmed, "" and "." missing; a record without any transcript is a NULL row
+            // and so, in tidy mode, is every sample row of a record but the first (src/bcf_reader.c:1370-1373, 1463-1541).
+            const uint32_t d = a.dir[(size_t)(2 + cd.slot) * a.stride + rec];
+            if ((cd.flags & BF_NULL_ALWAYS) || (a.tidy && row % a.n_smp != 0) || !d) { valid = false; break; }
+            uint64_t p = o + d; int n, t; bcf_dec_size(u, p, n, t);
+            if (n <= 0) { valid = false; break; }
+            const uint32_t l = cstr_len(u + p, (uint32_t)n);
+            const uint8_t *s = u + p;
+            uint32_t i = 0;
+            while (i < l) {
+                if (s[i] == ',') { i++; continue; }
+                uint32_t e = i; while (e < l && s[e] != ',') e++;              // transcript = s[i, e)
+                uint32_t f0 = i; bool have = true;
+                for (int k = 0; k < cd.vep_field; k++) {                       // skip to the field; fewer fields than asked for = missing
+                    while (f0 < e && s[f0] != '|') f0++;
+                    if (f0 >= e) { have = false; break; }
+                    f0++;
+                }
+                uint32_t f1 = f0;
+                if (have) { while (f1 < e && s[f1] != '|') f1++; while (f0 < f1 && c_isspace(s[f0])) f0++; while (f1 > f0 + 1 && c_isspace(s[f1 - 1])) f1--; }
+                const uint32_t tl = have ? f1 - f0 : 0;
+                const bool miss = tl == 0 || (tl == 1 && s[f0] == '.');
+                if (WRITE) cd.child_valid[cbase + cnt] = miss ? 0 : 1;
+                if (cd.htype == 1) {                                           // Integer: (int32_t)strtol(token, &end, 10), INT32_MIN unless the whole token is a number (vep_parse_int :207-220)
+                    uint32_t w = 0;
+                    if (!miss) {
+                        uint32_t q = f0; const bool neg = s[q] == '-'; if (s[q] == '-' || s[q] == '+') q++;
+                        uint64_t acc = 0; bool sat = false, ok = q < f1;
+                        for (; q < f1; q++) {
+                            const uint32_t dg = (uint32_t)s[q] - '0'; if (dg > 9) { ok = false; break; }
+                            if (acc > (0x7fffffffffffffffull - dg) / 10) sat = true; else acc = acc * 10 + dg;
+                        }
+                        if (!ok) w = 0x80000000u;
+                        else if (sat || (neg ? acc > 0x8000000000000000ull : acc > 0x7fffffffffffffffull)) w = neg ? 0u : 0xffffffffu;   // LONG_MIN / LONG_MAX, truncated
+                        else w = (uint32_t)(neg ? (uint64_t)0 - acc : acc);
+                    }
+                    put_child_w(w);
+                } else put_child_str(s + f0, miss ? 0 : tl);                   // String; Float travels as its text (DHTS_ENC_FLOAT_TEXT)
+                i = e;
+            }
+            if (cnt == 0) valid = false;
         } break;
     case BK_INFO: {
             const uint32_t d = a.dir[(size_t)(2 + cd.slot) * a.stride + rec];

@@ -327,6 +327,14 @@ extern "C" void dhts_release_pools(void) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pin.size();) { if (!g_pin[i].busy) { (void)hipHostFree(g_pin[i].p); g_pin.erase(g_pin.begin() + i); } else i++; }
 }
+// free / total HBM of a device as the driver reports it (what the leak tests and the pool sizing look at)
+extern "C" int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return -1;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
 extern "C" void dhts_host_free(void *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pin_mu);
@@ -1918,7 +1926,6 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
         if (!dhts::bcf_parse_header(text.c_str(), c->bh, &perr)) return fail(c, "Failed to read BCF/VCF header");
         break;
     }
-    if (c->bh.has_vep_tag) return fail(c, "read_bcf: VEP/CSQ annotation columns are not supported by this build");
     dhts::bcf_build_schema(c->bh, tidy_format != 0, c->bsch);
     c->bcf_tidy_req = tidy_format != 0;
     c->first_rec_uoff = text_end; c->scan_first_uoff = text_end;
@@ -1926,7 +1933,8 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
     c->bcf_colinfo.clear(); c->bcf_ctg_p.clear(); c->bcf_dict_p.clear(); c->bcf_smp_p.clear();
     for (auto &col : c->bsch.cols) {
         dhts_bcf_colinfo ci; ci.name = col.name.c_str(); ci.type = col.duck_type; ci.is_list = col.is_list ? 1 : 0; ci.reserved = 0;
-        ci.encoding = col.kind == dhts::BK_CHROM ? DHTS_ENC_CONTIG : col.kind == dhts::BK_FILTER ? DHTS_ENC_DICT : col.kind == dhts::BK_SAMPLE_ID ? DHTS_ENC_SAMPLE : DHTS_ENC_PLAIN;
+        ci.encoding = col.kind == dhts::BK_CHROM ? DHTS_ENC_CONTIG : col.kind == dhts::BK_FILTER ? DHTS_ENC_DICT : col.kind == dhts::BK_SAMPLE_ID ? DHTS_ENC_SAMPLE :
+                      (col.kind == dhts::BK_VEP && col.duck_type == dhts::DT_FLOAT) ? DHTS_ENC_FLOAT_TEXT : DHTS_ENC_PLAIN;
         c->bcf_colinfo.push_back(ci);
     }
     for (size_t i = 0; i < c->bh.ctg.size(); i++) c->bcf_ctg_p.push_back(c->bh.ctg_present[i] ? c->bh.ctg[i].c_str() : nullptr);
@@ -2141,6 +2149,10 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                 BcfColDev &d = cd[i]; memset(&d, 0, sizeof(d));
                 d.kind = col.kind; d.is_list = col.is_list ? 1 : 0; d.sample = col.sample; d.slot = col.field < 0 ? 0 : col.field; d.flags = 0; d.sa_cnt = d.sa_bytes = -1;
                 if (col.kind == dhts::BK_INFO) d.htype = c->bsch.info_fields[col.field].htype;
+                if (col.kind == dhts::BK_VEP) {                                                      // one field of every transcript of the annotation tag
+                    d.slot = c->bsch.vep_info_field; d.vep_field = col.field; d.htype = c->bsch.vep_fields[col.field].htype;
+                    if (c->bsch.info_fields[c->bsch.vep_info_field].htype != dhts::BCF_HT_STR) d.flags |= BF_NULL_ALWAYS;   // bcf_get_info_string's type check (vcf.c:6056-6066)
+                }
                 if (col.kind == dhts::BK_FORMAT) {
                     const dhts::BcfField &f = c->bsch.format_fields[col.field];
                     d.htype = f.htype;
@@ -2149,7 +2161,8 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                     else if (f.htype == dhts::BCF_HT_STR && f.is_list) d.flags |= BF_NULL_ALWAYS;       // LIST(VARCHAR) FORMAT strings: undefined in the reference, NULL here
                     if (f.name == "GT" && f.htype != dhts::BCF_HT_STR) d.flags |= BF_NULL_ALWAYS;      // getter type check vcf.c:6183-6187
                 }
-                const bool varchar = col.duck_type == dhts::DT_VARCHAR && col.kind != dhts::BK_CHROM && col.kind != dhts::BK_SAMPLE_ID && col.kind != dhts::BK_FILTER;
+                const bool varchar = (col.duck_type == dhts::DT_VARCHAR && col.kind != dhts::BK_CHROM && col.kind != dhts::BK_SAMPLE_ID && col.kind != dhts::BK_FILTER) ||
+                                     (col.kind == dhts::BK_VEP && col.duck_type == dhts::DT_FLOAT);      // Float fields of a transcript travel as text (DHTS_ENC_FLOAT_TEXT)
                 if (col.is_list) { d.sa_cnt = nsa++; if (varchar) d.sa_bytes = nsa++; }
                 else if (varchar) d.sa_bytes = nsa++;
                 const size_t w = fixed_width(col);
@@ -2187,8 +2200,9 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 for (int k = 0; k < nsa; k++) if (tot[k] >= (1ull << 32)) return fail(c, "read_bcf: a column exceeds 4 GiB in one batch; use a smaller max_blocks");
                 // arena for children / bytes
-                size_t var_bytes = 0; std::vector<size_t> at_child(ncols, 0), at_coff(ncols, 0), at_bytes(ncols, 0);
+                size_t var_bytes = 0; std::vector<size_t> at_child(ncols, 0), at_coff(ncols, 0), at_bytes(ncols, 0), at_cvalid(ncols, 0);
                 for (int i = 0; i < ncols; i++) {
+                    if (cd[i].kind == dhts::BK_VEP) { at_cvalid[i] = var_bytes; var_bytes += (tot[cd[i].sa_cnt] + 63) & ~(size_t)63; }
                     if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes < 0) { at_child[i] = var_bytes; var_bytes += (tot[cd[i].sa_cnt] * 4 + 63) & ~(size_t)63; }
                     if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes >= 0) { at_coff[i] = var_bytes; var_bytes += ((tot[cd[i].sa_cnt] + 1) * 4 + 63) & ~(size_t)63; }
                     if (cd[i].sa_bytes >= 0) { at_bytes[i] = var_bytes; var_bytes += (tot[cd[i].sa_bytes] + 63) & ~(size_t)63; }
@@ -2199,6 +2213,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                     if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes < 0) cd[i].child_fixed = (uint32_t *)(base + at_child[i]);
                     if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes >= 0) cd[i].child_off = (uint32_t *)(base + at_coff[i]);
                     if (cd[i].sa_bytes >= 0) cd[i].bytes = base + at_bytes[i];
+                    if (cd[i].kind == dhts::BK_VEP) cd[i].child_valid = base + at_cvalid[i];
                 }
                 HIPCHK(c, hipMemcpyAsync(c->b_coldev.p, cd.data(), sizeof(BcfColDev) * ncols, hipMemcpyHostToDevice, c->stream));
                 {
@@ -2210,7 +2225,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
             for (int i = 0; i < ncols; i++) {
                 dhts_bcf_col &o = c->bcf_out[i];
                 o.valid = cd[i].valid; o.fixed = cd[i].fixed;
-                if (cd[i].sa_cnt >= 0) { o.off = (const uint32_t *)c->b_offs.p + (size_t)cd[i].sa_cnt * ostride; o.child_n = tot[cd[i].sa_cnt]; o.child_fixed = cd[i].child_fixed; o.child_off = cd[i].child_off; }
+                if (cd[i].sa_cnt >= 0) { o.off = (const uint32_t *)c->b_offs.p + (size_t)cd[i].sa_cnt * ostride; o.child_n = tot[cd[i].sa_cnt]; o.child_fixed = cd[i].child_fixed; o.child_off = cd[i].child_off; o.child_valid = cd[i].child_valid; }
                 else if (cd[i].sa_bytes >= 0) o.off = (const uint32_t *)c->b_offs.p + (size_t)cd[i].sa_bytes * ostride;
                 if (cd[i].sa_bytes >= 0) { o.bytes = cd[i].bytes; o.nbytes = tot[cd[i].sa_bytes]; }
             }

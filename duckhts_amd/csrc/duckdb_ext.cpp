@@ -28,6 +28,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <vector>
@@ -641,7 +642,7 @@ struct BcfBind {
 };
 struct HostCol {
     int col = 0;
-    std::vector<uint8_t> valid, fixed, bytes;
+    std::vector<uint8_t> valid, fixed, bytes, child_valid;      // child_valid empty = every element valid
     std::vector<uint32_t> off, child_off, child_fixed;
     uint64_t child_n = 0;
 };
@@ -702,8 +703,7 @@ static void bcf_read_bind(duckdb_bind_info info) {
         set_error(info, err); destroy_bcf_bind(b); return;
     }
     if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bcf_open(b->ctx, tidy) != 0 || dhts_bcf_info_get(b->ctx, &b->inf) != 0) {
-        const char *m = dhts_error(b->ctx);
-        set_error(info, (m && strstr(m, "VEP")) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505
+        set_error(info, "Failed to read BCF/VCF header");       // bcf_reader.c:505
         destroy_bcf_bind(b); return;
     }
     for (const std::string &f : {idx, b->path + ".csi", b->path + ".tbi"}) if (!f.empty() && file_exists(f)) { b->index_file = f; break; }
@@ -788,6 +788,20 @@ static int bcf_next_host_batch(BcfBind *bind, BcfLocal *l) {
         h.child_n = d.child_n;
         if (d.child_fixed) { h.child_fixed.resize(d.child_n + 1); if (dhts_memcpy_d2h(c, h.child_fixed.data(), d.child_fixed, d.child_n * 4)) return -1; }
         if (d.child_off) { h.child_off.resize(d.child_n + 1); if (dhts_memcpy_d2h(c, h.child_off.data(), d.child_off, (d.child_n + 1) * 4)) return -1; }
+        h.child_valid.clear();
+        if (d.child_valid && d.child_n) { h.child_valid.resize(d.child_n); if (dhts_memcpy_d2h(c, h.child_valid.data(), d.child_valid, d.child_n)) return -1; }
+        if (ci.encoding == DHTS_ENC_FLOAT_TEXT) {
+            // Float fields of a transcript arrive as text: (float)strtod, NaN unless the whole token converts (vep_parse_float, src/vep_parser.c:222-235)
+            h.child_fixed.assign(d.child_n + 1, 0);
+            std::string tok;
+            for (uint64_t k = 0; k < d.child_n; k++) {
+                if (!h.child_valid.empty() && !h.child_valid[k]) continue;
+                tok.assign((const char *)h.bytes.data() + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
+                char *end = nullptr; const double v = strtod(tok.c_str(), &end);
+                const float f = (end == tok.c_str() || *end) ? NAN : (float)v;
+                memcpy(&h.child_fixed[k], &f, 4);
+            }
+        }
     }
     return 0;
 }
@@ -855,8 +869,18 @@ static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk outpu
             }
             if (c1 > c0) {
                 if (names) for (uint32_t k = c0; k < c1; k++) { const char *nm = name_of((int32_t)h.child_fixed[k]); assign_len(child, base + (k - c0), nm, strlen(nm)); }
-                else if (inf.type == DHTS_T_VARCHAR) for (uint32_t k = c0; k < c1; k++) assign_len(child, base + (k - c0), (const char *)h.bytes.data() + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
-                else memcpy((uint32_t *)get_data(child) + base, h.child_fixed.data() + c0, (size_t)(c1 - c0) * 4);
+                else if (inf.type == DHTS_T_VARCHAR) {
+                    for (uint32_t k = c0; k < c1; k++)
+                        if (h.child_valid.empty() || h.child_valid[k]) assign_len(child, base + (k - c0), (const char *)h.bytes.data() + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
+                } else memcpy((uint32_t *)get_data(child) + base, h.child_fixed.data() + c0, (size_t)(c1 - c0) * 4);
+                if (!h.child_valid.empty()) {                       // NULL elements: a field the transcript does not have (bcf_reader.c:1485-1530)
+                    API(void, duckdb_vector_ensure_validity_writable, duckdb_vector)(child);
+                    uint64_t *cv = API(uint64_t *, duckdb_vector_get_validity, duckdb_vector)(child);
+                    for (uint32_t k = c0; k < c1; k++) {
+                        const idx_t at = base + (k - c0);
+                        if (h.child_valid[k]) cv[at / 64] |= (uint64_t)1 << (at % 64); else cv[at / 64] &= ~((uint64_t)1 << (at % 64));
+                    }
+                }
             }
         }
         row_count += take; l->cur += (int64_t)take;

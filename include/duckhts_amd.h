@@ -66,6 +66,7 @@ typedef struct dhts_col {
     const uint32_t *off;
     const uint8_t *bytes; uint64_t nbytes;
     const uint32_t *child_fixed; const uint32_t *child_off; uint64_t child_n;
+    const uint8_t *child_valid; /* child_n bytes, 0 = NULL element; NULL pointer = every element valid (only VEP_* columns have NULL elements) */
 } dhts_col;
 typedef dhts_col dhts_bcf_col;
 
@@ -219,7 +220,8 @@ int dhts_bam_next_batch(dhts_ctx *, int64_t max_blocks, uint32_t colmask, dhts_b
  *   dhts_bcf_next_batch             <- the loop body of bcf_read_function src/bcf_reader.c:1155-2049 over bcf_read
  *                                      vcf.c:2255-2265 (bcf_read1_core 1874-1911, bcf_record_check 2040-2212),
  *                                      bcf_unpack 4234-4302 and the bcf_get_info_* / bcf_get_format_* getters 6056-6248
- * Sequential (no index) mode; VEP_* columns are not produced: dhts_bcf_open fails on headers that would add them. */
+ * VEP_* columns (a CSQ / BCSQ / ANN / VEP / vep INFO tag in the header, src/vep_parser.c:100-182, src/bcf_reader.c:582-603,
+ * 1463-1541): LIST columns with one element per transcript and NULL elements (dhts_bcf_col.child_valid) for missing fields. */
 
 /* element types of a read_bcf column (values of DUCKDB_TYPE_* in duckdb.h) */
 enum { DHTS_T_BOOLEAN = 1, DHTS_T_INTEGER = 4, DHTS_T_BIGINT = 5, DHTS_T_FLOAT = 10, DHTS_T_DOUBLE = 11, DHTS_T_VARCHAR = 17 };
@@ -227,7 +229,11 @@ enum { DHTS_T_BOOLEAN = 1, DHTS_T_INTEGER = 4, DHTS_T_BIGINT = 5, DHTS_T_FLOAT =
 enum { DHTS_ENC_PLAIN = 0,      /* payload is the value itself                                              */
        DHTS_ENC_CONTIG = 1,     /* int32 contig id   -> dhts_bcf_info.contig_name[id]   (CHROM)               */
        DHTS_ENC_DICT = 2,       /* int32 dictionary id -> dhts_bcf_info.dict_name[id], -1 = "PASS" (FILTER)    */
-       DHTS_ENC_SAMPLE = 3 };   /* int32 sample index -> dhts_bcf_info.sample_name[i]   (SAMPLE_ID)           */
+       DHTS_ENC_SAMPLE = 3,     /* int32 sample index -> dhts_bcf_info.sample_name[i]   (SAMPLE_ID)           */
+       DHTS_ENC_FLOAT_TEXT = 4 };/* LIST(FLOAT) whose elements arrive as their decimal TEXT (child_off / bytes, like a LIST(VARCHAR)):
+                                   the consumer converts every non-NULL element with (float)strtod(text, &end), NaN unless the whole
+                                   text converts (vep_parse_float src/vep_parser.c:222-235).  Used by the Float fields of VEP_* columns;
+                                   host text conversion, like the %g of AUXILIARY_TAGS. */
 
 typedef struct {
     const char *name;        /* result column name, as duckdb_bind_add_result_column receives it           */
@@ -277,6 +283,7 @@ void dhts_host_free(void *p);
 /* Device buffers of destroyed contexts and freed pinned buffers are kept in process-wide pools (a context per query would otherwise pay
  * hipMalloc / hipHostMalloc of gigabytes each time); this returns every idle pooled buffer to the driver. */
 void dhts_release_pools(void);
+int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);   /* hipMemGetInfo after a device synchronise */
 uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
 int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);
 

@@ -11,14 +11,16 @@
  *   writers     src/bcf_reader.c:1381-1982 (core, INFO, FORMAT wide/tidy, GT text)
  *
  * Mode restated: sequential scan (no index), i.e. every record in file order until EOF or the first bad record
- * (bcf_reader.c:1319-1349: ret < 0 ends the scan silently).  VEP_* columns (a CSQ/BCSQ/ANN/vep INFO tag in the
- * header) are outside this round's scope: orc_bcf_read returns ORC_BCF_EVEP for such files.
+ * (bcf_reader.c:1319-1349: ret < 0 ends the scan silently).
+ *   VEP_*       src/vep_parser.c:33-182 (tag detection, "Format: a|b|c" field list, type inference), 207-326 (record parse),
+ *               src/bcf_reader.c:582-603 (columns behind FILTER), 1370-1373 + 1463-1541 (LIST per transcript, NULL elements)
  *
  * Parity pinning: tests/golden/vcf_file.bcf against its upstream text form vcf_file.vcf and the expectations of
  * test/sql/duckhts.test:28-84 (see tests/test_oracle_bcf.py).
  */
 #include "dhts_oracle.h"
 #include <ctype.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,7 +33,7 @@ enum { HL_FLT = 0, HL_INFO, HL_FMT, HL_CTG, HL_STR, HL_GEN };
 enum { HT_FLAG = 0, HT_INT, HT_REAL, HT_STR };
 enum { VL_FIXED = 0, VL_VAR, VL_A, VL_G, VL_R, VL_P, VL_LA, VL_LG, VL_LR, VL_M };
 
-typedef struct { char *key; int has[3]; int type[3]; int vl[3]; } dict_ent;      /* key == NULL: hole */
+typedef struct { char *key; int has[3]; int type[3]; int vl[3]; char *info_desc; } dict_ent;      /* key == NULL: hole; info_desc: Description of the INFO line */
 typedef struct {
     dict_ent *ids; int n_ids;
     char **ctg; int n_ctg;
@@ -225,12 +227,13 @@ static int register_hrec(hdr_t *h, const hrec_t *r)
         if (set_idx_id(h, idx, name, &k) < 0) { free(name); return -1; }
     } else if (h->ids[k].has[hl]) return 0;
     h->ids[k].has[hl] = 1; h->ids[k].type[hl] = type & 0xf; h->ids[k].vl[hl] = var & 0xf;
+    if (hl == HL_INFO) for (int i = 0; i < r->nkeys; i++) if (!strcmp(r->keys[i], "Description")) { h->ids[k].info_desc = strdup(r->vals[i]); break; }   /* what vep_schema_parse reads off the hrec */
     return 1;
 }
 
 static void hdr_free(hdr_t *h)
 {
-    for (int i = 0; i < h->n_ids; i++) free(h->ids[i].key);
+    for (int i = 0; i < h->n_ids; i++) { free(h->ids[i].key); free(h->ids[i].info_desc); }
     for (int i = 0; i < h->n_ctg; i++) free(h->ctg[i]);
     for (int i = 0; i < h->n_smp; i++) free(h->smp[i]);
     free(h->ids); free(h->ctg); free(h->smp);
@@ -378,7 +381,17 @@ static int elem_word(const uint8_t *p, int type, int j, uint32_t *w, int *is_end
 /* ------------------------------------------------------------------ the scan ------------------------------------ */
 #define ORC_BCF_EOPEN (-100)
 #define ORC_BCF_EHDR (-101)
-#define ORC_BCF_EVEP (-102)
+
+/* ---- VEP / CSQ / BCSQ / ANN (src/vep_parser.c) ---- */
+typedef struct { char *name; int htype; } vepf_t;
+static int vep_infer(const char *n)                                            /* vep_infer_type :70-90 */
+{
+    if (!strcmp(n, "DISTANCE") || !strcmp(n, "STRAND") || !strcmp(n, "TSL") || !strcmp(n, "GENE_PHENO") || !strcmp(n, "HGVS_OFFSET") ||
+        strstr(n, "MOTIF_POS") == n) return HT_INT;
+    if (!strcmp(n, "Consequence") || !strcmp(n, "FLAGS") || !strcmp(n, "CLIN_SIG")) return HT_STR;
+    if (strstr(n, "_AF") || strstr(n, "AF_") || strstr(n, "MOTIF_SCORE_CHANGE") || strstr(n, "SpliceAI_pred_DS_") == n) return HT_REAL;   /* (the *_AF names of :82-84 all contain "_AF") */
+    return HT_STR;
+}
 
 typedef struct {
     hdr_t h;
@@ -386,6 +399,7 @@ typedef struct {
     field_t *info, *fmt;
     col_t *col;
     int c_info0, c_sample, c_fmt0;
+    int n_vep, vep_id; vepf_t *vep;           /* VEP_* columns sit at 7 .. 7 + n_vep - 1; vep_id = dictionary id of the tag */
     int gt_id;
     int64_t n_rows, n_recs;
     buf_t rec_rid, rec_pos, rec_rlen;      /* per emitted record: contig id, 0-based pos, rlen (region-oracle inputs) */
@@ -397,7 +411,8 @@ static void scan_free(scan_t *s)
     free(s->col);
     for (int i = 0; i < s->n_info; i++) free(s->info[i].name);
     for (int i = 0; i < s->n_fmt; i++) free(s->fmt[i].name);
-    free(s->info); free(s->fmt);
+    for (int i = 0; i < s->n_vep; i++) free(s->vep[i].name);
+    free(s->info); free(s->fmt); free(s->vep);
     free(s->rec_rid.p); free(s->rec_pos.p); free(s->rec_rlen.p);
     hdr_free(&s->h);
 }
@@ -405,8 +420,29 @@ static void scan_free(scan_t *s)
 static int build_schema(scan_t *s)
 {
     hdr_t *h = &s->h;
-    static const char *veptags[] = { "CSQ", "BCSQ", "ANN", "vep", "VEP", NULL };
-    for (int i = 0; veptags[i]; i++) { int id = dict_find(h, veptags[i]); if (id >= 0 && h->ids[id].has[HL_INFO]) return ORC_BCF_EVEP; }
+    /* vep_detect_tag :102-119 (first of CSQ, BCSQ, ANN, VEP, vep that is an INFO tag) + vep_schema_parse :125-182 */
+    static const char *veptags[] = { "CSQ", "BCSQ", "ANN", "VEP", "vep", NULL };
+    s->vep_id = -1;
+    for (int i = 0; veptags[i]; i++) { int id = dict_find(h, veptags[i]); if (id >= 0 && h->ids[id].has[HL_INFO]) { s->vep_id = id; break; } }
+    if (s->vep_id >= 0) {
+        const char *desc = h->ids[s->vep_id].info_desc, *fmt = desc ? strstr(desc, "Format: ") : NULL;
+        int nf = 0;
+        if (fmt) {                                                             /* parse_format_string :33-45 */
+            fmt += 8;
+            const char *end = strchr(fmt, '"'); if (!end) end = fmt + strlen(fmt);
+            nf = 1; for (const char *q = fmt; q < end; q++) if (*q == '|') nf++;
+        }
+        if (!fmt || nf > 256) s->vep_id = -1;
+        else {                                                                 /* split_format_fields :47-68 */
+            s->vep = (vepf_t *)calloc((size_t)nf, sizeof(vepf_t));
+            const char *st = fmt;
+            for (const char *q = fmt;; q++) if (*q == '|' || *q == 0 || *q == '"') {
+                s->vep[s->n_vep].name = dupn(st, (size_t)(q - st)); s->vep[s->n_vep].htype = vep_infer(s->vep[s->n_vep].name); s->n_vep++;
+                if (*q == 0 || *q == '"') break;
+                st = q + 1;
+            }
+        }
+    }
     for (int i = 0; i < h->n_ids; i++) if (h->ids[i].key && h->ids[i].has[HL_INFO]) s->n_info++;
     s->info = (field_t *)calloc((size_t)s->n_info + 1, sizeof(field_t));
     for (int i = 0, k = 0; i < h->n_ids; i++) if (h->ids[i].key && h->ids[i].has[HL_INFO]) {
@@ -430,12 +466,16 @@ static int build_schema(scan_t *s)
         }
     }
     int nf = h->n_smp > 0 ? (s->tidy ? 1 + s->n_fmt : h->n_smp * s->n_fmt) : 0;
-    s->ncol = 7 + s->n_info + nf;
+    s->ncol = 7 + s->n_vep + s->n_info + nf;
     s->col = (col_t *)calloc((size_t)s->ncol, sizeof(col_t));
     col_init(&s->col[0], "CHROM", T_VARCHAR, 0); col_init(&s->col[1], "POS", T_BIGINT, 0); col_init(&s->col[2], "ID", T_VARCHAR, 0);
     col_init(&s->col[3], "REF", T_VARCHAR, 0); col_init(&s->col[4], "ALT", T_VARCHAR, 1); col_init(&s->col[5], "QUAL", T_DOUBLE, 0);
     col_init(&s->col[6], "FILTER", T_VARCHAR, 1);
     int c = 7; char nm[640];
+    for (int v = 0; v < s->n_vep; v++) {                                       /* bcf_reader.c:587-600: char col_name[256] */
+        snprintf(nm, 256, "VEP_%s", s->vep[v].name);
+        col_init(&s->col[c], nm, duck_type(s->vep[v].htype), 1); s->col[c].has_cvalid = 1; c++;
+    }
     s->c_info0 = c;
     for (int i = 0; i < s->n_info; i++) { snprintf(nm, sizeof nm, "INFO_%s", s->info[i].name); col_init(&s->col[c++], nm, duck_type(s->info[i].htype), s->info[i].is_list); }
     s->c_sample = -1; s->c_fmt0 = c;
@@ -517,6 +557,64 @@ static void emit_format(scan_t *s, col_t *c, const field_t *f, const ent_t *e, i
     if (!e || f->is_list) { col_null(c); return; }
     const uint8_t *p = e->p + (size_t)smp * (size_t)e->n;
     col_str(c, p, e->n > 0 ? char_len(p, e->n) : 0);
+}
+
+/* One record's VEP_* cells.  vep_record_parse_bcf :317-326 (bcf_get_info_string: the tag must be declared String, present, len > 0),
+ * vep_record_parse :286-315 (strtok_r on ','), parse_single_transcript :243-284 ('|' split, trim, "" / "." missing),
+ * vep_parse_int / vep_parse_float :207-235; cells as bcf_reader.c:1463-1541 writes them; in tidy mode only a record's first sample
+ * row carries the annotation (bcf_reader.c:1370-1373). */
+static void emit_vep(scan_t *s, col_t *vc, const ent_t *info, int n_info, int rep)
+{
+    const ent_t *e = NULL;
+    for (int i = 0; i < n_info; i++) if (info[i].key == s->vep_id) { e = &info[i]; break; }
+    char *str = NULL;
+    if (rep == 0 && e && e->n > 0 && s->h.ids[s->vep_id].type[HL_INFO] == HT_STR) {
+        str = (char *)malloc((size_t)e->n + 1); memcpy(str, e->p, (size_t)e->n); str[e->n] = 0;         /* vcf.c:6071-6081 */
+    }
+    /* transcripts: the non-empty ','-separated pieces */
+    char **tr = NULL; int ntr = 0;
+    if (str && *str) {
+        tr = (char **)malloc(sizeof(char *) * (strlen(str) + 1));
+        char *save = NULL;
+        for (char *t = strtok_r(str, ",", &save); t; t = strtok_r(NULL, ",", &save)) tr[ntr++] = t;
+    }
+    if (ntr == 0) { for (int v = 0; v < s->n_vep; v++) col_null(&vc[v]); free(tr); free(str); return; }
+    /* tokens of every transcript: tok[t * n_vep + v] (NULL = missing) */
+    char **tok = (char **)calloc((size_t)ntr * (size_t)s->n_vep, sizeof(char *));
+    for (int t = 0; t < ntr; t++) {
+        char *token = tr[t]; int fi = 0;
+        while (fi < s->n_vep) {
+            char *np = strchr(token, '|');
+            if (np) *np = 0;
+            while (*token && isspace((unsigned char)*token)) token++;
+            char *end = token + strlen(token) - 1;
+            while (end > token && isspace((unsigned char)*end)) *end-- = 0;
+            if (*token && strcmp(token, ".") != 0) tok[(size_t)t * (size_t)s->n_vep + (size_t)fi] = token;
+            fi++;
+            if (!np) break;
+            token = np + 1;
+        }
+    }
+    for (int v = 0; v < s->n_vep; v++) {
+        col_t *cc = &vc[v];
+        list_begin(cc);
+        for (int t = 0; t < ntr; t++) {
+            const char *tk = tok[(size_t)t * (size_t)s->n_vep + (size_t)v];
+            if (s->vep[v].htype == HT_INT) {
+                int32_t iv = INT32_MIN;
+                if (tk) { char *endp; long val = strtol(tk, &endp, 10); if (!(endp == tk || *endp)) iv = (int32_t)val; }
+                list_fixed(cc, tk ? (uint64_t)(uint32_t)iv : 0);
+            } else if (s->vep[v].htype == HT_REAL) {
+                float fv = NAN;
+                if (tk) { char *endp; double val = strtod(tk, &endp); if (!(endp == tk || *endp)) fv = (float)val; }
+                uint32_t b; memcpy(&b, &fv, 4);
+                list_fixed(cc, tk ? b : 0);
+            } else list_str(cc, tk ? tk : "", tk ? strlen(tk) : 0);
+            list_cvalid(cc, tk != NULL);
+        }
+        list_end(cc);
+    }
+    free(tok); free(tr); free(str);
 }
 
 static int scan_records(scan_t *s, const uint8_t *u, size_t ulen, size_t pos, int materialise)
@@ -646,6 +744,7 @@ static int scan_records(scan_t *s, const uint8_t *u, size_t ulen, size_t pos, in
             if (n_flt == 0) list_str(&c[6], "PASS", 4);
             else for (int f = 0; f < n_flt; f++) list_str(&c[6], h->ids[flt[f]].key, strlen(h->ids[flt[f]].key));
             list_end(&c[6]);
+            if (s->n_vep) emit_vep(s, c + 7, info, n_info, rep);
             for (int k = 0; k < s->n_info; k++) {
                 const field_t *f = &s->info[k]; col_t *cc = &c[s->c_info0 + k];
                 const ent_t *e = NULL;

@@ -97,7 +97,7 @@ int orc_bam_read_aux_map(const uint8_t *file, size_t flen, int exclude_standard,
 /* Sequential read_bcf scan of a whole BCF file; `blob` receives the canonical serialisation of every schema column
  * (layout documented above orc_bcf_read in bcf_oracle.c; free with orc_free).  materialise = 0 only frames and
  * validates records (row count).  Returns 0 clean EOF, -2 stream ended at a bad record (rows before it kept),
- * -100 not a BGZF/BCF file, -101 header unreadable, -102 VEP columns would be required (out of scope). */
+ * -100 not a BGZF/BCF file, -101 header unreadable. */
 int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, uint8_t **blob, size_t *blob_len, int64_t *n_rows);
 void orc_free(void *p);
 

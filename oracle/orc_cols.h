@@ -32,6 +32,7 @@ typedef struct {
     buf_t valid, fixed, soff, sbytes, lent;
     uint64_t child_n;
     buf_t cfixed, csoff, csbytes;
+    int has_cvalid; buf_t cvalid;            /* lists with NULL elements (VEP_* columns): one byte per child, serialised with is_list = 2 */
 } col_t;
 
 static inline void col_init(col_t *c, const char *name, int type, int is_list)
@@ -45,7 +46,7 @@ static inline void col_init(col_t *c, const char *name, int type, int is_list)
 static inline void col_free(col_t *c)
 {
     free(c->valid.p); free(c->fixed.p); free(c->soff.p); free(c->sbytes.p); free(c->lent.p);
-    free(c->cfixed.p); free(c->csoff.p); free(c->csbytes.p);
+    free(c->cfixed.p); free(c->csoff.p); free(c->csbytes.p); free(c->cvalid.p);
 }
 static inline void col_null(col_t *c)
 {
@@ -67,6 +68,7 @@ static uint64_t g_list_start;
 static inline void list_begin(col_t *c) { g_list_start = c->child_n; }
 static inline void list_fixed(col_t *c, uint64_t bits) { buf_u64(&c->cfixed, bits); c->child_n++; }
 static inline void list_str(col_t *c, const void *s, size_t n) { buf_push(&c->csbytes, s, n); buf_u64(&c->csoff, c->csbytes.n); c->child_n++; }
+static inline void list_cvalid(col_t *c, int v) { buf_u8(&c->cvalid, (uint8_t)v); }       /* after list_fixed / list_str of a has_cvalid column */
 static inline void list_end(col_t *c)
 {
     buf_u8(&c->valid, 1); c->n++; buf_u64(&c->lent, g_list_start); buf_u64(&c->lent, c->child_n - g_list_start);
@@ -76,7 +78,7 @@ static inline void ser_col(buf_t *o, const col_t *c, int64_t n)
 {
     uint16_t nl = (uint16_t)strlen(c->name);
     buf_push(o, &nl, 2); buf_push(o, c->name, nl);
-    buf_u8(o, (uint8_t)c->type); buf_u8(o, (uint8_t)c->is_list);
+    buf_u8(o, (uint8_t)c->type); buf_u8(o, (uint8_t)(c->is_list && c->has_cvalid ? 2 : c->is_list));
     buf_push(o, c->valid.p, (size_t)n);
     if (!c->is_list) {
         if (c->type == T_VARCHAR) { buf_push(o, c->soff.p, c->soff.n); buf_push(o, c->sbytes.p, c->sbytes.n); }
@@ -86,6 +88,7 @@ static inline void ser_col(buf_t *o, const col_t *c, int64_t n)
         buf_u64(o, c->child_n);
         if (c->type == T_VARCHAR) { buf_push(o, c->csoff.p, c->csoff.n); buf_push(o, c->csbytes.p, c->csbytes.n); }
         else buf_push(o, c->cfixed.p, c->cfixed.n);
+        if (c->has_cvalid) buf_push(o, c->cvalid.p, c->cvalid.n);
     }
 }
 

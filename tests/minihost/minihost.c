@@ -7,7 +7,7 @@
  *   per chunk: u64 n_rows; per projected column: u32 type id, validity words (NULL pointer = all ones, tail bits
  *   masked), then the payload: fixed width = n x width bytes (invalid rows zeroed); VARCHAR = per row u32 len
  *   (0xFFFFFFFF for NULL) + bytes; LIST = n x (u64 offset, u64 length) exactly as written, u64 child size, u32 child type,
- *   then the child payload in the scalar encoding (child validity is not used by the readers: children are always valid).
+ *   then the child payload in the scalar encoding and the child's validity words (NULL elements: the VEP_* columns of read_bcf).
  * usage: minihost [--direct] <ext.so> <function> <path> [-n name=value]... [-p 0,3,5] [-o out.bin]
  * --direct plays a reference-built src/duckhts.c (src/duckhts.c:13-16,48-55): it fills the extension's `duckdb_ext_api`
  * global the way DUCKDB_EXTENSION_API_INIT does and calls register_read_bcf_function / register_read_bam_function
@@ -28,7 +28,7 @@
 
 typedef struct LType { int id; struct LType *child; } LType;
 typedef struct Value { int is_null; int is_bool; int b; char *s; } Value;
-typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap, heap_used, heap_cap; int child_type; struct Vec *child; idx_t list_size, list_cap; struct Vec *kids[2]; } Vec;
+typedef struct Vec { int type; void *data; uint64_t *validity; char **heap; size_t nheap, heap_used, heap_cap; int child_type; struct Vec *child; idx_t list_size, list_cap; struct Vec *kids[2]; idx_t vcap; /* rows the validity mask covers: a list child grows with the list, 0 = VSIZE */ } Vec;
 typedef struct Chunk { Vec *vecs; size_t ncol; idx_t size; } Chunk;
 typedef struct TF {
     char name[64]; duckdb_table_function_bind_t bind; duckdb_table_function_init_t init, local_init; duckdb_table_function_t func;
@@ -96,7 +96,7 @@ static void h_chunk_set_size(duckdb_data_chunk c, idx_t n) { ((Chunk *)c)->size 
 static idx_t h_chunk_get_size(duckdb_data_chunk c) { return ((Chunk *)c)->size; }
 static void *h_vector_get_data(duckdb_vector v) { return ((Vec *)v)->data; }
 static uint64_t *h_vector_get_validity(duckdb_vector v) { return ((Vec *)v)->validity; }
-static void h_vector_ensure_validity_writable(duckdb_vector v) { Vec *x = v; if (!x->validity) { x->validity = malloc(VSIZE / 8); memset(x->validity, 0xff, VSIZE / 8); } }
+static void h_vector_ensure_validity_writable(duckdb_vector v) { Vec *x = v; if (!x->validity) { size_t nb = (size_t)(x->vcap ? x->vcap : VSIZE) / 8; x->validity = malloc(nb); memset(x->validity, 0xff, nb); } }
 static void h_validity_set_row_invalid(uint64_t *val, idx_t row) { val[row / 64] &= ~((uint64_t)1 << (row % 64)); }
 static void h_assign_len(duckdb_vector v, idx_t row, const char *s, idx_t len) {
     Vec *x = v; duckdb_string_t *d = (duckdb_string_t *)x->data + row;
@@ -129,6 +129,9 @@ static void list_grow(Vec *x, idx_t need) {
     } else {
         size_t w = (size_t)type_width(x->child->type);
         x->child->data = realloc(x->child->data, nc * w); memset((char *)x->child->data + x->list_cap * w, 0, (nc - x->list_cap) * w);
+        /* the child's validity mask (NULL elements: VEP_* columns) covers the child's capacity */
+        if (x->child->validity) { x->child->validity = realloc(x->child->validity, nc / 8); memset((char *)x->child->validity + x->list_cap / 8, 0xff, (nc - x->list_cap) / 8); }
+        x->child->vcap = nc;
     }
     x->list_cap = nc;
 }
@@ -171,6 +174,8 @@ static void write_chunk(FILE *fo, Chunk *cp, uint64_t n) {
                 if (ct == DUCKDB_TYPE_VARCHAR) { duckdb_string_t *d = (duckdb_string_t *)v->child->data + r; uint32_t len = d->value.inlined.length; fwrite(&len, 4, 1, fo); fwrite(len <= 12 ? d->value.inlined.inlined : d->value.pointer.ptr, 1, len, fo); }
                 else fwrite((char *)v->child->data + r * type_width((int)ct), 1, (size_t)type_width((int)ct), fo);
             }
+            /* child validity words (all ones when the reader never touched the mask) */
+            for (uint64_t w = 0, cw = (cn + 63) / 64; w < cw; w++) { uint64_t m = v->child->validity ? v->child->validity[w] : ~0ull; if (w == cw - 1 && (cn % 64)) m &= (1ull << (cn % 64)) - 1; fwrite(&m, 8, 1, fo); }
             continue;
         }
         for (uint64_t r = 0; r < n; r++) {
@@ -211,7 +216,7 @@ static void *worker_main(void *arg) {
             Vec *v = &c.vecs[k];
             free(v->validity); v->validity = NULL; vec_release(v);
             if (v->type == DUCKDB_TYPE_LIST || v->type == DUCKDB_TYPE_MAP) memset(v->data, 0, (size_t)VSIZE * 16);    /* entries of NULL rows are left untouched by the readers: keep the dump deterministic */
-            if (v->child) { v->list_size = 0; if (v->child->type == DUCKDB_TYPE_STRUCT) { for (int q = 0; q < 2; q++) vec_release(v->child->kids[q]); } else vec_release(v->child); }
+            if (v->child) { v->list_size = 0; if (v->child->type == DUCKDB_TYPE_STRUCT) { for (int q = 0; q < 2; q++) vec_release(v->child->kids[q]); } else { vec_release(v->child); free(v->child->validity); v->child->validity = NULL; } }
         }
         if (n == 0) break;
         w->rows += n; w->chunks++;
@@ -219,7 +224,7 @@ static void *worker_main(void *arg) {
     for (size_t k = 0; k < c.ncol; k++) {
         Vec *ch = c.vecs[k].child;
         if (ch && ch->type == DUCKDB_TYPE_STRUCT) { for (int q = 0; q < 2; q++) { Vec *kv = ch->kids[q]; vec_release(kv); free(kv->data); free(kv); } free(ch); ch = NULL; }
-        if (ch) { vec_release(ch); free(ch->data); free(ch); }
+        if (ch) { vec_release(ch); free(ch->data); free(ch->validity); free(ch); }
         vec_release(&c.vecs[k]); free(c.vecs[k].data); free(c.vecs[k].validity); }
     free(c.vecs);
     return NULL;

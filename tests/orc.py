@@ -185,7 +185,7 @@ def decode_bcf_blob(blob: bytes):
         nl = int(take(1, np.uint16)[0])
         name = bytes(take(nl, np.uint8)).decode()
         t, il = (int(x) for x in take(2, np.uint8))
-        c = {"name": name, "type": t, "is_list": il, "valid": take(n, np.uint8)}
+        c = {"name": name, "type": t, "is_list": 1 if il else 0, "valid": take(n, np.uint8)}
         if not il:
             payload(c, n, "")
         else:
@@ -193,6 +193,8 @@ def decode_bcf_blob(blob: bytes):
             c["loff"], c["llen"] = le[:, 0].copy(), le[:, 1].copy()
             c["child_n"] = int(take(1, np.uint64)[0])
             payload(c, c["child_n"], "c")
+            if il == 2:                                   # list with NULL elements (VEP_* columns)
+                c["cvalid"] = take(c["child_n"], np.uint8)
         cols.append(c)
     nrec = int(take(1, np.uint64)[0])
     rec = {"rid": take(nrec, np.int64).copy(), "pos0": take(nrec, np.int64).copy(), "rlen": take(nrec, np.int64).copy()}
@@ -253,7 +255,7 @@ def bcf_col_py(c):
             out.append(None)
         elif c["is_list"]:
             o, l = int(c["loff"][i]), int(c["llen"][i])
-            out.append([_scalar_py(c, j, "c") for j in range(o, o + l)])
+            out.append([_scalar_py(c, j, "c") if ("cvalid" not in c or c["cvalid"][j]) else None for j in range(o, o + l)])
         else:
             out.append(_scalar_py(c, i))
     return out
@@ -269,7 +271,7 @@ def bcf_cols_diff(a, b):
         for k in ("name", "type", "is_list"):
             if ca[k] != cb[k]:
                 return f"{ca['name']}: {k} {ca[k]} != {cb[k]}"
-        for k in ("valid", "fixed", "soff", "sbytes", "loff", "llen", "cfixed", "csoff", "csbytes"):
+        for k in ("valid", "fixed", "soff", "sbytes", "loff", "llen", "cfixed", "csoff", "csbytes", "cvalid"):
             if (k in ca) != (k in cb):
                 return f"{ca['name']}: field {k} presence"
             if k in ca and not np.array_equal(ca[k], cb[k]):
@@ -306,6 +308,8 @@ def bcf_take_rows(table, rows):
                 o["cfixed"] = c["cfixed"][kid]
             else:
                 o["csoff"], o["csbytes"] = gather(c["csoff"], c["csbytes"], kid)
+            if "cvalid" in c:
+                o["cvalid"] = c["cvalid"][kid]
         cols.append(o)
     return {"n_rows": len(rows), "cols": cols, "by_name": {c["name"]: c for c in cols}}
 
