@@ -78,7 +78,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
-           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
+           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
 
 
 def lib():
@@ -688,6 +688,16 @@ def shard_cut(coff, comp_len, rank, world):
     if lib().dhts_shard_cut(coff.ctypes.data, len(coff), int(comp_len), rank, world, C.byref(b0), C.byref(b1)) != 0:
         raise ValueError("bad shard arguments")
     return b0.value, b1.value
+
+
+def shard_window(path, rank, world, header_bytes):
+    """(win_begin, win_end, own_end) of `rank` when `world` ranks share ONE file (dhts_open_path_shard's cut; host only, no device)."""
+    a, b, t = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    L = lib()
+    L.dhts_shard_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    if L.dhts_shard_window(os.fsencode(path), rank, world, int(header_bytes), C.byref(a), C.byref(b), C.byref(t)) != 0:
+        raise ValueError("bad shard arguments or unreadable file")
+    return a.value, b.value, t.value
 
 
 def check_handoff(spans):

@@ -803,13 +803,8 @@ static uint64_t shard_target(uint64_t fsize, uint64_t hdr, int r, int world) {
 static bool host_is_bgzf_header(const uint8_t *p) {
     return p[0] == 31 && p[1] == 139 && p[2] == 8 && (p[3] & 4) && p[10] == 6 && p[11] == 0 && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0;
 }
-int dhts_open_path_shard(dhts_ctx *c, const char *path, int rank, int world, uint64_t header_bytes) {
-    if (!c || world < 1 || rank < 0 || rank >= world) return -1;
-    discard_prefetch(c);
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return fail(c, "cannot open %s", path);
-    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
-    const uint64_t fsize = (uint64_t)sb.st_size;
+// the byte window [wbeg, wend) of rank `rank` (host only: signature probe on the open file); t1 = where the rank's ownership ends
+static void shard_window_fd(int fd, uint64_t fsize, uint64_t header_bytes, int rank, int world, uint64_t *wbeg_o, uint64_t *wend_o, uint64_t *t1_o) {
     if (header_bytes > fsize) header_bytes = fsize;
     const uint64_t t0 = shard_target(fsize, header_bytes, rank, world), t1 = shard_target(fsize, header_bytes, rank + 1, world);
     uint64_t wend = t1 + DHTS_SHARD_HALO; if (wend > fsize || rank == world - 1) wend = fsize;
@@ -843,6 +838,33 @@ int dhts_open_path_shard(dhts_ctx *c, const char *path, int rank, int world, uin
         }
         if (wbeg >= wend) wbeg = wend = fsize > 0 ? fsize : 0;          // no block starts in this rank's range: it scans nothing
     }
+    *wbeg_o = wbeg; *wend_o = wend; *t1_o = t1;
+}
+// host-only view of the cut (no device needed): rank r stages file[win_begin, win_end) behind the header blocks and owns the blocks
+// that start in [win_begin, own_end)
+extern "C" int dhts_shard_window(const char *path, int rank, int world, uint64_t header_bytes, uint64_t *win_begin, uint64_t *win_end, uint64_t *own_end) {
+    if (!path || world < 1 || rank < 0 || rank >= world) return -1;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return -1; }
+    uint64_t a = 0, b = 0, t1 = 0;
+    shard_window_fd(fd, (uint64_t)sb.st_size, header_bytes, rank, world, &a, &b, &t1);
+    close(fd);
+    if (win_begin) *win_begin = a;
+    if (win_end) *win_end = b;
+    if (own_end) *own_end = t1;
+    return 0;
+}
+int dhts_open_path_shard(dhts_ctx *c, const char *path, int rank, int world, uint64_t header_bytes) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return -1;
+    discard_prefetch(c);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(c, "cannot open %s", path);
+    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    if (header_bytes > fsize) header_bytes = fsize;
+    uint64_t wbeg = 0, wend = 0, t1_ = 0;
+    shard_window_fd(fd, fsize, header_bytes, rank, world, &wbeg, &wend, &t1_);
     if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
     reset_file_state(c);
     const uint64_t n_hdr = rank > 0 ? header_bytes : 0, n_win = wend > wbeg ? wend - wbeg : 0, n = n_hdr + n_win;

@@ -156,6 +156,8 @@ int64_t dhts_blocks_ahead(const dhts_ctx *);
  * opened (the head of) the file.  dhts_voffset turns a position of the inflated stream into a BGZF virtual offset (bgzf_tell,
  * htslib/bgzf.h): adjacent ranks hand off end == first-record as virtual offsets. */
 int dhts_open_path_shard(dhts_ctx *, const char *path, int rank, int world, uint64_t header_bytes);
+/* the cut itself, host only (no device): rank r stages file[win_begin, win_end) and owns the blocks that start in [win_begin, own_end) */
+int dhts_shard_window(const char *path, int rank, int world, uint64_t header_bytes, uint64_t *win_begin, uint64_t *win_end, uint64_t *own_end);
 int dhts_bam_set_file_shard(dhts_ctx *, int rank, int world);
 uint64_t dhts_bam_header_bytes(const dhts_ctx *);
 uint64_t dhts_voffset(const dhts_ctx *, uint64_t uoff);
