@@ -78,7 +78,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
-           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
+           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
 
 
 def lib():
@@ -326,6 +326,20 @@ class Context:
     def load_index(self, bai_bytes):
         buf = np.frombuffer(bai_bytes, dtype=np.uint8)
         self._chk(self.L.dhts_bam_load_index(self.h, buf.ctypes.data, buf.nbytes))
+
+    def region_segments(self, index_bytes, cap=4096):
+        """file byte ranges (beg[], end[]) the regions set on this context need, or None for the whole file (dhts_bam_region_segments)"""
+        buf = np.frombuffer(index_bytes, dtype=np.uint8)
+        beg, end, n = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64), C.c_int64(0)
+        self.L.dhts_bam_region_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        self._chk(self.L.dhts_bam_region_segments(self.h, buf.ctypes.data, buf.nbytes, beg.ctypes.data, end.ctypes.data, cap, C.byref(n)))
+        return None if n.value < 0 else (beg[:n.value].copy(), end[:n.value].copy())
+
+    def open_segments(self, path, header_bytes, beg, end):
+        beg, end = np.ascontiguousarray(beg, np.uint64), np.ascontiguousarray(end, np.uint64)
+        self.L.dhts_open_path_segments.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64]
+        self._chk(self.L.dhts_open_path_segments(self.h, os.fsencode(path), int(header_bytes), beg.ctypes.data, end.ctypes.data, len(beg)))
+        return self
 
     def next_batch(self, max_blocks=0, colmask=0x1FFF):
         b = BamBatch()
@@ -625,12 +639,16 @@ def std_tags():
     return _STD_TAGS
 
 
-def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None, overlap=None):
+def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None, overlap=None, sparse=None):
     """Full sequential scan (reference mode (i)): all rows in file order.
-    region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window."""
+    region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window.
+    sparse=(header_bytes, beg[], end[]) with a path: only the header blocks and those file ranges are staged (Context.region_segments)."""
     ctx = Context(device)
     try:
-        ctx.open(src)
+        if sparse is not None:
+            ctx.open_segments(src, *sparse)
+        else:
+            ctx.open(src)
         ctx.bgzf_index()
         hdr = ctx.bam_open()
         if shard is not None:

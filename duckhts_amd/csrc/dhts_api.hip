@@ -35,41 +35,83 @@
 // device.  A long-lived host (DuckDB) creates one context per query, so buffers go back to a per-device free list when a context is
 // destroyed and the next one picks them up.  The list is bounded (DHTS_POOL_GB, default 96 GB per process); beyond it memory is freed.
 namespace {
-struct PoolBuf { void *p; size_t cap; int dev; };
+// A pooled buffer may keep its CONTENTS: the compressed bytes of a file that was staged whole are tagged with the file's identity (path,
+// device, inode, size, mtime), and the next context that opens the same unchanged file takes the buffer instead of reading and copying
+// the file again -- 288 GB of HBM is the file cache of a long-lived host (DHTS_FILE_CACHE=0 turns it off).  Tagged buffers are the last
+// to be reused for something else and the pool evicts its least recently used entries when it is over its limit.
+struct PoolBuf { void *p; size_t cap; int dev; std::string tag; uint64_t tag_len; uint64_t stamp; };
 std::mutex g_pool_mu;
 std::vector<PoolBuf> g_pool;
 size_t g_pool_bytes = 0;
+uint64_t g_pool_clock = 0;
 size_t pool_limit() { static const size_t lim = (size_t)(getenv("DHTS_POOL_GB") ? atof(getenv("DHTS_POOL_GB")) : 96.0) * (size_t)(1u << 30); return lim; }
+bool file_cache_on() { static const bool on = !(getenv("DHTS_FILE_CACHE") && atoi(getenv("DHTS_FILE_CACHE")) == 0); return on; }
 void *pool_take(size_t n, size_t *cap_out) {
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     int best = -1;
-    for (size_t i = 0; i < g_pool.size(); i++)
-        if (g_pool[i].dev == dev && g_pool[i].cap >= n && g_pool[i].cap / 4 <= n + 65536 && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = (int)i;
+    for (int pass = 0; pass < 2 && best < 0; pass++)             // untagged buffers first; a cached file only when nothing else fits (oldest first)
+        for (size_t i = 0; i < g_pool.size(); i++) {
+            if (g_pool[i].dev != dev || g_pool[i].cap < n || g_pool[i].cap / 4 > n + 65536 || g_pool[i].tag.empty() != (pass == 0)) continue;
+            if (best < 0 || (pass == 0 ? g_pool[i].cap < g_pool[best].cap : g_pool[i].stamp < g_pool[best].stamp)) best = (int)i;
+        }
     if (best < 0) return nullptr;
     void *p = g_pool[best].p; *cap_out = g_pool[best].cap; g_pool_bytes -= g_pool[best].cap;
     g_pool[best] = g_pool.back(); g_pool.pop_back();
     return p;
 }
-void pool_give(void *p, size_t cap) {
+// the buffer that holds `tag`'s bytes, if it is idle in the pool
+void *pool_take_tagged(const std::string &tag, size_t *cap_out, uint64_t *len_out) {
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++) if (g_pool[i].dev == dev && !g_pool[i].tag.empty() && g_pool[i].tag == tag) {
+        void *p = g_pool[i].p; *cap_out = g_pool[i].cap; *len_out = g_pool[i].tag_len; g_pool_bytes -= g_pool[i].cap;
+        g_pool[i] = g_pool.back(); g_pool.pop_back();
+        return p;
+    }
+    return nullptr;
+}
+void pool_give(void *p, size_t cap, const std::string &tag = std::string(), uint64_t tag_len = 0) {
     int dev = 0; hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device; else (void)hipGetDevice(&dev);
+    std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool_bytes + cap <= pool_limit() && g_pool.size() < 4096) { g_pool.push_back({p, cap, dev}); g_pool_bytes += cap; return; }
+        if (cap > pool_limit() || g_pool.size() >= 4096) drop.push_back(p);
+        else {
+            if (!tag.empty()) for (size_t i = 0; i < g_pool.size();) {      // one copy of a file per device
+                if (g_pool[i].dev == dev && g_pool[i].tag == tag) { drop.push_back(g_pool[i].p); g_pool_bytes -= g_pool[i].cap; g_pool[i] = g_pool.back(); g_pool.pop_back(); } else i++;
+            }
+            g_pool.push_back({p, cap, dev, tag, tag_len, ++g_pool_clock}); g_pool_bytes += cap;
+            while (g_pool_bytes > pool_limit() && g_pool.size() > 1) {     // over the limit: the least recently used entries go (never the one just given)
+                size_t o = 0; for (size_t i = 1; i + 1 < g_pool.size(); i++) if (g_pool[i].stamp < g_pool[o].stamp) o = i;
+                if (o + 1 == g_pool.size()) break;
+                drop.push_back(g_pool[o].p); g_pool_bytes -= g_pool[o].cap; g_pool[o] = g_pool.back(); g_pool.pop_back();
+            }
+        }
     }
-    (void)hipFree(p);
+    for (void *q : drop) (void)hipFree(q);
 }
 }
 // Owning device allocation: returned to the pool by its destructor, so deleting a context gives back every byte of HBM it held.
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
+    std::string tag; uint64_t tag_len = 0;      // set when the buffer holds a whole file that may serve the next context (see the pool)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
+    void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; tag.swap(o.tag); uint64_t tl = tag_len; tag_len = o.tag_len; o.tag_len = tl; }
+    // takes the pooled buffer that holds `t`'s bytes; returns their length, or -1 when it is not there
+    int64_t adopt(const std::string &t) {
+        size_t got = 0; uint64_t len = 0;
+        void *q = pool_take_tagged(t, &got, &len);
+        if (!q) return -1;
+        release(); p = q; cap = got; tag = t; tag_len = len;
+        return (int64_t)len;
+    }
     int ensure(size_t n) {
+        tag.clear(); tag_len = 0;                // whoever asks for room is about to write: the old contents are nobody's cache any more
         if (n <= cap) return 0;
         release();
         size_t want = n + n / 8 + 4096, got = 0;
@@ -81,7 +123,7 @@ struct DevBuf {
         }
         cap = want; return 0;
     }
-    void release() { if (p) pool_give(p, cap); p = nullptr; cap = 0; }
+    void release() { if (p) pool_give(p, cap, tag, tag_len); p = nullptr; cap = 0; tag.clear(); tag_len = 0; }
 };
 
 // progress of a staging run: `frontier` = contiguous bytes of the range that are in HBM (their copies have completed)
@@ -109,6 +151,11 @@ struct dhts_ctx {
     DevBuf comp; uint64_t comp_len = 0; uint64_t file_off = 0, file_size = 0;   // resident bytes = file bytes [file_off, file_off + comp_len)
     // dhts_open_path_shard: resident bytes = file[0, seg_split) ++ file[seg_file_off, ...): the header blocks, then this rank's window
     uint64_t seg_split = 0, seg_file_off = 0; bool partial_tail = false; uint64_t hdr_bytes_known = 0;
+    // dhts_open_path_segments: resident bytes = a concatenation of file ranges (the header blocks, then the index windows of a region
+    // query), each made of whole BGZF blocks; sorted by file offset, so resident order = file order
+    struct Seg { uint64_t res_off, file_off, len; };
+    std::vector<Seg> segs;
+    bool cache_hit = false; std::string pending_tag;       // the file's bytes came out of the pool (no read, no copy); tag to put on `comp` once staging has succeeded
     // dhts_open_path_async: the file is still arriving; the block table covers the staged prefix and grows (dhts_bgzf_index_staged)
     std::thread stager; StageProg *prog = nullptr; bool growing = false; uint64_t stage_total = 0;
     // block table
@@ -259,11 +306,13 @@ const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no cont
 
 static void stop_stager(dhts_ctx *c) {
     if (c->stager.joinable()) c->stager.join();            // (a staging run always terminates: it only reads a file)
+    if (c->prog && !c->pending_tag.empty() && c->prog->finished && c->prog->rc == 0 && c->prog->frontier == c->prog->len) { c->comp.tag = c->pending_tag; c->comp.tag_len = c->prog->len; }
+    c->pending_tag.clear();
     delete c->prog; c->prog = nullptr; c->growing = false;
 }
 static void reset_file_state(dhts_ctx *c) {
     stop_stager(c);
-    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false;
+    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false; c->segs.clear(); c->cache_hit = false;
     c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
     c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
 }
@@ -383,6 +432,55 @@ static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uin
     return rc.load();
 }
 
+// identity of an unchanged file: what a cached copy of its bytes is valid for
+static std::string file_tag(const struct stat &sb) {
+    char b[160];
+    snprintf(b, sizeof(b), "%llx:%llx:%llu:%lld.%09ld:%lld.%09ld", (unsigned long long)sb.st_dev, (unsigned long long)sb.st_ino, (unsigned long long)sb.st_size,
+             (long long)sb.st_mtim.tv_sec, (long)sb.st_mtim.tv_nsec, (long long)sb.st_ctim.tv_sec, (long)sb.st_ctim.tv_nsec);
+    return b;
+}
+
+// several file ranges in one go (the index windows of a region query): one set of reader threads works through all their pieces
+struct StagePiece { uint64_t file_off; size_t len; uint8_t *dst; };
+static int stage_file_pieces(dhts_ctx *c, int fd, const std::vector<StagePiece> &ranges) {
+    const size_t CH = 8u << 20;
+    std::vector<StagePiece> pc;
+    for (auto &r : ranges) for (size_t o = 0; o < r.len; o += CH) pc.push_back({r.file_off + o, r.len - o < CH ? r.len - o : CH, r.dst + o});
+    if (pc.empty()) return 0;
+    static const int env_thr = getenv("DHTS_READ_THREADS") ? atoi(getenv("DHTS_READ_THREADS")) : 0;
+    int nthr = env_thr > 0 ? env_thr : 4; if ((size_t)nthr > pc.size()) nthr = (int)pc.size();
+    size_t tot = 0; for (auto &x : pc) tot += x.len;
+    if (tot <= (1u << 20)) nthr = 1;                            // a sliver: thread start-up would cost more than the copy
+    std::atomic<size_t> next(0); std::atomic<int> rc(0);
+    const int dev = c->device;
+    auto worker = [&]() {
+        if (hipSetDevice(dev) != hipSuccess) { rc = -1; return; }
+        hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; void *pin[2] = {dhts_host_alloc(CH), dhts_host_alloc(CH)}; bool used[2] = {false, false};
+        if (!pin[0] || !pin[1] || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = -2;
+        int k = 0;
+        while (rc == 0) {
+            const size_t pi = next.fetch_add(1);
+            if (pi >= pc.size()) break;
+            const StagePiece &x = pc[pi];
+            if (used[k]) { (void)hipEventSynchronize(ev[k]); used[k] = false; }
+            size_t got = 0;
+            while (got < x.len) { ssize_t r = pread(fd, (char *)pin[k] + got, x.len - got, (off_t)(x.file_off + got)); if (r <= 0) { rc = -3; break; } got += (size_t)r; }
+            if (rc != 0) break;
+            if (hipMemcpyAsync(x.dst, pin[k], x.len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { rc = -4; break; }
+            used[k] = true; k ^= 1;
+        }
+        if (st) (void)hipStreamSynchronize(st);
+        for (int q = 0; q < 2; q++) { if (ev[q]) (void)hipEventDestroy(ev[q]); dhts_host_free(pin[q]); }
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return rc.load();
+}
+
 // htslib hts_open + the reads underneath bgzf_read_block, for a BYTE RANGE of the file: [off, off+len) (len = 0: to the end of the
 // file) becomes the context's resident bytes.  A rank of a multi-GPU scan stages only its own block range plus the halo.
 int dhts_open_path_range(dhts_ctx *c, const char *path, uint64_t off, uint64_t len) {
@@ -396,6 +494,13 @@ int dhts_open_path_range(dhts_ctx *c, const char *path, uint64_t off, uint64_t l
     uint64_t n = fsize - off; if (len != 0 && len < n) n = len;
     if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
     reset_file_state(c);
+    const bool whole = off == 0 && n == fsize && n > 0 && file_cache_on();
+    const std::string tag = whole ? file_tag(sb) : std::string();
+    if (whole && c->comp.adopt(tag) == (int64_t)n) {            // the unchanged file is still in HBM from an earlier query
+        close(fd);
+        c->comp_len = n; c->file_off = 0; c->file_size = fsize; c->cache_hit = true;
+        return 0;
+    }
     if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc of %llu bytes failed", (unsigned long long)(n + PAD_BYTES)); }
     int rc = n ? stage_file_range(c, fd, off, n, (uint8_t *)c->comp.p) : 0;
     close(fd);
@@ -403,9 +508,62 @@ int dhts_open_path_range(dhts_ctx *c, const char *path, uint64_t off, uint64_t l
     HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->comp_len = n; c->file_off = off; c->file_size = fsize;
+    if (whole) { c->comp.tag = tag; c->comp.tag_len = n; }
     return 0;
 }
 int dhts_open_path(dhts_ctx *c, const char *path) { return dhts_open_path_range(c, path, 0, 0); }
+
+static bool host_is_bgzf_header(const uint8_t *p);
+// Only the parts of a file a region query needs (htslib seeks to each chunk, hts.c:4320-4607; here they are staged): the header blocks
+// file[0, header_bytes) and the windows [beg[k], end[k] + length of the BGZF block at end[k]) from dhts_bam_region_segments, merged where
+// they touch, laid out one after the other in file order.  dhts_bgzf_index, dhts_bam_open, dhts_bam_set_regions and dhts_bam_load_index
+// follow as for a whole file; the block table maps resident blocks back to file offsets, so virtual offsets stay those of the file.
+extern "C" int dhts_open_path_segments(dhts_ctx *c, const char *path, uint64_t header_bytes, const uint64_t *beg, const uint64_t *end, int64_t n) {
+    if (!c || n < 0 || (n > 0 && (!beg || !end))) return -1;
+    discard_prefetch(c);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(c, "cannot open %s", path);
+    struct stat sb; if (fstat(fd, &sb) != 0) { close(fd); return fail(c, "cannot stat %s", path); }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    if (header_bytes > fsize) header_bytes = fsize;
+    std::vector<std::pair<uint64_t, uint64_t>> rg;              // [first byte, one past the last byte)
+    if (header_bytes) rg.push_back({0, header_bytes});
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t b = beg[k], e = end[k];
+        if (b >= fsize) continue;
+        if (e == ~0ull || e >= fsize) e = fsize;
+        else {
+            uint8_t h[18];
+            if (e + 18 > fsize || pread(fd, h, 18, (off_t)e) != 18 || !host_is_bgzf_header(h)) { close(fd); return fail(c, "index does not match the file (no BGZF block at offset %llu)", (unsigned long long)e); }
+            e += ((uint64_t)h[16] | ((uint64_t)h[17] << 8)) + 1;
+            if (e > fsize) e = fsize;
+        }
+        if (e > b) rg.push_back({b, e});
+    }
+    std::sort(rg.begin(), rg.end());
+    std::vector<std::pair<uint64_t, uint64_t>> mg;
+    for (auto &x : rg) { if (!mg.empty() && x.first <= mg.back().second) { if (x.second > mg.back().second) mg.back().second = x.second; } else mg.push_back(x); }
+    uint64_t tot = 0; for (auto &x : mg) tot += x.second - x.first;
+    if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
+    reset_file_state(c);
+    if (c->comp.ensure(tot + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc of %llu bytes failed", (unsigned long long)(tot + PAD_BYTES)); }
+    uint64_t at = 0;
+    std::vector<StagePiece> ranges;
+    for (auto &x : mg) {
+        ranges.push_back({x.first, (size_t)(x.second - x.first), (uint8_t *)c->comp.p + at});
+        c->segs.push_back({at, x.first, x.second - x.first});
+        at += x.second - x.first;
+    }
+    const int rc = stage_file_pieces(c, fd, ranges);
+    close(fd);
+    if (rc) { c->segs.clear(); return fail(c, rc == -3 ? "read error on %s" : "staging %s failed", path); }
+    HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + tot, 0, PAD_BYTES, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->comp_len = tot; c->file_off = 0; c->file_size = fsize; c->hdr_bytes_known = header_bytes;
+    c->partial_tail = mg.empty() || mg.back().second < fsize;
+    if (c->segs.size() == 1 && c->segs[0].file_off == 0 && c->segs[0].len == fsize) c->segs.clear();      // everything is resident after all
+    return 0;
+}
 
 // The same for a scan that starts before the file has arrived: staging runs on background threads, dhts_stage_wait reports how many
 // contiguous bytes are resident, dhts_bgzf_index_staged (re)builds the block table over that prefix, and dhts_bam_next_batch serves the
@@ -419,10 +577,18 @@ int dhts_open_path_async(dhts_ctx *c, const char *path) {
     const uint64_t n = (uint64_t)sb.st_size;
     if (hipSetDevice(c->device) != hipSuccess) { close(fd); return fail(c, "hipSetDevice failed"); }
     reset_file_state(c);
+    const std::string tag = (n > 0 && file_cache_on()) ? file_tag(sb) : std::string();
+    if (!tag.empty() && c->comp.adopt(tag) == (int64_t)n) {     // still in HBM from an earlier query: nothing to stage
+        close(fd);
+        c->prog = new StageProg(); c->prog->len = n; c->prog->frontier = n; c->prog->finished = true;
+        c->stage_total = n; c->file_off = 0; c->file_size = n; c->comp_len = 0; c->growing = true; c->cache_hit = true;
+        return 0;
+    }
     if (c->comp.ensure(n + PAD_BYTES) != 0) { close(fd); return fail(c, "hipMalloc of %llu bytes failed", (unsigned long long)(n + PAD_BYTES)); }
     HIPCHK(c, hipMemsetAsync((uint8_t *)c->comp.p + n, 0, PAD_BYTES, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->prog = new StageProg(); c->prog->len = n; c->stage_total = n; c->file_off = 0; c->file_size = n; c->comp_len = 0; c->growing = true;
+    c->pending_tag = tag;
     StageProg *pg = c->prog; uint8_t *dst = (uint8_t *)c->comp.p;
     c->stager = std::thread([c, fd, n, dst, pg]() {
         int rc = n ? stage_file_range(c, fd, 0, n, dst, pg) : 0;
@@ -453,6 +619,7 @@ int64_t dhts_bgzf_index_staged(dhts_ctx *c) {
 int64_t dhts_blocks_ahead(const dhts_ctx *c) { return c ? c->n_blocks - c->next_block : 0; }
 
 uint64_t dhts_resident_bytes(const dhts_ctx *c) { return c ? c->comp_len : 0; }
+extern "C" int dhts_resident_from_cache(const dhts_ctx *c) { return c && c->cache_hit ? 1 : 0; }
 
 // ---- scans --------------------------------------------------------------------------------
 static int run_scan(dhts_ctx *c, int narr, const uint32_t **in, uint32_t **out32, uint64_t **out64, int64_t n, uint64_t *totals_host) {
@@ -883,6 +1050,11 @@ int dhts_open_path_shard(dhts_ctx *c, const char *path, int rank, int world, uin
 // file offset of resident block i (the two-segment layout of dhts_open_path_shard; identity otherwise)
 static uint64_t block_file_off(const dhts_ctx *c, int64_t i) {
     const uint64_t o = i < c->n_blocks ? c->h_coff[i] : c->comp_len;
+    if (!c->segs.empty()) {
+        size_t lo = 0, hi = c->segs.size();                   // last segment with res_off <= o
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (c->segs[mid].res_off <= o) lo = mid; else hi = mid; }
+        return o - c->segs[lo].res_off + c->segs[lo].file_off;
+    }
     return (c->seg_split && o >= c->seg_split) ? o - c->seg_split + c->seg_file_off : o + c->file_off;
 }
 int dhts_bam_set_file_shard(dhts_ctx *c, int rank, int world) {
@@ -1121,43 +1293,80 @@ static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::ve
     return 0;
 }
 
+// Disjoint windows of a query: the chunks sorted by their start, neighbours merged while the gap between them is cheaper to scan than a
+// window is to start (a window costs a batch: ~1.5 ms of launches and hand-shakes, i.e. tens of MB at scan speed).  Rows are decided by
+// the overlap predicate, so merging never changes the result; the windows only bound what is staged and inflated.  !multi: one
+// covering window [vmin, vmax].
+static std::vector<std::pair<uint64_t, uint64_t>> merged_windows(const IdxWindow &w, bool multi) {
+    std::vector<std::pair<uint64_t, uint64_t>> mg;
+    if (!w.any) return mg;
+    if (!multi || w.chunks.size() <= 1) { mg.push_back({w.vmin, w.vmax}); return mg; }
+    const uint64_t gap_bytes = (uint64_t)(getenv("DHTS_WINDOW_GAP_MB") ? atof(getenv("DHTS_WINDOW_GAP_MB")) : 32.0) * (1u << 20);
+    std::vector<std::pair<uint64_t, uint64_t>> ch = w.chunks;
+    std::sort(ch.begin(), ch.end());
+    for (auto &x : ch) {
+        if (!mg.empty() && (x.first >> 16) <= (mg.back().second >> 16) + gap_bytes) { if (x.second > mg.back().second) mg.back().second = x.second; }
+        else mg.push_back(x);
+    }
+    if (mg.size() == 1) { mg[0] = {w.vmin, w.vmax}; }
+    return mg;
+}
+
+// The byte ranges of the file a region query needs, from a context that holds only the header (bam_open done) with the regions set:
+// beg[k] = file offset of the window's first BGZF block, end[k] = file offset of its LAST block (the opener adds that block's length),
+// ~0 = up to the end of the file (the "*" region).  *count = -1: the query needs the whole file.  Same windows as dhts_bam_load_index
+// builds afterwards on the context that holds the staged ranges.
+extern "C" int dhts_bam_region_segments(dhts_ctx *c, const void *index_bytes, uint64_t n, uint64_t *beg, uint64_t *end, int64_t cap, int64_t *count) {
+    if (!c || !c->bam_open || !count) return -1;
+    std::vector<QIv> q;
+    if (c->rg_active) for (size_t t = 0; t + 1 < c->rg_tid_first.size(); t++) for (uint32_t k = c->rg_tid_first[t]; k < c->rg_tid_first[t + 1]; k++) q.push_back({(int32_t)t, c->rg_beg[k], c->rg_end[k]});
+    const bool whole = !c->rg_active || c->rg_all;
+    if (whole) { *count = -1; return 0; }
+    IdxWindow w;
+    if (index_window(c, (const uint8_t *)index_bytes, n, q, whole, w)) return -1;
+    std::vector<std::pair<uint64_t, uint64_t>> sg;
+    if (c->rg_nocoor) { const uint64_t s0 = w.any ? w.vmin : w.last_end; sg.push_back({s0 >> 16, ~0ull}); }
+    else for (auto &x : merged_windows(w, true)) sg.push_back({x.first >> 16, x.second >> 16});
+    *count = (int64_t)sg.size();
+    if ((int64_t)sg.size() > cap) return fail(c, "room for %lld segments, the query has %lld", (long long)cap, (long long)sg.size());
+    for (size_t k = 0; k < sg.size(); k++) { beg[k] = sg[k].first; end[k] = sg[k].second; }
+    return 0;
+}
+
 // turns a window into the context's scan range; nocoor = also everything after the last mapped chunk ("*")
 static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor, bool multi = false) {
     int64_t b0 = 0, b1 = c->n_blocks; uint64_t first_uoff = c->first_rec_uoff;
-    auto block_of = [&](uint64_t coffset) -> int64_t {
+    auto block_of = [&](uint64_t coffset) -> int64_t {          // first resident block at or behind FILE offset coffset
         int64_t lo = 0, hi = c->n_blocks;
-        while (lo < hi) { int64_t mid = (lo + hi) / 2; if (c->h_coff[mid] < coffset) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { int64_t mid = (lo + hi) / 2; if (block_file_off(c, mid) < coffset) lo = mid + 1; else hi = mid; }
         return lo;
     };
+    const bool sparse = !c->segs.empty();                       // only the windows are resident: every window is cut exactly at its end
     c->rg_empty_window = false;
     c->wins.clear(); c->win_cur = 0; c->scan_end_uoff = ~0ull;
     if (!whole && !nocoor) {
         if (!w.any) { c->rg_empty_window = true; return 0; }
-        b0 = block_of(w.vmin >> 16); b1 = block_of(w.vmax >> 16) + 1; if (b1 > c->n_blocks) b1 = c->n_blocks;
-        if (b0 >= c->n_blocks || c->h_coff[b0] != (w.vmin >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(w.vmin >> 16));
-        first_uoff = c->h_uoff[b0] + (w.vmin & 0xffff);
-        if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
-        if (multi && w.chunks.size() > 1) {
+        const bool windows = (multi && w.chunks.size() > 1) || sparse;
+        if (!windows || merged_windows(w, multi).size() <= 1) {      // (the covering window starts at the smallest chunk start, which the linear index may have pruned from a list of windows)
+            b0 = block_of(w.vmin >> 16); b1 = block_of(w.vmax >> 16) + 1; if (b1 > c->n_blocks) b1 = c->n_blocks;
+            if (b0 >= c->n_blocks || block_file_off(c, b0) != (w.vmin >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(w.vmin >> 16));
+            first_uoff = c->h_uoff[b0] + (w.vmin & 0xffff);
+            if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
+        }
+        if (windows) {
             // Disjoint windows: the chunks sorted by their start, neighbours merged while the gap between them is cheaper to scan than a
             // window is to start (a window costs a batch: ~1.5 ms of launches and hand-shakes, i.e. tens of MB at scan speed).  Rows are
             // decided by the overlap predicate, so merging never changes the result; the windows only bound what is inflated.
-            const uint64_t gap_bytes = (uint64_t)(getenv("DHTS_WINDOW_GAP_MB") ? atof(getenv("DHTS_WINDOW_GAP_MB")) : 32.0) * (1u << 20);
-            std::vector<std::pair<uint64_t, uint64_t>> ch = w.chunks;
-            std::sort(ch.begin(), ch.end());
-            std::vector<std::pair<uint64_t, uint64_t>> mg;
-            for (auto &x : ch) {
-                if (!mg.empty() && (x.first >> 16) <= (mg.back().second >> 16) + gap_bytes) { if (x.second > mg.back().second) mg.back().second = x.second; }
-                else mg.push_back(x);
-            }
-            if (mg.size() > 1) {
+            std::vector<std::pair<uint64_t, uint64_t>> mg = merged_windows(w, multi);
+            if (mg.size() > 1 || sparse) {
                 for (auto &x : mg) {
                     dhts_ctx::ScanWin sw;
                     sw.b0 = block_of(x.first >> 16);
-                    if (sw.b0 >= c->n_blocks || c->h_coff[sw.b0] != (x.first >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(x.first >> 16));
+                    if (sw.b0 >= c->n_blocks || block_file_off(c, sw.b0) != (x.first >> 16)) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(x.first >> 16));
                     int64_t be = block_of(x.second >> 16); if (be >= c->n_blocks) be = c->n_blocks - 1;
                     sw.b1 = be + 1;
                     sw.first_uoff = c->h_uoff[sw.b0] + (x.first & 0xffff); if (sw.first_uoff < c->first_rec_uoff) sw.first_uoff = c->first_rec_uoff;
-                    sw.end_uoff = (c->h_coff[be] == (x.second >> 16)) ? c->h_uoff[be] + (x.second & 0xffff) : c->h_uoff[be + 1];
+                    sw.end_uoff = (block_file_off(c, be) == (x.second >> 16)) ? c->h_uoff[be] + (x.second & 0xffff) : c->h_uoff[be + 1];
                     c->wins.push_back(sw);
                 }
                 b0 = c->wins[0].b0; b1 = c->wins[0].b1; first_uoff = c->wins[0].first_uoff; c->scan_end_uoff = c->wins[0].end_uoff;
@@ -1166,7 +1375,9 @@ static int apply_window(dhts_ctx *c, const IdxWindow &w, bool whole, bool nocoor
     } else if (!whole && nocoor) {
         const uint64_t s0 = w.any ? w.vmin : w.last_end;
         b0 = block_of(s0 >> 16); if (b0 >= c->n_blocks) b0 = c->n_blocks > 0 ? c->n_blocks - 1 : 0;
-        if (c->n_blocks > 0 && c->h_coff[b0] == (s0 >> 16)) first_uoff = c->h_uoff[b0] + (s0 & 0xffff); else { b0 = 0; first_uoff = c->first_rec_uoff; }
+        if (c->n_blocks > 0 && block_file_off(c, b0) == (s0 >> 16)) first_uoff = c->h_uoff[b0] + (s0 & 0xffff);
+        else if (sparse) return fail(c, "index does not match the file (chunk offset %llu)", (unsigned long long)(s0 >> 16));
+        else { b0 = 0; first_uoff = c->first_rec_uoff; }
         if (first_uoff < c->first_rec_uoff) first_uoff = c->first_rec_uoff;
     }
     c->shard_b0 = b0; c->shard_b1 = b1; c->shard_rank = 0; c->shard_world = (b1 < c->n_blocks) ? 2 : 1; c->scan_first_uoff = first_uoff;
@@ -1652,7 +1863,9 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) { blk_err = bs[k]; ulen = carry + (c->h_uoff[b0 + k] - c->h_uoff[b0]); break; }
     }
-    B.final_batch = B.last_of_stream || blk_err != 0;
+    // (where only index windows are resident, the last resident block is not the end of the FILE: the record that runs out of it is cut by
+    // the staging, not truncated)
+    B.final_batch = (B.last_of_stream && !(c->partial_tail && !c->segs.empty())) || blk_err != 0;
     B.carry = carry; B.ulen = ulen; B.out_base = out_base; B.u = u; B.blk_err = blk_err;
     return 0;
 }
@@ -1663,7 +1876,7 @@ static int batch_end(dhts_ctx *c, const Batch &B, uint64_t carry_start, bool rec
     if (rec_err || B.blk_err || shard_finished || B.last_of_stream) discard_prefetch(c);
     if (rec_err || B.blk_err) { c->stream_done = true; *status = B.blk_err ? B.blk_err * 100 : -4; }
     else if (shard_finished) { c->stream_done = true; *status = 1; }
-    else if (B.last_of_stream) { c->stream_done = true; *status = (c->bgzf_status != 0) ? c->bgzf_status : 1; if (carry_start < B.ulen && *status == 1) *status = -4; }
+    else if (B.last_of_stream) { c->stream_done = true; *status = (c->bgzf_status != 0) ? c->bgzf_status : 1; if (carry_start < B.ulen && *status == 1 && !(c->partial_tail && !c->segs.empty())) *status = -4; }
     else {
         // move the incomplete tail to the front of the other buffer
         uint64_t tail = B.ulen - carry_start;
@@ -1861,6 +2074,9 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
         }
         if (filtered) {
             if (sharded_tail && out_base + ulen > shard_end_u && carry_start >= shard_end_u - out_base) shard_finished = true;   // rows past the index window never match
+            // the window's exact end lies inside this batch: the window is done, whatever follows it (with only the windows resident the
+            // last one ends in the last resident block, and the records behind the cut are not a truncated tail)
+            if (c->scan_end_uoff != ~0ull && out_base + ulen >= c->scan_end_uoff && !rec_err) shard_finished = true;
             nrows = (int64_t)kept_total;
         } else if (nrows > 0 && sharded_tail && out_base + ulen > shard_end_u) {
             // drop rows whose record starts at/after the shard end (they belong to the next shard): binary search on rec_off

@@ -98,6 +98,7 @@ struct BamScan {
     std::vector<Producer *> prod; size_t cur_prod = 0;
     std::string error; bool cancel = false, handoff_checked = false;
     std::vector<uint8_t> index_bytes;
+    std::vector<uint64_t> seg_beg, seg_end; int64_t seg_count = -1;      // region query: the file byte ranges to stage (-1: the whole file)
     ~BamScan() {
         { std::lock_guard<std::mutex> lk(mu); cancel = true; }
         cv_free.notify_all(); cv_ready.notify_all();
@@ -285,15 +286,19 @@ static void producer_main(BamScan *g, Producer *p) {
     };
     dhts_ctx *c = dhts_create(p->device);
     if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
+    const double t_created = now_s() - t_start; double t_staged = 0;
     int rc;
     // a plain whole-file scan on one device starts decoding while the file is still being staged: the block table is built over the
     // resident prefix and extended as more bytes arrive (DHTS_STREAM=0 stages the whole file first)
     static const bool env_nostream = getenv("DHTS_STREAM") && atoi(getenv("DHTS_STREAM")) == 0;
     const bool streaming = p->world == 1 && bind->region.empty() && !env_nostream;
     int staged_all = 1;
-    if (p->world > 1) rc = dhts_open_path_shard(c, bind->path.c_str(), p->rank, p->world, bind->header_bytes);
+    if (g->seg_count >= 0) rc = dhts_open_path_segments(c, bind->path.c_str(), bind->header_bytes, g->seg_beg.data(), g->seg_end.data(), g->seg_count);
+    else if (p->world > 1) rc = dhts_open_path_shard(c, bind->path.c_str(), p->rank, p->world, bind->header_bytes);
     else if (streaming) rc = dhts_open_path_async(c, bind->path.c_str());
     else rc = dhts_open_path(c, bind->path.c_str());
+    t_staged = now_s() - t_start;
+    const bool from_cache = rc == 0 && dhts_resident_from_cache(c) != 0;
     if (rc == 0 && !streaming) { if (dhts_bgzf_index(c) <= 0 || dhts_bam_open(c) != 0) rc = -1; }
     if (rc == 0 && streaming) {
         // the header needs the first blocks only: start with what the bind saw, four times more whenever that is not enough
@@ -358,8 +363,8 @@ static void producer_main(BamScan *g, Producer *p) {
         { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
     }
     dhts_destroy(c);
-    if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: open+index+header %.3f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
-                       p->rank, p->world, p->device, t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
+    if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: context %.3f s, staged at %.3f s%s, open+index+header %.3f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
+                       p->rank, p->world, p->device, t_created, t_staged, from_cache ? " (file still resident in HBM)" : "", t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
     { std::lock_guard<std::mutex> lk(g->mu); p->done = true; }
     g->cv_ready.notify_all();
 }
@@ -399,6 +404,12 @@ static void bam_read_global_init(duckdb_init_info info) {
             fclose(f);
             const bool known = ib.size() >= 4 && (memcmp(ib.data(), "BAI\1", 4) == 0 || memcmp(ib.data(), "CSI\1", 4) == 0 || (ib[0] == 0x1f && ib[1] == 0x8b));
             if (known) g->index_bytes.swap(ib);
+        }
+        // only the index windows are staged (the reference seeks to them): byte ranges from the bind context, which holds the header
+        static const bool env_nosparse = getenv("DHTS_SPARSE") && atoi(getenv("DHTS_SPARSE")) == 0;
+        if (!g->index_bytes.empty() && !env_nosparse) {
+            g->seg_beg.resize(4096); g->seg_end.resize(4096);
+            if (dhts_bam_region_segments(bind->ctx, g->index_bytes.data(), g->index_bytes.size(), g->seg_beg.data(), g->seg_end.data(), 4096, &g->seg_count) != 0) g->seg_count = -1;   // fall back to the whole file
         }
     }
     // sequential mode unless the user asks for parallel fill (bam_reader.c:577-585: the reference goes parallel only with an index)

@@ -156,6 +156,14 @@ int64_t dhts_blocks_ahead(const dhts_ctx *);
  * opened (the head of) the file.  dhts_voffset turns a position of the inflated stream into a BGZF virtual offset (bgzf_tell,
  * htslib/bgzf.h): adjacent ranks hand off end == first-record as virtual offsets. */
 int dhts_open_path_shard(dhts_ctx *, const char *path, int rank, int world, uint64_t header_bytes);
+/* A region query stages only what it needs (htslib seeks to each index chunk, hts.c:4320-4607): dhts_bam_region_segments -- on a context
+ * that holds the header (dhts_bam_open) and the regions (dhts_bam_set_regions) -- turns the index into file byte ranges: beg[k] = offset
+ * of a window's first BGZF block, end[k] = offset of its LAST block (~0 = to the end of the file), *count = -1 when the whole file is
+ * needed; dhts_open_path_segments stages the header blocks file[0, header_bytes) and those windows (whole blocks, merged where they
+ * touch).  dhts_bgzf_index / dhts_bam_open / dhts_bam_set_regions / dhts_bam_load_index follow as for a whole file; virtual offsets
+ * (dhts_voffset, the index) stay those of the FILE. */
+int dhts_bam_region_segments(dhts_ctx *, const void *index_bytes, uint64_t n, uint64_t *beg, uint64_t *end, int64_t cap, int64_t *count);
+int dhts_open_path_segments(dhts_ctx *, const char *path, uint64_t header_bytes, const uint64_t *beg, const uint64_t *end, int64_t n);
 /* the cut itself, host only (no device): rank r stages file[win_begin, win_end) and owns the blocks that start in [win_begin, own_end) */
 int dhts_shard_window(const char *path, int rank, int world, uint64_t header_bytes, uint64_t *win_begin, uint64_t *win_end, uint64_t *own_end);
 int dhts_bam_set_file_shard(dhts_ctx *, int rank, int world);
@@ -285,6 +293,10 @@ void dhts_host_free(void *p);
 /* Device buffers of destroyed contexts and freed pinned buffers are kept in process-wide pools (a context per query would otherwise pay
  * hipMalloc / hipHostMalloc of gigabytes each time); this returns every idle pooled buffer to the driver. */
 void dhts_release_pools(void);
+/* 1 when the context's file bytes were taken over from an earlier context of this process instead of being read and copied again: a file
+ * staged WHOLE stays in HBM (in the device pool, tagged with device / inode / size / mtime / ctime) after its context is destroyed, until
+ * the pool needs the room (least recently used first) or dhts_release_pools.  DHTS_FILE_CACHE=0 disables it. */
+int dhts_resident_from_cache(const dhts_ctx *);
 int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);   /* hipMemGetInfo after a device synchronise */
 uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
 int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);

@@ -682,3 +682,110 @@ def test_region_query_disjoint_index_windows(gap_mb):
             del os.environ["DHTS_WINDOW_GAP_MB"]
         else:
             os.environ["DHTS_WINDOW_GAP_MB"] = old
+
+
+def test_region_query_stages_only_its_index_windows(tmp_path):
+    """dhts_bam_region_segments + dhts_open_path_segments: header blocks + the index windows are the only resident bytes; rows, order and
+    the virtual offsets of the hand-off are those of the whole-file scan (and of the region oracle)."""
+    import ctypes as C
+    import region_oracle
+    data = synth.bam_file(300000, seed=31)
+    path = os.path.join(str(tmp_path), "w.bam")
+    open(path, "wb").write(data)
+    exp = orc.bam_read(data)
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(data); ctx.bgzf_index(); ctx.bam_open()
+        bai = ctx.build_index()
+        L = duckhts_amd.lib()
+        L.dhts_bam_header_bytes.restype = C.c_uint64
+        L.dhts_bam_header_bytes.argtypes = [C.c_void_p]
+        hb = L.dhts_bam_header_bytes(ctx.h)
+        regions = ["chr1:1,000,000-1,200,000", "chr1:1,000,000-1,200,000,chr5:40000000-41000000,chrX:1-3,000,000,chr1:200,000,000-201,000,000",
+                   "chr2:5000000-5100000,chr2:5,050,000-5,300,000,chr20,chr3:100-200", "chrM", "chr22:50,000,000-60,000,000,*", "*", "chrY:1-10",
+                   ",".join(f"chr{1 + k % 22}:{1_000_000 * (1 + 7 * k % 40)}-{1_000_000 * (1 + 7 * k % 40) + 150_000}" for k in range(60))]
+        old = os.environ.get("DHTS_WINDOW_GAP_MB")
+        try:
+            for gap in ("0", "0.25", "32"):
+                os.environ["DHTS_WINDOW_GAP_MB"] = gap
+                for region in regions:
+                    assert ctx.set_regions(region)
+                    seg = ctx.region_segments(bai)
+                    assert seg is not None
+                    keep = region_oracle.keep_mask(exp, region)
+                    want = [q for q, k in zip(exp["QNAME"], keep) if k]
+                    for mb in (0, 3):
+                        a = duckhts_amd.read_bam(path, region=region, index=bai, max_blocks=mb, sparse=(hb, seg[0], seg[1]))
+                        assert a["status"] == 1 and a["n_rows"] == len(want) and a["QNAME"] == want, (region[:40], gap, mb, a["n_rows"], len(want))
+                        assert list(a["POS"]) == [int(p) for p, k in zip(exp["POS"], keep) if k]
+                    if gap == "0" and region == regions[0]:
+                        staged = hb + sum(int(e) - int(b) for b, e in zip(*seg)) + 65536 * len(seg[0])
+                        assert staged < len(data) // 10, (staged, len(data))             # a 200 kb region of a 3.1 Gb genome: a sliver of the file
+            assert ctx.set_regions("chr1")                                               # a whole-file query has no segments
+        finally:
+            if old is None:
+                del os.environ["DHTS_WINDOW_GAP_MB"]
+            else:
+                os.environ["DHTS_WINDOW_GAP_MB"] = old
+    finally:
+        ctx.close()
+
+
+def test_whole_file_stays_resident_for_the_next_query(tmp_path):
+    """a file staged whole is kept in HBM (tagged pool buffer) when its context goes away; the next context on the unchanged file takes it
+    over without reading the file; a changed file (size / mtime) is staged afresh"""
+    import ctypes as C
+    L = duckhts_amd.lib()
+    L.dhts_resident_from_cache.argtypes = [C.c_void_p]
+    data = synth.bam_file(60000, seed=5)
+    path = os.path.join(str(tmp_path), "c.bam")
+    open(path, "wb").write(data)
+    exp = orc.bam_read(data)
+
+    def scan(asynchronous):
+        ctx = duckhts_amd.Context(0)
+        try:
+            if asynchronous:
+                L.dhts_open_path_async.argtypes = [C.c_void_p, C.c_char_p]
+                L.dhts_stage_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
+                L.dhts_stage_wait.restype = C.c_int64
+                L.dhts_bgzf_index_staged.argtypes = [C.c_void_p]
+                L.dhts_bgzf_index_staged.restype = C.c_int64
+                assert L.dhts_open_path_async(ctx.h, os.fsencode(path)) == 0
+                done = C.c_int(0)
+                assert L.dhts_stage_wait(ctx.h, 1 << 62, C.byref(done)) == os.path.getsize(path) and done.value == 1
+                assert L.dhts_bgzf_index_staged(ctx.h) > 0
+            else:
+                ctx.open(path)
+                ctx.bgzf_index()
+            hit = L.dhts_resident_from_cache(ctx.h)
+            hdr = ctx.bam_open()
+            names = []
+            while True:
+                b = ctx.next_batch(0)
+                if b.n_rows:
+                    names += ctx.batch_to_host(b, hdr)["QNAME"]
+                if b.status != 0:
+                    break
+            return hit, names
+        finally:
+            ctx.close()
+
+    L.dhts_release_pools()
+    hit, names = scan(False)
+    assert hit == 0 and names == exp["QNAME"]
+    for asynchronous in (False, True, True, False):
+        hit, names = scan(asynchronous)
+        assert hit == 1 and names == exp["QNAME"]
+    data2 = synth.bam_file(50000, seed=6)
+    open(path, "wb").write(data2)
+    hit, names = scan(False)
+    assert hit == 0 and names == orc.bam_read(data2)["QNAME"]
+    hit, names = scan(True)
+    assert hit == 1
+    L.dhts_release_pools()
+    hit, names = scan(True)                                     # staged by the background readers: tagged when the context goes away
+    assert hit == 0 and names == orc.bam_read(data2)["QNAME"]
+    hit, names = scan(False)
+    assert hit == 1
+    L.dhts_release_pools()

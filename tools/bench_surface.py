@@ -30,6 +30,8 @@ def run(fn, path, proj=None, named=(), threads=1, repeat=4, env=None):
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout + r.stderr
+    if os.environ.get("DHTS_TRACE"):
+        sys.stderr.write(r.stderr)
     rows = int(r.stdout.split("OK rows=")[1].split()[0])
     runs = [float(l.split("seconds=")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("RUN ")]
     return rows, dt, runs
@@ -45,12 +47,34 @@ def main():
     run("read_bam", bam, proj=[1], repeat=1)                         # warm the page cache
     for name, proj in (("count(*) (QNAME)", [0]), ("fixed-width (FLAG,POS,MAPQ)", [1, 3, 4]), ("all 13 columns", None)):
         for thr in (1, threads):
-            rows, dt, runs = run("read_bam", bam, proj=proj, threads=thr, env={"DHTS_THREADS": str(thr)})
-            warm = sorted(runs[1:])[len(runs[1:]) // 2]
-            print(json.dumps({"operator": "read_bam through the DuckDB table function (mini host); includes pread + H2D + scan + D2H + chunk fill", "projection": name, "rows": rows,
-                              "DHTS_THREADS": thr, "file_GB": round(size / 1e9, 3), "first_query_s": round(runs[0], 3), "warm_query_s": round(warm, 4),
-                              "records_per_s": round(rows / warm, 1), "bgzf_GBps": round(size / warm / 1e9, 3), "first_query_records_per_s": round(rows / runs[0], 1),
-                              "process_wall_s": round(dt, 3)}), flush=True)
+            # DHTS_FILE_CACHE=0: every query reads the file and copies it to the device; default: a file staged whole stays in HBM for the next query
+            for cache in ("0", "1"):
+                rows, dt, runs = run("read_bam", bam, proj=proj, threads=thr, env={"DHTS_THREADS": str(thr), "DHTS_FILE_CACHE": cache})
+                warm = sorted(runs[1:])[len(runs[1:]) // 2]
+                print(json.dumps({"operator": "read_bam through the DuckDB table function (mini host)",
+                                  "includes": "pread + H2D + scan + D2H + chunk fill" if cache == "0" else "scan + D2H + chunk fill (file still resident in HBM from the previous query)",
+                                  "projection": name, "rows": rows, "DHTS_THREADS": thr, "file_GB": round(size / 1e9, 3), "first_query_s": round(runs[0], 3), "warm_query_s": round(warm, 4),
+                                  "records_per_s": round(rows / warm, 1), "bgzf_GBps": round(size / warm / 1e9, 3), "first_query_records_per_s": round(rows / runs[0], 1),
+                                  "process_wall_s": round(dt, 3)}), flush=True)
+    if os.environ.get("BENCH_REGION", "1") != "0":
+        # region queries (config 5 through the operator): a BAI written by dhts_bam_build_index next to the file; with DHTS_SPARSE=0 the whole
+        # file is staged and only the windows are inflated, by default only the header blocks and the windows are staged at all
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(bam); ctx.bgzf_index(); hdr = ctx.bam_open()
+            open(bam + ".bai", "wb").write(ctx.build_index())
+        finally:
+            ctx.close()
+        duckhts_amd.lib().dhts_release_pools()
+        regions = {"1 region of 1 Mb": "chr1:10,000,000-11,000,000",
+                   "100 regions of 100 kb": ",".join(f"chr{1 + k % 22}:{1_000_000 * (1 + 7 * k % 40)}-{1_000_000 * (1 + 7 * k % 40) + 100_000}" for k in range(100))}
+        for name, region in regions.items():
+            for sparse in ("1", "0"):
+                rows, dt, runs = run("read_bam", bam, named=[("region", region)], threads=1, env={"DHTS_THREADS": "1", "DHTS_SPARSE": sparse, "DHTS_FILE_CACHE": "0"})
+                warm = sorted(runs[1:])[len(runs[1:]) // 2]
+                print(json.dumps({"operator": "read_bam(region := ...) through the DuckDB table function (mini host), all 13 columns", "query": name, "rows": rows,
+                                  "staging": "header + index windows" if sparse == "1" else "whole file", "file_GB": round(size / 1e9, 3),
+                                  "first_query_s": round(runs[0], 3), "warm_query_ms": round(warm * 1e3, 2)}), flush=True)
     if os.environ.get("BENCH_BCF", "1") == "0":
         return
     nb = n // 8
