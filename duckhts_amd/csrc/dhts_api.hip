@@ -211,6 +211,7 @@ struct dhts_ctx {
     dhts::BcfHeader bh; dhts::BcfSchema bsch;
     std::vector<dhts_bcf_colinfo> bcf_colinfo; std::vector<const char *> bcf_ctg_p, bcf_dict_p, bcf_smp_p;
     std::vector<int32_t> bcf_proj; std::vector<dhts_bcf_col> bcf_out;
+    struct Arena { const uint8_t *p = nullptr; uint64_t n = 0; } bcf_ar[4];      // device arenas of the last batch's columns: validity, fixed payloads, offsets, children / bytes
     bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
     DevBuf b_keep, b_map, b_sel;
     DevBuf d_ctg_ok, d_id_ok, d_info_slot, d_fmt_slot, b_rec_off, b_dir, b_lens, b_offs, b_partial, b_total, b_coldev, b_fixed, b_valid, b_var;
@@ -2262,6 +2263,7 @@ static size_t fixed_width(const dhts::BcfColumn &col) {
 int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     if (!c || !out) return -1;
     memset(out, 0, sizeof(*out));
+    for (auto &a : c->bcf_ar) { a.p = nullptr; a.n = 0; }
     if (!c->bcf_open) return fail(c, "dhts_bcf_open not called");
     HIPCHK(c, hipSetDevice(c->device));
     const int ncols = (int)c->bcf_proj.size();
@@ -2423,6 +2425,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                 hipLaunchKernelGGL(bcf_cells<false>, dim3((unsigned)(((nrows + 255) / 256) * ncols)), dim3(256), 0, c->stream, st, ca);
             }
             std::vector<uint64_t> tot(nsa ? nsa : 1, 0);
+            uint64_t var_total = 0;
             if (nsa > 0) {
                 MScanArgs ma; ma.in = (const uint32_t *)c->b_lens.p; ma.out = (uint32_t *)c->b_offs.p; ma.stride = ostride; ma.n = nrows;
                 ma.nparts = (nrows + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS; if (ma.nparts < 1) ma.nparts = 1;
@@ -2445,7 +2448,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                     if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes >= 0) { at_coff[i] = var_bytes; var_bytes += ((tot[cd[i].sa_cnt] + 1) * 4 + 63) & ~(size_t)63; }
                     if (cd[i].sa_bytes >= 0) { at_bytes[i] = var_bytes; var_bytes += (tot[cd[i].sa_bytes] + 63) & ~(size_t)63; }
                 }
-                ENSURE(c, c->b_var, var_bytes + 64);
+                ENSURE(c, c->b_var, var_bytes + 64); var_total = var_bytes;
                 for (int i = 0; i < ncols; i++) {
                     uint8_t *base = (uint8_t *)c->b_var.p;
                     if (cd[i].sa_cnt >= 0 && cd[i].sa_bytes < 0) cd[i].child_fixed = (uint32_t *)(base + at_child[i]);
@@ -2460,6 +2463,10 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
                 }
             }
             HIPCHK(c, hipGetLastError());
+            c->bcf_ar[0].p = (const uint8_t *)c->b_valid.p; c->bcf_ar[0].n = (uint64_t)ncols * (uint64_t)nrows;
+            c->bcf_ar[1].p = (const uint8_t *)c->b_fixed.p; c->bcf_ar[1].n = fixed_bytes;
+            c->bcf_ar[2].p = (const uint8_t *)c->b_offs.p; c->bcf_ar[2].n = (uint64_t)nsa * ostride * 4;
+            c->bcf_ar[3].p = (const uint8_t *)c->b_var.p; c->bcf_ar[3].n = var_total;
             for (int i = 0; i < ncols; i++) {
                 dhts_bcf_col &o = c->bcf_out[i];
                 o.valid = cd[i].valid; o.fixed = cd[i].fixed;
@@ -2584,6 +2591,43 @@ int dhts_bam_batch_fetch(dhts_ctx *c, const dhts_bam_batch *b, uint32_t m, void 
         oc[k]->bytes = (const uint8_t *)put(sc[k]->bytes, sc[k]->nbytes);
         at = at0 + al64(sc[k]->nbytes + 1);                             // (one readable byte behind the heap, as in the size formula)
         if (!oc[k]->off || !oc[k]->len || !oc[k]->bytes) return fail(c, "hipMemcpyAsync failed");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// read_bcf batches in host memory: the columns of a batch live in four device arenas (validity, fixed payloads, the offset matrix,
+// children / bytes), so the read-back is four queued copies and one wait, and every column pointer is re-based onto the host copy
+uint64_t dhts_bcf_batch_host_bytes(const dhts_ctx *c) {
+    if (!c) return 0;
+    uint64_t t = 0; for (auto &a : c->bcf_ar) t += al64(a.n);
+    return t;
+}
+int dhts_bcf_batch_fetch(dhts_ctx *c, const dhts_bcf_batch *b, void *dst, uint64_t cap, dhts_bcf_col *out_cols) {
+    if (!c || !b || (b->n_cols > 0 && !out_cols)) return -1;
+    for (int i = 0; i < b->n_cols; i++) out_cols[i] = b->cols[i];
+    if (b->n_rows <= 0 || b->n_cols <= 0) return 0;
+    const uint64_t need = dhts_bcf_batch_host_bytes(c);
+    if (need > cap || (need && !dst)) return fail(c, "host arena too small for the batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t *h = (uint8_t *)dst; uint64_t at = 0; const uint8_t *hb[4];
+    for (int k = 0; k < 4; k++) {
+        hb[k] = h + at;
+        if (c->bcf_ar[k].n) HIPCHK(c, hipMemcpyAsync(h + at, c->bcf_ar[k].p, c->bcf_ar[k].n, hipMemcpyDeviceToHost, c->stream));
+        at += al64(c->bcf_ar[k].n);
+    }
+    auto rebase = [&](const void *p) -> const void * {
+        if (!p) return nullptr;
+        const uint8_t *q = (const uint8_t *)p;
+        for (int k = 0; k < 4; k++) if (c->bcf_ar[k].p && q >= c->bcf_ar[k].p && q <= c->bcf_ar[k].p + c->bcf_ar[k].n) return hb[k] + (q - c->bcf_ar[k].p);
+        return nullptr;
+    };
+    for (int i = 0; i < b->n_cols; i++) {
+        dhts_bcf_col &o = out_cols[i]; const dhts_bcf_col &d = b->cols[i];
+        o.valid = (const uint8_t *)rebase(d.valid); o.fixed = rebase(d.fixed); o.off = (const uint32_t *)rebase(d.off); o.bytes = (const uint8_t *)rebase(d.bytes);
+        o.child_fixed = (const uint32_t *)rebase(d.child_fixed); o.child_off = (const uint32_t *)rebase(d.child_off); o.child_valid = (const uint8_t *)rebase(d.child_valid);
+        if ((d.valid && !o.valid) || (d.fixed && !o.fixed) || (d.off && !o.off) || (d.bytes && !o.bytes) || (d.child_fixed && !o.child_fixed) || (d.child_off && !o.child_off) || (d.child_valid && !o.child_valid))
+            return fail(c, "batch column outside the batch arenas");
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;

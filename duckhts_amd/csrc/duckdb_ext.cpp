@@ -651,32 +651,40 @@ struct BcfBind {
     dhts_bcf_info inf;
     int has_index = 0;
 };
-struct HostCol {
-    int col = 0;
-    std::vector<uint8_t> valid, fixed, bytes, child_valid;      // child_valid empty = every element valid
-    std::vector<uint32_t> off, child_off, child_fixed;
-    uint64_t child_n = 0;
+// ---- scan pipeline, as for read_bam: a producer thread drives the device and reads every batch back into a pinned arena (four queued
+// copies, dhts_bcf_batch_fetch); the scan callbacks fill DataChunks from those arenas while the device works on the next batch.
+// DHTS_THREADS = 1 (default): one worker, rows in file order, full 2048-row chunks (the reference's only mode for read_bcf without
+// an index); DHTS_THREADS = k: k workers claim 2048-row slices, row order across workers unspecified.
+struct BcfHostBatch {
+    void *arena = nullptr; uint64_t cap = 0;
+    std::vector<dhts_bcf_col> cols;                 // HOST pointers, projection order (deduplicated)
+    std::vector<std::vector<uint32_t>> conv;        // per column: DHTS_ENC_FLOAT_TEXT children converted to float bits
+    int64_t n = 0; int status = 0;
+    int64_t next = 0; int readers = 0; bool retired = false;
+};
+struct BcfScan {
+    BcfBind *bind = nullptr;
+    std::vector<idx_t> column_ids;       // schema ids per output vector
+    std::vector<int> slot;               // output vector -> index into the batch's columns (or -1 for unknown ids)
+    std::vector<int32_t> proj;           // projected (deduplicated) schema columns
+    int n_workers = 1;
+    std::mutex mu; std::condition_variable cv_ready, cv_free;
+    std::deque<BcfHostBatch *> ready; std::vector<BcfHostBatch *> free_slots, all;
+    std::thread th; bool done = false, cancel = false; std::string error;
+    ~BcfScan() {
+        { std::lock_guard<std::mutex> lk(mu); cancel = true; }
+        cv_free.notify_all(); cv_ready.notify_all();
+        if (th.joinable()) th.join();
+        for (auto hb : all) { dhts_host_free(hb->arena); delete hb; }
+    }
 };
 struct BcfLocal {
-    std::vector<idx_t> column_ids;       // schema ids per output vector
-    std::vector<int> slot;               // output vector -> index into `cols` (or -1 for unknown ids)
-    std::vector<HostCol> cols;           // projected (deduplicated) columns of the current batch
-    bool done = false; int64_t n = 0, cur = 0; int status = 0;
-    size_t next_region = 0;              // chained single-region iterators (bcf_reader.c:1327-1345)
+    bool done = false;
+    BcfHostBatch *cur = nullptr; int64_t pos = 0, end = 0;      // rows [pos, end) of `cur` are this worker's
 };
-// advance to the next region that yields an iterator; false when none is left
-static bool bcf_next_region(BcfBind *bind, BcfLocal *l) {
-    while (l->next_region < bind->regions.size()) {
-        const std::string &rg = bind->regions[l->next_region++];
-        if (dhts_bcf_set_region(bind->ctx, rg.c_str()) == 0) {                  // unknown contig / malformed: skipped (bcf_reader.c:944-953)
-            if (!bind->index_bytes.empty()) (void)dhts_bcf_load_index(bind->ctx, bind->index_bytes.data(), bind->index_bytes.size());   // window only: a failure keeps the full scan
-            return true;
-        }
-    }
-    return false;
-}
 static void destroy_bcf_bind(void *p) { BcfBind *b = (BcfBind *)p; if (!b) return; if (b->ctx) dhts_destroy(b->ctx); delete b; }
 static void destroy_bcf_local(void *p) { delete (BcfLocal *)p; }
+static void destroy_bcf_global(void *p) { delete (BcfScan *)p; }
 
 static void bcf_read_bind(duckdb_bind_info info) {
     auto set_error = API(void, duckdb_bind_set_error, duckdb_bind_info, const char *);
@@ -737,6 +745,73 @@ static void bcf_read_bind(duckdb_bind_info info) {
     API(void, duckdb_bind_set_bind_data, duckdb_bind_info, void *, duckdb_delete_callback_t)(info, b, destroy_bcf_bind);
 }
 
+// chained single-region iterators (bcf_reader.c:1327-1345): the next region that yields an iterator; false when none is left
+static bool bcf_next_region(BcfBind *bind, size_t *next_region) {
+    while (*next_region < bind->regions.size()) {
+        const std::string &rg = bind->regions[(*next_region)++];
+        if (dhts_bcf_set_region(bind->ctx, rg.c_str()) == 0) {                  // unknown contig / malformed: skipped (bcf_reader.c:944-953)
+            if (!bind->index_bytes.empty()) (void)dhts_bcf_load_index(bind->ctx, bind->index_bytes.data(), bind->index_bytes.size());   // window only: a failure keeps the full scan
+            return true;
+        }
+    }
+    return false;
+}
+
+static void bcf_producer_main(BcfScan *g) {
+    BcfBind *bind = g->bind; dhts_ctx *c = bind->ctx;
+    auto finish = [&](const std::string &err) {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (!err.empty() && g->error.empty()) g->error = err;
+        g->done = true; g->cv_ready.notify_all();
+    };
+    if (dhts_bcf_set_projection(c, g->proj.data(), (int32_t)g->proj.size()) != 0 || dhts_bcf_set_region(c, nullptr) != 0) { finish("Failed to open BCF/VCF file"); return; }
+    size_t next_region = 0;
+    if (!bind->regions.empty() && !bcf_next_region(bind, &next_region)) { finish(""); return; }     // no region produced an iterator: zero rows (bcf_reader.c:955-959)
+    static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
+    const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;
+    for (;;) {
+        dhts_bcf_batch b;
+        if (dhts_bcf_next_batch(c, max_blocks, &b) != 0) { finish(dhts_error(c)); return; }
+        if (b.n_rows > 0) {
+            BcfHostBatch *hb = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(g->mu);
+                g->cv_free.wait(lk, [&] { return g->cancel || !g->free_slots.empty(); });
+                if (g->cancel) break;
+                hb = g->free_slots.back(); g->free_slots.pop_back();
+            }
+            const uint64_t need = dhts_bcf_batch_host_bytes(c);
+            if (need > hb->cap) { dhts_host_free(hb->arena); hb->arena = dhts_host_alloc(need); hb->cap = hb->arena ? need : 0; }
+            hb->cols.assign((size_t)b.n_cols, dhts_bcf_col());
+            if ((need && !hb->arena) || dhts_bcf_batch_fetch(c, &b, hb->arena, hb->cap, hb->cols.data()) != 0) { finish(hb->arena || !need ? dhts_error(c) : "read_bcf: out of pinned host memory"); return; }
+            hb->conv.assign((size_t)b.n_cols, std::vector<uint32_t>());
+            for (int i = 0; i < b.n_cols; i++) {
+                const dhts_bcf_col &h = hb->cols[i];
+                if (bind->inf.cols[h.col].encoding != DHTS_ENC_FLOAT_TEXT) continue;
+                // Float fields of a transcript arrive as text: (float)strtod, NaN unless the whole token converts (vep_parse_float, src/vep_parser.c:222-235)
+                std::vector<uint32_t> &cv = hb->conv[i]; cv.assign(h.child_n + 1, 0);
+                std::string tok;
+                for (uint64_t k = 0; k < h.child_n; k++) {
+                    if (h.child_valid && !h.child_valid[k]) continue;
+                    tok.assign((const char *)h.bytes + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
+                    char *end = nullptr; const double v = strtod(tok.c_str(), &end);
+                    const float f = (end == tok.c_str() || *end) ? NAN : (float)v;
+                    memcpy(&cv[k], &f, 4);
+                }
+            }
+            hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false;
+            { std::lock_guard<std::mutex> lk(g->mu); g->ready.push_back(hb); }
+            g->cv_ready.notify_all();
+        }
+        if (b.status != 0) {                                     // EOF, or the silent stop at the first bad record (bcf_reader.c:1319-1349)
+            if (!bind->regions.empty() && bcf_next_region(bind, &next_region)) continue;
+            break;
+        }
+        { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
+    }
+    finish("");
+}
+
 static void bcf_read_global_init(duckdb_init_info info) {
     BcfBind *bind = (BcfBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
     if (!bind->regions.empty() && !bind->has_index) {
@@ -745,31 +820,57 @@ static void bcf_read_global_init(duckdb_init_info info) {
         API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, err);
         return;
     }
-    API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, 1);
-    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, calloc(1, 16), free);
+    BcfScan *g = new BcfScan();
+    g->bind = bind;
+    idx_t n = API(idx_t, duckdb_init_get_column_count, duckdb_init_info)(info);
+    for (idx_t i = 0; i < n; i++) {
+        idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
+        g->column_ids.push_back(id);
+        int sl = -1;
+        if (id < (idx_t)bind->inf.n_cols) {
+            for (size_t k = 0; k < g->proj.size(); k++) if (g->proj[k] == (int32_t)id) sl = (int)k;
+            if (sl < 0) { sl = (int)g->proj.size(); g->proj.push_back((int32_t)id); }
+        }
+        g->slot.push_back(sl);
+    }
+    int thr = getenv("DHTS_THREADS") ? atoi(getenv("DHTS_THREADS")) : 1; if (thr < 1) thr = 1; if (thr > 64) thr = 64;
+    g->n_workers = thr;
+    for (int q = 0; q < 3; q++) { BcfHostBatch *hb = new BcfHostBatch(); g->free_slots.push_back(hb); g->all.push_back(hb); }
+    g->th = std::thread(bcf_producer_main, g);
+    API(void, duckdb_init_set_max_threads, duckdb_init_info, idx_t)(info, (idx_t)thr);
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, g, destroy_bcf_global);
 }
 
 static void bcf_read_local_init(duckdb_init_info info) {
-    BcfBind *bind = (BcfBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
-    BcfLocal *l = new BcfLocal();
-    idx_t n = API(idx_t, duckdb_init_get_column_count, duckdb_init_info)(info);
-    std::vector<int32_t> proj;
-    for (idx_t i = 0; i < n; i++) {
-        idx_t id = API(idx_t, duckdb_init_get_column_index, duckdb_init_info, idx_t)(info, i);
-        l->column_ids.push_back(id);
-        int sl = -1;
-        if (id < (idx_t)bind->inf.n_cols) {
-            for (size_t k = 0; k < proj.size(); k++) if (proj[k] == (int32_t)id) sl = (int)k;
-            if (sl < 0) { sl = (int)proj.size(); proj.push_back((int32_t)id); }
+    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, new BcfLocal(), destroy_bcf_local);
+}
+
+// rows of the next ready batch for this worker (ordered mode: the whole batch; parallel mode: a slice); false = the scan is over
+static bool bcf_next_rows(BcfScan *g, BcfLocal *l, idx_t want) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (l->cur) {
+        BcfHostBatch *hb = l->cur;
+        hb->readers--;
+        if (g->n_workers == 1 || (hb->retired && hb->readers == 0)) { g->free_slots.push_back(hb); g->cv_free.notify_all(); }
+        l->cur = nullptr;
+    }
+    for (;;) {
+        if (!g->error.empty()) return false;
+        while (!g->ready.empty()) {
+            BcfHostBatch *hb = g->ready.front();
+            if (g->n_workers == 1) { g->ready.pop_front(); hb->readers = 1; l->cur = hb; l->pos = 0; l->end = hb->n; return true; }
+            if (hb->next >= hb->n) {
+                g->ready.pop_front(); hb->retired = true;
+                if (hb->readers == 0) { g->free_slots.push_back(hb); g->cv_free.notify_all(); }
+                continue;
+            }
+            l->cur = hb; l->pos = hb->next; l->end = hb->next + (int64_t)want < hb->n ? hb->next + (int64_t)want : hb->n;
+            hb->next = l->end; hb->readers++;
+            return true;
         }
-        l->slot.push_back(sl);
+        if (g->done) return false;
+        g->cv_ready.wait(lk);
     }
-    l->cols.resize(proj.size());
-    if (dhts_bcf_set_projection(bind->ctx, proj.data(), (int32_t)proj.size()) != 0 || dhts_bcf_set_region(bind->ctx, nullptr) != 0) {
-        API(void, duckdb_init_set_error, duckdb_init_info, const char *)(info, "Failed to open BCF/VCF file"); delete l; return;
-    }
-    if (!bind->regions.empty() && !bcf_next_region(bind, l)) l->done = true;      // no region produced an iterator: zero rows (bcf_reader.c:955-959)
-    API(void, duckdb_init_set_init_data, duckdb_init_info, void *, duckdb_delete_callback_t)(info, l, destroy_bcf_local);
 }
 
 static size_t bcf_fixed_width(const dhts_bcf_colinfo &ci) {
@@ -778,51 +879,8 @@ static size_t bcf_fixed_width(const dhts_bcf_colinfo &ci) {
     switch (ci.type) { case DHTS_T_BOOLEAN: return 1; case DHTS_T_INTEGER: case DHTS_T_FLOAT: return 4; case DHTS_T_BIGINT: case DHTS_T_DOUBLE: return 8; default: return 0; }
 }
 
-static int bcf_next_host_batch(BcfBind *bind, BcfLocal *l) {
-    dhts_bcf_batch b;
-    for (;;) {
-        if (dhts_bcf_next_batch(bind->ctx, 0, &b) != 0) return -1;
-        l->status = b.status;
-        if (b.n_rows > 0 || b.status != 0) break;
-    }
-    const int64_t n = b.n_rows; l->n = n; l->cur = 0;
-    if (n == 0) return 0;
-    dhts_ctx *c = bind->ctx;
-    for (int i = 0; i < b.n_cols; i++) {
-        const dhts_bcf_col &d = b.cols[i]; HostCol &h = l->cols[i]; h.col = d.col;
-        const dhts_bcf_colinfo &ci = bind->inf.cols[d.col];
-        h.valid.resize(n); if (dhts_memcpy_d2h(c, h.valid.data(), d.valid, n)) return -1;
-        const size_t w = bcf_fixed_width(ci);
-        if (w) { h.fixed.resize(w * n); if (dhts_memcpy_d2h(c, h.fixed.data(), d.fixed, w * n)) return -1; }
-        if (d.off) { h.off.resize(n + 1); if (dhts_memcpy_d2h(c, h.off.data(), d.off, (n + 1) * 4)) return -1; }
-        if (d.bytes) { h.bytes.resize(d.nbytes + 1); if (dhts_memcpy_d2h(c, h.bytes.data(), d.bytes, d.nbytes)) return -1; }
-        h.child_n = d.child_n;
-        if (d.child_fixed) { h.child_fixed.resize(d.child_n + 1); if (dhts_memcpy_d2h(c, h.child_fixed.data(), d.child_fixed, d.child_n * 4)) return -1; }
-        if (d.child_off) { h.child_off.resize(d.child_n + 1); if (dhts_memcpy_d2h(c, h.child_off.data(), d.child_off, (d.child_n + 1) * 4)) return -1; }
-        h.child_valid.clear();
-        if (d.child_valid && d.child_n) { h.child_valid.resize(d.child_n); if (dhts_memcpy_d2h(c, h.child_valid.data(), d.child_valid, d.child_n)) return -1; }
-        if (ci.encoding == DHTS_ENC_FLOAT_TEXT) {
-            // Float fields of a transcript arrive as text: (float)strtod, NaN unless the whole token converts (vep_parse_float, src/vep_parser.c:222-235)
-            h.child_fixed.assign(d.child_n + 1, 0);
-            std::string tok;
-            for (uint64_t k = 0; k < d.child_n; k++) {
-                if (!h.child_valid.empty() && !h.child_valid[k]) continue;
-                tok.assign((const char *)h.bytes.data() + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
-                char *end = nullptr; const double v = strtod(tok.c_str(), &end);
-                const float f = (end == tok.c_str() || *end) ? NAN : (float)v;
-                memcpy(&h.child_fixed[k], &f, 4);
-            }
-        }
-    }
-    return 0;
-}
-
-static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk output) {
-    BcfBind *bind = (BcfBind *)API(void *, duckdb_function_get_bind_data, duckdb_function_info)(info);
-    BcfLocal *l = (BcfLocal *)API(void *, duckdb_function_get_local_init_data, duckdb_function_info)(info);
-    auto set_size = API(void, duckdb_data_chunk_set_size, duckdb_data_chunk, idx_t);
-    if (!l || l->done) { set_size(output, 0); return; }                                       // bcf_reader.c:1166-1169
-    const idx_t vector_size = API(idx_t, duckdb_vector_size, void)();
+// rows [s, s + take) of a host batch -> rows [row_count, row_count + take) of the output chunk
+static void bcf_fill(const BcfBind *bind, const BcfScan *g, const BcfHostBatch *hb, int64_t s, idx_t take, duckdb_data_chunk output, idx_t row_count) {
     auto get_vec = API(duckdb_vector, duckdb_data_chunk_get_vector, duckdb_data_chunk, idx_t);
     auto get_data = API(void *, duckdb_vector_get_data, duckdb_vector);
     auto assign_len = API(void, duckdb_vector_assign_string_element_len, duckdb_vector, idx_t, const char *, idx_t);
@@ -830,72 +888,81 @@ static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk outpu
     auto list_reserve = API(duckdb_state, duckdb_list_vector_reserve, duckdb_vector, idx_t);
     auto list_set_size = API(duckdb_state, duckdb_list_vector_set_size, duckdb_vector, idx_t);
     auto list_child = API(duckdb_vector, duckdb_list_vector_get_child, duckdb_vector);
+    for (size_t ci = 0; ci < g->column_ids.size(); ci++) {
+        if (g->slot[ci] < 0) continue;                          // ids outside the schema write nothing
+        const dhts_bcf_col &h = hb->cols[g->slot[ci]];
+        const dhts_bcf_colinfo &inf = bind->inf.cols[h.col];
+        duckdb_vector vec = get_vec(output, ci);
+        const char *const *names = inf.encoding == DHTS_ENC_CONTIG ? bind->inf.contig_name : inf.encoding == DHTS_ENC_DICT ? bind->inf.dict_name :
+                                   inf.encoding == DHTS_ENC_SAMPLE ? bind->inf.sample_name : nullptr;
+        auto name_of = [&](int32_t id) -> const char * { if (id < 0) return "PASS"; const char *nm = names[id]; return nm ? nm : "."; };
+        if (!inf.is_list) {
+            const size_t w = bcf_fixed_width(inf);
+            if (names) {
+                for (idx_t r = 0; r < take; r++) { const char *nm = name_of(((const int32_t *)h.fixed)[s + r]); assign_len(vec, row_count + r, nm, strlen(nm)); }
+            } else if (w) {
+                memcpy((uint8_t *)get_data(vec) + row_count * w, (const uint8_t *)h.fixed + (size_t)s * w, take * w);
+                for (idx_t r = 0; r < take; r++) if (!h.valid[s + r]) set_null(vec, row_count + r);
+            } else {
+                for (idx_t r = 0; r < take; r++) {
+                    if (h.valid[s + r]) assign_len(vec, row_count + r, (const char *)h.bytes + h.off[s + r], h.off[s + r + 1] - h.off[s + r]);
+                    else set_null(vec, row_count + r);
+                }
+            }
+            continue;
+        }
+        // LIST: entries {offset = current child size, length}; children appended in row order (bcf_reader.c:1403-1424, 1436-1461, 1584-1610)
+        duckdb_list_entry *le = (duckdb_list_entry *)get_data(vec);
+        idx_t base = list_size(vec);
+        const uint32_t c0 = h.off[s], c1 = h.off[s + take];
+        if (c1 > c0) { list_reserve(vec, base + (c1 - c0)); list_set_size(vec, base + (c1 - c0)); }
+        duckdb_vector child = list_child(vec);
+        for (idx_t r = 0; r < take; r++) {
+            le[row_count + r].offset = base + (h.off[s + r] - c0); le[row_count + r].length = h.off[s + r + 1] - h.off[s + r];
+            if (!h.valid[s + r]) set_null(vec, row_count + r);
+        }
+        if (c1 > c0) {
+            const std::vector<uint32_t> &cv32 = hb->conv[g->slot[ci]];
+            if (names) for (uint32_t k = c0; k < c1; k++) { const char *nm = name_of((int32_t)h.child_fixed[k]); assign_len(child, base + (k - c0), nm, strlen(nm)); }
+            else if (inf.type == DHTS_T_VARCHAR) {
+                for (uint32_t k = c0; k < c1; k++)
+                    if (!h.child_valid || h.child_valid[k]) assign_len(child, base + (k - c0), (const char *)h.bytes + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
+            } else memcpy((uint32_t *)get_data(child) + base, (inf.encoding == DHTS_ENC_FLOAT_TEXT ? cv32.data() : h.child_fixed) + c0, (size_t)(c1 - c0) * 4);
+            if (h.child_valid) {                                // NULL elements: a field the transcript does not have (bcf_reader.c:1485-1530)
+                API(void, duckdb_vector_ensure_validity_writable, duckdb_vector)(child);
+                uint64_t *cv = API(uint64_t *, duckdb_vector_get_validity, duckdb_vector)(child);
+                for (uint32_t k = c0; k < c1; k++) {
+                    const idx_t at = base + (k - c0);
+                    if (h.child_valid[k]) cv[at / 64] |= (uint64_t)1 << (at % 64); else cv[at / 64] &= ~((uint64_t)1 << (at % 64));
+                }
+            }
+        }
+    }
+}
+
+static void bcf_read_function(duckdb_function_info info, duckdb_data_chunk output) {
+    BcfBind *bind = (BcfBind *)API(void *, duckdb_function_get_bind_data, duckdb_function_info)(info);
+    BcfScan *g = (BcfScan *)API(void *, duckdb_function_get_init_data, duckdb_function_info)(info);
+    BcfLocal *l = (BcfLocal *)API(void *, duckdb_function_get_local_init_data, duckdb_function_info)(info);
+    auto set_size = API(void, duckdb_data_chunk_set_size, duckdb_data_chunk, idx_t);
+    if (!l || !g || l->done) { set_size(output, 0); return; }                                 // bcf_reader.c:1166-1169
+    const idx_t vector_size = API(idx_t, duckdb_vector_size, void)();
     idx_t row_count = 0;
     while (row_count < vector_size) {
-        if (l->cur >= l->n) {
-            if (l->status != 0) {                                    // EOF, or silent stop at the first bad record (bcf_reader.c:1319-1349)
-                if (!bind->regions.empty() && bcf_next_region(bind, l)) { l->status = 0; l->n = l->cur = 0; }
-                else { l->done = true; break; }
-            }
-            if (bcf_next_host_batch(bind, l) != 0) {
-                API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, dhts_error(bind->ctx));
-                l->done = true; set_size(output, 0); return;
-            }
-            if (l->n == 0) { if (l->status != 0) continue; l->done = true; break; }
-        }
-        idx_t take = (idx_t)(l->n - l->cur); if (take > vector_size - row_count) take = vector_size - row_count;
-        const int64_t s = l->cur;
-        for (size_t ci = 0; ci < l->column_ids.size(); ci++) {
-            if (l->slot[ci] < 0) continue;                          // ids outside the schema write nothing
-            const HostCol &h = l->cols[l->slot[ci]];
-            const dhts_bcf_colinfo &inf = bind->inf.cols[h.col];
-            duckdb_vector vec = get_vec(output, ci);
-            const char *const *names = inf.encoding == DHTS_ENC_CONTIG ? bind->inf.contig_name : inf.encoding == DHTS_ENC_DICT ? bind->inf.dict_name :
-                                       inf.encoding == DHTS_ENC_SAMPLE ? bind->inf.sample_name : nullptr;
-            auto name_of = [&](int32_t id) -> const char * { if (id < 0) return "PASS"; const char *nm = names[id]; return nm ? nm : "."; };
-            if (!inf.is_list) {
-                const size_t w = bcf_fixed_width(inf);
-                if (names) {
-                    for (idx_t r = 0; r < take; r++) { const char *nm = name_of(((const int32_t *)h.fixed.data())[s + r]); assign_len(vec, row_count + r, nm, strlen(nm)); }
-                } else if (w) {
-                    memcpy((uint8_t *)get_data(vec) + row_count * w, h.fixed.data() + (size_t)s * w, take * w);
-                    for (idx_t r = 0; r < take; r++) if (!h.valid[s + r]) set_null(vec, row_count + r);
-                } else {
-                    for (idx_t r = 0; r < take; r++) {
-                        if (h.valid[s + r]) assign_len(vec, row_count + r, (const char *)h.bytes.data() + h.off[s + r], h.off[s + r + 1] - h.off[s + r]);
-                        else set_null(vec, row_count + r);
-                    }
-                }
-                continue;
-            }
-            // LIST: entries {offset = current child size, length}; children appended in row order (bcf_reader.c:1403-1424, 1436-1461, 1584-1610)
-            duckdb_list_entry *le = (duckdb_list_entry *)get_data(vec);
-            idx_t base = list_size(vec);
-            const uint32_t c0 = h.off[s], c1 = h.off[s + take];
-            if (c1 > c0) { list_reserve(vec, base + (c1 - c0)); list_set_size(vec, base + (c1 - c0)); }
-            duckdb_vector child = list_child(vec);
-            for (idx_t r = 0; r < take; r++) {
-                le[row_count + r].offset = base + (h.off[s + r] - c0); le[row_count + r].length = h.off[s + r + 1] - h.off[s + r];
-                if (!h.valid[s + r]) set_null(vec, row_count + r);
-            }
-            if (c1 > c0) {
-                if (names) for (uint32_t k = c0; k < c1; k++) { const char *nm = name_of((int32_t)h.child_fixed[k]); assign_len(child, base + (k - c0), nm, strlen(nm)); }
-                else if (inf.type == DHTS_T_VARCHAR) {
-                    for (uint32_t k = c0; k < c1; k++)
-                        if (h.child_valid.empty() || h.child_valid[k]) assign_len(child, base + (k - c0), (const char *)h.bytes.data() + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
-                } else memcpy((uint32_t *)get_data(child) + base, h.child_fixed.data() + c0, (size_t)(c1 - c0) * 4);
-                if (!h.child_valid.empty()) {                       // NULL elements: a field the transcript does not have (bcf_reader.c:1485-1530)
-                    API(void, duckdb_vector_ensure_validity_writable, duckdb_vector)(child);
-                    uint64_t *cv = API(uint64_t *, duckdb_vector_get_validity, duckdb_vector)(child);
-                    for (uint32_t k = c0; k < c1; k++) {
-                        const idx_t at = base + (k - c0);
-                        if (h.child_valid[k]) cv[at / 64] |= (uint64_t)1 << (at % 64); else cv[at / 64] &= ~((uint64_t)1 << (at % 64));
-                    }
-                }
+        if (!l->cur || l->pos >= l->end) {
+            if (g->n_workers > 1 && row_count > 0) break;       // parallel mode: one slice per chunk
+            if (!bcf_next_rows(g, l, vector_size)) {
+                l->done = true;
+                std::string err; { std::lock_guard<std::mutex> lk(g->mu); err = g->error; }
+                if (!err.empty()) { API(void, duckdb_function_set_error, duckdb_function_info, const char *)(info, err.c_str()); set_size(output, 0); return; }
+                break;
             }
         }
-        row_count += take; l->cur += (int64_t)take;
+        idx_t take = (idx_t)(l->end - l->pos); if (take > vector_size - row_count) take = vector_size - row_count;
+        bcf_fill(bind, g, l->cur, l->pos, take, output, row_count);
+        row_count += take; l->pos += (int64_t)take;
     }
+    if (l->done && l->cur) { std::lock_guard<std::mutex> lk(g->mu); l->cur->readers--; if (g->n_workers == 1 || (l->cur->retired && l->cur->readers == 0)) { g->free_slots.push_back(l->cur); g->cv_free.notify_all(); } l->cur = nullptr; }
     set_size(output, row_count);
 }
 

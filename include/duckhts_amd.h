@@ -298,6 +298,10 @@ void dhts_release_pools(void);
  * the pool needs the room (least recently used first) or dhts_release_pools.  DHTS_FILE_CACHE=0 disables it. */
 int dhts_resident_from_cache(const dhts_ctx *);
 int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);   /* hipMemGetInfo after a device synchronise */
+/* read_bcf: the room the LAST batch of the context needs, and its read-back: out_cols[b->n_cols] = b->cols with HOST pointers (four queued
+ * copies -- validity, fixed payloads, offsets, children / bytes -- and one wait) */
+uint64_t dhts_bcf_batch_host_bytes(const dhts_ctx *);
+int dhts_bcf_batch_fetch(dhts_ctx *, const dhts_bcf_batch *b, void *dst, uint64_t cap, dhts_bcf_col *out_cols);
 uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
 int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);
 

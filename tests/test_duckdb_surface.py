@@ -465,3 +465,65 @@ def test_read_bam_two_ranks_error_in_first_rank_ends_the_scan(tmp_path):
     for env in ({}, {"DHTS_DEVICES": "0,0"}):
         rc, out, dump = run_host(fn, proj=[0, 3], env=env)
         assert rc == 0 and f"rows={exp['n_rows']} " in out, out
+
+
+@pytest.mark.gpu
+def test_read_bcf_parallel_fill(tmp_path):
+    """read_bcf with DHTS_THREADS=4: the workers fill chunks from 2048-row slices of the producer's pinned batches; the row multiset
+    (scalars, lists, NULL rows and NULL elements) equals the oracle's table"""
+    from duckhts_amd import synth
+    import vep_cases
+    files = [(synth.bcf_file(12000, seed=9) if hasattr(synth, "bcf_file") else synth.bcf_segment(12000, seed=9)[0].tobytes(), False),
+             ({n: d for n, d, t in vep_cases.edge_cases()}["many"], False)]
+    for data, tidy in files:
+        fn = os.path.join(str(tmp_path), "p.bcf")
+        open(fn, "wb").write(data)
+        exp = orc.bcf_read(data, tidy)
+        ncol = len(exp["cols"])
+        proj = list(range(min(ncol, 14))) + [ncol - 1]
+        rc, out, dump = run_host(fn, proj=proj, fn="read_bcf", threads=4, env={"DHTS_THREADS": "4", "DHTS_BATCH_BLOCKS": "3"})
+        assert rc == 0, out
+        assert f"rows={exp['n_rows']} " in out and "max_threads=4" in out
+        schema, chunks = parse_chunks(dump)
+        got = []
+        for n, cols in chunks:
+            assert n <= 2048
+            per_col = []
+            for t, val, vals in cols:
+                bits = [(int(val[i >> 6]) >> (i & 63)) & 1 for i in range(n)]
+                if t == LIST:
+                    ent, ct, child = vals
+                    rows_ = []
+                    for i in range(n):
+                        if not bits[i]:
+                            rows_.append(None); continue
+                        o, ln = int(ent[i, 0]), int(ent[i, 1])
+                        rows_.append(tuple(None if not vals.cvalid[k] else (bytes(child[k]) if ct == VARCHAR else int(child[k]) & 0xFFFFFFFF) for k in range(o, o + ln)))
+                    per_col.append(rows_)
+                elif t == VARCHAR:
+                    per_col.append([None if x is None else bytes(x) for x in vals])
+                else:
+                    w = TYPE_W[t]
+                    per_col.append([(int(x) & ((1 << (8 * w)) - 1)) if bits[i] else None for i, x in enumerate(vals)])
+            got += list(zip(*per_col))
+        want_cols = []
+        for j in proj:
+            c = exp["cols"][j]
+            if c["is_list"]:
+                rows_ = []
+                for i in range(exp["n_rows"]):
+                    if not c["valid"][i]:
+                        rows_.append(None); continue
+                    o, ln = int(c["loff"][i]), int(c["llen"][i])
+                    cvd = c.get("cvalid")
+                    if c["type"] == 1:
+                        rows_.append(tuple(None if (cvd is not None and not cvd[k]) else bytes(c["csbytes"][int(c["csoff"][k]):int(c["csoff"][k + 1])]) for k in range(o, o + ln)))
+                    else:
+                        rows_.append(tuple(None if (cvd is not None and not cvd[k]) else int(c["cfixed"][k]) & 0xFFFFFFFF for k in range(o, o + ln)))
+                want_cols.append(rows_)
+            elif c["type"] == 1:
+                want_cols.append([bytes(c["sbytes"][int(c["soff"][i]):int(c["soff"][i + 1])]) if c["valid"][i] else None for i in range(exp["n_rows"])])
+            else:
+                want_cols.append([int(c["fixed"][i]) if c["valid"][i] else None for i in range(exp["n_rows"])])
+        want = list(zip(*want_cols))
+        assert sorted(got, key=repr) == sorted(want, key=repr)
