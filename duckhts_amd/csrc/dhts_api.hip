@@ -267,12 +267,27 @@ int dhts_abi_version(void) { return DHTS_ABI_VERSION; }
 
 int dhts_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+// Streams and events of destroyed contexts are kept per device and handed to the next context: creating two streams costs a few
+// milliseconds, which is most of what a query on a small file or a narrow region spends in dhts_create.
+namespace {
+struct StreamSet { int dev; hipStream_t s, sb; hipEvent_t ev; };
+std::mutex g_ss_mu;
+std::vector<StreamSet> g_ss;
+}
 dhts_ctx *dhts_create(int device_id) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return nullptr;
     if (hipSetDevice(device_id) != hipSuccess) return nullptr;
     dhts_ctx *c = new dhts_ctx();
     c->device = device_id;
+    {
+        std::lock_guard<std::mutex> lk(g_ss_mu);
+        for (size_t i = 0; i < g_ss.size(); i++) if (g_ss[i].dev == device_id) {
+            c->stream = g_ss[i].s; c->stream_b = g_ss[i].sb; c->pf_done = g_ss[i].ev;
+            g_ss[i] = g_ss.back(); g_ss.pop_back();
+            return c;                                           // (a pooled set comes from a context that went through everything below)
+        }
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
     // the prefetch stream has the LOWEST priority: the record-stage kernels of the current batch (short, latency-bound) should get wave
     // slots as soon as they ask, the next batch's phase B fills what is left
@@ -294,12 +309,12 @@ void dhts_destroy(dhts_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     stop_stager(c);
-    (void)hipStreamSynchronize(c->stream_b);
-    (void)hipStreamSynchronize(c->stream);
+    const bool clean = hipStreamSynchronize(c->stream_b) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
     timing_collect(c);
-    (void)hipEventDestroy(c->pf_done); (void)hipStreamDestroy(c->stream_b);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(c->stream);
+    bool kept = false;
+    if (clean) { std::lock_guard<std::mutex> lk(g_ss_mu); if (g_ss.size() < 32) { g_ss.push_back({c->device, c->stream, c->stream_b, c->pf_done}); kept = true; } }
+    if (!kept) { (void)hipEventDestroy(c->pf_done); (void)hipStreamDestroy(c->stream_b); (void)hipStreamDestroy(c->stream); }
     delete c;                                               // every DevBuf member frees its allocation (device `c->device` is current)
 }
 
@@ -373,6 +388,7 @@ extern "C" void *dhts_host_alloc(uint64_t n) {
 }
 // gives the idle pooled buffers (device and pinned host) back to the driver; buffers in use are untouched
 extern "C" void dhts_release_pools(void) {
+    { std::lock_guard<std::mutex> lk(g_ss_mu); for (auto &x : g_ss) { (void)hipSetDevice(x.dev); (void)hipEventDestroy(x.ev); (void)hipStreamDestroy(x.sb); (void)hipStreamDestroy(x.s); } g_ss.clear(); }
     { std::lock_guard<std::mutex> lk(g_pool_mu); for (auto &b : g_pool) (void)hipFree(b.p); g_pool.clear(); g_pool_bytes = 0; }
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pin.size();) { if (!g_pin[i].busy) { (void)hipHostFree(g_pin[i].p); g_pin.erase(g_pin.begin() + i); } else i++; }

@@ -44,6 +44,8 @@ extern "C" __attribute__((visibility("default"))) void dhts_set_duckdb_api(const
     if (api_table) memcpy((void *)duckdb_ext_api, api_table, sizeof(void *) * DUCKDB_ABI_V120_NSLOTS);
 }
 
+static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
 static inline void set_null(duckdb_vector vec, idx_t row) {           // src/bam_reader.c:38-42
     API(void, duckdb_vector_ensure_validity_writable, duckdb_vector)(vec);
     uint64_t *v = API(uint64_t *, duckdb_vector_get_validity, duckdb_vector)(vec);
@@ -171,7 +173,10 @@ static void bam_read_bind(duckdb_bind_info info) {
         snprintf(err, sizeof(err), "Failed to open SAM/BAM/CRAM file: %s", b->path.c_str());   // bam_reader.c:446
         set_error(info, err); delete b; return;
     }
+    static const bool trace_bind = getenv("DHTS_TRACE") != nullptr;
+    const double tb0 = now_s();
     b->ctx = dhts_create(device_list()[0]);
+    const double tb1 = now_s();
     if (!b->ctx) { set_error(info, "read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); destroy_bind(b); return; }
     // like the reference, bind reads the header only (sam_open + sam_hdr_read, bam_reader.c:441-461): the head of the file is staged,
     // four times more whenever the header turns out to be longer.  The scan stages the file itself (bam_read_global_init).
@@ -190,6 +195,7 @@ static void bam_read_bind(duckdb_bind_info info) {
         destroy_bind(b); return;
     }
     b->header_bytes = dhts_bam_header_bytes(b->ctx);
+    if (trace_bind) fprintf(stderr, "[dhts] bind: context %.4f s, head of the file + block table + header %.4f s\n", tb1 - tb0, now_s() - tb1);
     for (int32_t i = 0; i < b->hdr.n_ref; i++) { duckdb_string_t t; b->ref_is_inl.push_back(inl_string(&t, b->hdr.ref_name[i], strlen(b->hdr.ref_name[i])) ? 1 : 0); b->ref_inl.push_back(t); }
     inl_string(&b->star_inl, "*", 1);
     // index lookup order of sam_index_load3 (hts.c:4720-4790): explicit path, <file>.csi, <file>.bai, <file minus .bam>.bai/.csi
@@ -274,7 +280,6 @@ static int fetch_optional(dhts_ctx *c, BamScan *g, const dhts_bam_batch &b, Host
 }
 
 // producer thread: one GPU, one scan context, one block range of the file
-static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void producer_main(BamScan *g, Producer *p) {
     BamBind *bind = g->bind;
     static const bool trace = getenv("DHTS_TRACE") != nullptr;       // stage timings of every producer on stderr
@@ -299,7 +304,14 @@ static void producer_main(BamScan *g, Producer *p) {
     else rc = dhts_open_path(c, bind->path.c_str());
     t_staged = now_s() - t_start;
     const bool from_cache = rc == 0 && dhts_resident_from_cache(c) != 0;
-    if (rc == 0 && !streaming) { if (dhts_bgzf_index(c) <= 0 || dhts_bam_open(c) != 0) rc = -1; }
+    double t_idx = 0, t_hdr = 0;
+    if (rc == 0 && !streaming) {
+        const double q0 = now_s();
+        if (dhts_bgzf_index(c) <= 0) rc = -1;
+        const double q1 = now_s(); t_idx = q1 - q0;
+        if (rc == 0 && dhts_bam_open(c) != 0) rc = -1;
+        t_hdr = now_s() - q1;
+    }
     if (rc == 0 && streaming) {
         // the header needs the first blocks only: start with what the bind saw, four times more whenever that is not enough
         uint64_t want = bind->header_bytes + (32u << 20);
@@ -363,8 +375,8 @@ static void producer_main(BamScan *g, Producer *p) {
         { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
     }
     dhts_destroy(c);
-    if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: context %.3f s, staged at %.3f s%s, open+index+header %.3f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
-                       p->rank, p->world, p->device, t_created, t_staged, from_cache ? " (file still resident in HBM)" : "", t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
+    if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: context %.4f s, staged at %.4f s%s, block table %.4f s, header %.4f s, open+index+header %.4f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
+                       p->rank, p->world, p->device, t_created, t_staged, from_cache ? " (file still resident in HBM)" : "", t_idx, t_hdr, t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
     { std::lock_guard<std::mutex> lk(g->mu); p->done = true; }
     g->cv_ready.notify_all();
 }

@@ -66,15 +66,19 @@ def main():
         finally:
             ctx.close()
         duckhts_amd.lib().dhts_release_pools()
-        regions = {"1 region of 1 Mb": "chr1:10,000,000-11,000,000",
-                   "100 regions of 100 kb": ",".join(f"chr{1 + k % 22}:{1_000_000 * (1 + 7 * k % 40)}-{1_000_000 * (1 + 7 * k % 40) + 100_000}" for k in range(100))}
-        for name, region in regions.items():
+        # the reference's only published read_bam figures are region queries on a 330 MB exome BAM (Benchmark.md:772-776, 1037-1038): COUNT(*) of
+        # a region with 240,068 rows in 0.046 s, and QNAME,RNAME,POS,MAPQ,CIGAR of the same region in 0.061 s; same shape here (~240 k rows)
+        regions = [("count(*), 1 region with ~240 k rows (the shape of Benchmark.md:772)", "chr1:10,000,000-10,372,000", [0]),
+                   ("QNAME,RNAME,POS,MAPQ,CIGAR, same region (Benchmark.md:773)", "chr1:10,000,000-10,372,000", [0, 2, 3, 4, 5]),
+                   ("all 13 columns, 1 region of 1 Mb", "chr1:10,000,000-11,000,000", None),
+                   ("all 13 columns, 100 regions of 100 kb", ",".join(f"chr{1 + k % 22}:{1_000_000 * (1 + 7 * k % 40)}-{1_000_000 * (1 + 7 * k % 40) + 100_000}" for k in range(100)), None)]
+        for name, region, proj in regions:
             for sparse in ("1", "0"):
-                rows, dt, runs = run("read_bam", bam, named=[("region", region)], threads=1, env={"DHTS_THREADS": "1", "DHTS_SPARSE": sparse, "DHTS_FILE_CACHE": "0"})
+                rows, dt, runs = run("read_bam", bam, proj=proj, named=[("region", region)], threads=1, repeat=6, env={"DHTS_THREADS": "1", "DHTS_SPARSE": sparse, "DHTS_FILE_CACHE": "0"})
                 warm = sorted(runs[1:])[len(runs[1:]) // 2]
-                print(json.dumps({"operator": "read_bam(region := ...) through the DuckDB table function (mini host), all 13 columns", "query": name, "rows": rows,
+                print(json.dumps({"operator": "read_bam(region := ...) through the DuckDB table function (mini host)", "query": name, "rows": rows,
                                   "staging": "header + index windows" if sparse == "1" else "whole file", "file_GB": round(size / 1e9, 3),
-                                  "first_query_s": round(runs[0], 3), "warm_query_ms": round(warm * 1e3, 2)}), flush=True)
+                                  "first_query_s": round(runs[0], 3), "warm_query_ms": round(warm * 1e3, 2), "rows_per_s": round(rows / warm, 1)}), flush=True)
     if os.environ.get("BENCH_BCF", "1") == "0":
         return
     nb = n // 8
