@@ -431,12 +431,19 @@ class BcfScan:
         ctx._chk(ctx.L.dhts_bcf_info_get(ctx.h, C.byref(inf)))
         self.schema = [{"name": inf.cols[i].name.decode(), "type": inf.cols[i].type, "is_list": inf.cols[i].is_list, "encoding": inf.cols[i].encoding}
                        for i in range(inf.n_cols)]
-        self.contigs = [inf.contig_name[i] if inf.contig_name[i] is not None else b"" for i in range(inf.n_contigs)]
-        self.dict_names = [inf.dict_name[i] if inf.dict_name[i] is not None else b"." for i in range(inf.n_dict)] + [b"PASS"]   # id -1 -> literal PASS
+        self._names(inf)
         self.samples = [inf.sample_name[i] for i in range(inf.n_samples)]
         self.tidy = bool(inf.tidy)
         self.first_rec_uoff = inf.first_rec_uoff
         self.projection = list(range(len(self.schema)))
+
+    def _names(self, inf=None):
+        """contig / dictionary names; a scan of VCF text adds the names records use without a header definition (ask again after a batch)"""
+        if inf is None:
+            inf = BcfInfo()
+            self.ctx._chk(self.ctx.L.dhts_bcf_info_get(self.ctx.h, C.byref(inf)))
+        self.contigs = [inf.contig_name[i] if inf.contig_name[i] is not None else b"" for i in range(inf.n_contigs)]
+        self.dict_names = [inf.dict_name[i] if inf.dict_name[i] is not None else b"." for i in range(inf.n_dict)] + [b"PASS"]   # id -1 -> literal PASS
 
     def set_projection(self, cols):
         ids = [c if isinstance(c, int) else [s["name"] for s in self.schema].index(c) for c in cols]
@@ -469,6 +476,7 @@ class BcfScan:
         n = int(b.n_rows)
         d2h = self.ctx.d2h
         cols = []
+        self._names()
         for i in range(b.n_cols):
             dc = b.cols[i]
             sc = self.schema[dc.col]

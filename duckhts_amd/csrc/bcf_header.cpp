@@ -245,6 +245,14 @@ bool bcf_parse_header(const char *text, BcfHeader &h, std::string *err) {
     return true;
 }
 
+// one more "##" line into an existing header: what vcf_parse does for names a record uses without a definition (bcf_hdr_parse_line +
+// bcf_hdr_add_hrec of a generated line, vcf.c:3744-3761, 3788-3803, 3846-3862); false when the line does not parse or register
+bool bcf_header_add_line(BcfHeader &h, const char *line) {
+    HeaderLine r; size_t len = 0;
+    if (parse_line(line, r, len) != 1) return false;
+    return register_line(h, r) >= 0;
+}
+
 void bcf_build_schema(const BcfHeader &h, bool tidy_format, BcfSchema &s) {
     s = BcfSchema();
     s.n_samples = (int)h.samples.size();

@@ -37,6 +37,8 @@ struct BcfHeader {
 // returns false (and *err) when htslib's bcf_hdr_parse would fail
 bool bcf_parse_header(const char *text, BcfHeader &h, std::string *err);
 
+bool bcf_header_add_line(BcfHeader &h, const char *line);
+
 // DuckDB logical type codes used by the schema (values of DUCKDB_TYPE_* in duckdb.h)
 enum { DT_BOOLEAN = 1, DT_INTEGER = 4, DT_BIGINT = 5, DT_FLOAT = 10, DT_DOUBLE = 11, DT_VARCHAR = 17 };
 

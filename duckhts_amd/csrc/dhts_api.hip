@@ -7,6 +7,7 @@
 #include "bam_records.hip"
 #include "bam_tiles_lds.hip"
 #include "bcf_records.hip"
+#include "vcf_text.hip"
 #include "bam_tags.hip"
 #include "bcf_header.h"
 
@@ -155,6 +156,9 @@ struct dhts_ctx {
     // query), each made of whole BGZF blocks; sorted by file offset, so resident order = file order
     struct Seg { uint64_t res_off, file_off, len; };
     std::vector<Seg> segs;
+    bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
+    bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
+    DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ;
     bool cache_hit = false; std::string pending_tag;       // the file's bytes came out of the pool (no read, no copy); tag to put on `comp` once staging has succeeded
     // dhts_open_path_async: the file is still arriving; the block table covers the staged prefix and grows (dhts_bgzf_index_staged)
     std::thread stager; StageProg *prog = nullptr; bool growing = false; uint64_t stage_total = 0;
@@ -328,7 +332,7 @@ static void stop_stager(dhts_ctx *c) {
 }
 static void reset_file_state(dhts_ctx *c) {
     stop_stager(c);
-    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false; c->segs.clear(); c->cache_hit = false;
+    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false; c->segs.clear(); c->cache_hit = false; c->plain_text = false; c->vcf_text = false;
     c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
     c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
 }
@@ -671,6 +675,24 @@ static int64_t index_impl(dhts_ctx *c, bool extend) {
     const int64_t old_nb = c->n_blocks;
     if (!extend) c->huff_b0 = c->huff_nb = 0;
     if (c->comp_len == 0) { c->n_blocks = 0; return 0; }
+    if (!extend && !c->growing && c->comp_len >= 16) {
+        // not gzip at all but VCF text (hts_detect_format: "##fileformat=VCF"): the bytes are the stream; pieces of 65,280 bytes stand in for blocks
+        uint8_t head[16];
+        HIPCHK(c, hipMemcpy(head, c->comp.p, 16, hipMemcpyDeviceToHost));
+        if (!(head[0] == 0x1f && head[1] == 0x8b) && memcmp(head, "##fileformat=VCF", 16) == 0) {
+            const uint64_t P = 65280; const int64_t nb = (int64_t)((c->comp_len + P - 1) / P);
+            c->h_coff.resize(nb); c->h_clen.resize(nb); c->h_isize.resize(nb); c->h_uoff.resize(nb + 1);
+            for (int64_t i = 0; i < nb; i++) { c->h_coff[i] = (uint64_t)i * P; c->h_uoff[i] = (uint64_t)i * P; const uint64_t l = c->comp_len - (uint64_t)i * P < P ? c->comp_len - (uint64_t)i * P : P; c->h_clen[i] = (uint32_t)l; c->h_isize[i] = (uint32_t)l; }
+            c->h_uoff[nb] = c->comp_len;
+            ENSURE(c, c->coff, (size_t)nb * 8 + 64); ENSURE(c, c->clen, (size_t)nb * 4 + 64); ENSURE(c, c->isize, (size_t)nb * 4 + 64); ENSURE(c, c->uoff, (size_t)(nb + 1) * 8 + 64); ENSURE(c, c->blk_status, (size_t)(nb + 1) * 4);
+            HIPCHK(c, hipMemcpy(c->coff.p, c->h_coff.data(), nb * 8, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->clen.p, c->h_clen.data(), nb * 4, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->isize.p, c->h_isize.data(), nb * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->uoff.p, c->h_uoff.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemset(c->blk_status.p, 0, (size_t)(nb + 1) * 4));
+            c->n_blocks = nb; c->bgzf_status = 0; c->plain_text = true;
+            c->shard_b0 = 0; c->shard_b1 = nb; c->shard_rank = 0; c->shard_world = 1;
+            return nb;
+        }
+    }
     const uint8_t *d = (const uint8_t *)c->comp.p; const uint64_t n = c->comp_len;
     int64_t nspans = (int64_t)((n + 65535) / 65536);
     DevBuf &cnt = c->sg_cnt, &base = c->sg_base, &cand = c->sg_cand, &hits = c->sg_hits; uint64_t total = 0; int rc = 0;   // kept across calls
@@ -800,6 +822,10 @@ static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t
 }
 static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
     if (nb <= 0) return 0;
+    if (c->plain_text) {                                     // nothing to inflate: the pieces are copied to their place in the stream
+        HIPCHK(c, hipMemcpyAsync(out + (c->h_uoff[b0] - out_base), (const uint8_t *)c->comp.p + c->h_coff[b0], c->h_uoff[b0 + nb] - c->h_uoff[b0], hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
     discard_prefetch(c);                                   // (phase A below may reallocate the scratch a prefetched phase B reads)
     // (a block whose ISIZE field exceeds 64 KiB is recorded and placed as 65,537 bytes -- isize_placed in bam_records.hip -- and fails
     //  phase B's outlen == ISIZE test like any other block with a wrong ISIZE: the stream ends there, rows before it are kept)
@@ -2156,6 +2182,47 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
 }
 
 // ---- read_bcf ---------------------------------------------------------------------------------------
+// (re)builds everything derived from the header dictionaries: the name arrays of dhts_bcf_info, the validity / slot tables of bcf_rec_check
+// and, for VCF text, the sorted name tables the text encoder looks names up in.  Called again when a text scan has added names.
+static int bcf_upload_dicts(dhts_ctx *c) {
+    const size_t nc = c->bh.ctg.size(), ni = c->bh.ids.size();
+    if (c->vcf_text && (nc > c->bcf_ctg_p.capacity() || ni > c->bcf_dict_p.capacity())) return fail(c, "read_bcf: too many names without a header definition");
+    c->bcf_ctg_p.clear(); c->bcf_dict_p.clear();
+    for (size_t i = 0; i < nc; i++) c->bcf_ctg_p.push_back(c->bh.ctg_present[i] ? c->bh.ctg[i].c_str() : nullptr);
+    for (auto &e : c->bh.ids) c->bcf_dict_p.push_back(e.present ? e.key.c_str() : nullptr);
+    std::vector<uint8_t> ctg_ok(nc + 1, 0), id_ok(ni + 1, 0); std::vector<int16_t> islot(ni + 1, -1), fslot(ni + 1, -1);
+    for (size_t i = 0; i < nc; i++) ctg_ok[i] = c->bh.ctg_present[i] ? 1 : 0;
+    for (size_t i = 0; i < ni; i++) id_ok[i] = c->bh.ids[i].present ? 1 : 0;
+    for (size_t f = 0; f < c->bsch.info_fields.size(); f++) islot[c->bsch.info_fields[f].id] = (int16_t)f;
+    for (size_t f = 0; f < c->bsch.format_fields.size(); f++) if (c->bsch.format_fields[f].id >= 0) fslot[c->bsch.format_fields[f].id] = (int16_t)f;
+    ENSURE(c, c->d_ctg_ok, nc + 16); ENSURE(c, c->d_id_ok, ni + 16); ENSURE(c, c->d_info_slot, ni * 2 + 16); ENSURE(c, c->d_fmt_slot, ni * 2 + 16);
+    HIPCHK(c, hipMemcpy(c->d_ctg_ok.p, ctg_ok.data(), nc + 1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_id_ok.p, id_ok.data(), ni + 1, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_info_slot.p, islot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_fmt_slot.p, fslot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
+    if (!c->vcf_text) return 0;
+    auto upload = [&](std::vector<std::pair<std::string, int32_t>> &names, const std::vector<uint8_t> *typ_of_id, DevBuf &d_off, DevBuf &d_bytes, DevBuf &d_id, DevBuf *d_typ) -> int {
+        std::sort(names.begin(), names.end(), [](const std::pair<std::string, int32_t> &a, const std::pair<std::string, int32_t> &b) {
+            const size_t n = a.first.size() < b.first.size() ? a.first.size() : b.first.size();
+            const int cmp = memcmp(a.first.data(), b.first.data(), n);
+            return cmp != 0 ? cmp < 0 : a.first.size() < b.first.size(); });
+        std::vector<uint32_t> off(names.size() + 1, 0); std::string bytes; std::vector<int32_t> ids(names.size() + 1, 0); std::vector<uint8_t> typ(names.size() + 1, 15);
+        for (size_t i = 0; i < names.size(); i++) { off[i] = (uint32_t)bytes.size(); bytes += names[i].first; ids[i] = names[i].second; if (typ_of_id) typ[i] = (*typ_of_id)[names[i].second]; }
+        off[names.size()] = (uint32_t)bytes.size();
+        if (d_off.ensure(off.size() * 4 + 64) || d_bytes.ensure(bytes.size() + 64) || d_id.ensure(ids.size() * 4 + 64) || (d_typ && d_typ->ensure(typ.size() + 64))) return fail(c, "hipMalloc failed");
+        HIPCHK(c, hipMemcpy(d_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+        if (!bytes.empty()) HIPCHK(c, hipMemcpy(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_id.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+        if (d_typ) HIPCHK(c, hipMemcpy(d_typ->p, typ.data(), typ.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    std::vector<std::pair<std::string, int32_t>> cn, in; std::vector<uint8_t> ityp(ni + 1, 15);
+    for (size_t i = 0; i < nc; i++) if (c->bh.ctg_present[i]) cn.push_back({c->bh.ctg[i], (int32_t)i});
+    for (size_t i = 0; i < ni; i++) if (c->bh.ids[i].present) { in.push_back({c->bh.ids[i].key, (int32_t)i}); if (c->bh.ids[i].has[dhts::BCF_HL_INFO]) ityp[i] = (uint8_t)c->bh.ids[i].type[dhts::BCF_HL_INFO]; }
+    if (upload(cn, nullptr, c->vd_ctg_off, c->vd_ctg_bytes, c->vd_ctg_id, nullptr) || upload(in, &ityp, c->vd_id_off, c->vd_id_bytes, c->vd_id_id, &c->vd_id_typ)) return -1;
+    return 0;
+}
+
 int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2163,7 +2230,7 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
     if (c->n_blocks <= 0) return fail(c, "Failed to read BCF/VCF header");
     int64_t k = c->n_blocks < 4 ? c->n_blocks : 4;
     std::vector<uint8_t> h; std::vector<int32_t> bs;
-    uint64_t text_end = 0;
+    uint64_t text_end = 0; bool is_text = false;
     for (;;) {
         uint64_t total = c->h_uoff[k];
         h.assign(total + 16, 0); bs.resize(k);
@@ -2172,6 +2239,31 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
         for (int64_t b = 0; b < k; b++) if (bs[b] != 0) { good = c->h_uoff[b]; break; }
         const bool more = (good == total && k < c->n_blocks);
         if (good < 9) { if (more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; } return fail(c, "Failed to read BCF/VCF header"); }
+        if (good >= 16 && memcmp(h.data(), "##fileformat=VCF", 16) == 0) {
+            // VCF text (vcf_hdr_read vcf.c:2594-2680): lines up to and including the first one that does not start with "##"; empty lines are
+            // skipped, a line that does not start with '#' before that is "No sample line"
+            std::string text; uint64_t p = 0; bool found = false, broken = false;
+            while (p < good) {
+                const uint8_t *nl = (const uint8_t *)memchr(h.data() + p, '\n', good - p);
+                if (!nl && (more || good < total)) break;                       // the line may continue in blocks not read yet
+                const uint64_t ls = p, e = nl ? (uint64_t)(nl - h.data()) : good;
+                uint64_t l = e - ls;
+                if (l && h[e - 1] == '\r') l--;
+                { uint64_t z = 0; while (z < l && h[ls + z]) z++; l = z; }    // (a C string to the parser)
+                p = nl ? e + 1 : good;
+                if (l == 0) continue;
+                if (h[ls] != '#') { broken = true; break; }
+                text.append((const char *)h.data() + ls, l); text.push_back('\n');
+                if (l < 2 || h[ls + 1] != '#') { found = true; break; }
+            }
+            if (broken) return fail(c, "Failed to read BCF/VCF header");
+            if (!found) { if (more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; } return fail(c, "Failed to read BCF/VCF header"); }
+            std::string perr;
+            if (!dhts::bcf_parse_header(text.c_str(), c->bh, &perr)) return fail(c, "Failed to read BCF/VCF header");
+            if (!c->bh.samples.empty()) return fail(c, "read_bcf: VCF text input with sample columns is not supported yet (sites-only VCF text and BCF are)");
+            text_end = p; is_text = true;
+            break;
+        }
         if (memcmp(h.data(), "BCF\2\2", 5) != 0) return fail(c, "Failed to read BCF/VCF header");       // vcf.c:1733-1740
         const uint64_t l_text = hle32(h.data() + 5);
         if (9 + l_text > good) { if (more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; } return fail(c, "Failed to read BCF/VCF header"); }
@@ -2184,30 +2276,25 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
     dhts::bcf_build_schema(c->bh, tidy_format != 0, c->bsch);
     c->bcf_tidy_req = tidy_format != 0;
     c->first_rec_uoff = text_end; c->scan_first_uoff = text_end;
+    c->vcf_text = is_text;
+    if (is_text) {
+        // names a record uses without a definition are added to the dictionaries while scanning (vcf_parse): room is reserved now so that
+        // the name arrays handed out by dhts_bcf_info_get never move
+        c->bh.ctg.reserve(c->bh.ctg.size() + 65536); c->bh.ctg_present.reserve(c->bh.ctg.size() + 65536); c->bh.ids.reserve(c->bh.ids.size() + 65536);
+        c->bcf_ctg_p.clear(); c->bcf_dict_p.clear();
+        c->bcf_ctg_p.reserve(c->bh.ctg.size() + 65536); c->bcf_dict_p.reserve(c->bh.ids.size() + 65536);
+    }
     // host-visible dictionaries
-    c->bcf_colinfo.clear(); c->bcf_ctg_p.clear(); c->bcf_dict_p.clear(); c->bcf_smp_p.clear();
+    c->bcf_colinfo.clear(); c->bcf_smp_p.clear();
     for (auto &col : c->bsch.cols) {
         dhts_bcf_colinfo ci; ci.name = col.name.c_str(); ci.type = col.duck_type; ci.is_list = col.is_list ? 1 : 0; ci.reserved = 0;
         ci.encoding = col.kind == dhts::BK_CHROM ? DHTS_ENC_CONTIG : col.kind == dhts::BK_FILTER ? DHTS_ENC_DICT : col.kind == dhts::BK_SAMPLE_ID ? DHTS_ENC_SAMPLE :
                       (col.kind == dhts::BK_VEP && col.duck_type == dhts::DT_FLOAT) ? DHTS_ENC_FLOAT_TEXT : DHTS_ENC_PLAIN;
         c->bcf_colinfo.push_back(ci);
     }
-    for (size_t i = 0; i < c->bh.ctg.size(); i++) c->bcf_ctg_p.push_back(c->bh.ctg_present[i] ? c->bh.ctg[i].c_str() : nullptr);
-    for (auto &e : c->bh.ids) c->bcf_dict_p.push_back(e.present ? e.key.c_str() : nullptr);
     for (auto &sm : c->bh.samples) c->bcf_smp_p.push_back(sm.c_str());
-    // device tables
-    const size_t nc = c->bh.ctg.size(), ni = c->bh.ids.size();
-    std::vector<uint8_t> ctg_ok(nc + 1, 0), id_ok(ni + 1, 0); std::vector<int16_t> islot(ni + 1, -1), fslot(ni + 1, -1);
     if (c->bsch.info_fields.size() > 30000 || c->bsch.format_fields.size() > 30000) return fail(c, "read_bcf: too many INFO/FORMAT fields");
-    for (size_t i = 0; i < nc; i++) ctg_ok[i] = c->bh.ctg_present[i] ? 1 : 0;
-    for (size_t i = 0; i < ni; i++) id_ok[i] = c->bh.ids[i].present ? 1 : 0;
-    for (size_t f = 0; f < c->bsch.info_fields.size(); f++) islot[c->bsch.info_fields[f].id] = (int16_t)f;
-    for (size_t f = 0; f < c->bsch.format_fields.size(); f++) if (c->bsch.format_fields[f].id >= 0) fslot[c->bsch.format_fields[f].id] = (int16_t)f;
-    ENSURE(c, c->d_ctg_ok, nc + 16); ENSURE(c, c->d_id_ok, ni + 16); ENSURE(c, c->d_info_slot, ni * 2 + 16); ENSURE(c, c->d_fmt_slot, ni * 2 + 16);
-    HIPCHK(c, hipMemcpy(c->d_ctg_ok.p, ctg_ok.data(), nc + 1, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_id_ok.p, id_ok.data(), ni + 1, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_info_slot.p, islot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_fmt_slot.p, fslot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
+    if (bcf_upload_dicts(c)) return -1;
     c->bcf_proj.clear();
     for (size_t i = 0; i < c->bsch.cols.size(); i++) c->bcf_proj.push_back((int32_t)i);
     c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1;
@@ -2276,6 +2363,136 @@ static size_t fixed_width(const dhts::BcfColumn &col) {
     return col.duck_type == dhts::DT_BOOLEAN ? 1 : col.duck_type == dhts::DT_VARCHAR ? 0 : 4;
 }
 
+// ---- VCF text batches (vcf_text.hip): the lines of the batch become BCF2 records in v_out; rec_off / dir as for binary input ----------
+// out: nrec, carry_start (start of the incomplete last line), rec_err (a line failed: the scan ends before it), rec0_text (text offset of
+// the first line), st re-pointed at the records.  Names without a definition are added to the header and the batch is measured again.
+static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t &nrec, uint64_t &carry_start, bool &rec_err, uint32_t &rec0_text, uint32_t &stride, unsigned long long &bad_rec) {
+    const uint8_t *u = B.u; const uint64_t ulen = B.ulen, out_base = B.out_base;
+    uint64_t t0 = 0;
+    if (c->first_batch) { if (c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch"); t0 = c->scan_first_uoff - out_base; }
+    nrec = 0; carry_start = ulen; rec_err = false; rec0_text = (uint32_t)t0; bad_rec = ~0ull;
+    if (t0 >= ulen) { carry_start = ulen; return 0; }
+    const int64_t nchunks = (int64_t)((ulen - t0 + 255) / 256);
+    ENSURE(c, c->v_cnt, (size_t)nchunks * 4 + 64); ENSURE(c, c->v_base, (size_t)(nchunks + 1) * 4 + 64);
+    hipLaunchKernelGGL(vcf_line_count, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, c->stream, u, t0, ulen, (uint32_t *)c->v_cnt.p, nchunks);
+    const uint32_t *kin[1] = {(const uint32_t *)c->v_cnt.p}; uint32_t *kout[1] = {(uint32_t *)c->v_base.p}; uint64_t nl = 0;
+    if (run_scan(c, 1, kin, kout, nullptr, nchunks, &nl)) return -1;
+    if (nl + 2 >= (1ull << 32)) return fail(c, "batch too large");
+    ENSURE(c, c->v_line_off, (size_t)(nl + 2) * 4 + 64);
+    hipLaunchKernelGGL(vcf_line_fill, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, c->stream, u, t0, ulen, (const uint32_t *)c->v_base.p, (uint32_t *)c->v_line_off.p, nchunks);
+    uint32_t last_start = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_start, (const uint32_t *)c->v_line_off.p + nl, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t nlines = (int64_t)nl; int last_open = 0;
+    carry_start = last_start;
+    if (B.final_batch && last_start < ulen) { nlines++; last_open = 1; carry_start = ulen; }     // the last line of the file need not end in a newline
+    if (nlines == 0) return 0;
+    ENSURE(c, c->v_rec_len, (size_t)(nlines + 1) * 4 + 64); ENSURE(c, c->b_rec_off, (size_t)(nlines + 1) * 4 + 64); ENSURE(c, c->v_ctr, 64);
+    const uint32_t UCAP = 65536, PCAP = 1u << 20;
+    ENSURE(c, c->v_undef, (size_t)UCAP * sizeof(VcfUndef)); ENSURE(c, c->v_patch, (size_t)PCAP * sizeof(VcfPatch));
+    VcfArgs a; memset(&a, 0, sizeof(a));
+    a.u = u; a.line_off = (const uint32_t *)c->v_line_off.p; a.nlines = nlines; a.text_end = ulen; a.last_open = last_open;
+    a.rec_len = (uint32_t *)c->v_rec_len.p; a.rec_off = (const uint32_t *)c->b_rec_off.p; a.first_bad = (unsigned long long *)((uint64_t *)c->v_ctr.p + 2);
+    a.counters = (uint32_t *)c->v_ctr.p; a.undef = (VcfUndef *)c->v_undef.p; a.undef_cap = UCAP; a.patch = (VcfPatch *)c->v_patch.p; a.patch_cap = PCAP;
+    unsigned long long first_bad = ~0ull;
+    for (int round = 0;; round++) {
+        if (round > 1000) return fail(c, "read_bcf: too many names without a header definition");
+        a.ctg = {(const uint32_t *)c->vd_ctg_off.p, (const uint8_t *)c->vd_ctg_bytes.p, (const int32_t *)c->vd_ctg_id.p, nullptr, 0};
+        a.ids = {(const uint32_t *)c->vd_id_off.p, (const uint8_t *)c->vd_id_bytes.p, (const int32_t *)c->vd_id_id.p, (const uint8_t *)c->vd_id_typ.p, 0};
+        { int32_t n1 = 0, n2 = 0; for (size_t i = 0; i < c->bh.ctg.size(); i++) n1 += c->bh.ctg_present[i] ? 1 : 0; for (auto &e : c->bh.ids) n2 += e.present ? 1 : 0; a.ctg.n = n1; a.ids.n = n2; }
+        HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream)); HIPCHK(c, hipMemsetAsync((uint64_t *)c->v_ctr.p + 2, 0xff, 8, c->stream));
+        hipLaunchKernelGGL(vcf_encode<false>, dim3((unsigned)((nlines + 127) / 128)), dim3(128), 0, c->stream, a);
+        uint64_t ctr[3] = {0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(ctr, c->v_ctr.p, 24, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        first_bad = ctr[2];
+        const uint32_t n_undef = (uint32_t)(ctr[0] & 0xffffffffu);
+        if (n_undef == 0) break;
+        // names used without a definition: htslib adds dummy definitions as it meets them, so ids follow the order of first appearance
+        const uint32_t got = n_undef < UCAP ? n_undef : UCAP;
+        std::vector<VcfUndef> ud(got);
+        HIPCHK(c, hipMemcpy(ud.data(), c->v_undef.p, (size_t)got * sizeof(VcfUndef), hipMemcpyDeviceToHost));
+        std::sort(ud.begin(), ud.end(), [](const VcfUndef &x, const VcfUndef &y) { return x.line != y.line ? x.line < y.line : x.pos < y.pos; });
+        bool added = false;
+        for (auto &x : ud) {
+            if ((unsigned long long)x.line >= first_bad) break;                  // lines behind the first bad one are never parsed
+            std::string name(x.len, '\0');
+            if (x.len) HIPCHK(c, hipMemcpy(&name[0], u + x.pos, x.len, hipMemcpyDeviceToHost));
+            bool have = false;
+            if (x.cls == 0) { for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i] && c->bh.ctg[i] == name) have = true; }
+            else { const int id = c->bh.find_id(name); have = id >= 0 && (x.cls == 1 || c->bh.ids[id].has[dhts::BCF_HL_INFO]); }
+            if (have) continue;
+            const std::string line = x.cls == 0 ? "##contig=<ID=" + name + ">" : x.cls == 1 ? "##FILTER=<ID=" + name + ",Description=\"Dummy\">"
+                                                : "##INFO=<ID=" + name + ",Number=1,Type=String,Description=\"Dummy\">";
+            bool ok = name.find('\n') == std::string::npos && dhts::bcf_header_add_line(c->bh, line.c_str());
+            if (ok) {
+                if (x.cls == 0) { ok = false; for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i] && c->bh.ctg[i] == name) ok = true; }
+                else { const int id = c->bh.find_id(name); ok = id >= 0 && (x.cls == 1 || c->bh.ids[id].has[dhts::BCF_HL_INFO]); }
+            }
+            if (!ok) { if ((unsigned long long)x.line < first_bad) first_bad = x.line; break; }      // "Could not add dummy header": the record is an error
+            added = true;
+        }
+        if (added && bcf_upload_dicts(c)) return -1;
+        if (!added) {
+            // nothing could be added: the remaining undefined names sit on or behind the first bad line
+            if (first_bad == ~0ull) return fail(c, "internal: undefined names without a bad line");
+            a.nlines = nlines = (int64_t)first_bad; rec_err = true; a.last_open = 0;
+            if (nlines == 0) { nrec = 0; return 0; }
+        }
+        st.n_ctg = (int32_t)c->bh.ctg.size(); st.n_ids = (int32_t)c->bh.ids.size();
+        st.ctg_ok = (const uint8_t *)c->d_ctg_ok.p; st.id_ok = (const uint8_t *)c->d_id_ok.p; st.info_slot = (const int16_t *)c->d_info_slot.p; st.fmt_slot = (const int16_t *)c->d_fmt_slot.p;
+    }
+    nrec = nlines;
+    if (first_bad < (unsigned long long)nlines) { nrec = (int64_t)first_bad; rec_err = true; }
+    if (nrec == 0) return 0;
+    const uint32_t *lin[1] = {(const uint32_t *)c->v_rec_len.p}; uint32_t *lout[1] = {(uint32_t *)c->b_rec_off.p}; uint64_t total = 0;
+    if (run_scan(c, 1, lin, lout, nullptr, nrec, &total)) return -1;
+    if (total + PAD_BYTES >= (1ull << 32)) return fail(c, "batch too large");
+    ENSURE(c, c->v_out, total + PAD_BYTES + 64);
+    a.nlines = nrec; a.out = (uint8_t *)c->v_out.p;
+    if (nrec < nlines) { a.last_open = 0; }
+    HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream));
+    hipLaunchKernelGGL(vcf_encode<true>, dim3((unsigned)((nrec + 127) / 128)), dim3(128), 0, c->stream, a);
+    HIPCHK(c, hipMemsetAsync((uint8_t *)c->v_out.p + total, 0, PAD_BYTES, c->stream));
+    uint32_t ctr2[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(ctr2, c->v_ctr.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ctr2[1] > PCAP) return fail(c, "read_bcf: too many numbers outside the fast conversion path in one batch; use a smaller max_blocks");
+    if (ctr2[1]) {
+        // numbers hts_str2dbl hands to strtod (exponents, > 14 digits, inf / nan / hex) and QUAL values outside that form: converted here
+        std::vector<VcfPatch> pt(ctr2[1]);
+        HIPCHK(c, hipMemcpy(pt.data(), c->v_patch.p, (size_t)ctr2[1] * sizeof(VcfPatch), hipMemcpyDeviceToHost));
+        std::string tok;
+        for (auto &x : pt) {
+            tok.assign(x.len, '\0');
+            if (x.len) HIPCHK(c, hipMemcpy(&tok[0], u + x.pos, x.len, hipMemcpyDeviceToHost));
+            uint32_t bits;
+            if (x.kind == 0) { const float f = (float)atof(tok.c_str()); memcpy(&bits, &f, 4); }
+            else {
+                char *end = nullptr; const double d = strtod(tok.c_str(), &end);
+                if (end == tok.c_str()) bits = 0x7F800001u; else { const float f = (float)d; memcpy(&bits, &f, 4); }
+            }
+            HIPCHK(c, hipMemcpy((uint8_t *)c->v_out.p + x.dst, &bits, 4, hipMemcpyHostToDevice));
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(&rec0_text, c->v_line_off.p, 4, hipMemcpyDeviceToHost, c->stream));
+    st.u = (const uint8_t *)c->v_out.p; st.ulen = total;
+    st.n_ctg = (int32_t)c->bh.ctg.size(); st.n_ids = (int32_t)c->bh.ids.size();
+    st.ctg_ok = (const uint8_t *)c->d_ctg_ok.p; st.id_ok = (const uint8_t *)c->d_id_ok.p; st.info_slot = (const int16_t *)c->d_info_slot.p; st.fmt_slot = (const int16_t *)c->d_fmt_slot.p;
+    const size_t n = (size_t)nrec; const int D = 2 + st.n_info_f + st.n_fmt_f;
+    stride = (uint32_t)((n + 63) & ~(size_t)63);
+    ENSURE(c, c->b_dir, (size_t)D * stride * 4 + 16); ENSURE(c, c->d_res, 64);
+    HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_res.p + 4, 0xff, 8, c->stream));
+    {
+        KTimer tm(c, DHTS_K_BCF_CHECK);
+        hipLaunchKernelGGL(bcf_rec_check, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, st, (const uint32_t *)c->b_rec_off.p, nrec, (uint32_t *)c->b_dir.p, stride,
+                           (unsigned long long *)((uint64_t *)c->d_res.p + 4));
+    }
+    HIPCHK(c, hipMemcpyAsync(&bad_rec, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     if (!c || !out) return -1;
     memset(out, 0, sizeof(*out));
@@ -2320,6 +2537,12 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     uint32_t rec0_off = 0;
     unsigned long long bad = ~0ull;
     uint32_t stride = 64;
+    if (c->vcf_text) {
+        if (c->shard_world > 1 || c->bcf_rg_active) return fail(c, "read_bcf: block-range shards and region queries are not supported on VCF text input yet");
+        uint32_t rec0_text = 0;
+        if (vcf_text_records(c, B, st, nrec, carry_start, rec_err, rec0_text, stride, bad)) return -1;
+        rec0_off = rec0_text;
+    } else
     for (;;) {
         to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
         to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;

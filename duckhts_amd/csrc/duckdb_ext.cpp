@@ -734,7 +734,8 @@ static void bcf_read_bind(duckdb_bind_info info) {
         set_error(info, err); destroy_bcf_bind(b); return;
     }
     if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bcf_open(b->ctx, tidy) != 0 || dhts_bcf_info_get(b->ctx, &b->inf) != 0) {
-        set_error(info, "Failed to read BCF/VCF header");       // bcf_reader.c:505
+        const char *m = dhts_error(b->ctx);
+        set_error(info, (m && strncmp(m, "read_bcf:", 9) == 0) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505 (or what this build does not read yet)
         destroy_bcf_bind(b); return;
     }
     for (const std::string &f : {idx, b->path + ".csi", b->path + ".tbi"}) if (!f.empty() && file_exists(f)) { b->index_file = f; break; }

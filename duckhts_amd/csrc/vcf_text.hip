@@ -1,0 +1,235 @@
+// vcf_text.hip -- VCF TEXT lines -> BCF2 records on the device (gfx950), so that read_bcf's record stage (bcf_rec_check, bcf_cells) serves
+// text input unchanged.  SURVEY.md 8(f) item 3, first half; included by dhts_api.hip.
+//
+// Replaces, for sites-only files (no sample columns):
+//   vcf_read / hts_getline                       htslib vcf.c:4170-4176          -> vcf_line_count / vcf_line_fill (line index of a batch)
+//   vcf_parse (CHROM .. INFO)                    vcf.c:3987-4165                 -> vcf_encode<false> (sizes, undefined names) + vcf_encode<true>
+//   vcf_parse_filter, vcf_parse_info             vcf.c:3763-3816, 3818-3985
+//   hts_str2uint / hts_str2int / hts_str2dbl     textutils_internal.h:218-428    (the fast path of hts_str2dbl is one IEEE division; what it
+//                                                                                 hands to strtod -- exponents, > 14 digits, inf / nan / hex --
+//                                                                                 and QUAL's atof outside that form go to the host as patches)
+//   bcf_enc_size / bcf_enc_int1 / bcf_enc_vchar  htslib/vcf.h, vcf.c:2834-2980   (integers are written as int32 vectors: every width decodes to
+//                                                                                 the same values in the getters)
+// Names a record uses without a header definition (contig, FILTER, INFO key) are reported to the host, which adds htslib's dummy definitions
+// (fix_chromosome vcf.c:3744-3761, the "Dummy" lines of vcf_parse_filter / vcf_parse_info) in order of first appearance and runs the batch
+// again.  One lane per line; two passes (measure, then write behind an exclusive scan of the record lengths).
+#pragma once
+
+struct VcfDictDev { const uint32_t *off; const uint8_t *bytes; const int32_t *id; const uint8_t *ityp; int32_t n; };   // sorted by name (byte order)
+struct VcfUndef { uint32_t line, pos, len, cls; };        // cls: 0 contig, 1 FILTER, 2 INFO key; pos = offset of the name in the batch text
+struct VcfPatch { uint32_t pos, len, dst, kind; };        // kind 0: (float)atof(token) -> f32 at dst; 1: hts_str2dbl(token) -> f32 (or missing) at dst
+struct VcfArgs {
+    const uint8_t *u; const uint32_t *line_off; int64_t nlines; uint64_t text_end;   // line i = u[line_off[i], line_off[i+1] - 1) (the last one ends at text_end when it has no newline)
+    int32_t last_open;                                      // 1: the last line has no terminating newline
+    VcfDictDev ctg, ids;
+    uint32_t *rec_len; const uint32_t *rec_off; uint8_t *out;
+    unsigned long long *first_bad;
+    uint32_t *counters;                                     // [0] undefined names, [1] patches
+    VcfUndef *undef; uint32_t undef_cap; VcfPatch *patch; uint32_t patch_cap;
+};
+
+extern "C" __global__ void __launch_bounds__(256)
+vcf_line_count(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, uint32_t *__restrict__ cnt, int64_t nchunks) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nchunks) return;
+    const uint64_t a = start + (uint64_t)k * 256, b = a + 256 < ulen ? a + 256 : ulen;
+    uint32_t n = 0;
+    for (uint64_t i = a; i < b; i++) n += u[i] == '\n';
+    cnt[k] = n;
+}
+extern "C" __global__ void __launch_bounds__(256)
+vcf_line_fill(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, const uint32_t *__restrict__ base, uint32_t *__restrict__ line_off, int64_t nchunks) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nchunks) return;
+    if (k == 0) line_off[0] = (uint32_t)start;
+    const uint64_t a = start + (uint64_t)k * 256, b = a + 256 < ulen ? a + 256 : ulen;
+    uint32_t n = base[k];
+    for (uint64_t i = a; i < b; i++) if (u[i] == '\n') line_off[++n] = (uint32_t)(i + 1);
+}
+
+__device__ __forceinline__ int vcf_dict_find(const VcfDictDev &d, const uint8_t *s, uint32_t l) {
+    int lo = 0, hi = d.n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint8_t *m = d.bytes + d.off[mid]; const uint32_t ml = d.off[mid + 1] - d.off[mid];
+        const uint32_t n = ml < l ? ml : l;
+        int c = 0;
+        for (uint32_t i = 0; i < n; i++) if (m[i] != s[i]) { c = m[i] < s[i] ? -1 : 1; break; }
+        if (c == 0) c = ml < l ? -1 : ml > l ? 1 : 0;
+        if (c == 0) return mid;
+        if (c < 0) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// byte sink of one record: counts in the measure pass, stores in the write pass
+template <bool WRITE> struct VcfSink {
+    uint8_t *p; uint32_t n;
+    __device__ __forceinline__ void b(uint8_t v) { if (WRITE) p[n] = v; n++; }
+    __device__ __forceinline__ void w32(uint32_t v) { if (WRITE) { p[n] = (uint8_t)v; p[n + 1] = (uint8_t)(v >> 8); p[n + 2] = (uint8_t)(v >> 16); p[n + 3] = (uint8_t)(v >> 24); } n += 4; }
+    __device__ __forceinline__ void bytes(const uint8_t *s, uint32_t l) { if (WRITE) for (uint32_t i = 0; i < l; i++) p[n + i] = s[i]; n += l; }
+    __device__ __forceinline__ void size(uint32_t cnt, uint32_t type) {                               // bcf_enc_size
+        if (cnt < 15) { b((uint8_t)(cnt << 4 | type)); return; }
+        b((uint8_t)(0xF0 | type));
+        if (cnt < 128) { b(0x11); b((uint8_t)cnt); }
+        else if (cnt < 32768) { b(0x12); b((uint8_t)cnt); b((uint8_t)(cnt >> 8)); }
+        else { b(0x13); w32(cnt); }
+    }
+    __device__ __forceinline__ void key(int32_t x) {                                                  // bcf_enc_int1 of a dictionary id
+        if (x <= 127) { b(0x11); b((uint8_t)x); }
+        else if (x <= 32767) { b(0x12); b((uint8_t)x); b((uint8_t)(x >> 8)); }
+        else { b(0x13); w32((uint32_t)x); }
+    }
+    __device__ __forceinline__ void vchar(const uint8_t *s, uint32_t l) { size(l, 7); bytes(s, l); }
+};
+
+__device__ __forceinline__ bool vcf_isspace(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+// hts_str2dbl's fast path: 0 = converted (*val, *end), 1 = the form strtod has to handle (host patch)
+__device__ __forceinline__ int vcf_str2dbl_fast(const uint8_t *s, uint32_t l, double *val, uint32_t *end) {
+    uint32_t v = 0; bool neg = false;
+    while (v < l && vcf_isspace(s[v])) v++;
+    if (v < l && s[v] == '-') { neg = true; v++; } else if (v < l && s[v] == '+') v++;
+    const uint8_t c0 = v < l ? s[v] : 0, c1 = v + 1 < l ? s[v + 1] : 0;
+    if (!((c0 >= '1' && c0 <= '9') || (c0 == '0' && c1 != 'x' && c1 != 'X'))) return 1;
+    while (v < l && s[v] == '0') v++;
+    const uint32_t start = v; uint64_t n = 0; int max_len = 15, point = -1;
+    while (--max_len && v < l && s[v] >= '0' && s[v] <= '9') n = n * 10 + (s[v++] - '0');
+    if (max_len && v < l && s[v] == '.') { point = (int)(v - start); v++; while (--max_len && v < l && s[v] >= '0' && s[v] <= '9') n = n * 10 + (s[v++] - '0'); }
+    if (point < 0) point = (int)(v - start);
+    if (!max_len || (v < l && (s[v] == 'e' || s[v] == 'E'))) return 1;
+    const int k = (int)(v - start) - point;                  // 0, or 1 + number of fraction digits
+    double p10 = 1.0; for (int i = 1; i < k; i++) p10 *= 10.0;                                       // exact: k - 1 <= 14
+    const double d = __ddiv_rn((double)n, p10);
+    *val = neg ? -d : d; *end = v;
+    return 0;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.nlines) return;
+    const uint32_t l0 = a.line_off[li];
+    uint32_t l1 = (li + 1 == a.nlines && a.last_open) ? (uint32_t)a.text_end : a.line_off[li + 1] - 1;
+    const uint8_t *u = a.u;
+    if (l1 > l0 && u[l1 - 1] == '\r') l1--;                                                          // KS_SEP_LINE drops the carriage return
+    { uint32_t e = l0; while (e < l1 && u[e]) e++; l1 = e; }                                         // the parser works on a C string
+    VcfSink<WRITE> o; o.p = WRITE ? a.out + a.rec_off[li] : nullptr; o.n = 0;
+    bool bad = false;
+    // the eight mandatory columns (kstrtok on '\t': empty tokens count); a ninth one is not looked at (no samples: vcf_parse_format returns at once)
+    uint32_t fs[8], fe[8]; int nf = 0;
+    {
+        uint32_t p = l0;
+        for (;;) {
+            fs[nf] = p; while (p < l1 && u[p] != '\t') p++; fe[nf] = p; nf++;
+            if (p >= l1 || nf == 8) break;
+            p++;
+        }
+    }
+    if (nf < 8) bad = true;
+    int32_t rid = 0; int64_t pos = 0; uint32_t n_allele = 1, n_info = 0, qbits = 0x7F800001u; int32_t rlen = 0;
+    if (!bad) {
+        // CHROM
+        const int k = vcf_dict_find(a.ctg, u + fs[0], fe[0] - fs[0]);
+        if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, fs[0], fe[0] - fs[0], 0u}; } }
+        else rid = a.ctg.id[k];
+        // POS: hts_str2uint(.., 62 bits), the whole token
+        {
+            uint32_t v = fs[1]; uint64_t n = 0; bool over = false; const uint64_t limit = (1ull << 62) - 1;
+            if (v < fe[1] && u[v] == '+') v++;
+            for (; v < fe[1] && u[v] >= '0' && u[v] <= '9'; v++) { const uint32_t d = u[v] - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
+            if (over || v != fe[1]) bad = true;
+            pos = (int64_t)n - 1;
+            if (pos >= 0x7fffffffll) bad = true;                                                     // (the BCF2 core holds 32-bit positions)
+        }
+    }
+    if (!bad) {
+        o.n = 32;                                                                                    // lengths + core, written last
+        // ID
+        if (fe[2] - fs[2] == 1 && u[fs[2]] == '.') o.size(0, 7); else o.vchar(u + fs[2], fe[2] - fs[2]);
+        // REF, ALT
+        o.vchar(u + fs[3], fe[3] - fs[3]); rlen = (int32_t)(fe[3] - fs[3]);
+        if (!(fe[4] - fs[4] == 1 && u[fs[4]] == '.')) {
+            uint32_t t = fs[4];
+            for (uint32_t r = fs[4];; r++) {
+                if (r == fe[4] || u[r] == ',') { if (n_allele == 65535) { bad = true; break; } o.vchar(u + t, r - t); t = r + 1; n_allele++; }
+                if (r == fe[4]) break;
+            }
+        }
+    }
+    if (!bad) {
+        // QUAL: (float)atof
+        if (!(fe[5] - fs[5] == 1 && u[fs[5]] == '.')) {
+            double d; uint32_t e;
+            if (vcf_str2dbl_fast(u + fs[5], fe[5] - fs[5], &d, &e) == 0) { const float f = __double2float_rn(d); qbits = __float_as_uint(f); }
+            else { qbits = 0; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {fs[5], fe[5] - fs[5], a.rec_off[li] + 20u, 0u}; } }
+        }
+        // FILTER
+        if (fe[6] - fs[6] == 1 && u[fs[6]] == '.') o.b(0x00);
+        else {
+            uint32_t e6 = fe[6]; if (e6 > fs[6] && u[e6 - 1] == ';') e6--;                             // one trailing ';' is dropped
+            uint32_t n_flt = 1; for (uint32_t r = fs[6]; r < e6; r++) n_flt += u[r] == ';';
+            o.size(n_flt, 3);
+            uint32_t t = fs[6];
+            for (uint32_t r = fs[6];; r++) if (r == e6 || u[r] == ';') {
+                const int k = vcf_dict_find(a.ids, u + t, r - t);
+                if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t, r - t, 1u}; } o.w32(0); }
+                else o.w32((uint32_t)a.ids.id[k]);
+                t = r + 1;
+                if (r == e6) break;
+            }
+        }
+        // INFO
+        if (!(fe[7] - fs[7] == 1 && u[fs[7]] == '.')) {
+            uint32_t e7 = fe[7]; if (e7 > fs[7] && u[e7 - 1] == ';') e7--;
+            uint32_t r = fs[7], key = fs[7];
+            for (;; r++) {
+                while (r < e7 && u[r] != ';' && u[r] != '=') r++;
+                if (n_info == 65535) { bad = true; break; }
+                uint32_t val = 0xffffffffu, end; uint8_t c = r < e7 ? u[r] : 0; const uint32_t kend = r;
+                if (c == '=') { val = r + 1; for (end = val; end < e7 && u[end] != ';'; end++) {} c = end < e7 ? u[end] : 0; } else end = r;
+                if (kend == key) { if (c == 0) break; r = end; key = r + 1; continue; }             // empty key (";;"): skipped
+                const int k = vcf_dict_find(a.ids, u + key, kend - key);
+                int ht = 3; int32_t id = 0;
+                if (k < 0 || a.ids.ityp[k] == 15) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, key, kend - key, 2u}; } }
+                else { ht = a.ids.ityp[k]; id = a.ids.id[k]; }
+                n_info++;
+                o.key(id);
+                if (val == 0xffffffffu) o.b(0x00);
+                else if (ht == 0 || ht == 3) o.vchar(u + val, end - val);
+                else {
+                    uint32_t n_val = 1; for (uint32_t t = val; t < end; t++) n_val += u[t] == ',';
+                    if (ht == 1 && n_val == 1) o.b(0x13); else o.size(n_val, ht == 1 ? 3 : 5);
+                    uint32_t t = val;
+                    for (uint32_t i = 0; i < n_val; i++, t++) {
+                        uint32_t te = t, w;
+                        if (ht == 1) {                                                               // hts_str2int, 64 bits
+                            bool neg = false, over = false; uint64_t n = 0, limit = (1ull << 63) - 1;
+                            if (te < end && u[te] == '-') { limit++; neg = true; te++; } else if (te < end && u[te] == '+') te++;
+                            for (; te < end && u[te] >= '0' && u[te] <= '9'; te++) { const uint32_t d = u[te] - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
+                            const int64_t v = neg ? (int64_t)(0 - n) : (int64_t)n;
+                            w = (te == t || over || v < -2147483640ll || v > 2147483647ll) ? 0x80000000u : (uint32_t)(int32_t)v;
+                        } else {
+                            uint32_t tok_end = t; while (tok_end < end && u[tok_end] != ',') tok_end++;
+                            double d; uint32_t e;
+                            if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { w = __float_as_uint(__double2float_rn(d)); te = t + e; }
+                            else { w = 0x7F800001u; te = tok_end; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t, tok_end - t, a.rec_off[li] + o.n, 1u}; } }
+                        }
+                        o.w32(w);
+                        for (t = te; t < end && u[t] != ','; t++) {}
+                    }
+                }
+                if (c == 0) break;
+                r = end; key = r + 1;
+            }
+        }
+    }
+    if (bad) { atomicMin(a.first_bad, (unsigned long long)li); if (!WRITE) a.rec_len[li] = 0; return; }
+    if (!WRITE) { a.rec_len[li] = o.n; return; }
+    const uint32_t total = o.n;
+    o.n = 0;
+    o.w32(total - 8); o.w32(0);                                                                      // l_shared (core + shared block), l_indiv
+    o.w32((uint32_t)rid); o.w32((uint32_t)(int32_t)pos); o.w32((uint32_t)rlen);
+    o.w32(qbits);
+    o.w32(n_info | (n_allele << 16)); o.w32(0);
+}

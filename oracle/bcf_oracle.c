@@ -797,6 +797,236 @@ static int scan_records(scan_t *s, const uint8_t *u, size_t ulen, size_t pos, in
 /* Canonical blob: u32 ncol, u64 nrows, i32 status, u64 first_rec_uoff, u32 n_samples; per column: u16 name_len, name, u8 type, u8 is_list,
  * valid[nrows]; scalar fixed: nrows x u64 raw bits | scalar varchar: (nrows+1) x u64 offsets + bytes | list: nrows x (u64 off, u64 len),
  * u64 child_n, child payload in the scalar encoding.  Trailer: u64 n_rec, then i64 rid[n_rec], i64 pos0[n_rec], i64 rlen[n_rec]. */
+/* ------------------------------------------------------------------ VCF text input -------------------------------- */
+/* read_bcf on a text VCF (plain or BGZF-compressed): the reference reads it through the same htsFile -- vcf_hdr_read vcf.c:2594-2680 for the
+ * header, vcf_read -> vcf_parse vcf.c:3987-4165 (vcf_parse_filter 3763-3816, vcf_parse_info 3818-3985) for every line -- into the same
+ * bcf1_t the binary reader fills, and the column writers do not know the difference.  Restated here as "text line -> BCF2 record bytes",
+ * after which scan_records() above runs unchanged.  Number parsers: hts_str2uint / hts_str2int / hts_str2dbl textutils_internal.h:218-428.
+ * Names a record uses without a header definition are added on the fly with dummy definitions, as htslib does (fix_chromosome 3744-3761 and
+ * the "Dummy" lines of vcf_parse_filter / vcf_parse_info); the columns were bound before, so only the dictionaries grow.
+ * Restated for SITES-ONLY files (no sample columns): vcf_parse_format is not restated yet -> ORC_BCF_ESAMPLES.  Records whose POS does not
+ * fit the BCF2 core (>= 2^31 - 1) end the scan (the reference keeps 64-bit positions in memory). */
+#define ORC_BCF_ESAMPLES (-103)
+
+static void enc_typed_int(buf_t *o, int64_t x)                                 /* bcf_enc_int1 (htslib/vcf.h): smallest width; missing as int8 missing */
+{
+    if (x == (int32_t)0x80000000) { buf_u8(o, 0x11); buf_u8(o, 0x80); return; }
+    if (x <= 127 && x > -121) { buf_u8(o, 0x11); buf_u8(o, (uint8_t)(int8_t)x); }
+    else if (x <= 32767 && x > -32761) { int16_t v = (int16_t)x; buf_u8(o, 0x12); buf_push(o, &v, 2); }
+    else { int32_t v = (int32_t)x; buf_u8(o, 0x13); buf_push(o, &v, 4); }
+}
+static void enc_size(buf_t *o, int64_t n, int type)                            /* bcf_enc_size */
+{
+    if (n < 15) buf_u8(o, (uint8_t)(n << 4 | type));
+    else {
+        buf_u8(o, (uint8_t)(15 << 4 | type));
+        if (n < 128) { buf_u8(o, 0x11); buf_u8(o, (uint8_t)n); }
+        else if (n < 32768) { int16_t v = (int16_t)n; buf_u8(o, 0x12); buf_push(o, &v, 2); }
+        else { int32_t v = (int32_t)n; buf_u8(o, 0x13); buf_push(o, &v, 4); }
+    }
+}
+static void enc_vchar(buf_t *o, size_t l, const char *a) { enc_size(o, (int64_t)l, 7); buf_push(o, a, l); }
+static void enc_vint32(buf_t *o, int n, const int32_t *a)                      /* (any width decodes to the same values: int32 throughout) */
+{
+    if (n <= 0) { buf_u8(o, 0x00); return; }                                   /* bcf_enc_vint n == 0: typed NULL */
+    enc_size(o, n, 3); buf_push(o, a, (size_t)n * 4);
+}
+
+/* hts_str2uint(in, &end, bits, &failed): optional '+', digits; saturates at 2^bits - 1 with *failed = 1 */
+static uint64_t str2uint(const char *in, const char **end, int bits, int *failed)
+{
+    const unsigned char *v = (const unsigned char *)in; uint64_t n = 0, limit = (bits < 64 ? (1ULL << bits) : 0) - 1; int over = 0;
+    if (*v == '+') v++;
+    for (; *v >= '0' && *v <= '9'; v++) { unsigned d = *v - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else { n = limit; over = 1; } }
+    if (over) *failed = 1;
+    *end = (const char *)v; return n;
+}
+/* hts_str2int(in, &end, 64, &failed): sign, digits; the end pointer moves past a lone sign */
+static int64_t str2int64(const char *in, const char **end, int *failed)
+{
+    const unsigned char *v = (const unsigned char *)in; uint64_t n = 0, limit = (1ULL << 63) - 1; int neg = 0, over = 0;
+    if (*v == '-') { limit++; neg = 1; v++; } else if (*v == '+') v++;
+    for (; *v >= '0' && *v <= '9'; v++) { unsigned d = *v - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else { n = limit; over = 1; } }
+    if (over) *failed = 1;
+    *end = (const char *)v; return neg ? (int64_t)(0 - n) : (int64_t)n;
+}
+/* hts_str2dbl: [+-]?digits[.digits] with at most 14 digits after the leading zeros -> n / 10^k in double arithmetic; everything else strtod */
+static double str2dbl(const char *in, const char **end, int *failed)
+{
+    static const double D[] = { 1, 1, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20 };
+    const unsigned char *v = (const unsigned char *)in; uint64_t n = 0; int max_len = 15, neg = 0, point = -1; char *e;
+    while (isspace(*v)) v++;
+    if (*v == '-') { neg = 1; v++; } else if (*v == '+') v++;
+    if (!((*v >= '1' && *v <= '9') || (*v == '0' && v[1] != 'x' && v[1] != 'X'))) { double d = strtod(in, &e); *end = e; if (e == in) *failed = 1; return d; }
+    while (*v == '0') ++v;
+    const unsigned char *start = v;
+    while (--max_len && *v >= '0' && *v <= '9') n = n * 10 + *v++ - '0';
+    if (max_len && *v == '.') { point = (int)(v - start); v++; while (--max_len && *v >= '0' && *v <= '9') n = n * 10 + *v++ - '0'; }
+    if (point < 0) point = (int)(v - start);
+    if (!max_len || *v == 'e' || *v == 'E') { double d = strtod(in, &e); *end = e; if (e == in) *failed = 1; return d; }
+    *end = (const char *)v;
+    double d = (double)n / D[v - start - point];
+    return neg ? -d : d;
+}
+
+static int hdr_add_dummy(hdr_t *h, const char *fmt, const char *name)          /* bcf_hdr_parse_line + bcf_hdr_add_hrec of a generated line */
+{
+    size_t l = strlen(fmt) + strlen(name) + 8; char *line = (char *)malloc(l);
+    snprintf(line, l, fmt, name);
+    int len; hrec_t *r = parse_line(line, &len);
+    free(line);
+    if (!r) return -1;
+    int rc = register_hrec(h, r);
+    hrec_free(r);
+    return rc < 0 ? -1 : 0;
+}
+
+/* one line -> one BCF2 record appended to `out`; < 0: the line is an error (the scan ends before it) */
+static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
+{
+    char *f[8]; int nf = 0; char *p = line;
+    for (;;) {                                                                /* kstrtok on '\t': empty tokens count, all eight are required */
+        f[nf++] = p;
+        char *t = strchr(p, '\t');
+        if (!t) break;
+        *t = 0; p = t + 1;
+        if (nf == 8) break;                                                   /* a ninth column (FORMAT) is cut off: no samples in the header, vcf_parse_format returns at once */
+    }
+    if (nf < 8) return -1;
+    buf_t sh = { 0 };
+    /* CHROM */
+    int rid = ctg_find(h, f[0]);
+    if (rid < 0) { if (hdr_add_dummy(h, "##contig=<ID=%s>", f[0]) < 0 || (rid = ctg_find(h, f[0])) < 0) { free(sh.p); return -1; } }
+    /* POS */
+    int failed = 0; const char *e;
+    uint64_t pos1 = str2uint(f[1], &e, 62, &failed);
+    if (failed || *e) { free(sh.p); return -1; }
+    int64_t pos = (int64_t)pos1 - 1;
+    if (pos >= 0x7fffffffLL) { free(sh.p); return -1; }                        /* (restatement limit: the BCF2 core holds 32-bit positions) */
+    /* ID, REF, ALT */
+    if (strcmp(f[2], ".")) enc_vchar(&sh, strlen(f[2]), f[2]); else enc_size(&sh, 0, 7);
+    enc_vchar(&sh, strlen(f[3]), f[3]);
+    int n_allele = 1; int32_t rlen = (int32_t)strlen(f[3]);
+    if (strcmp(f[4], ".")) {
+        char *t = f[4];
+        for (char *r = f[4];; ++r) if (*r == ',' || *r == 0) {
+            if (n_allele == 65535) { free(sh.p); return -1; }
+            enc_vchar(&sh, (size_t)(r - t), t); t = r + 1; ++n_allele;
+            if (*r == 0) break;
+        }
+    }
+    /* QUAL: atof */
+    uint32_t qbits = 0x7F800001u;
+    if (strcmp(f[5], ".")) { float q = (float)atof(f[5]); memcpy(&qbits, &q, 4); }
+    /* FILTER */
+    if (strcmp(f[6], ".")) {
+        size_t l = strlen(f[6]);
+        if (l && f[6][l - 1] == ';') f[6][l - 1] = 0;
+        int n_flt = 1; for (char *r = f[6]; *r; ++r) if (*r == ';') ++n_flt;
+        int32_t *a = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_flt); int i = 0;
+        for (char *t = f[6];;) {
+            char *sc = strchr(t, ';'); if (sc) *sc = 0;
+            int k = dict_find(h, t);
+            if (k < 0) { if (hdr_add_dummy(h, "##FILTER=<ID=%s,Description=\"Dummy\">", t) < 0 || (k = dict_find(h, t)) < 0) { free(a); free(sh.p); return -1; } }
+            a[i++] = k;
+            if (!sc) break;
+            t = sc + 1;
+        }
+        enc_vint32(&sh, n_flt, a);
+        free(a);
+    } else buf_u8(&sh, 0x00);
+    /* INFO */
+    int n_info = 0;
+    if (strcmp(f[7], ".")) {
+        size_t l = strlen(f[7]);
+        if (l && f[7][l - 1] == ';') f[7][l - 1] = 0;
+        char *r, *key;
+        for (r = key = f[7];; ++r) {
+            while (*r != ';' && *r != '=' && *r != 0) r++;
+            if (n_info == 65535) { free(sh.p); return -1; }
+            char *val = NULL, *end; int c = *r; *r = 0;
+            if (c == '=') { val = r + 1; for (end = val; *end != ';' && *end != 0; ++end); c = *end; *end = 0; } else end = r;
+            if (!*key) { if (c == 0) break; r = end; key = r + 1; continue; }
+            int k = dict_find(h, key);
+            if (k < 0 || !h->ids[k].has[HL_INFO]) {
+                if (hdr_add_dummy(h, "##INFO=<ID=%s,Number=1,Type=String,Description=\"Dummy\">", key) < 0 || (k = dict_find(h, key)) < 0 || !h->ids[k].has[HL_INFO]) { free(sh.p); return -1; }
+            }
+            int ht = h->ids[k].type[HL_INFO];
+            ++n_info;
+            enc_typed_int(&sh, k);
+            if (!val) buf_u8(&sh, 0x00);
+            else if (ht == HT_FLAG || ht == HT_STR) enc_vchar(&sh, (size_t)(end - val), val);
+            else {
+                int n_val = 1; for (char *t = val; *t; ++t) if (*t == ',') ++n_val;
+                int32_t *a = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_val);
+                const char *t = val, *te;
+                for (int i = 0; i < n_val; ++i, ++t) {
+                    int over = 0;
+                    if (ht == HT_INT) {
+                        int64_t v = str2int64(t, &te, &over);
+                        if (te == t) v = (int32_t)0x80000000;
+                        else if (over || v < -2147483640LL || v > 2147483647LL) v = (int32_t)0x80000000;
+                        a[i] = (int32_t)v;
+                    } else {
+                        float fv = (float)str2dbl(t, &te, &over);
+                        uint32_t b; memcpy(&b, &fv, 4);
+                        if (te == t || over) b = 0x7F800001u;
+                        a[i] = (int32_t)b;
+                    }
+                    for (t = te; *t && *t != ','; t++);
+                }
+                if (ht == HT_INT) { if (n_val == 1) enc_typed_int(&sh, a[0]); else enc_vint32(&sh, n_val, a); }
+                else { enc_size(&sh, n_val, 5); buf_push(&sh, a, (size_t)n_val * 4); }
+                free(a);
+            }
+            if (c == 0) break;
+            r = end; key = r + 1;
+        }
+    }
+    uint32_t l_shared = 24 + (uint32_t)sh.n, l_indiv = 0, w;
+    buf_push(out, &l_shared, 4); buf_push(out, &l_indiv, 4);
+    int32_t i32 = rid; buf_push(out, &i32, 4); i32 = (int32_t)pos; buf_push(out, &i32, 4); buf_push(out, &rlen, 4); buf_push(out, &qbits, 4);
+    w = (uint32_t)n_info | ((uint32_t)n_allele << 16); buf_push(out, &w, 4);
+    w = 0; buf_push(out, &w, 4);
+    buf_push(out, sh.p, sh.n);
+    free(sh.p);
+    return 0;
+}
+
+/* text stream -> header (parsed into s->h, schema built) + BCF2 record bytes; returns ORC_BCF_* or 0; *bad = 1 when a line failed */
+static int vcf_text_load(scan_t *s, const uint8_t *u, size_t ulen, buf_t *recs, int *bad)
+{
+    buf_t txt = { 0 }; size_t pos = 0; int have_sample_line = 0;
+    char *line = NULL;
+    #define NEXT_LINE(ok) do { ok = pos < ulen; if (ok) { const uint8_t *nl = (const uint8_t *)memchr(u + pos, '\n', ulen - pos); size_t e = nl ? (size_t)(nl - u) : ulen, l = e - pos; \
+        free(line); line = dupn((const char *)u + pos, l); if (l && line[l - 1] == '\r') line[l - 1] = 0; pos = nl ? e + 1 : ulen; } } while (0)
+    int ok;
+    for (;;) {                                                                /* vcf_hdr_read */
+        NEXT_LINE(ok);
+        if (!ok) break;
+        if (!line[0]) continue;
+        if (line[0] != '#') { free(line); free(txt.p); return ORC_BCF_EHDR; }  /* "No sample line" */
+        buf_push(&txt, line, strlen(line)); buf_u8(&txt, '\n');
+        if (line[1] != '#') { have_sample_line = 1; break; }
+    }
+    if (!txt.n) { free(line); free(txt.p); return ORC_BCF_EHDR; }
+    (void)have_sample_line;
+    buf_u8(&txt, 0);
+    if (hdr_parse(&s->h, (const char *)txt.p) < 0) { free(line); free(txt.p); return ORC_BCF_EHDR; }
+    free(txt.p);
+    if (s->h.n_smp > 0) { free(line); return ORC_BCF_ESAMPLES; }
+    int rc = build_schema(s);
+    if (rc < 0) { free(line); return rc; }
+    for (;;) {
+        NEXT_LINE(ok);
+        if (!ok) break;
+        if (vcf_line_to_bcf(&s->h, line, recs) < 0) { *bad = 1; break; }
+    }
+    free(line);
+    #undef NEXT_LINE
+    return 0;
+}
+
 int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, uint8_t **blob, size_t *blob_len, int64_t *n_rows)
 {
     orc_bgzf_t bz;
@@ -804,9 +1034,31 @@ int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, ui
     if (n_rows) *n_rows = 0;
     /* any content that is not a readable BCF2.2 header ends in "Failed to read BCF/VCF header" (bcf_reader.c:505); hts_open itself
      * only fails for a missing file (ORC_BCF_EOPEN is kept for that case at the surface) */
-    if (orc_bgzf_inflate_all(file, flen, &bz) < 0 && bz.len == 0) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
-    const uint8_t *u = bz.data; size_t ulen = bz.len;
-    if (ulen < 9 || memcmp(u, "BCF\2\2", 5)) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
+    const int is_bgzf = flen >= 18 && file[0] == 31 && file[1] == 139 && file[2] == 8 && (file[3] & 4);
+    memset(&bz, 0, sizeof bz);
+    if (is_bgzf && orc_bgzf_inflate_all(file, flen, &bz) < 0 && bz.len == 0) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
+    const uint8_t *u = is_bgzf ? bz.data : file; size_t ulen = is_bgzf ? bz.len : flen;
+    if (ulen >= 16 && !memcmp(u, "##fileformat=VCF", 16)) {                     /* text VCF (hts_detect_format) */
+        scan_t s; memset(&s, 0, sizeof s); s.tidy = tidy;
+        buf_t recs = { 0 }; int bad = 0;
+        int rc = vcf_text_load(&s, u, ulen, &recs, &bad);
+        if (rc < 0) { free(recs.p); scan_free(&s); orc_bgzf_free(&bz); return rc; }
+        int status = scan_records(&s, recs.p, recs.n, 0, materialise);
+        if (status == 0 && bad) status = -2;
+        if (status == 0 && is_bgzf && bz.status < 0) status = bz.status;
+        if (n_rows) *n_rows = s.n_rows;
+        if (blob && materialise) {
+            buf_t o = { 0 };
+            uint32_t nc = (uint32_t)s.ncol; uint64_t nr = (uint64_t)s.n_rows, fr = 0; int32_t st = status; uint32_t ns = 0;
+            buf_push(&o, &nc, 4); buf_push(&o, &nr, 8); buf_push(&o, &st, 4); buf_push(&o, &fr, 8); buf_push(&o, &ns, 4);
+            for (int i = 0; i < s.ncol; i++) ser_col(&o, &s.col[i], s.n_rows);
+            { uint64_t nrec = (uint64_t)s.n_recs; buf_push(&o, &nrec, 8); buf_push(&o, s.rec_rid.p, s.rec_rid.n); buf_push(&o, s.rec_pos.p, s.rec_pos.n); buf_push(&o, s.rec_rlen.p, s.rec_rlen.n); }
+            *blob = o.p; *blob_len = o.n;
+        }
+        free(recs.p); scan_free(&s); orc_bgzf_free(&bz);
+        return status;
+    }
+    if (!is_bgzf || ulen < 9 || memcmp(u, "BCF\2\2", 5)) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
     size_t hlen = rd_u32(u + 5);
     if (ulen - 9 < hlen) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }
     char *txt = dupn((const char *)u + 9, hlen);

@@ -1,0 +1,157 @@
+"""read_bcf on VCF TEXT (plain or BGZF), sites-only files: vcf_hdr_read + vcf_parse (htslib vcf.c:2594-2680, 3987-4165) in front of the
+same column writers.
+
+CPU: the oracle's text restatement pinned on the reference's own fixtures -- test/data/test_vep.vcf read as TEXT (duckhts.test:107-121
+literally, and cell for cell against the independent BCF re-encoding of tests/vep_cases.py) and test/data/no_contig.vcf.gz (duckhts.test:
+395-397: a contig the header does not define) -- plus hand-derived number / field / undefined-name cases.  GPU: the HIP path against the
+oracle, bit for bit, through the C ABI and through the table function.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import vcf_text_cases as V
+import vep_cases
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = V.all_cases()
+
+
+def _col(t, name):
+    return orc.bcf_col_py(t["by_name"][name])
+
+
+def test_reference_fixture_test_vep_vcf_as_text():
+    txt = vep_cases.fixture_text().encode()
+    t = orc.bcf_read(txt)
+    assert t["n_rows"] == 802 and t["status"] == 0
+    assert _col(t, "VEP_Allele")[0] is not None                                   # duckhts.test:108-113
+    assert (_col(t, "VEP_Allele")[0][0], _col(t, "VEP_SYMBOL")[0][0]) == (b"T", b"WASH7P")   # duckhts.test:116-121
+    bcf, fields, rows = vep_cases.fixture_bcf()                                   # the same records encoded to BCF2 by an independent Python reading of the text
+    assert orc.bcf_cols_diff(t, orc.bcf_read(bcf)) is None
+    assert [int(p) for p in _col(t, "POS")] == [p for p, _ in rows]
+
+
+def test_reference_fixture_no_contig_vcf_gz():
+    data = open(os.path.join(GOLD, "no_contig.vcf.gz"), "rb").read()
+    t = orc.bcf_read(data)
+    assert t["n_rows"] == 1 and t["status"] == 0                                  # duckhts.test:395-397
+    assert (_col(t, "CHROM"), _col(t, "POS"), _col(t, "REF"), _col(t, "ALT"), _col(t, "QUAL"), _col(t, "FILTER"), _col(t, "INFO_DP")) == \
+           ([b"chr1"], [1], [b"A"], [[b"T"]], [None], [[b"PASS"]], [1])
+
+
+def test_numbers():
+    t = orc.bcf_read(dict(CASES)["numbers_plain"])
+    assert orc.bcf_cols_diff(t, orc.bcf_read(dict(CASES)["numbers_bgzf"])) is None
+    f32 = lambda x: float(np.float32(x))
+    q = _col(t, "QUAL")
+    assert q[:5] == [30.0, None, 12.0, 100.0, 7.25] and q[5] == 0.0 and q[6] == math.inf and q[7] == f32(0.1)      # atof: prefix parse, "-" -> 0
+    assert _col(t, "INFO_DP") == [35, 5, None, None, None, None, None, None]       # "+5"; 99999999999 and "." and "" are missing
+    ac = _col(t, "INFO_AC")
+    assert ac[1] == [0, 0, 12, 7]                                                  # "-" and "+" convert to 0 (the end pointer moves past the sign), "12abc" to 12, "" is missing
+    assert ac[2] == [2147483647, -2147483640]                                      # BCF_MIN_BT_INT32 = INT32_MIN + 8; everything outside is missing
+    fv = _col(t, "INFO_FV")
+    assert fv[1][:5] == [5.0, -0.0, 12.5, f32(1e-3), 100.0] and math.copysign(1, fv[1][1]) == -1
+    assert math.isnan(fv[1][5]) and fv[1][6:] == [math.inf, -math.inf, 16.0]       # strtod's forms: nan, inf, hex; "abc", "" and "." are missing
+    assert fv[3] == [f32(0.1234567890123), f32(0.12345678901234), f32(0.123456789012345), f32(1234567890123456789)]
+    assert fv[4] == [1.5, -2.5, 4.0, 1.0, f32(1e-15), f32(1e14)]                    # leading white space is skipped, trailing garbage ignored
+    assert fv[6] == [f32(3.4028235e38), math.inf, 0.0, 0.0] and fv[7][3] == 16777216.0
+    mq = _col(t, "INFO_MQ")
+    assert mq[:5] == [59.5, 0.5, None, f32(123456789012345.5), 3.5] and mq[5] is None
+    assert _col(t, "INFO_DB") == [True, False, False, False, False, True, False, False]
+
+
+def test_fields_and_line_endings():
+    t = orc.bcf_read(dict(CASES)["fields"])
+    assert orc.bcf_cols_diff(t, orc.bcf_read(dict(CASES)["fields_crlf_no_final_eol"])) is None      # "\r\n" and a last line without newline
+    assert t["n_rows"] == 19 and t["status"] == 0
+    assert _col(t, "ID")[:2] == [b"rs1;rs2", None] and _col(t, "REF")[:2] == [b"ACGT", b"."]           # an empty REF prints as "." (bcf_fmt_array of 0 bytes)
+    alt = _col(t, "ALT")
+    assert alt[0] == [b"A", b"<DEL>", b"ACGTT"] and alt[1] == [b"."] and alt[2] == [] and alt[3] == [b"A", b"."] and alt[4] == [b".", b"A"]
+    flt = _col(t, "FILTER")
+    assert flt[5] == [b"PASS"] and flt[6] == [b"q10", b"s50"] and flt[7] == [b"q10"] and flt[9] == [b"DP"]
+    dp = _col(t, "INFO_DP")
+    assert dp[10:16] == [1, 2, 3, 4, 5, 6]                                           # ";;", a leading ';', an empty key, '=' inside a value, a trailing ';', a repeated key (first wins)
+    assert _col(t, "INFO_ANN_S")[13] == b"a=b=c"
+    assert _col(t, "POS")[16:] == [0, 30, 2147483646] and _col(t, "CHROM")[18] == b"chr2"
+
+
+def test_undefined_names_get_dummy_definitions():
+    t = orc.bcf_read(dict(CASES)["undefined_names"])
+    assert t["n_rows"] == 4 and t["status"] == 0 and len(t["cols"]) == 16           # the columns were bound before the records were read
+    assert _col(t, "CHROM") == [b"chrUn_1", b"chr2", b"chrUn_2", b"chrUn_1"]          # fix_chromosome (vcf.c:3744-3761)
+    assert _col(t, "FILTER") == [[b"lowq"], [b"lowq", b"other"], [b"PASS"], [b"other"]]
+    assert _col(t, "INFO_DP") == [1, None, None, None] and _col(t, "INFO_AF")[3] == [0.5]
+    t2 = orc.bcf_read(dict(CASES)["undefined_names_bgzf_small_blocks"])
+    assert t2["n_rows"] == 160 and _col(t2, "CHROM")[:4] == _col(t, "CHROM")
+
+
+@pytest.mark.parametrize("name,rows", [("bad_pos", 3), ("bad_pos_overflow", 3), ("pos_too_large_for_bcf", 3), ("too_few_columns", 3), ("empty_line", 3),
+                                       ("undefined_contig_with_bad_name", 3), ("nul_in_line", 2)])
+def test_the_first_bad_line_ends_the_scan(name, rows):
+    t = orc.bcf_read(dict(CASES)[name])
+    assert t["n_rows"] == rows and t["status"] < 0                                  # rows before it are kept, silently (bcf_reader.c:1319-1349)
+
+
+def test_sample_columns_are_not_restated_yet():
+    txt = "\n".join(V.HDR[:-1] + ["#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1", "chr1\t1\t.\tA\tT\t.\t.\t.\tGT\t0/1"]) + "\n"
+    assert orc.bcf_read(txt.encode())["status"] == -103
+
+
+# ---- GPU parity -------------------------------------------------------------------------------------------------------------
+def _check(data, **kw):
+    import duckhts_amd
+    exp = orc.bcf_read(data)
+    got = duckhts_amd.read_bcf(data, **kw)
+    d = orc.bcf_cols_diff(exp, got)
+    assert d is None, d
+    assert (got["status"] == 1) == (exp["status"] == 0), (got["status"], exp["status"])
+    return exp, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,data", CASES, ids=[c[0] for c in CASES])
+def test_gpu_cases(name, data):
+    _check(data)
+    if len(data) > 3000:
+        _check(data, max_blocks=1)
+
+
+@pytest.mark.gpu
+def test_gpu_reference_fixtures():
+    txt = vep_cases.fixture_text().encode()
+    exp, got = _check(txt)
+    assert got["n_rows"] == 802
+    assert (orc.bcf_col_py(got["by_name"]["VEP_Allele"])[0][0], orc.bcf_col_py(got["by_name"]["VEP_SYMBOL"])[0][0]) == (b"T", b"WASH7P")   # duckhts.test:116-121
+    _check(txt, max_blocks=2)
+    import bamwriter
+    _check(bamwriter.bgzf_file(txt, payload=5000), max_blocks=3)
+    exp, got = _check(open(os.path.join(GOLD, "no_contig.vcf.gz"), "rb").read())
+    assert got["n_rows"] == 1 and orc.bcf_col_py(got["by_name"]["CHROM"]) == [b"chr1"]   # duckhts.test:395-397
+
+
+@pytest.mark.gpu
+def test_gpu_projection_and_sample_columns():
+    import duckhts_amd
+    data = dict(CASES)["many_bgzf"]
+    exp = orc.bcf_read(data)
+    names = [c["name"] for c in exp["cols"]]
+    want = ["INFO_FV", "POS", "QUAL", "INFO_AF"]
+    got = duckhts_amd.read_bcf(data, columns=[names.index(w) for w in want])
+    assert orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": [exp["by_name"][w] for w in want]}, got) is None
+    txt = "\n".join(V.HDR[:-1] + ["#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1", "chr1\t1\t.\tA\tT\t.\t.\t.\tGT\t0/1"]) + "\n"
+    with pytest.raises(duckhts_amd.DhtsError, match="sample columns"):
+        duckhts_amd.read_bcf(txt.encode())
+
+
+@pytest.mark.gpu
+def test_gpu_vcf_text_through_the_table_function(tmp_path):
+    """the reference's own queries on its own files: read_bcf('test_vep.vcf') (plain text) and read_bcf('no_contig.vcf.gz')"""
+    from test_duckdb_surface import compare_bcf, run_host
+    compare_bcf(vep_cases.fixture_text().encode(), tmp_path)
+    compare_bcf(open(os.path.join(GOLD, "no_contig.vcf.gz"), "rb").read(), tmp_path)
+    compare_bcf(dict(CASES)["undefined_names_bgzf_small_blocks"], tmp_path)
+    compare_bcf(dict(CASES)["many_plain"], tmp_path, proj=[0, 1, 5, 6, 8, 15])
