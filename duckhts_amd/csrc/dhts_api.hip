@@ -304,6 +304,8 @@ dhts_ctx *dhts_create(int device_id) {
         hipFuncSetAttribute((const void *)bgzf_huff_decode, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return nullptr;     // no gfx950 code object for this device
     }
+    (void)hipFuncSetAttribute((const void *)vcf_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)vcf_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
     hipLaunchKernelGGL(crc_const_init, dim3(1), dim3(64), 0, c->stream);      // per-device CRC constants (idempotent)
     if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     return c;
@@ -317,7 +319,14 @@ void dhts_destroy(dhts_ctx *c) {
     timing_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     bool kept = false;
-    if (clean) { std::lock_guard<std::mutex> lk(g_ss_mu); if (g_ss.size() < 32) { g_ss.push_back({c->device, c->stream, c->stream_b, c->pf_done}); kept = true; } }
+    if (clean) {
+        std::lock_guard<std::mutex> lk(g_ss_mu);
+        // (pooled streams are destroyed before the HIP runtime shuts down: a process that exits with live streams can hang in the
+        //  runtime's teardown when a profiler is attached)
+        static bool at_exit = false;
+        if (!at_exit) { at_exit = true; std::atexit([]() { std::lock_guard<std::mutex> lk2(g_ss_mu); for (auto &x : g_ss) { if (hipSetDevice(x.dev) != hipSuccess) continue; (void)hipEventDestroy(x.ev); (void)hipStreamDestroy(x.sb); (void)hipStreamDestroy(x.s); } g_ss.clear(); }); }
+        if (g_ss.size() < 32) { g_ss.push_back({c->device, c->stream, c->stream_b, c->pf_done}); kept = true; }
+    }
     if (!kept) { (void)hipEventDestroy(c->pf_done); (void)hipStreamDestroy(c->stream_b); (void)hipStreamDestroy(c->stream); }
     delete c;                                               // every DevBuf member frees its allocation (device `c->device` is current)
 }
@@ -2372,14 +2381,14 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     if (c->first_batch) { if (c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch"); t0 = c->scan_first_uoff - out_base; }
     nrec = 0; carry_start = ulen; rec_err = false; rec0_text = (uint32_t)t0; bad_rec = ~0ull;
     if (t0 >= ulen) { carry_start = ulen; return 0; }
-    const int64_t nchunks = (int64_t)((ulen - t0 + 255) / 256);
+    const int64_t nchunks = (int64_t)((ulen - (t0 & ~(uint64_t)15) + VCF_CHUNK - 1) / VCF_CHUNK);
     ENSURE(c, c->v_cnt, (size_t)nchunks * 4 + 64); ENSURE(c, c->v_base, (size_t)(nchunks + 1) * 4 + 64);
-    hipLaunchKernelGGL(vcf_line_count, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, c->stream, u, t0, ulen, (uint32_t *)c->v_cnt.p, nchunks);
+    hipLaunchKernelGGL(vcf_line_count, dim3((unsigned)nchunks), dim3(256), 0, c->stream, u, t0, ulen, (uint32_t *)c->v_cnt.p, nchunks);
     const uint32_t *kin[1] = {(const uint32_t *)c->v_cnt.p}; uint32_t *kout[1] = {(uint32_t *)c->v_base.p}; uint64_t nl = 0;
     if (run_scan(c, 1, kin, kout, nullptr, nchunks, &nl)) return -1;
     if (nl + 2 >= (1ull << 32)) return fail(c, "batch too large");
     ENSURE(c, c->v_line_off, (size_t)(nl + 2) * 4 + 64);
-    hipLaunchKernelGGL(vcf_line_fill, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, c->stream, u, t0, ulen, (const uint32_t *)c->v_base.p, (uint32_t *)c->v_line_off.p, nchunks);
+    hipLaunchKernelGGL(vcf_line_fill, dim3((unsigned)nchunks), dim3(256), 0, c->stream, u, t0, ulen, (const uint32_t *)c->v_base.p, (uint32_t *)c->v_line_off.p, nchunks);
     uint32_t last_start = 0;
     HIPCHK(c, hipMemcpyAsync(&last_start, (const uint32_t *)c->v_line_off.p + nl, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2392,6 +2401,7 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     ENSURE(c, c->v_undef, (size_t)UCAP * sizeof(VcfUndef)); ENSURE(c, c->v_patch, (size_t)PCAP * sizeof(VcfPatch));
     VcfArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.line_off = (const uint32_t *)c->v_line_off.p; a.nlines = nlines; a.text_end = ulen; a.last_open = last_open;
+    { static const bool no_stage = getenv("DHTS_VCF_STAGE") && atoi(getenv("DHTS_VCF_STAGE")) == 0; a.lds_budget = no_stage ? 0u : VCF_LDS_BYTES; if (getenv("DHTS_VCF_STAGE") && atoi(getenv("DHTS_VCF_STAGE")) == 2) a.lds_budget = VCF_LDS_BYTES - 15u; }
     a.rec_len = (uint32_t *)c->v_rec_len.p; a.rec_off = (const uint32_t *)c->b_rec_off.p; a.first_bad = (unsigned long long *)((uint64_t *)c->v_ctr.p + 2);
     a.counters = (uint32_t *)c->v_ctr.p; a.undef = (VcfUndef *)c->v_undef.p; a.undef_cap = UCAP; a.patch = (VcfPatch *)c->v_patch.p; a.patch_cap = PCAP;
     unsigned long long first_bad = ~0ull;
@@ -2401,7 +2411,7 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
         a.ids = {(const uint32_t *)c->vd_id_off.p, (const uint8_t *)c->vd_id_bytes.p, (const int32_t *)c->vd_id_id.p, (const uint8_t *)c->vd_id_typ.p, 0};
         { int32_t n1 = 0, n2 = 0; for (size_t i = 0; i < c->bh.ctg.size(); i++) n1 += c->bh.ctg_present[i] ? 1 : 0; for (auto &e : c->bh.ids) n2 += e.present ? 1 : 0; a.ctg.n = n1; a.ids.n = n2; }
         HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream)); HIPCHK(c, hipMemsetAsync((uint64_t *)c->v_ctr.p + 2, 0xff, 8, c->stream));
-        hipLaunchKernelGGL(vcf_encode<false>, dim3((unsigned)((nlines + 127) / 128)), dim3(128), 0, c->stream, a);
+        hipLaunchKernelGGL(vcf_encode<false>, dim3((unsigned)((nlines + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
         uint64_t ctr[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(ctr, c->v_ctr.p, 24, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2452,7 +2462,7 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     a.nlines = nrec; a.out = (uint8_t *)c->v_out.p;
     if (nrec < nlines) { a.last_open = 0; }
     HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream));
-    hipLaunchKernelGGL(vcf_encode<true>, dim3((unsigned)((nrec + 127) / 128)), dim3(128), 0, c->stream, a);
+    hipLaunchKernelGGL(vcf_encode<true>, dim3((unsigned)((nrec + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
     HIPCHK(c, hipMemsetAsync((uint8_t *)c->v_out.p + total, 0, PAD_BYTES, c->stream));
     uint32_t ctr2[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(ctr2, c->v_ctr.p, 8, hipMemcpyDeviceToHost, c->stream));

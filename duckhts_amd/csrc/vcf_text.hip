@@ -21,6 +21,7 @@ struct VcfPatch { uint32_t pos, len, dst, kind; };        // kind 0: (float)atof
 struct VcfArgs {
     const uint8_t *u; const uint32_t *line_off; int64_t nlines; uint64_t text_end;   // line i = u[line_off[i], line_off[i+1] - 1) (the last one ends at text_end when it has no newline)
     int32_t last_open;                                      // 1: the last line has no terminating newline
+    uint32_t lds_budget;                                    // bytes of LDS a workgroup may stage its lines in (0: parse from HBM)
     VcfDictDev ctg, ids;
     uint32_t *rec_len; const uint32_t *rec_off; uint8_t *out;
     unsigned long long *first_bad;
@@ -28,23 +29,54 @@ struct VcfArgs {
     VcfUndef *undef; uint32_t undef_cap; VcfPatch *patch; uint32_t patch_cap;
 };
 
-extern "C" __global__ void __launch_bounds__(256)
-vcf_line_count(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, uint32_t *__restrict__ cnt, int64_t nchunks) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nchunks) return;
-    const uint64_t a = start + (uint64_t)k * 256, b = a + 256 < ulen ? a + 256 : ulen;
-    uint32_t n = 0;
-    for (uint64_t i = a; i < b; i++) n += u[i] == '\n';
-    cnt[k] = n;
+// Line index of a batch: chunks of 4 KiB (one workgroup, 16 bytes per lane, coalesced); newline count per chunk, an exclusive scan over
+// the chunks on the host side (run_scan), then every newline's successor position lands at its rank.
+#define VCF_CHUNK 4096u
+__device__ __forceinline__ uint32_t vcf_nl_mask16(const uint8_t *__restrict__ u, uint64_t p, uint64_t ulen) {      // bit k set: u[p + k] == '\n'
+    uint32_t m = 0;
+    if (p + 16 <= ulen && (p & 15) == 0) {
+        const uint4 v = *(const uint4 *)(u + p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t x = w[q] ^ 0x0a0a0a0au;                              // zero bytes where the byte is '\n'
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (((x >> (8 * b)) & 0xffu) == 0) m |= 1u << (4 * q + b);
+        }
+    } else for (uint32_t k = 0; k < 16 && p + k < ulen; k++) if (u[p + k] == '\n') m |= 1u << k;
+    return m;
 }
 extern "C" __global__ void __launch_bounds__(256)
-vcf_line_fill(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, const uint32_t *__restrict__ base, uint32_t *__restrict__ line_off, int64_t nchunks) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nchunks) return;
-    if (k == 0) line_off[0] = (uint32_t)start;
-    const uint64_t a = start + (uint64_t)k * 256, b = a + 256 < ulen ? a + 256 : ulen;
-    uint32_t n = base[k];
-    for (uint64_t i = a; i < b; i++) if (u[i] == '\n') line_off[++n] = (uint32_t)(i + 1);
+vcf_line_count(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, uint32_t *__restrict__ cnt, int64_t nchunks) {
+    __shared__ uint32_t wsum[4];
+    const int64_t k = blockIdx.x;
+    const uint64_t base = (start & ~(uint64_t)15) + (uint64_t)k * VCF_CHUNK, p = base + threadIdx.x * 16u;
+    uint32_t m = p < ulen ? vcf_nl_mask16(u, p, ulen) : 0u;
+    if (p < start) m = p + 16 <= start ? 0u : m & ~((1u << (start - p)) - 1u);       // bytes in front of the first line do not count
+    uint32_t n = __popc(m);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[k] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+extern "C" __global__ void __launch_bounds__(256)
+vcf_line_fill(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, const uint32_t *__restrict__ base_of, uint32_t *__restrict__ line_off, int64_t nchunks) {
+    __shared__ uint32_t wsum[4];
+    const int64_t k = blockIdx.x;
+    if (k == 0 && threadIdx.x == 0) line_off[0] = (uint32_t)start;
+    const uint64_t base = (start & ~(uint64_t)15) + (uint64_t)k * VCF_CHUNK, p = base + threadIdx.x * 16u;
+    uint32_t m = p < ulen ? vcf_nl_mask16(u, p, ulen) : 0u;
+    if (p < start) m = p + 16 <= start ? 0u : m & ~((1u << (start - p)) - 1u);
+    const uint32_t n = __popc(m);
+    uint32_t incl = n;                                                          // inclusive scan inside the wave, then across the four waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += t; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t rank = base_of[k] + incl - n;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) rank += wsum[w];
+    while (m) { const uint32_t b = __ffs(m) - 1; m &= m - 1; line_off[++rank] = (uint32_t)(p + b + 1); }
 }
 
 __device__ __forceinline__ int vcf_dict_find(const VcfDictDev &d, const uint8_t *s, uint32_t l) {
@@ -66,8 +98,15 @@ __device__ __forceinline__ int vcf_dict_find(const VcfDictDev &d, const uint8_t 
 template <bool WRITE> struct VcfSink {
     uint8_t *p; uint32_t n;
     __device__ __forceinline__ void b(uint8_t v) { if (WRITE) p[n] = v; n++; }
-    __device__ __forceinline__ void w32(uint32_t v) { if (WRITE) { p[n] = (uint8_t)v; p[n + 1] = (uint8_t)(v >> 8); p[n + 2] = (uint8_t)(v >> 16); p[n + 3] = (uint8_t)(v >> 24); } n += 4; }
-    __device__ __forceinline__ void bytes(const uint8_t *s, uint32_t l) { if (WRITE) for (uint32_t i = 0; i < l; i++) p[n + i] = s[i]; n += l; }
+    __device__ __forceinline__ void w32(uint32_t v) { if (WRITE) __builtin_memcpy(p + n, &v, 4); n += 4; }                    // (unaligned dword store)
+    __device__ __forceinline__ void bytes(const uint8_t *s, uint32_t l) {
+        if (WRITE) {                                        // byte reads (the source may be the LDS copy behind a generic pointer), 8-byte unaligned stores
+            uint32_t i = 0;
+            for (; i + 8 <= l; i += 8) { uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)s[i + k] << (8 * k); __builtin_memcpy(p + n + i, &v, 8); }
+            for (; i < l; i++) p[n + i] = s[i];
+        }
+        n += l;
+    }
     __device__ __forceinline__ void size(uint32_t cnt, uint32_t type) {                               // bcf_enc_size
         if (cnt < 15) { b((uint8_t)(cnt << 4 | type)); return; }
         b((uint8_t)(0xF0 | type));
@@ -105,13 +144,33 @@ __device__ __forceinline__ int vcf_str2dbl_fast(const uint8_t *s, uint32_t l, do
     return 0;
 }
 
+#define VCF_LDS_BYTES 40960u
+#define VCF_ENC_THREADS 64
+template <bool WRITE> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias);
+
+// The lines of a workgroup are consecutive in the text: their span is staged in LDS with coalesced 16-byte loads and parsed from there (a
+// lane walks its line byte by byte); a span that does not fit is parsed from HBM.  Two separate calls, so that the LDS copy is reached
+// through LDS instructions: a pointer that may be either kind becomes a flat access, and flat accesses to LDS fault on this system.
 template <bool WRITE>
-__global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
-    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= a.nlines) return;
-    const uint32_t l0 = a.line_off[li];
-    uint32_t l1 = (li + 1 == a.nlines && a.last_open) ? (uint32_t)a.text_end : a.line_off[li + 1] - 1;
-    const uint8_t *u = a.u;
+__global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t vcf_lds[];
+    const int64_t li0 = (int64_t)blockIdx.x * blockDim.x, li = li0 + threadIdx.x;
+    const int64_t liN = li0 + blockDim.x < a.nlines ? li0 + blockDim.x : a.nlines;
+    const uint32_t s0 = a.line_off[li0] & ~15u;
+    const uint32_t s1 = (liN == a.nlines && a.last_open) ? (uint32_t)a.text_end : a.line_off[liN];
+    const bool staged = a.lds_budget >= 16u && s1 - s0 <= a.lds_budget - 16u;
+    if (staged) {
+        for (uint32_t q = threadIdx.x * 16u; s0 + q < s1; q += blockDim.x * 16u) *(uint4 *)(vcf_lds + q) = *(const uint4 *)(a.u + s0 + q);   // (the stream is padded: reading up to 15 bytes past s1 is safe)
+        __syncthreads();
+        if (li < a.nlines) vcf_encode_line<WRITE>(a, li, vcf_lds, s0);
+    } else if (li < a.nlines) vcf_encode_line<WRITE>(a, li, a.u, 0u);
+}
+
+// every position below is relative to `bias` (the start of the staged span, or 0): u[] is either the LDS copy or the stream itself
+template <bool WRITE>
+__device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias) {
+    const uint32_t l0 = a.line_off[li] - bias;
+    uint32_t l1 = ((li + 1 == a.nlines && a.last_open) ? (uint32_t)a.text_end : a.line_off[li + 1] - 1) - bias;
     if (l1 > l0 && u[l1 - 1] == '\r') l1--;                                                          // KS_SEP_LINE drops the carriage return
     { uint32_t e = l0; while (e < l1 && u[e]) e++; l1 = e; }                                         // the parser works on a C string
     VcfSink<WRITE> o; o.p = WRITE ? a.out + a.rec_off[li] : nullptr; o.n = 0;
@@ -131,7 +190,7 @@ __global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
     if (!bad) {
         // CHROM
         const int k = vcf_dict_find(a.ctg, u + fs[0], fe[0] - fs[0]);
-        if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, fs[0], fe[0] - fs[0], 0u}; } }
+        if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, fs[0] + bias, fe[0] - fs[0], 0u}; } }
         else rid = a.ctg.id[k];
         // POS: hts_str2uint(.., 62 bits), the whole token
         {
@@ -162,7 +221,7 @@ __global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
         if (!(fe[5] - fs[5] == 1 && u[fs[5]] == '.')) {
             double d; uint32_t e;
             if (vcf_str2dbl_fast(u + fs[5], fe[5] - fs[5], &d, &e) == 0) { const float f = __double2float_rn(d); qbits = __float_as_uint(f); }
-            else { qbits = 0; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {fs[5], fe[5] - fs[5], a.rec_off[li] + 20u, 0u}; } }
+            else { qbits = 0; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {fs[5] + bias, fe[5] - fs[5], a.rec_off[li] + 20u, 0u}; } }
         }
         // FILTER
         if (fe[6] - fs[6] == 1 && u[fs[6]] == '.') o.b(0x00);
@@ -173,7 +232,7 @@ __global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
             uint32_t t = fs[6];
             for (uint32_t r = fs[6];; r++) if (r == e6 || u[r] == ';') {
                 const int k = vcf_dict_find(a.ids, u + t, r - t);
-                if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t, r - t, 1u}; } o.w32(0); }
+                if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, r - t, 1u}; } o.w32(0); }
                 else o.w32((uint32_t)a.ids.id[k]);
                 t = r + 1;
                 if (r == e6) break;
@@ -191,7 +250,7 @@ __global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
                 if (kend == key) { if (c == 0) break; r = end; key = r + 1; continue; }             // empty key (";;"): skipped
                 const int k = vcf_dict_find(a.ids, u + key, kend - key);
                 int ht = 3; int32_t id = 0;
-                if (k < 0 || a.ids.ityp[k] == 15) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, key, kend - key, 2u}; } }
+                if (k < 0 || a.ids.ityp[k] == 15) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, key + bias, kend - key, 2u}; } }
                 else { ht = a.ids.ityp[k]; id = a.ids.id[k]; }
                 n_info++;
                 o.key(id);
@@ -213,7 +272,7 @@ __global__ void __launch_bounds__(128) vcf_encode(VcfArgs a) {
                             uint32_t tok_end = t; while (tok_end < end && u[tok_end] != ',') tok_end++;
                             double d; uint32_t e;
                             if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { w = __float_as_uint(__double2float_rn(d)); te = t + e; }
-                            else { w = 0x7F800001u; te = tok_end; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t, tok_end - t, a.rec_off[li] + o.n, 1u}; } }
+                            else { w = 0x7F800001u; te = tok_end; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + o.n, 1u}; } }
                         }
                         o.w32(w);
                         for (t = te; t < end && u[t] != ','; t++) {}

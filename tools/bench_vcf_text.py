@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""read_bcf on bgzipped VCF TEXT through the table function: the shape of the reference's published read_bcf numbers (Benchmark.md:517-523:
+ClinVar vcf.gz, 189 MB compressed, 4.35 M sites-only records with a dozen INFO keys; COUNT(*) 1.234 s, CHROM/POS/REF/ALT and six INFO
+columns with LIMIT 200 000 in 0.26-0.29 s, unstated x86-64, 4 DuckDB threads).  A synthetic file of that shape is generated here."""
+import json
+import os
+import random
+import subprocess
+import sys
+import tempfile
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import duckhts_amd  # noqa: E402
+import bamwriter  # noqa: E402
+
+HOST = os.path.join(ROOT, "tests", "minihost", "minihost")
+HDR = ["##fileformat=VCFv4.1", "##fileDate=2025-01-01", "##source=ClinVar", "##reference=GRCh38"] + \
+      ['##INFO=<ID=%s,Number=%s,Type=%s,Description="x">' % kv for kv in (("AF_ESP", "1", "Float"), ("AF_EXAC", "1", "Float"), ("AF_TGP", "1", "Float"), ("ALLELEID", "1", "Integer"),
+       ("CLNDN", ".", "String"), ("CLNDISDB", ".", "String"), ("CLNHGVS", ".", "String"), ("CLNREVSTAT", ".", "String"), ("CLNSIG", ".", "String"), ("CLNVC", "1", "String"),
+       ("CLNVCSO", "1", "String"), ("GENEINFO", "1", "String"), ("MC", ".", "String"), ("ORIGIN", ".", "String"), ("RS", ".", "String"))] + \
+      ["##contig=<ID=%s>" % c for c in list(map(str, range(1, 23))) + ["X", "Y", "MT"]] + ["#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+
+
+def generate(path, n, seed=1):
+    rnd = random.Random(seed)
+    chroms = list(map(str, range(1, 23))) + ["X", "Y", "MT"]
+    per = n // len(chroms) + 1
+    co = []
+    buf = ["\n".join(HDR) + "\n"]
+    size = 0
+    with open(path, "wb") as f:
+        def flush(final=False):
+            nonlocal buf
+            raw = "".join(buf).encode()
+            buf = []
+            f.write(bamwriter.bgzf_file(raw, eof=final, level=6))
+        k = 0
+        for c in chroms:
+            pos = 10000
+            for _ in range(per):
+                if k >= n:
+                    break
+                pos += rnd.randrange(1, 700)
+                ref = rnd.choice("ACGT"); alt = rnd.choice([x for x in "ACGT" if x != ref])
+                aid = 15000 + k
+                info = [f"ALLELEID={aid}", "CLNDISDB=MedGen:C%07d,OMIM:%06d" % (rnd.randrange(10 ** 7), rnd.randrange(10 ** 6)), "CLNDN=" + rnd.choice(["not_provided", "Hereditary_cancer-predisposing_syndrome", "Inborn_genetic_diseases", "not_specified"]),
+                        f"CLNHGVS=NC_0000{len(c):02d}.11:g.{pos}{ref}>{alt}", "CLNREVSTAT=criteria_provided,_single_submitter", "CLNSIG=" + rnd.choice(["Benign", "Likely_benign", "Uncertain_significance", "Pathogenic"]),
+                        "CLNVC=single_nucleotide_variant", "CLNVCSO=SO:0001483", f"GENEINFO=GENE{rnd.randrange(20000)}:{rnd.randrange(100000)}", "MC=SO:0001583|missense_variant", "ORIGIN=1"]
+                if rnd.random() < 0.3:
+                    info.insert(0, "AF_EXAC=%.5f" % rnd.random())
+                if rnd.random() < 0.5:
+                    info.append("RS=%d" % rnd.randrange(10 ** 9))
+                buf.append(f"{c}\t{pos}\t{aid}\t{ref}\t{alt}\t.\t.\t{';'.join(info)}\n")
+                k += 1
+                if len(buf) >= 200000:
+                    flush()
+        flush(final=True)
+    return k
+
+
+def run(path, proj, threads, repeat=4, env=None):
+    cmd = [HOST, duckhts_amd.LIB_PATH, "read_bcf", path, "-t", str(threads), "-r", str(repeat), "-p", ",".join(map(str, proj))]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = int(r.stdout.split("OK rows=")[1].split()[0])
+    return rows, [float(l.split("seconds=")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("RUN ")]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_352_930
+    d = tempfile.mkdtemp(dir="/tmp")
+    path = os.path.join(d, "clinvar_like.vcf.gz")
+    t0 = time.time()
+    generate(path, n)
+    size = os.path.getsize(path)
+    print(json.dumps({"generated": path, "records": n, "compressed_bytes": size, "seconds": round(time.time() - t0, 1)}), flush=True)
+    names = ["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER"] + ["INFO_" + x for x in ("AF_ESP", "AF_EXAC", "AF_TGP", "ALLELEID", "CLNDN", "CLNDISDB", "CLNHGVS", "CLNREVSTAT", "CLNSIG", "CLNVC", "CLNVCSO", "GENEINFO", "MC", "ORIGIN", "RS")]
+    queries = [("COUNT(*) (Benchmark.md:517: 1.234 s)", [0]), ("CHROM,POS,REF,ALT (Benchmark.md:518: LIMIT 200000 in 0.257 s)", [0, 1, 3, 4]),
+               ("6 INFO columns (Benchmark.md:519: LIMIT 200000 in 0.294 s)", [names.index("INFO_" + x) for x in ("ALLELEID", "CLNSIG", "CLNVC", "GENEINFO", "MC", "RS")]),
+               ("all 22 columns", list(range(len(names))))]
+    for qn, proj in queries:
+        for thr in (1, 4):
+            for cache in ("0", "1"):
+                rows, runs = run(path, proj, thr, env={"DHTS_THREADS": str(thr), "DHTS_FILE_CACHE": cache})
+                warm = sorted(runs[1:])[len(runs[1:]) // 2]
+                print(json.dumps({"operator": "read_bcf on bgzipped VCF text through the DuckDB table function (mini host), full scan", "query": qn, "rows": rows, "DHTS_THREADS": thr,
+                                  "file_resident": cache == "1", "first_query_s": round(runs[0], 3), "warm_query_s": round(warm, 4), "rows_per_s": round(rows / warm, 1),
+                                  "compressed_MBps": round(size / warm / 1e6, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
