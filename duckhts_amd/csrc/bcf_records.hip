@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
             cnt = 0; nbytes = 0;
             if (cd.fixed && cd.kind != BK_QUAL) {
                 if (cd.kind == BK_POS) ((int64_t *)cd.fixed)[row] = 0;
-                else if (cd.htype == 0 && cd.kind == BK_INFO) ((uint8_t *)cd.fixed)[row] = 0;
+                else if (cd.htype == 0 && (cd.kind == BK_INFO || cd.kind == BK_FORMAT)) ((uint8_t *)cd.fixed)[row] = 0;   // BOOLEAN columns are one byte wide (a 4-byte store here ran into the next column's payload)
                 else ((uint32_t *)cd.fixed)[row] = 0;
             }
         }

@@ -158,7 +158,7 @@ struct dhts_ctx {
     std::vector<Seg> segs;
     bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
     bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
-    DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ;
+    DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ, vd_id_ftyp;
     bool cache_hit = false; std::string pending_tag;       // the file's bytes came out of the pool (no read, no copy); tag to put on `comp` once staging has succeeded
     // dhts_open_path_async: the file is still arriving; the block table covers the staged prefix and grows (dhts_bgzf_index_staged)
     std::thread stager; StageProg *prog = nullptr; bool growing = false; uint64_t stage_total = 0;
@@ -2210,7 +2210,7 @@ static int bcf_upload_dicts(dhts_ctx *c) {
     HIPCHK(c, hipMemcpy(c->d_info_slot.p, islot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_fmt_slot.p, fslot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
     if (!c->vcf_text) return 0;
-    auto upload = [&](std::vector<std::pair<std::string, int32_t>> &names, const std::vector<uint8_t> *typ_of_id, DevBuf &d_off, DevBuf &d_bytes, DevBuf &d_id, DevBuf *d_typ) -> int {
+    auto upload = [&](std::vector<std::pair<std::string, int32_t>> &names, const std::vector<uint8_t> *typ_of_id, DevBuf &d_off, DevBuf &d_bytes, DevBuf &d_id, DevBuf *d_typ, const std::vector<uint8_t> *ftyp_of_id = nullptr, DevBuf *d_ftyp = nullptr) -> int {
         std::sort(names.begin(), names.end(), [](const std::pair<std::string, int32_t> &a, const std::pair<std::string, int32_t> &b) {
             const size_t n = a.first.size() < b.first.size() ? a.first.size() : b.first.size();
             const int cmp = memcmp(a.first.data(), b.first.data(), n);
@@ -2223,12 +2223,22 @@ static int bcf_upload_dicts(dhts_ctx *c) {
         if (!bytes.empty()) HIPCHK(c, hipMemcpy(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(d_id.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
         if (d_typ) HIPCHK(c, hipMemcpy(d_typ->p, typ.data(), typ.size(), hipMemcpyHostToDevice));
+        if (d_ftyp) {
+            std::vector<uint8_t> ft(names.size() + 1, 15);
+            for (size_t i = 0; i < names.size(); i++) ft[i] = (*ftyp_of_id)[names[i].second];
+            if (d_ftyp->ensure(ft.size() + 64)) return fail(c, "hipMalloc failed");
+            HIPCHK(c, hipMemcpy(d_ftyp->p, ft.data(), ft.size(), hipMemcpyHostToDevice));
+        }
         return 0;
     };
-    std::vector<std::pair<std::string, int32_t>> cn, in; std::vector<uint8_t> ityp(ni + 1, 15);
+    std::vector<std::pair<std::string, int32_t>> cn, in; std::vector<uint8_t> ityp(ni + 1, 15), ftyp(ni + 1, 15);
     for (size_t i = 0; i < nc; i++) if (c->bh.ctg_present[i]) cn.push_back({c->bh.ctg[i], (int32_t)i});
-    for (size_t i = 0; i < ni; i++) if (c->bh.ids[i].present) { in.push_back({c->bh.ids[i].key, (int32_t)i}); if (c->bh.ids[i].has[dhts::BCF_HL_INFO]) ityp[i] = (uint8_t)c->bh.ids[i].type[dhts::BCF_HL_INFO]; }
-    if (upload(cn, nullptr, c->vd_ctg_off, c->vd_ctg_bytes, c->vd_ctg_id, nullptr) || upload(in, &ityp, c->vd_id_off, c->vd_id_bytes, c->vd_id_id, &c->vd_id_typ)) return -1;
+    for (size_t i = 0; i < ni; i++) if (c->bh.ids[i].present) {
+        in.push_back({c->bh.ids[i].key, (int32_t)i});
+        if (c->bh.ids[i].has[dhts::BCF_HL_INFO]) ityp[i] = (uint8_t)c->bh.ids[i].type[dhts::BCF_HL_INFO];
+        if (c->bh.ids[i].has[dhts::BCF_HL_FMT]) ftyp[i] = (uint8_t)c->bh.ids[i].type[dhts::BCF_HL_FMT];
+    }
+    if (upload(cn, nullptr, c->vd_ctg_off, c->vd_ctg_bytes, c->vd_ctg_id, nullptr) || upload(in, &ityp, c->vd_id_off, c->vd_id_bytes, c->vd_id_id, &c->vd_id_typ, &ftyp, &c->vd_id_ftyp)) return -1;
     return 0;
 }
 
@@ -2269,7 +2279,6 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
             if (!found) { if (more) { k = (k * 4 < c->n_blocks) ? k * 4 : c->n_blocks; continue; } return fail(c, "Failed to read BCF/VCF header"); }
             std::string perr;
             if (!dhts::bcf_parse_header(text.c_str(), c->bh, &perr)) return fail(c, "Failed to read BCF/VCF header");
-            if (!c->bh.samples.empty()) return fail(c, "read_bcf: VCF text input with sample columns is not supported yet (sites-only VCF text and BCF are)");
             text_end = p; is_text = true;
             break;
         }
@@ -2372,6 +2381,15 @@ static size_t fixed_width(const dhts::BcfColumn &col) {
     return col.duck_type == dhts::DT_BOOLEAN ? 1 : col.duck_type == dhts::DT_VARCHAR ? 0 : 4;
 }
 
+// debugging aid (not part of the public header): the BCF2 records the last VCF text batch was turned into
+extern "C" int64_t dhts_debug_vcf_records(dhts_ctx *c, uint8_t *dst, uint64_t cap, uint32_t *rec_off, int64_t nrec) {
+    if (!c || !c->v_out.p) return -1;
+    const uint64_t n = cap < c->v_out.cap ? cap : c->v_out.cap;
+    HIPCHK(c, hipMemcpy(dst, c->v_out.p, n, hipMemcpyDeviceToHost));
+    if (rec_off && nrec > 0) HIPCHK(c, hipMemcpy(rec_off, c->b_rec_off.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+    return (int64_t)n;
+}
+
 // ---- VCF text batches (vcf_text.hip): the lines of the batch become BCF2 records in v_out; rec_off / dir as for binary input ----------
 // out: nrec, carry_start (start of the incomplete last line), rec_err (a line failed: the scan ends before it), rec0_text (text offset of
 // the first line), st re-pointed at the records.  Names without a definition are added to the header and the batch is measured again.
@@ -2401,14 +2419,15 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     ENSURE(c, c->v_undef, (size_t)UCAP * sizeof(VcfUndef)); ENSURE(c, c->v_patch, (size_t)PCAP * sizeof(VcfPatch));
     VcfArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.line_off = (const uint32_t *)c->v_line_off.p; a.nlines = nlines; a.text_end = ulen; a.last_open = last_open;
+    a.n_smp = (int32_t)c->bh.samples.size(); a.v44 = c->bh.version >= 4004000 ? 1 : 0;
     { static const bool no_stage = getenv("DHTS_VCF_STAGE") && atoi(getenv("DHTS_VCF_STAGE")) == 0; a.lds_budget = no_stage ? 0u : VCF_LDS_BYTES; if (getenv("DHTS_VCF_STAGE") && atoi(getenv("DHTS_VCF_STAGE")) == 2) a.lds_budget = VCF_LDS_BYTES - 15u; }
     a.rec_len = (uint32_t *)c->v_rec_len.p; a.rec_off = (const uint32_t *)c->b_rec_off.p; a.first_bad = (unsigned long long *)((uint64_t *)c->v_ctr.p + 2);
     a.counters = (uint32_t *)c->v_ctr.p; a.undef = (VcfUndef *)c->v_undef.p; a.undef_cap = UCAP; a.patch = (VcfPatch *)c->v_patch.p; a.patch_cap = PCAP;
     unsigned long long first_bad = ~0ull;
     for (int round = 0;; round++) {
         if (round > 1000) return fail(c, "read_bcf: too many names without a header definition");
-        a.ctg = {(const uint32_t *)c->vd_ctg_off.p, (const uint8_t *)c->vd_ctg_bytes.p, (const int32_t *)c->vd_ctg_id.p, nullptr, 0};
-        a.ids = {(const uint32_t *)c->vd_id_off.p, (const uint8_t *)c->vd_id_bytes.p, (const int32_t *)c->vd_id_id.p, (const uint8_t *)c->vd_id_typ.p, 0};
+        a.ctg = {(const uint32_t *)c->vd_ctg_off.p, (const uint8_t *)c->vd_ctg_bytes.p, (const int32_t *)c->vd_ctg_id.p, nullptr, nullptr, 0};
+        a.ids = {(const uint32_t *)c->vd_id_off.p, (const uint8_t *)c->vd_id_bytes.p, (const int32_t *)c->vd_id_id.p, (const uint8_t *)c->vd_id_typ.p, (const uint8_t *)c->vd_id_ftyp.p, 0};
         { int32_t n1 = 0, n2 = 0; for (size_t i = 0; i < c->bh.ctg.size(); i++) n1 += c->bh.ctg_present[i] ? 1 : 0; for (auto &e : c->bh.ids) n2 += e.present ? 1 : 0; a.ctg.n = n1; a.ids.n = n2; }
         HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream)); HIPCHK(c, hipMemsetAsync((uint64_t *)c->v_ctr.p + 2, 0xff, 8, c->stream));
         hipLaunchKernelGGL(vcf_encode<false>, dim3((unsigned)((nlines + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
@@ -2418,36 +2437,42 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
         first_bad = ctr[2];
         const uint32_t n_undef = (uint32_t)(ctr[0] & 0xffffffffu);
         if (n_undef == 0) break;
-        // names used without a definition: htslib adds dummy definitions as it meets them, so ids follow the order of first appearance
+        // names used without a definition: htslib adds dummy definitions as it meets them, so ids follow the order of first appearance;
+        // FORMAT Floats in strtod's forms are checked here (the number has to end where the token ends)
         const uint32_t got = n_undef < UCAP ? n_undef : UCAP;
         std::vector<VcfUndef> ud(got);
         HIPCHK(c, hipMemcpy(ud.data(), c->v_undef.p, (size_t)got * sizeof(VcfUndef), hipMemcpyDeviceToHost));
         std::sort(ud.begin(), ud.end(), [](const VcfUndef &x, const VcfUndef &y) { return x.line != y.line ? x.line < y.line : x.pos < y.pos; });
-        bool added = false;
+        bool added = false; unsigned long long cut = first_bad;
         for (auto &x : ud) {
-            if ((unsigned long long)x.line >= first_bad) break;                  // lines behind the first bad one are never parsed
+            if ((unsigned long long)x.line >= cut) break;                        // lines behind the first bad one are never parsed
             std::string name(x.len, '\0');
             if (x.len) HIPCHK(c, hipMemcpy(&name[0], u + x.pos, x.len, hipMemcpyDeviceToHost));
-            bool have = false;
-            if (x.cls == 0) { for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i] && c->bh.ctg[i] == name) have = true; }
-            else { const int id = c->bh.find_id(name); have = id >= 0 && (x.cls == 1 || c->bh.ids[id].has[dhts::BCF_HL_INFO]); }
-            if (have) continue;
-            const std::string line = x.cls == 0 ? "##contig=<ID=" + name + ">" : x.cls == 1 ? "##FILTER=<ID=" + name + ",Description=\"Dummy\">"
-                                                : "##INFO=<ID=" + name + ",Number=1,Type=String,Description=\"Dummy\">";
-            bool ok = name.find('\n') == std::string::npos && dhts::bcf_header_add_line(c->bh, line.c_str());
-            if (ok) {
-                if (x.cls == 0) { ok = false; for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i] && c->bh.ctg[i] == name) ok = true; }
-                else { const int id = c->bh.find_id(name); ok = id >= 0 && (x.cls == 1 || c->bh.ids[id].has[dhts::BCF_HL_INFO]); }
+            if (x.cls == 4) {
+                char *end = nullptr; (void)strtod(name.c_str(), &end);
+                if (strlen(name.c_str()) != name.size() || end != name.c_str() + name.size()) { cut = x.line; break; }      // "Invalid character": the record is an error
+                continue;
             }
-            if (!ok) { if ((unsigned long long)x.line < first_bad) first_bad = x.line; break; }      // "Could not add dummy header": the record is an error
+            const int hl = x.cls == 3 ? dhts::BCF_HL_FMT : dhts::BCF_HL_INFO;
+            auto defined = [&]() {
+                if (x.cls == 0) { for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i] && c->bh.ctg[i] == name) return true; return false; }
+                const int id = c->bh.find_id(name); return id >= 0 && (x.cls == 1 || c->bh.ids[id].has[hl]);
+            };
+            if (defined()) continue;
+            const std::string line = x.cls == 0 ? "##contig=<ID=" + name + ">" : x.cls == 1 ? "##FILTER=<ID=" + name + ",Description=\"Dummy\">"
+                                   : x.cls == 2 ? "##INFO=<ID=" + name + ",Number=1,Type=String,Description=\"Dummy\">" : "##FORMAT=<ID=" + name + ",Number=1,Type=String,Description=\"Dummy\">";
+            if (name.find('\n') != std::string::npos || !dhts::bcf_header_add_line(c->bh, line.c_str()) || !defined()) { cut = x.line; break; }   // "Could not add dummy header": the record is an error
             added = true;
         }
         if (added && bcf_upload_dicts(c)) return -1;
-        if (!added) {
-            // nothing could be added: the remaining undefined names sit on or behind the first bad line
-            if (first_bad == ~0ull) return fail(c, "internal: undefined names without a bad line");
-            a.nlines = nlines = (int64_t)first_bad; rec_err = true; a.last_open = 0;
+        const bool shortened = cut < (unsigned long long)nlines;
+        if (shortened) {
+            first_bad = cut; a.nlines = nlines = (int64_t)cut; rec_err = true; a.last_open = 0;
             if (nlines == 0) { nrec = 0; return 0; }
+        }
+        if (!added && !shortened) {
+            if (n_undef > UCAP) return fail(c, "read_bcf: too many names without a header definition in one batch; use a smaller max_blocks");
+            break;                                                               // only float checks are left, and they passed
         }
         st.n_ctg = (int32_t)c->bh.ctg.size(); st.n_ids = (int32_t)c->bh.ids.size();
         st.ctg_ok = (const uint8_t *)c->d_ctg_ok.p; st.id_ok = (const uint8_t *)c->d_id_ok.p; st.info_slot = (const int16_t *)c->d_info_slot.p; st.fmt_slot = (const int16_t *)c->d_fmt_slot.p;
@@ -2480,7 +2505,8 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
             if (x.kind == 0) { const float f = (float)atof(tok.c_str()); memcpy(&bits, &f, 4); }
             else {
                 char *end = nullptr; const double d = strtod(tok.c_str(), &end);
-                if (end == tok.c_str()) bits = 0x7F800001u; else { const float f = (float)d; memcpy(&bits, &f, 4); }
+                if (end == tok.c_str() && x.kind == 1) bits = 0x7F800001u;                     // INFO: a failed conversion is a missing value
+                else { const float f = (end == tok.c_str()) ? 0.0f : (float)d; memcpy(&bits, &f, 4); }   // (FORMAT stores what strtod returned: 0.0)
             }
             HIPCHK(c, hipMemcpy((uint8_t *)c->v_out.p + x.dst, &bits, 4, hipMemcpyHostToDevice));
         }

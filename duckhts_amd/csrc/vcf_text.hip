@@ -15,13 +15,15 @@
 // again.  One lane per line; two passes (measure, then write behind an exclusive scan of the record lengths).
 #pragma once
 
-struct VcfDictDev { const uint32_t *off; const uint8_t *bytes; const int32_t *id; const uint8_t *ityp; int32_t n; };   // sorted by name (byte order)
-struct VcfUndef { uint32_t line, pos, len, cls; };        // cls: 0 contig, 1 FILTER, 2 INFO key; pos = offset of the name in the batch text
-struct VcfPatch { uint32_t pos, len, dst, kind; };        // kind 0: (float)atof(token) -> f32 at dst; 1: hts_str2dbl(token) -> f32 (or missing) at dst
+struct VcfDictDev { const uint32_t *off; const uint8_t *bytes; const int32_t *id; const uint8_t *ityp; const uint8_t *ftyp; int32_t n; };   // sorted by name (byte order); ityp / ftyp: INFO / FORMAT type of the id, 15 = none
+struct VcfUndef { uint32_t line, pos, len, cls; };        // cls: 0 contig, 1 FILTER, 2 INFO key, 3 FORMAT key; 4: a FORMAT Float the host has to convert AND check (strtod must stop at the
+                                                          // end of the token, else "Invalid character"); pos = offset of the name / token in the batch text
+struct VcfPatch { uint32_t pos, len, dst, kind; };        // kind 0: (float)atof(token) -> f32 at dst; 1: hts_str2dbl(token) -> f32 (or missing) at dst; 2: the same, 0.0 when it fails (FORMAT)
 struct VcfArgs {
     const uint8_t *u; const uint32_t *line_off; int64_t nlines; uint64_t text_end;   // line i = u[line_off[i], line_off[i+1] - 1) (the last one ends at text_end when it has no newline)
     int32_t last_open;                                      // 1: the last line has no terminating newline
     uint32_t lds_budget;                                    // bytes of LDS a workgroup may stage its lines in (0: parse from HBM)
+    int32_t n_smp, v44;                                     // samples of the header; header version >= VCFv4.4 (a leading '/' or '|' in GT is a phasing prefix)
     VcfDictDev ctg, ids;
     uint32_t *rec_len; const uint32_t *rec_off; uint8_t *out;
     unsigned long long *first_bad;
@@ -146,6 +148,7 @@ __device__ __forceinline__ int vcf_str2dbl_fast(const uint8_t *s, uint32_t l, do
 
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
+#define VCF_MAXF 32
 template <bool WRITE> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias);
 
 // The lines of a workgroup are consecutive in the text: their span is staged in LDS with coalesced 16-byte loads and parsed from there (a
@@ -283,12 +286,180 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
             }
         }
     }
+    // FORMAT + sample columns (vcf_parse_format vcf.c:3686-3742; steps 3137-3684): per-sample text A:B:C becomes per-field arrays
+    uint32_t n_fmt_kept = 0, n_sample = 0; const uint32_t indiv0 = o.n;
+    if (!bad && a.n_smp > 0 && fe[7] < l1) {
+        const uint32_t fp = fe[7] + 1; uint32_t fq = fp; while (fq < l1 && u[fq] != '\t') fq++;
+        if (fq >= l1) bad = true;                                                                     // "FORMAT column with no sample columns"
+        else if (fq - fp == 1 && u[fp] == '.') n_sample = (uint32_t)a.n_smp;                          // FORMAT ".": nothing to parse, the sample columns are not looked at
+        else {
+            // dict2: the keys
+            int32_t key[VCF_MAXF]; uint8_t ht[VCF_MAXF], flg[VCF_MAXF]; uint32_t mx_l[VCF_MAXF], mx_m[VCF_MAXF], mx_g[VCF_MAXF], fsz[VCF_MAXF], fat[VCF_MAXF];   // flg: 1 = GT, 2 = dropped duplicate
+            int n_fmt = 0;
+            for (uint32_t t = fp;;) {
+                uint32_t c = t; while (c < fq && u[c] != ':') c++;
+                if (n_fmt >= VCF_MAXF) { bad = true; break; }                                       // (htslib allows 255 identifiers; this encoder 32)
+                const int k = vcf_dict_find(a.ids, u + t, c - t);
+                key[n_fmt] = 0; ht[n_fmt] = 3;
+                if (k < 0 || a.ids.ftyp[k] == 15) {
+                    if (c - t == 1 && u[t] == '.') { bad = true; break; }                            // "Invalid FORMAT tag name '.'"
+                    if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, c - t, 3u}; }
+                } else { key[n_fmt] = a.ids.id[k]; ht[n_fmt] = a.ids.ftyp[k]; }
+                flg[n_fmt] = (c - t == 2 && u[t] == 'G' && u[t + 1] == 'T') ? 1 : 0;
+                mx_l[n_fmt] = mx_m[n_fmt] = mx_g[n_fmt] = 0;
+                n_fmt++;
+                if (c >= fq) break;
+                t = c + 1;
+            }
+            const uint32_t body = fq + 1, end = l1;
+            // max3: widths of every field over the samples
+            if (!bad) {
+                uint32_t r = body, l = 0, m = 1, g = 1;
+                while (r < end && !bad) {
+                    int j = 0; uint32_t r_start = r;
+                    for (;;) {
+                        while (r < end && u[r] != '\t' && u[r] != ',' && u[r] != '/' && u[r] != ':' && u[r] != '|') r++;
+                        const uint8_t ch = r < end ? u[r] : 0;
+                        if (ch == ',') m++;
+                        else if (ch == '|' || ch == '/') { if (flg[j] & 1) g++; }
+                        else {
+                            l = r - r_start; r_start = r;
+                            if (mx_m[j] < m) mx_m[j] = m;
+                            if (mx_l[j] < l) mx_l[j] = l;
+                            if ((flg[j] & 1) && mx_g[j] < g) mx_g[j] = g;
+                            l = 0; m = g = 1;
+                            if (ch == ':') { j++; if (j >= n_fmt) { bad = true; break; } }             // "Incorrect number of FORMAT fields"
+                            else break;
+                        }
+                        if (r >= end) break;
+                        r++;
+                    }
+                    n_sample++;
+                    if (n_sample == (uint32_t)a.n_smp) break;
+                    r++;
+                }
+            }
+            // alloc4: slot sizes, duplicates, and where every field's array sits in the indiv block
+            if (!bad) {
+                for (int j = 0; j < n_fmt; j++) {
+                    if (!mx_m[j]) mx_m[j] = 1;
+                    if (ht[j] == 3) fsz[j] = (flg[j] & 1) ? mx_g[j] << 2 : mx_l[j];
+                    else if (ht[j] == 1 || ht[j] == 2) fsz[j] = mx_m[j] << 2;
+                    else { bad = true; break; }                                                       // a FORMAT Flag: "currently not supported"
+                }
+                for (int i = 1; i < n_fmt && !bad; i++) for (int j = 0; j < i; j++) if (!(flg[j] & 2) && key[i] == key[j] && ht[i] != 15) { flg[i] |= 2; break; }
+            }
+            if (!bad && n_sample != (uint32_t)a.n_smp) bad = true;                                   // check7 (fill5 errors found below are errors either way)
+            if (!bad) {
+                for (int j = 0; j < n_fmt; j++) {
+                    if (flg[j] & 2) continue;
+                    n_fmt_kept++;
+                    o.key(key[j]);
+                    if (ht[j] == 3 && !(flg[j] & 1)) o.size(fsz[j], 7); else o.size(fsz[j] >> 2, ht[j] == 2 ? 5 : 3);
+                    fat[j] = o.n; o.n += fsz[j] * n_sample;
+                }
+                // fill5: every sample, field by field (validated in the measure pass, stored in the write pass)
+                uint32_t t = body; uint32_t m = 0;
+                while (t < end && !bad) {
+                    if (m == (uint32_t)a.n_smp) break;
+                    int j = 0;
+                    while (t < end) {
+                        const int z = j++;
+                        const uint32_t at = fat[z] + fsz[z] * m;
+                        auto put32 = [&](uint32_t idx, uint32_t v) { if (WRITE) { const uint32_t keep = o.n; o.n = at + 4 * idx; o.w32(v); o.n = keep; } };
+                        auto ch = [&](uint32_t p) -> uint8_t { return (p < end && u[p] != '\t') ? u[p] : (uint8_t)0; };       // a sample column is a C string
+                        if (flg[z] & 2) { while (ch(t) != ':' && ch(t)) t++; }
+                        else if (ht[z] == 3 && (flg[z] & 1)) {                                        // GT: ([/|])?val([/|]val)*, val = digits or '.'
+                            uint32_t is_phased = 0, maxv = 0, x0 = 0; bool unreadable = false; int l = 0, ploidy = 0, anyunphased = 0, prfx = 0, unknown1 = 0;
+                            if (a.v44 && (ch(t) == '|' || ch(t) == '/')) { is_phased = ch(t) == '|'; t++; prfx = 1; }
+                            for (;; ++t) {
+                                ploidy++;
+                                uint32_t xv;
+                                if (ch(t) == '.') { ++t; xv = is_phased; if (l == 0) unknown1 = 1; }
+                                else {
+                                    const uint32_t tt = t; uint64_t n = 0;
+                                    if (ch(t) == '+') t++;
+                                    while (ch(t) >= '0' && ch(t) <= '9') n = n * 10 + (uint64_t)(ch(t++) - '0');
+                                    const uint32_t val = (uint32_t)n;
+                                    unreadable |= tt == t;
+                                    if (maxv < val) maxv = val;
+                                    xv = (val + 1) << 1 | is_phased;
+                                }
+                                if (l == 0) x0 = xv; else put32((uint32_t)l, xv);
+                                l++;
+                                anyunphased |= (ploidy != 1) && !is_phased;
+                                is_phased = ch(t) == '|';
+                                if (ch(t) != '|' && ch(t) != '/') break;
+                            }
+                            if (!prfx) { if (ploidy == 1) { if (!unknown1) x0 |= 1; } else x0 |= anyunphased ? 0u : 1u; }
+                            if (maxv > (0x7fffffffu >> 1) - 1 || unreadable) { bad = true; break; }
+                            put32(0, x0);
+                            for (; (uint32_t)l < fsz[z] >> 2; ++l) put32((uint32_t)l, 0x80000001u);
+                        } else if (ht[z] == 3) {
+                            uint32_t l = 0;
+                            for (; ch(t) != ':' && ch(t); ++t, ++l) if (WRITE) o.p[at + l] = u[t];
+                            if (WRITE) for (; l < fsz[z]; l++) o.p[at + l] = 0;
+                        } else if (ht[z] == 1) {
+                            uint32_t l = 0;
+                            for (;; ++t) {
+                                if (ch(t) == '.') { put32(l++, 0x80000000u); ++t; }
+                                else {
+                                    uint32_t te = t; bool neg = false, over = false; uint64_t n = 0, limit = (1ull << 63) - 1;
+                                    if (ch(te) == '-') { limit++; neg = true; te++; } else if (ch(te) == '+') te++;
+                                    for (; ch(te) >= '0' && ch(te) <= '9'; te++) { const uint32_t d = ch(te) - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
+                                    const int64_t v = neg ? (int64_t)(0 - n) : (int64_t)n;
+                                    put32(l++, (te == t || over || v < -2147483640ll || v > 2147483647ll) ? 0x80000000u : (uint32_t)(int32_t)v);
+                                    t = te;
+                                }
+                                if (ch(t) != ',') break;
+                            }
+                            for (; l < fsz[z] >> 2; ++l) put32(l, 0x80000001u);
+                        } else {
+                            uint32_t l = 0;
+                            for (;; ++t) {
+                                const uint8_t c1 = ch(t + 1);
+                                if (ch(t) == '.' && !(c1 >= '0' && c1 <= '9')) { put32(l++, 0x7F800001u); ++t; }
+                                else {
+                                    uint32_t tok_end = t; while (ch(tok_end) && ch(tok_end) != ',' && ch(tok_end) != ':') tok_end++;
+                                    double d; uint32_t e;
+                                    if (tok_end == t) put32(l++, 0u);                               // an empty value: strtod converts nothing and returns 0.0
+                                    else if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { put32(l++, __float_as_uint(__double2float_rn(d))); t += e; }
+                                    else {
+                                        // strtod's forms: the host converts (write pass) and checks that the number ends where the token ends (measure pass)
+                                        if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, tok_end - t, 4u}; }
+                                        else { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + at + 4 * l, 2u}; }
+                                        put32(l++, 0u);
+                                        t = tok_end;
+                                    }
+                                }
+                                if (ch(t) != ',') break;
+                            }
+                            for (; l < fsz[z] >> 2; ++l) put32(l, 0x7F800002u);
+                        }
+                        if (ch(t) == 0) break;
+                        else if (ch(t) == ':') t++;
+                        else { bad = true; break; }                                                   // "Invalid character"
+                    }
+                    if (bad) break;
+                    for (; j < n_fmt; ++j) {                                                          // trailing fields the sample leaves out
+                        if (flg[j] & 2) continue;
+                        const uint32_t at = fat[j] + fsz[j] * m;
+                        if (!WRITE) continue;
+                        if (ht[j] == 3 && !(flg[j] & 1)) { for (uint32_t l = 0; l < fsz[j]; l++) o.p[at + l] = l == 0 ? '.' : 0; }
+                        else for (uint32_t l = 0; l < fsz[j] >> 2; l++) { const uint32_t keep = o.n; o.n = at + 4 * l; o.w32(l == 0 ? (ht[j] == 2 ? 0x7F800001u : 0x80000000u) : (ht[j] == 2 ? 0x7F800002u : 0x80000001u)); o.n = keep; }
+                    }
+                    m++; t++;
+                }
+                if (!bad && n_sample == 0) { o.n = indiv0; n_fmt_kept = 0; }
+            }
+        }
+    }
     if (bad) { atomicMin(a.first_bad, (unsigned long long)li); if (!WRITE) a.rec_len[li] = 0; return; }
     if (!WRITE) { a.rec_len[li] = o.n; return; }
     const uint32_t total = o.n;
     o.n = 0;
-    o.w32(total - 8); o.w32(0);                                                                      // l_shared (core + shared block), l_indiv
+    o.w32(indiv0 - 8); o.w32(total - indiv0);                                                        // l_shared (core + shared block), l_indiv
     o.w32((uint32_t)rid); o.w32((uint32_t)(int32_t)pos); o.w32((uint32_t)rlen);
     o.w32(qbits);
-    o.w32(n_info | (n_allele << 16)); o.w32(0);
+    o.w32(n_info | (n_allele << 16)); o.w32((n_sample & 0xffffffu) | (n_fmt_kept << 24));
 }

@@ -804,8 +804,7 @@ static int scan_records(scan_t *s, const uint8_t *u, size_t ulen, size_t pos, in
  * after which scan_records() above runs unchanged.  Number parsers: hts_str2uint / hts_str2int / hts_str2dbl textutils_internal.h:218-428.
  * Names a record uses without a header definition are added on the fly with dummy definitions, as htslib does (fix_chromosome 3744-3761 and
  * the "Dummy" lines of vcf_parse_filter / vcf_parse_info); the columns were bound before, so only the dictionaries grow.
- * Restated for SITES-ONLY files (no sample columns): vcf_parse_format is not restated yet -> ORC_BCF_ESAMPLES.  Records whose POS does not
- * fit the BCF2 core (>= 2^31 - 1) end the scan (the reference keeps 64-bit positions in memory). */
+ * Records whose POS does not fit the BCF2 core (>= 2^31 - 1) end the scan (the reference keeps 64-bit positions in memory). */
 #define ORC_BCF_ESAMPLES (-103)
 
 static void enc_typed_int(buf_t *o, int64_t x)                                 /* bcf_enc_int1 (htslib/vcf.h): smallest width; missing as int8 missing */
@@ -881,16 +880,175 @@ static int hdr_add_dummy(hdr_t *h, const char *fmt, const char *name)          /
     return rc < 0 ? -1 : 0;
 }
 
+/* FORMAT column + sample columns -> the indiv block (vcf_parse_format vcf.c:3686-3742 and its seven steps 3137-3684).
+ * rest = "FORMAT\tsample1\tsample2..." (NUL-terminated, modified in place).  Integers and genotypes are written as int32 vectors. */
+typedef struct { int key, ht, is_gt, max_l, max_m, max_g, size, skip; uint8_t *buf; } fmtaux_t;
+static int vcf_format_to_bcf(hdr_t *h, char *rest, buf_t *in, int *n_fmt_out, int *n_sample_out)
+{
+    const int nsamples = h->n_smp;
+    char *q = strchr(rest, '\t');                                             /* end of the FORMAT column */
+    if (!q) return -1;                                                        /* "FORMAT column with no sample columns" */
+    *q = 0;
+    *n_fmt_out = 0; *n_sample_out = 0;
+    if (rest[0] == '.' && rest[1] == 0) { *n_sample_out = nsamples; return 0; }   /* FORMAT ".": no fields, the sample columns are not looked at */
+    fmtaux_t fmt[255]; int n_fmt = 0;
+    for (char *t = rest;;) {                                                  /* vcf_parse_format_dict2 */
+        char *c = strchr(t, ':'); if (c) *c = 0;
+        if (n_fmt >= 255) return -1;
+        int k = dict_find(h, t);
+        if (k < 0 || !h->ids[k].has[HL_FMT]) {
+            if (t[0] == '.' && t[1] == 0) return -1;
+            if (hdr_add_dummy(h, "##FORMAT=<ID=%s,Number=1,Type=String,Description=\"Dummy\">", t) < 0 || (k = dict_find(h, t)) < 0 || !h->ids[k].has[HL_FMT]) return -1;
+        }
+        fmtaux_t *f = &fmt[n_fmt++]; memset(f, 0, sizeof *f);
+        f->key = k; f->ht = h->ids[k].type[HL_FMT]; f->is_gt = !strcmp(t, "GT");
+        if (!c) break;
+        t = c + 1;
+    }
+    char *body = q + 1; const char *end = body + strlen(body);
+    /* vcf_parse_format_max3: widths of every field over the samples; tabs become NULs */
+    int n_sample = 0;
+    {
+        char *r = body; int l = 0, m = 1, g = 1, j;
+        while (r < end) {
+            j = 0; fmtaux_t *f = fmt; char *r_start = r;
+            for (;;) {
+                while (*r != 0 && *r != '\t' && *r != ',' && *r != '/' && *r != ':' && *r != '|') r++;
+                if (*r == ',') m++;
+                else if (*r == '|' || *r == '/') { if (f->is_gt) g++; }
+                else {
+                    if (*r == '\t') *r = 0;
+                    l = (int)(r - r_start); r_start = r;
+                    if (f->max_m < m) f->max_m = m;
+                    if (f->max_l < l) f->max_l = l;
+                    if (f->is_gt && f->max_g < g) f->max_g = g;
+                    l = 0; m = g = 1;
+                    if (*r == ':') { j++; f++; if (j >= n_fmt) return -1; }     /* "Incorrect number of FORMAT fields" */
+                    else break;
+                }
+                if (r >= end) break;
+                r++;
+            }
+            n_sample++;
+            if (n_sample == nsamples) break;
+            r++;
+        }
+    }
+    /* vcf_parse_format_alloc4 */
+    for (int j = 0; j < n_fmt; j++) {
+        fmtaux_t *f = &fmt[j];
+        if (!f->max_m) f->max_m = 1;
+        if (f->ht == HT_STR) f->size = f->is_gt ? f->max_g << 2 : f->max_l;
+        else if (f->ht == HT_REAL || f->ht == HT_INT) f->size = f->max_m << 2;
+        else { for (int k = 0; k < j; k++) free(fmt[k].buf); return -1; }      /* "The format type ... is currently not supported" (Flag) */
+        f->buf = (uint8_t *)calloc((size_t)n_sample * (size_t)f->size + 8, 1);
+    }
+    for (int i = 1; i < n_fmt; i++) for (int j = 0; j < i; j++) if (!fmt[j].skip && fmt[i].key == fmt[j].key) { fmt[i].skip = 1; break; }   /* duplicate tags: the later one is dropped */
+    /* vcf_parse_format_fill5 */
+    int rc = 0;
+    {
+        const char *t = body; int m = 0;
+        const int v44 = h->version >= 4004000;
+        while (t < end && rc == 0) {
+            if (m == nsamples) break;
+            int j = 0;
+            while (t < end) {
+                fmtaux_t *z = &fmt[j++];
+                if (z->skip) { while (*t != ':' && *t) t++; }
+                else if (z->ht == HT_STR && z->is_gt) {
+                    uint32_t *x = (uint32_t *)(z->buf + (size_t)z->size * (size_t)m);
+                    uint32_t is_phased = 0, unreadable = 0, max = 0; int l, ploidy = 0, anyunphased = 0, phasingprfx = 0, unknown1 = 0;
+                    if (v44 && (*t == '|' || *t == '/')) { is_phased = *t++ == '|'; phasingprfx = 1; }
+                    for (l = 0;; ++t) {
+                        ploidy++;
+                        if (*t == '.') { ++t; x[l++] = is_phased; if (l == 1) unknown1 = 1; }
+                        else {
+                            const char *tt = t; uint64_t n = 0;
+                            if (*t == '+') t++;
+                            while (*t >= '0' && *t <= '9') n = n * 10 + (uint64_t)(*t++ - '0');          /* (hts_str2uint with a 506-bit limit: wraps, never saturates) */
+                            uint32_t val = (uint32_t)n;
+                            unreadable |= tt == t;
+                            if (max < val) max = val;
+                            x[l++] = (val + 1) << 1 | is_phased;
+                        }
+                        anyunphased |= (ploidy != 1) && !is_phased;
+                        is_phased = (*t == '|');
+                        if (*t != '|' && *t != '/') break;
+                    }
+                    if (!phasingprfx) { if (ploidy == 1) { if (!unknown1) x[0] |= 1; } else x[0] |= anyunphased ? 0 : 1; }
+                    if (max > (0x7fffffffu >> 1) - 1 || unreadable) { rc = -1; break; }
+                    if (!l) x[l++] = 0;
+                    for (; l < z->size >> 2; ++l) x[l] = 0x80000001u;
+                } else if (z->ht == HT_STR) {
+                    char *x = (char *)z->buf + (size_t)z->size * (size_t)m; int l;
+                    for (l = 0; *t != ':' && *t; ++t) x[l++] = *t;
+                } else if (z->ht == HT_INT) {
+                    int32_t *x = (int32_t *)(z->buf + (size_t)z->size * (size_t)m); int l;
+                    for (l = 0;; ++t) {
+                        if (*t == '.') { x[l++] = (int32_t)0x80000000; ++t; }
+                        else {
+                            int over = 0; const char *te; int64_t v = str2int64(t, &te, &over);
+                            if (te == t || over || v < -2147483640LL || v > 2147483647LL) v = (int32_t)0x80000000;
+                            x[l++] = (int32_t)v; t = te;
+                        }
+                        if (*t != ',') break;
+                    }
+                    if (!l) x[l++] = (int32_t)0x80000000;
+                    for (; l < z->size >> 2; ++l) x[l] = (int32_t)0x80000001;
+                } else {
+                    uint32_t *x = (uint32_t *)(z->buf + (size_t)z->size * (size_t)m); int l;
+                    for (l = 0;; ++t) {
+                        if (*t == '.' && !(t[1] >= '0' && t[1] <= '9')) { x[l++] = 0x7F800001u; ++t; }
+                        else { int over = 0; const char *te; float fv = (float)str2dbl(t, &te, &over); memcpy(&x[l++], &fv, 4); t = te; }   /* (a failed conversion stores 0.0) */
+                        if (*t != ',') break;
+                    }
+                    if (!l) x[l++] = 0x7F800001u;
+                    for (; l < z->size >> 2; ++l) x[l] = 0x7F800002u;
+                }
+                if (*t == 0) break;
+                else if (*t == ':') t++;
+                else { rc = -1; break; }                                      /* "Invalid character" */
+            }
+            if (rc) break;
+            for (; j < n_fmt; ++j) {                                          /* trailing fields the sample leaves out */
+                fmtaux_t *z = &fmt[j];
+                if (z->skip) continue;
+                if (z->ht == HT_STR && !z->is_gt) { char *x = (char *)z->buf + (size_t)z->size * (size_t)m; if (z->size) x[0] = '.'; }
+                else {
+                    uint32_t *x = (uint32_t *)(z->buf + (size_t)z->size * (size_t)m);
+                    if (z->size) x[0] = z->ht == HT_REAL ? 0x7F800001u : 0x80000000u;
+                    for (int l = 1; l < z->size >> 2; ++l) x[l] = z->ht == HT_REAL ? 0x7F800002u : 0x80000001u;
+                }
+            }
+            m++; t++;
+        }
+    }
+    /* vcf_parse_format_gt6 + check7 */
+    int kept = 0;
+    if (rc == 0 && n_sample != nsamples) rc = -1;                              /* "Number of columns ... does not match the number of samples" */
+    if (rc == 0 && n_sample > 0) for (int i = 0; i < n_fmt; i++) {
+        fmtaux_t *z = &fmt[i];
+        if (z->skip) continue;
+        kept++;
+        enc_typed_int(in, z->key);
+        if (z->ht == HT_STR && !z->is_gt) { enc_size(in, z->size, 7); buf_push(in, z->buf, (size_t)z->size * (size_t)n_sample); }
+        else { enc_size(in, z->size >> 2, z->ht == HT_REAL ? 5 : 3); buf_push(in, z->buf, (size_t)z->size * (size_t)n_sample); }
+    }
+    for (int j = 0; j < n_fmt; j++) free(fmt[j].buf);
+    *n_fmt_out = kept; *n_sample_out = n_sample;
+    return rc;
+}
+
 /* one line -> one BCF2 record appended to `out`; < 0: the line is an error (the scan ends before it) */
 static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
 {
-    char *f[8]; int nf = 0; char *p = line;
+    char *f[8]; int nf = 0; char *p = line; char *rest = NULL;                /* rest: FORMAT column and what follows it (NULL when there are only eight columns) */
     for (;;) {                                                                /* kstrtok on '\t': empty tokens count, all eight are required */
         f[nf++] = p;
         char *t = strchr(p, '\t');
         if (!t) break;
         *t = 0; p = t + 1;
-        if (nf == 8) break;                                                   /* a ninth column (FORMAT) is cut off: no samples in the header, vcf_parse_format returns at once */
+        if (nf == 8) { rest = p; break; }
     }
     if (nf < 8) return -1;
     buf_t sh = { 0 };
@@ -983,13 +1141,15 @@ static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
             r = end; key = r + 1;
         }
     }
-    uint32_t l_shared = 24 + (uint32_t)sh.n, l_indiv = 0, w;
+    buf_t in = { 0 }; int n_fmt = 0, n_sample = 0;
+    if (rest && h->n_smp > 0 && vcf_format_to_bcf(h, rest, &in, &n_fmt, &n_sample) < 0) { free(sh.p); free(in.p); return -1; }
+    uint32_t l_shared = 24 + (uint32_t)sh.n, l_indiv = (uint32_t)in.n, w;
     buf_push(out, &l_shared, 4); buf_push(out, &l_indiv, 4);
     int32_t i32 = rid; buf_push(out, &i32, 4); i32 = (int32_t)pos; buf_push(out, &i32, 4); buf_push(out, &rlen, 4); buf_push(out, &qbits, 4);
     w = (uint32_t)n_info | ((uint32_t)n_allele << 16); buf_push(out, &w, 4);
-    w = 0; buf_push(out, &w, 4);
-    buf_push(out, sh.p, sh.n);
-    free(sh.p);
+    w = ((uint32_t)n_sample & 0xffffff) | ((uint32_t)n_fmt << 24); buf_push(out, &w, 4);
+    buf_push(out, sh.p, sh.n); buf_push(out, in.p, in.n);
+    free(sh.p); free(in.p);
     return 0;
 }
 
@@ -1014,7 +1174,6 @@ static int vcf_text_load(scan_t *s, const uint8_t *u, size_t ulen, buf_t *recs, 
     buf_u8(&txt, 0);
     if (hdr_parse(&s->h, (const char *)txt.p) < 0) { free(line); free(txt.p); return ORC_BCF_EHDR; }
     free(txt.p);
-    if (s->h.n_smp > 0) { free(line); return ORC_BCF_ESAMPLES; }
     int rc = build_schema(s);
     if (rc < 0) { free(line); return rc; }
     for (;;) {

@@ -198,3 +198,12 @@ def test_no_hbm_leak_over_200_queries():
     L.dhts_release_pools()
     free1 = free_hbm()
     assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 10} KiB of HBM lost over 200 create -> scan -> destroy cycles"
+
+
+def test_format_flag_column_stays_inside_its_payload():
+    """a FORMAT Flag binds as a BOOLEAN column that is always NULL; clearing its one-byte payload used a 4-byte store and ran into the
+    next column's values (found by the VCF text cases of round 2)"""
+    import bcfwriter as W
+    hdr = bcf_cases.std_header(extra=['##FORMAT=<ID=FLG,Number=0,Type=Flag,Description="d">'])
+    _check(W.bcf_bytes(hdr, bcf_cases.basic_records() * 300))
+    _check(W.bcf_bytes(hdr, bcf_cases.basic_records() * 300), tidy=True)

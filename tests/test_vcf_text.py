@@ -96,16 +96,49 @@ def test_the_first_bad_line_ends_the_scan(name, rows):
     assert t["n_rows"] == rows and t["status"] < 0                                  # rows before it are kept, silently (bcf_reader.c:1319-1349)
 
 
-def test_sample_columns_are_not_restated_yet():
-    txt = "\n".join(V.HDR[:-1] + ["#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1", "chr1\t1\t.\tA\tT\t.\t.\t.\tGT\t0/1"]) + "\n"
-    assert orc.bcf_read(txt.encode())["status"] == -103
+def test_reference_fixture_formatcols_vcf_gz():
+    t = orc.bcf_read(open(os.path.join(GOLD, "formatcols.vcf.gz"), "rb").read())
+    assert t["n_rows"] == 1 and t["status"] == 0                                  # duckhts.test:16-18
+    assert (_col(t, "CHROM"), _col(t, "POS"), _col(t, "ID"), _col(t, "REF")) == ([b"1"], [100], [b"a"], [b"A"])      # duckhts.test:22-24
+    assert [c["name"] for c in t["cols"]][7:] == ["FORMAT_S_S1", "FORMAT_S_S\u00b2", "FORMAT_S_S3"]
+    assert [_col(t, n)[0] for n in ("FORMAT_S_S1", "FORMAT_S_S\u00b2", "FORMAT_S_S3")] == [b"a", b"bbbbbbb", b"ccccccccc"]
+
+
+@pytest.mark.parametrize("tidy", [False, True])
+def test_upstream_text_form_of_vcf_file_bcf_reads_like_the_binary(tidy):
+    """htslib's test/tabix/vcf_file.vcf is the text the reference's vcf_file.bcf was made from: both readers must give one table
+    (23 columns x 15 rows wide, 30 rows tidy; INFO of every type, FORMAT GT / GQ / DP / GL / TT of two samples)"""
+    a = orc.bcf_read(open(os.path.join(GOLD, "vcf_file.vcf"), "rb").read(), tidy)
+    b = orc.bcf_read(open(os.path.join(GOLD, "vcf_file.bcf"), "rb").read(), tidy)
+    assert a["n_rows"] == (30 if tidy else 15) and orc.bcf_cols_diff(a, b) is None
+
+
+def test_sample_columns():
+    t = orc.bcf_read(dict(CASES)["samples"])
+    assert t["n_rows"] == 14 and t["status"] == 0
+    gt = [_col(t, "FORMAT_GT_S%d" % k) for k in (1, 2, 3)]
+    assert [g[0] for g in gt] == [b"0/1", b"1|1", b"./."] and [g[1] for g in gt] == [b"0|1|2", b".", b"1"] and [g[3] for g in gt] == [b"0/1", None, b"1/1"]
+    assert _col(t, "FORMAT_GQ_S2")[3] == 6 and _col(t, "FORMAT_GQ_S2")[7] == 0       # a sample that leaves trailing fields out; "-" converts to 0
+    assert _col(t, "FORMAT_GL_S1")[6] == [0.0] and _col(t, "FORMAT_GL_S3")[6] == []   # an empty Float stores what strtod returned; ".,." is two missing values
+    assert _col(t, "FORMAT_GL_S1")[4] == [0.5, float(np.float32(1e-3)), 5.0] and math.isnan(_col(t, "FORMAT_GL_S2")[4][0])
+    assert all(_col(t, "FORMAT_GT_S1")[r] is None for r in (8, 9))                    # FORMAT "." and a line without FORMAT
+    assert _col(t, "FORMAT_GT_S1")[11] == b"0/1"                                      # duplicate tag: the first occurrence is kept
+    assert len(_col(t, "FORMAT_AD_S1")[13]) == 17
+    v44 = orc.bcf_read(dict(CASES)["samples_v44_bgzf"])
+    assert [_col(v44, "FORMAT_GT_S%d" % k)[0] for k in (1, 2, 3)] == [b"0/1", b"1|0", b"0"]   # VCFv4.4: a leading '/' or '|' is a phasing prefix
+
+
+@pytest.mark.parametrize("name", sorted(V.SAMPLE_ERRORS))
+def test_sample_column_errors_end_the_scan(name):
+    t = orc.bcf_read(dict(CASES)["samples_" + name])
+    assert t["n_rows"] == 2 and t["status"] < 0
 
 
 # ---- GPU parity -------------------------------------------------------------------------------------------------------------
-def _check(data, **kw):
+def _check(data, tidy=False, **kw):
     import duckhts_amd
-    exp = orc.bcf_read(data)
-    got = duckhts_amd.read_bcf(data, **kw)
+    exp = orc.bcf_read(data, tidy)
+    got = duckhts_amd.read_bcf(data, tidy=tidy, **kw)
     d = orc.bcf_cols_diff(exp, got)
     assert d is None, d
     assert (got["status"] == 1) == (exp["status"] == 0), (got["status"], exp["status"])
@@ -131,6 +164,12 @@ def test_gpu_reference_fixtures():
     _check(bamwriter.bgzf_file(txt, payload=5000), max_blocks=3)
     exp, got = _check(open(os.path.join(GOLD, "no_contig.vcf.gz"), "rb").read())
     assert got["n_rows"] == 1 and orc.bcf_col_py(got["by_name"]["CHROM"]) == [b"chr1"]   # duckhts.test:395-397
+    exp, got = _check(open(os.path.join(GOLD, "formatcols.vcf.gz"), "rb").read())
+    assert got["n_rows"] == 1 and orc.bcf_col_py(got["by_name"]["ID"]) == [b"a"]          # duckhts.test:16-24
+    for tidy in (False, True):
+        exp, got = _check(open(os.path.join(GOLD, "vcf_file.vcf"), "rb").read(), tidy=tidy)
+        import duckhts_amd
+        assert orc.bcf_cols_diff(got, duckhts_amd.read_bcf(open(os.path.join(GOLD, "vcf_file.bcf"), "rb").read(), tidy=tidy)) is None
 
 
 @pytest.mark.gpu
@@ -142,9 +181,6 @@ def test_gpu_projection_and_sample_columns():
     want = ["INFO_FV", "POS", "QUAL", "INFO_AF"]
     got = duckhts_amd.read_bcf(data, columns=[names.index(w) for w in want])
     assert orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": [exp["by_name"][w] for w in want]}, got) is None
-    txt = "\n".join(V.HDR[:-1] + ["#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1", "chr1\t1\t.\tA\tT\t.\t.\t.\tGT\t0/1"]) + "\n"
-    with pytest.raises(duckhts_amd.DhtsError, match="sample columns"):
-        duckhts_amd.read_bcf(txt.encode())
 
 
 @pytest.mark.gpu
@@ -155,3 +191,6 @@ def test_gpu_vcf_text_through_the_table_function(tmp_path):
     compare_bcf(open(os.path.join(GOLD, "no_contig.vcf.gz"), "rb").read(), tmp_path)
     compare_bcf(dict(CASES)["undefined_names_bgzf_small_blocks"], tmp_path)
     compare_bcf(dict(CASES)["many_plain"], tmp_path, proj=[0, 1, 5, 6, 8, 15])
+    compare_bcf(open(os.path.join(GOLD, "formatcols.vcf.gz"), "rb").read(), tmp_path)
+    compare_bcf(open(os.path.join(GOLD, "vcf_file.vcf"), "rb").read(), tmp_path)
+    compare_bcf(dict(CASES)["samples_many_bgzf"], tmp_path, tidy=True)

@@ -23,6 +23,10 @@ HDR = [
 ]
 
 
+def bamwriter_bgzf(raw, **kw):
+    return W.bgzf_file(raw, **kw)
+
+
 def text(lines, hdr=HDR, eol="\n", last_eol=True):
     s = eol.join(list(hdr) + list(lines))
     return (s + (eol if last_eol else "")).encode()
@@ -71,6 +75,41 @@ UNDEFINED = [
 ]
 
 
+SHDR = HDR[:-1] + [
+    '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="d">',
+    '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="d">',
+    '##FORMAT=<ID=GL,Number=G,Type=Float,Description="d">',
+    '##FORMAT=<ID=FT,Number=1,Type=String,Description="d">',
+    '##FORMAT=<ID=FLG,Number=0,Type=Flag,Description="a FORMAT Flag is not supported by the parser">',
+    "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\tS3",
+]
+
+
+def S(fmt, *samples, pos=100, info="."):
+    return L(pos=pos, info=info) + "\t" + "\t".join((fmt,) + samples)
+
+
+SAMPLES = [
+    S("GT:GQ:AD:GL:FT", "0/1:99:10,20:-0.1,-2.5,-30:PASS", "1|1:45:0,300:-1,-2,-3:lowq;x", "./.:.:.,.:.:.", pos=1),
+    S("GT:GQ", "0|1|2:5", ".:7", "1:.", pos=2),                                # ploidy 3, haploid
+    S("GT", "0", "1/2", ".|.", pos=3),
+    S("GQ:GT", "5:0/1", "6", "7:1/1", pos=4),                                  # GT not first; a sample that leaves the trailing field out
+    S("GT:AD:GL", "0/1:1,2,3:.5,1e-3,5.", "1/1:.:nan,inf", "0/0:7:1E2", pos=5),  # strtod forms in FORMAT floats
+    S("FT:GQ", "abc:1", ":2", "a:", pos=6),                                    # empty string, empty integer
+    S("GL", "", "1", ".,.", pos=7),                                            # an empty Float value stores 0.0
+    S("GT:GQ", "10/11:+5", "1/1:-", "0/0:2147483647", pos=8),
+    S(".", "whatever", "x", "y", pos=9),                                       # FORMAT ".": no fields
+    L(pos=10),                                                                 # eight columns only: no FORMAT at all
+    S("GT:NEWF:GQ", "0/1:xyz:3", "0/0:q:4", "1/1:r,s:5", pos=11),              # an undefined FORMAT key becomes a String
+    S("GT:GT", "0/1:1/1", "0/0:0/1", "1/1:0/0", pos=12),                       # duplicate tag: the second is dropped
+    S("GT:GQ", "0/1:5", "0/0:6", "1/1:7", "0/0:8", pos=13),                    # more columns than samples: ignored
+    S("GT:AD", "0/1:1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17", "1/1:1", "0/0:.", pos=14),
+]
+SAMPLE_ERRORS = {"fewer_columns_than_samples": S("GT", "0/1", "0/0"), "more_fields_than_format": S("GT", "0/1:5", "0/0", "1/1"), "gt_not_a_number": S("GT", "0/x", "0/0", "1/1"),
+                 "int_with_garbage": S("GQ", "12abc", "1", "2"), "float_with_garbage": S("GL", "1.5x", "1", "2"), "float_exponent_with_garbage": S("GL", "1e5x", "1", "2"),
+                 "format_flag": S("FLG", "1", "1", "1"), "format_dot_key": S("GT:.", "0/1:1", "0/0:1", "1/1:1"), "format_without_samples": L() + "\tGT", "gt_empty": S("GT", "", "0/0", "1/1")}
+
+
 def all_cases():
     """-> list of (name, file bytes)"""
     out = [("numbers_plain", text(NUMBERS)), ("numbers_bgzf", W.bgzf_file(text(NUMBERS))),
@@ -83,6 +122,20 @@ def all_cases():
     out.append(("ninth_column_ignored", text([L(pos=1, info="DP=1") + "\tGT\t0/1", L(pos=2)])))
     out.append(("header_with_empty_lines_and_no_filters", text([L(pos=1, flt="PASS")], hdr=["##fileformat=VCFv4.1", "", "##contig=<ID=chr1>", "", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"])))
     out.append(("header_only", text([])))
+    out.append(("samples", text(SAMPLES, hdr=SHDR)))
+    out.append(("samples_v44_bgzf", bamwriter_bgzf(text([S("GT:GQ", "/0/1:1", "|1|0:2", "0:3", pos=1), S("GT", "|0", "/1", ".", pos=2)], hdr=["##fileformat=VCFv4.4"] + SHDR[1:]))))
+    for name, bad in SAMPLE_ERRORS.items():
+        out.append(("samples_" + name, text(SAMPLES[:2] + [bad] + SAMPLES[2:4], hdr=SHDR)))
+    rs = random.Random(11)
+    big = []
+    for i in range(3000):
+        smp = []
+        for _ in range(3):
+            gt = rs.choice(["0/0", "0/1", "1|1", "./.", "1/2", "0"])
+            smp.append(":".join([gt, rs.choice([".", str(rs.randrange(100))]), ",".join(rs.choice([".", str(rs.randrange(300))]) for _ in range(rs.randrange(1, 4))),
+                                 ",".join(rs.choice([".", "%.3f" % -rs.random(), "%g" % -(rs.random() * 50)]) for _ in range(rs.randrange(1, 4))), rs.choice(["PASS", ".", "lowq"])][:rs.randrange(1, 6)]))
+        big.append(S("GT:GQ:AD:GL:FT", *smp, pos=1 + i, info=rs.choice([".", "DP=%d" % i, "AF=0.5;DB"])))
+    out.append(("samples_many_bgzf", bamwriter_bgzf(text(big, hdr=SHDR), payload=4000)))
     rnd = random.Random(7)
     many = []
     for i in range(6000):
