@@ -194,3 +194,20 @@ def test_gpu_vcf_text_through_the_table_function(tmp_path):
     compare_bcf(open(os.path.join(GOLD, "formatcols.vcf.gz"), "rb").read(), tmp_path)
     compare_bcf(open(os.path.join(GOLD, "vcf_file.vcf"), "rb").read(), tmp_path)
     compare_bcf(dict(CASES)["samples_many_bgzf"], tmp_path, tidy=True)
+
+
+@pytest.mark.gpu
+def test_gpu_region_on_vcf_text_through_the_table_function(tmp_path):
+    """duckhts.test:399-403: a region naming a contig nobody knows yields no iterator, i.e. zero rows; without an index the reference's
+    message; a region that would need the text scan's own predicate is refused for now"""
+    import shutil
+    from test_duckdb_surface import run_host
+    fn = os.path.join(str(tmp_path), "no_contig.vcf.gz")
+    shutil.copy(os.path.join(GOLD, "no_contig.vcf.gz"), fn)
+    rc, out, _ = run_host(fn, named=[("region", "no_such_contig:1-10")], fn="read_bcf")
+    assert rc == 3 and out == "ERROR init: Region query requires an index file (.tbi or .csi). Region: no_such_contig:1-10"   # bcf_reader.c:922-923
+    shutil.copy(os.path.join(GOLD, "no_contig.vcf.gz.tbi"), fn + ".tbi")
+    rc, out, _ = run_host(fn, named=[("region", "no_such_contig:1-10")], fn="read_bcf")
+    assert rc == 0 and "rows=0 " in out                                              # duckhts.test:401-403
+    rc, out, _ = run_host(fn, fn="read_bcf")
+    assert rc == 0 and "rows=1 " in out                                              # duckhts.test:395-397
