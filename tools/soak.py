@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--surface", action="store_true", help="per seed: the DuckDB table functions through the mini host, random projections, chunk-exact against the oracle")
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
     ap.add_argument("--isize", action="store_true", help="per seed: hostile ISIZE trailer values (bit flips, 0xFFFFxxxx, > 64 KiB) on random blocks: the scan must end at that block with the rows before it intact")
+    ap.add_argument("--vcf", action="store_true", help="per seed: a VCF TEXT file (sites-only or with samples, plain or BGZF) of lines made from a grammar and then damaged character by character, wide or tidy, random batch sizes")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
     args = ap.parse_args()
     import bamwriter as bw  # noqa: F401
@@ -163,6 +164,80 @@ def main():
                     msgs.append(f"bcf region {reg!r}: {type(e).__name__} {e}")
             done += 1
             print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs[:3])}", flush=True)
+            bad += bool(msgs)
+            continue
+        if args.vcf:
+            import vcf_text_cases as V
+            smp = rnd.random() < 0.5
+            hdr = list(V.SHDR if smp else V.HDR)
+            if rnd.random() < 0.3:
+                hdr[0] = "##fileformat=VCFv4.4"
+            specials = "\t;=,:/|.+-eE 0123456789ACGT<>x\r"
+            def tok(kind, strict=False):                  # strict: inside FORMAT, where trailing garbage is an error: such tokens are rare there
+                risky = (not strict) or rnd.random() < 0.01
+                if kind == "int":
+                    return rnd.choice([".", "", "-", "+5", str(rnd.randrange(-10, 10 ** rnd.randrange(1, 12)))] + (["12abc", "0x1f"] if risky else []))
+                if kind == "flt":
+                    return rnd.choice([".", "", ".5", "5.", "%g" % (rnd.random() * 10 ** rnd.randrange(-40, 40)), "%.*f" % (rnd.randrange(0, 18), rnd.random()), "nan", "inf", "-inf", "%d" % rnd.randrange(10 ** 18)] + (["1e", "abc", "0x10"] if risky else ["0x10"]))
+                return "".join(rnd.choice("abcXYZ_01. ") for _ in range(rnd.randrange(0, 9)))
+            def info():
+                parts = []
+                for _ in range(rnd.randrange(0, 7)):
+                    k = rnd.choice(["DP", "AF", "AC", "MQ", "DB", "SB", "ANN_S", "TAGS", "FV", "NEW" + str(rnd.randrange(4)), "q10", "GT", ""])
+                    if rnd.random() < 0.15:
+                        parts.append(k)
+                    else:
+                        kind = {"DP": "int", "AC": "int", "SB": "int", "AF": "flt", "MQ": "flt", "FV": "flt"}.get(k, "str")
+                        parts.append(k + "=" + ",".join(tok(kind) for _ in range(rnd.randrange(1, 4))))
+                return ";".join(parts) or "."
+            def sample(keys):
+                vals = []
+                for k in keys[:rnd.randrange(1, len(keys) + 1)]:
+                    if k == "GT":
+                        vals.append(rnd.choice(["0/1", "1|1", "./.", ".", "0", "1/2/3", "10/11"] + (["|0|1", "/1"] if hdr[0].endswith("4.4") or rnd.random() < 0.01 else []) + (["0/x", ""] if rnd.random() < 0.01 else [])))
+                    elif k in ("GQ", "AD"):
+                        vals.append(",".join(tok("int", True) for _ in range(rnd.randrange(1, 4))))
+                    elif k == "GL":
+                        vals.append(",".join(tok("flt", True) for _ in range(rnd.randrange(1, 4))))
+                    else:
+                        vals.append(tok("str").replace(" ", "_"))
+                return ":".join(vals)
+            lines = []
+            for i in range(rnd.choice([20, 200, 1500])):
+                l = "\t".join([rnd.choice(["chr1", "chr2", "chrUn" + str(rnd.randrange(3))]), str(rnd.randrange(0, 10 ** rnd.randrange(1, 10))), rnd.choice([".", "rs%d" % i, ""]),
+                               rnd.choice(["A", "ACGT", ""]), rnd.choice([".", "T", "T,G", "<DEL>", ",", ""]), tok("flt"), rnd.choice(["PASS", ".", "q10", "q10;s50", "new%d" % rnd.randrange(3), "q10;"] + ([""] if rnd.random() < 0.01 else [])), info()])
+                if smp and rnd.random() < 0.95:
+                    keys = rnd.choice([["GT", "GQ", "AD", "GL", "FT"], ["GT"], ["GQ", "GT"], ["GT", "NEWF" + str(rnd.randrange(3))], ["GL", "AD"], ["."], ["GT", "GT"]] + ([["FLG"], ["GT", "."]] if rnd.random() < 0.01 else []))
+                    l += "\t" + ":".join(keys) + "".join("\t" + sample(keys) for _ in range(3 if rnd.random() < 0.99 else rnd.choice([2, 4])))
+                if rnd.random() < 0.004:                    # damage: replace / insert / delete a character
+                    b = list(l)
+                    for _ in range(rnd.randrange(1, 3)):
+                        if not b:
+                            break
+                        j = rnd.randrange(len(b)); op = rnd.randrange(3)
+                        if op == 0:
+                            b[j] = rnd.choice(specials)
+                        elif op == 1:
+                            b.insert(j, rnd.choice(specials))
+                        else:
+                            del b[j]
+                    l = "".join(b).replace("\n", "")
+                lines.append(l)
+            raw = V.text(lines, hdr=hdr, eol=rnd.choice(["\n", "\n", "\r\n"]), last_eol=rnd.random() < 0.8)
+            data = raw if rnd.random() < 0.4 else bw.bgzf_file(raw, payload=rnd.choice([500, 3000, 65280]), level=rnd.choice([1, 6]))
+            tidy = smp and rnd.random() < 0.3
+            try:
+                exp = orc.bcf_read(data, tidy)
+                got = duckhts_amd.read_bcf(data, tidy=tidy, max_blocks=rnd.choice([0, 1, 2, 5]))
+                d = orc.bcf_cols_diff(exp, got)
+                if d is not None:
+                    msgs.append("vcf text: " + d)
+                elif (got["status"] == 1) != (exp["status"] == 0):
+                    msgs.append(f"vcf text status {got['status']} vs {exp['status']}")
+            except Exception as e:
+                msgs.append(f"vcf text: {type(e).__name__} {str(e)[:200]}")
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (vcf text: {len(lines)} lines{' samples' if smp else ''}{' tidy' if tidy else ''}, {exp['n_rows'] if 'exp' in dir() else '?'} rows)", flush=True)
             bad += bool(msgs)
             continue
         if args.surface:
