@@ -2492,7 +2492,11 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     uint32_t ctr2[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(ctr2, c->v_ctr.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ctr2[1] > PCAP) return fail(c, "read_bcf: too many numbers outside the fast conversion path in one batch; use a smaller max_blocks");
+    if (ctr2[1] > PCAP) {
+        VcfPatch p0; char tokb[48] = {0};
+        if (hipMemcpy(&p0, c->v_patch.p, sizeof(p0), hipMemcpyDeviceToHost) == hipSuccess && p0.len < sizeof(tokb)) (void)hipMemcpy(tokb, u + p0.pos, p0.len, hipMemcpyDeviceToHost);
+        return fail(c, "read_bcf: %u numbers outside the device's conversion path in one batch (e.g. '%s'); use a smaller max_blocks", ctr2[1], tokb);
+    }
     if (ctr2[1]) {
         // numbers hts_str2dbl hands to strtod (exponents, > 14 digits, inf / nan / hex) and QUAL values outside that form: converted here
         std::vector<VcfPatch> pt(ctr2[1]);

@@ -126,22 +126,44 @@ template <bool WRITE> struct VcfSink {
 
 __device__ __forceinline__ bool vcf_isspace(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
 
-// hts_str2dbl's fast path: 0 = converted (*val, *end), 1 = the form strtod has to handle (host patch)
+// Decimal text -> double, correctly rounded, for what hts_str2dbl / strtod / atof all agree on: [ws][+-](digits[.digits] | .digits)[e[+-]digits]
+// with at most 15 significant digits and a power of ten that keeps both operands of ONE IEEE multiplication or division exact (Clinger's
+// fast path: w < 2^53, 10^k <= 10^22).  hts_str2dbl's own fast path (n / 10^k, textutils_internal.h:354-428) is the k <= 14 slice of this;
+// a correctly rounded result is unique, so the values are the same whoever computes them.  0 = converted (*val, *end = characters the
+// number takes, as strtod's end pointer), 1 = something else (inf / nan / hex, more digits, far exponents, nothing numeric): the host
+// converts that token.
 __device__ __forceinline__ int vcf_str2dbl_fast(const uint8_t *s, uint32_t l, double *val, uint32_t *end) {
     uint32_t v = 0; bool neg = false;
     while (v < l && vcf_isspace(s[v])) v++;
     if (v < l && s[v] == '-') { neg = true; v++; } else if (v < l && s[v] == '+') v++;
     const uint8_t c0 = v < l ? s[v] : 0, c1 = v + 1 < l ? s[v + 1] : 0;
-    if (!((c0 >= '1' && c0 <= '9') || (c0 == '0' && c1 != 'x' && c1 != 'X'))) return 1;
-    while (v < l && s[v] == '0') v++;
-    const uint32_t start = v; uint64_t n = 0; int max_len = 15, point = -1;
-    while (--max_len && v < l && s[v] >= '0' && s[v] <= '9') n = n * 10 + (s[v++] - '0');
-    if (max_len && v < l && s[v] == '.') { point = (int)(v - start); v++; while (--max_len && v < l && s[v] >= '0' && s[v] <= '9') n = n * 10 + (s[v++] - '0'); }
-    if (point < 0) point = (int)(v - start);
-    if (!max_len || (v < l && (s[v] == 'e' || s[v] == 'E'))) return 1;
-    const int k = (int)(v - start) - point;                  // 0, or 1 + number of fraction digits
-    double p10 = 1.0; for (int i = 1; i < k; i++) p10 *= 10.0;                                       // exact: k - 1 <= 14
-    const double d = __ddiv_rn((double)n, p10);
+    if (!((c0 >= '0' && c0 <= '9') || (c0 == '.' && c1 >= '0' && c1 <= '9'))) return 1;
+    if (c0 == '0' && (c1 == 'x' || c1 == 'X')) return 1;
+    uint64_t n = 0; int nd = 0, fd = 0; bool seen_nz = false;
+    for (; v < l && s[v] >= '0' && s[v] <= '9'; v++) { if (s[v] != '0' || seen_nz) { seen_nz = true; if (++nd > 15) return 1; n = n * 10 + (s[v] - '0'); } }
+    if (v < l && s[v] == '.') {
+        v++;
+        for (; v < l && s[v] >= '0' && s[v] <= '9'; v++) { fd++; if (s[v] != '0' || seen_nz) { seen_nz = true; if (++nd > 15) return 1; n = n * 10 + (s[v] - '0'); } }
+    }
+    int ex = 0;
+    if (v < l && (s[v] == 'e' || s[v] == 'E')) {
+        uint32_t w = v + 1; bool eneg = false;
+        if (w < l && (s[w] == '-' || s[w] == '+')) { eneg = s[w] == '-'; w++; }
+        if (w < l && s[w] >= '0' && s[w] <= '9') {                                // (an 'e' without digits is not part of the number)
+            int e = 0;
+            for (; w < l && s[w] >= '0' && s[w] <= '9'; w++) if (e < 100000) e = e * 10 + (s[w] - '0');
+            ex = eneg ? -e : e; v = w;
+        }
+    }
+    double d;
+    if (n == 0) d = 0.0;
+    else {
+        int e10 = ex - fd;
+        while (e10 > 22 && nd < 15) { n *= 10; nd++; e10--; }                     // (digits to spare: the significand stays below 10^15 < 2^53)
+        if (e10 > 22 || e10 < -22) return 1;
+        double p10 = 1.0; for (int i = 0, m = e10 < 0 ? -e10 : e10; i < m; i++) p10 *= 10.0;      // exact up to 10^22
+        d = e10 < 0 ? __ddiv_rn((double)n, p10) : __dmul_rn((double)n, p10);
+    }
     *val = neg ? -d : d; *end = v;
     return 0;
 }

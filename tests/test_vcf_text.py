@@ -48,8 +48,8 @@ def test_numbers():
     assert orc.bcf_cols_diff(t, orc.bcf_read(dict(CASES)["numbers_bgzf"])) is None
     f32 = lambda x: float(np.float32(x))
     q = _col(t, "QUAL")
-    assert q[:5] == [30.0, None, 12.0, 100.0, 7.25] and q[5] == 0.0 and q[6] == math.inf and q[7] == f32(0.1)      # atof: prefix parse, "-" -> 0
-    assert _col(t, "INFO_DP") == [35, 5, None, None, None, None, None, None]       # "+5"; 99999999999 and "." and "" are missing
+    assert q[:5] == [30.0, None, 12.0, 100.0, 7.25] and q[5] == 0.0 and q[6] == math.inf and q[7] == f32(0.1) and q[8:] == [f32(3.98e-06), 0.5]      # atof: prefix parse, "-" -> 0
+    assert _col(t, "INFO_DP") == [35, 5, None, None, None, None, None, None, None, None]       # "+5"; 99999999999 and "." and "" are missing
     ac = _col(t, "INFO_AC")
     assert ac[1] == [0, 0, 12, 7]                                                  # "-" and "+" convert to 0 (the end pointer moves past the sign), "12abc" to 12, "" is missing
     assert ac[2] == [2147483647, -2147483640]                                      # BCF_MIN_BT_INT32 = INT32_MIN + 8; everything outside is missing
@@ -60,8 +60,11 @@ def test_numbers():
     assert fv[4] == [1.5, -2.5, 4.0, 1.0, f32(1e-15), f32(1e14)]                    # leading white space is skipped, trailing garbage ignored
     assert fv[6] == [f32(3.4028235e38), math.inf, 0.0, 0.0] and fv[7][3] == 16777216.0
     mq = _col(t, "INFO_MQ")
-    assert mq[:5] == [59.5, 0.5, None, f32(123456789012345.5), 3.5] and mq[5] is None
-    assert _col(t, "INFO_DB") == [True, False, False, False, False, True, False, False]
+    assert mq[:5] == [59.5, 0.5, None, f32(123456789012345.5), 3.5] and mq[5] is None and mq[8] == 1500.0
+    assert _col(t, "INFO_DB") == [True, False, False, False, False, True, False, False, False, False]
+    # exponent forms and the edges of the exact conversion (Clinger's fast path on the device, strtod on the host beyond it)
+    assert fv[8] == [f32(3.98e-06), f32(1.23456e-05), f32(1e22), f32(1e23), f32(123456789012345e8), f32(1e-22), f32(1e-23), 0.0, math.inf, 1.0, 1.0, 100.0, 5.0, 0.0, 0.0, 1.0, f32(9.99999999999999e22)]
+    assert fv[9] == [0.5, -0.25, 0.125, f32(1e-21), f32(1e21), f32(1e-22), f32(12345678901234e9)]
 
 
 def test_fields_and_line_endings():

@@ -45,6 +45,8 @@ NUMBERS = [
     L(pos=6, qual="-", info="DP=;AF=;ANN_S=;TAGS=;DB=yes;MQ"),
     L(pos=7, qual="inf", info="FV=3.4028235e38,3.5e38,1e-46,4.9e-324"),
     L(pos=8, qual="0.1", info="FV=0.1,0.2,0.3,16777217,0.30000000000000004"),
+    L(pos=9, qual="3.98e-06", info="MQ=1.5e3;FV=3.98e-06,1.23456e-05,1e22,1e23,123456789012345e8,1e-22,1e-23,5e-324,1.7976931348623157e308,1e,1e+,1.e2,.5e1,0.e0,00.00e5,1E-0,9.99999999999999e22"),
+    L(pos=10, qual=".5", info="FV=.5,-.25,+.125,.,-.,.e5,0.000000000000000000001,1000000000000000000000,0.1e-21,12345678901234e9"),
 ]
 FIELDS = [
     L(pos=10, vid="rs1;rs2", ref="ACGT", alt="A,<DEL>,ACGTT"),

@@ -62,6 +62,44 @@ def generate(path, n, seed=1):
     return k
 
 
+def generate_gnomad_shape(path, n, seed=2):
+    """the shape of Benchmark.md:801 (gnomAD exomes chr22 with VEP: 1.4 GB of vcf.bgz for 416,083 records, i.e. ~3.4 KB compressed and tens
+    of KB of text per line: hundreds of numeric INFO keys and a long `vep` string per record)"""
+    rnd = random.Random(seed)
+    pops = ["afr", "amr", "asj", "eas", "fin", "nfe", "oth", "sas"]
+    keys = [("AC", "A", "Integer"), ("AN", "1", "Integer"), ("AF", "A", "Float")]
+    for sub in ["", "non_neuro_", "non_cancer_", "controls_", "non_topmed_"]:
+        for pop in pops:
+            for sex in ["", "_female", "_male"]:
+                for k, t in (("AC", "Integer"), ("AN", "Integer"), ("AF", "Float"), ("nhomalt", "Integer")):
+                    keys.append((f"{sub}{k}_{pop}{sex}", "A" if k != "AN" else "1", t))
+    keys += [("FS", "1", "Float"), ("MQ", "1", "Float"), ("QD", "1", "Float"), ("VQSLOD", "1", "Float"), ("ReadPosRankSum", "1", "Float"), ("DP", "1", "Integer")]
+    vep_fmt = "Allele|Consequence|IMPACT|SYMBOL|Gene|Feature_type|Feature|BIOTYPE|EXON|INTRON|HGVSc|HGVSp|cDNA_position|CDS_position|Protein_position|Amino_acids|Codons|Existing_variation|ALLELE_NUM|DISTANCE|STRAND|FLAGS|VARIANT_CLASS|SYMBOL_SOURCE|HGNC_ID|CANONICAL|TSL|APPRIS|CCDS|ENSP|SWISSPROT|TREMBL|UNIPARC|GENE_PHENO|SIFT|PolyPhen|DOMAINS|HGVS_OFFSET|LoF|LoF_filter|LoF_flags|LoF_info"
+    hdr = ["##fileformat=VCFv4.2", '##FILTER=<ID=AC0,Description="x">', '##FILTER=<ID=RF,Description="x">'] + \
+          ['##INFO=<ID=%s,Number=%s,Type=%s,Description="x">' % k for k in keys] + \
+          ['##INFO=<ID=vep,Number=.,Type=String,Description="Consequence annotations from Ensembl VEP. Format: %s">' % vep_fmt, "##contig=<ID=22,length=50818468>", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    nv = vep_fmt.count("|") + 1
+    with open(path, "wb") as f:
+        buf = ["\n".join(hdr) + "\n"]; pos = 16000000
+        for k in range(n):
+            pos += rnd.randrange(1, 200)
+            ref = rnd.choice("ACGT"); alt = rnd.choice([x for x in "ACGT" if x != ref])
+            info = []
+            for name, num, typ in keys:
+                info.append(f"{name}={rnd.randrange(250000)}" if typ == "Integer" else f"{name}=%.5e" % rnd.random())
+            trs = []
+            for _ in range(rnd.randrange(3, 40)):
+                t = [alt, rnd.choice(["missense_variant", "intron_variant", "downstream_gene_variant"]), "MODIFIER", "GENE%d" % rnd.randrange(900), "ENSG%011d" % rnd.randrange(10 ** 9), "Transcript",
+                     "ENST%011d" % rnd.randrange(10 ** 9), "protein_coding"] + [rnd.choice(["", "", "x%d" % rnd.randrange(1000)]) for _ in range(nv - 8)]
+                trs.append("|".join(t))
+            info.append("vep=" + ",".join(trs))
+            buf.append(f"22\t{pos}\trs{k}\t{ref}\t{alt}\t{rnd.randrange(100000)}.{rnd.randrange(100)}\t{rnd.choice(['PASS', 'AC0', 'RF'])}\t{';'.join(info)}\n")
+            if len(buf) >= 4000:
+                f.write(bamwriter.bgzf_file("".join(buf).encode(), eof=False, level=6)); buf = []
+        f.write(bamwriter.bgzf_file("".join(buf).encode(), eof=True, level=6))
+    return n
+
+
 def run(path, proj, threads, repeat=4, env=None):
     cmd = [HOST, duckhts_amd.LIB_PATH, "read_bcf", path, "-t", str(threads), "-r", str(repeat), "-p", ",".join(map(str, proj))]
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
@@ -92,5 +130,24 @@ def main():
                                   "compressed_MBps": round(size / warm / 1e6, 1)}), flush=True)
 
 
+def main_gnomad():
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+    d = tempfile.mkdtemp(dir="/tmp")
+    path = os.path.join(d, "gnomad_like.vcf.bgz")
+    t0 = time.time()
+    generate_gnomad_shape(path, n)
+    size = os.path.getsize(path)
+    print(json.dumps({"generated": path, "records": n, "compressed_bytes": size, "compressed_bytes_per_record": round(size / n, 1), "seconds": round(time.time() - t0, 1)}), flush=True)
+    for qn, proj in (("COUNT(*) (Benchmark.md:801: 29.91 s for 416,083 records = 13.9 k rows/s, 44.8 MB/s)", [0]), ("CHROM,POS,REF,ALT,VEP_SYMBOL,VEP_Consequence", [0, 1, 3, 4, 10, 8])):
+        for thr in (1, 4):
+            rows, runs = run(path, proj, thr, env={"DHTS_THREADS": str(thr), "DHTS_FILE_CACHE": "0"})
+            warm = sorted(runs[1:])[len(runs[1:]) // 2]
+            print(json.dumps({"operator": "read_bcf on a gnomAD-shaped vcf.bgz through the DuckDB table function (mini host), full scan", "query": qn, "rows": rows, "DHTS_THREADS": thr,
+                              "first_query_s": round(runs[0], 3), "warm_query_s": round(warm, 4), "rows_per_s": round(rows / warm, 1), "compressed_MBps": round(size / warm / 1e6, 1)}), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gnomad":
+        main_gnomad()
+    else:
+        main()
