@@ -100,9 +100,11 @@ int register_line(BcfHeader &h, const HeaderLine &r) {
     else return 0;
     if (!r.structured) return 0;
     if (hl == 3) {
+        long long ctg_length = 0;
         if (const std::string *l = r.get("length", true)) {
             char *end = nullptr; long long v = strtoll(l->c_str(), &end, 10);
             if (end == l->c_str() || v < 0) return 0;
+            ctg_length = v;
         }
         const std::string *id = r.get("ID", true);
         if (!id) return 0;
@@ -112,7 +114,8 @@ int register_line(BcfHeader &h, const HeaderLine &r) {
         if (idx == -1) idx = (int)h.ctg.size();
         else if (idx < (int)h.ctg.size() && h.ctg_present[idx]) return -1;      // conflicting IDX (vcf.c:803-809)
         if (idx >= (int)h.ctg.size()) { h.ctg.resize(idx + 1); h.ctg_present.resize(idx + 1, 0); }
-        h.ctg[idx] = *id; h.ctg_present[idx] = 1;
+        if ((int)h.ctg_len.size() < (int)h.ctg.size()) h.ctg_len.resize(h.ctg.size(), 0);
+        h.ctg[idx] = *id; h.ctg_present[idx] = 1; h.ctg_len[idx] = ctg_length;
         return 1;
     }
     const std::string *id = nullptr, *desc = nullptr; int type = -1, var = -1, num = -1, idx = -1;

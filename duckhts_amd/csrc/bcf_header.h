@@ -28,6 +28,7 @@ struct BcfHeader {
     std::vector<BcfDictEntry> ids;        // BCF_DT_ID, index = dictionary id
     std::vector<std::string> ctg;         // BCF_DT_CTG, index = contig id
     std::vector<char> ctg_present;
+    std::vector<int64_t> ctg_len;         // length= of the contig line (0 when absent): what the CSI writer sizes its binning by
     std::vector<std::string> samples;
     int version = 0;                      // major*1000000 + minor*1000, e.g. 4002000 (vcf.c:139-186)
     bool has_vep_tag = false;             // CSQ / BCSQ / ANN / VEP / vep INFO tag (vep_parser.c:100-118)

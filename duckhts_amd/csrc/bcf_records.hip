@@ -551,6 +551,15 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
     }
 }
 
+// rid, pos, rlen of every record (the three int32 behind the two length words), packed for the index writer
+extern "C" __global__ void __launch_bounds__(256)
+bcf_index_rows(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t nrec, uint32_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint64_t o = rec_off[r];
+    out[3 * r] = ldu32(u + o + 8); out[3 * r + 1] = ldu32(u + o + 12); out[3 * r + 2] = ldu32(u + o + 16);
+}
+
 // ---- region predicate (bcf_itr_querys -> hts_itr_next hts.c:4287-4300 over bcf_readrec vcf.c:2267-2276) ----------------------
 // keep[r] = rid == tid && end > beg_q && end_q > beg, beg = pos, end = pos + rlen (a negative rlen falls back to the REF allele
 // length, the first choice of get_rlen vcf.c:6440-6560); all != 0 keeps every record (region ".").

@@ -156,6 +156,7 @@ struct dhts_ctx {
     // query), each made of whole BGZF blocks; sorted by file offset, so resident order = file order
     struct Seg { uint64_t res_off, file_off, len; };
     std::vector<Seg> segs;
+    const uint8_t *last_bcf_u = nullptr;   // where the records of the last read_bcf batch live (inflated stream or, for text, v_out)
     bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
     bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
     DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ, vd_id_ftyp;
@@ -1553,25 +1554,27 @@ static int bam_aux_map(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam
 // bgzf_tell's rule (bgzf.c bgzf_read: a read that ends exactly at a block end reports the NEXT block's address with offset 0).
 // Bins are written in ascending order (the reference writes them in khash order; readers do not depend on it).
 namespace {
-struct BaiBuild {
-    int n_ref = 0; const int min_shift = 14, n_lvls = 5; const uint32_t n_bins = ((1u << (3 * 5 + 3)) - 1) / 7;
+struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_finish / idx_save_core build it: BAI (min_shift 14, 5 levels) or CSI
+    int n_ref = 0; int min_shift = 14, n_lvls = 5; uint32_t n_bins = ((1u << (3 * 5 + 3)) - 1) / 7; bool csi = false;
+    std::vector<std::map<uint32_t, uint64_t>> loff;                        // CSI: per bin, the linear-index offset of its first window (update_loff, hts.c:2426-2455)
+    void set_csi(int ms, int lv) { csi = true; min_shift = ms; n_lvls = lv; n_bins = (uint32_t)((((uint64_t)1 << (3 * lv + 3)) - 1) / 7); }
     struct Ch { uint64_t u, v; };
     std::vector<std::map<uint32_t, std::vector<Ch>>> bidx; std::vector<char> has_b; std::vector<std::vector<uint64_t>> lidx;
     int32_t save_tid = -1, last_tid = -1; uint32_t save_bin = 0xffffffffu, last_bin = 0xffffffffu;
     uint64_t save_off = 0, last_off = 0, off_beg = 0, off_end = 0, n_mapped = 0, n_unmapped = 0, n_no_coor = 0; int64_t last_coor = 0xffffffffll;
     std::string err;
-    void init(int n, uint64_t offset0) { n_ref = n; bidx.assign(n, {}); has_b.assign(n, 0); lidx.assign(n, {}); save_off = last_off = off_beg = off_end = offset0; }
-    static uint32_t reg2bin(int64_t beg, int64_t end) {                    // hts_reg2bin, min_shift 14, 5 levels
-        int s = 14; uint32_t t = ((1u << 15) - 1) / 7;
+    void init(int n, uint64_t offset0) { n_ref = n; bidx.assign(n, {}); has_b.assign(n, 0); lidx.assign(n, {}); loff.assign(n, {}); save_off = last_off = off_beg = off_end = offset0; }
+    uint32_t reg2bin(int64_t beg, int64_t end) const {                     // hts_reg2bin (htslib/hts.h)
+        int s = min_shift; uint32_t t = (uint32_t)((((uint64_t)1 << ((n_lvls << 1) + n_lvls)) - 1) / 7);
         --end;
-        for (int l = 5; l > 0; --l, s += 3, t -= 1u << ((l << 1) + l)) if ((beg >> s) == (end >> s)) return t + (uint32_t)(beg >> s);
+        for (int l = n_lvls; l > 0; --l, s += 3, t -= 1u << ((l << 1) + l)) if ((beg >> s) == (end >> s)) return t + (uint32_t)(beg >> s);
         return 0;
     }
     bool push(int32_t tid, int64_t beg, int64_t end, uint64_t offset, bool mapped) {
         if (tid < 0) { beg = -1; end = 0; }
-        const int64_t maxpos = 1ll << (14 + 15);
-        if (tid >= 0 && !(beg <= maxpos && end <= maxpos)) { err = "Region cannot be stored in a bai index. Try using a csi index"; return false; }
-        if (tid >= n_ref) { err = "record refers to a reference beyond the header"; return false; }
+        const int64_t maxpos = 1ll << (min_shift + 3 * n_lvls);
+        if (tid >= 0 && !(beg <= maxpos && end <= maxpos)) { err = csi ? "Region cannot be stored in a csi index with these parameters. Please use a larger min_shift or depth" : "Region cannot be stored in a bai index. Try using a csi index"; return false; }
+        if (tid >= n_ref) { if (!csi) { err = "record refers to a reference beyond the header"; return false; } n_ref = tid + 1; bidx.resize(n_ref); has_b.resize(n_ref, 0); lidx.resize(n_ref); loff.resize(n_ref); }   // (hts_idx_push enlarges the index)
         if (last_tid != tid || (last_tid >= 0 && tid < 0)) {
             if (tid >= 0 && n_no_coor) { err = "NO_COOR reads not in a single block at the end"; return false; }
             if (tid >= 0 && has_b[tid]) { err = "Chromosome blocks not continuous"; return false; }
@@ -1583,7 +1586,7 @@ struct BaiBuild {
             if (beg < 0) beg = 0;
             if (end <= 0) end = 1;
             std::vector<uint64_t> &l = lidx[tid];
-            const int64_t b = beg >> 14, e = (end - 1) >> 14;
+            const int64_t b = beg >> min_shift, e = (end - 1) >> min_shift;
             if ((int64_t)l.size() < e + 1) l.resize((size_t)e + 1, ~0ull);
             for (int64_t i = b; i <= e; i++) if (l[(size_t)i] == ~0ull) l[(size_t)i] = last_off;
         } else n_no_coor++;
@@ -1613,6 +1616,16 @@ struct BaiBuild {
             for (int64_t k = (int64_t)l.size() - 2; k >= 0; k--) if (l[(size_t)k] == ~0ull) l[(size_t)k] = l[(size_t)k + 1];   // update_loff
             if (!has_b[i]) continue;
             auto &B = bidx[i];
+            if (csi) for (auto &kv : B) {                                            // the bins' loff, before compress_binning moves chunks into parents
+                uint64_t lo = 0;
+                if (kv.first < n_bins) {
+                    int lvl = 0; for (uint32_t b2 = kv.first; b2; b2 = (b2 - 1) >> 3) lvl++;                    // hts_bin_level
+                    const uint32_t first = (uint32_t)((((uint64_t)1 << ((lvl << 1) + lvl)) - 1) / 7);          // hts_bin_first
+                    const uint64_t bot = (uint64_t)(kv.first - first) << ((n_lvls - lvl) * 3);                // hts_bin_bot
+                    lo = bot < l.size() ? l[(size_t)bot] : 0;
+                }
+                loff[i][kv.first] = lo;
+            }
             auto by_u = [](const Ch &a, const Ch &b) { return a.u < b.u; };
             for (int lv = n_lvls; lv > 0; --lv) {                                    // compress_binning
                 const uint32_t start = ((1u << ((lv << 1) + lv)) - 1) / 7;
@@ -1645,7 +1658,19 @@ struct BaiBuild {
     void save(std::vector<uint8_t> &o) const {
         auto w32 = [&](uint32_t x) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(x >> (8 * k))); };
         auto w64 = [&](uint64_t x) { for (int k = 0; k < 8; k++) o.push_back((uint8_t)(x >> (8 * k))); };
-        o.clear(); o.push_back('B'); o.push_back('A'); o.push_back('I'); o.push_back(1);
+        o.clear();
+        if (csi) {                                                                   // hts_idx_save_as CSI (hts.c:2820-2900): magic, min_shift, depth, l_aux = 0
+            o.push_back('C'); o.push_back('S'); o.push_back('I'); o.push_back(1);
+            w32((uint32_t)min_shift); w32((uint32_t)n_lvls); w32(0);
+            w32((uint32_t)n_ref);
+            for (int i = 0; i < n_ref; i++) {
+                w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
+                if (has_b[i]) for (auto &kv : bidx[i]) { w32(kv.first); auto lf = loff[i].find(kv.first); w64(lf == loff[i].end() ? 0 : lf->second); w32((uint32_t)kv.second.size()); for (auto &ch : kv.second) { w64(ch.u); w64(ch.v); } }
+            }
+            w64(n_no_coor);
+            return;
+        }
+        o.push_back('B'); o.push_back('A'); o.push_back('I'); o.push_back(1);
         w32((uint32_t)n_ref);
         for (int i = 0; i < n_ref; i++) {
             w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
@@ -1717,6 +1742,99 @@ int dhts_bam_index_bytes(dhts_ctx *c, uint8_t *out, uint64_t cap) {
     if (cap < c->built_index.size()) return fail(c, "index buffer too small");
     memcpy(out, c->built_index.data(), c->built_index.size());
     return 0;
+}
+
+// CSI for the open BCF (bcf_index, htslib vcf.c:4657-4688: hts_idx_push(rid, pos, pos + rlen, bgzf_tell) per record; min_shift 14 by
+// default, the number of levels from the longest contig of the header, idx_calc_n_lvls_ids + hts_adjust_csi_settings hts.c:2367-2400).
+// One scan of the file: the device delivers every record's contig id, position and rlen (the core of the BCF2 record).  The bytes are the
+// UNCOMPRESSED index; dhts_bgzf_wrap makes the .csi file of them.
+int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->bcf_open) return fail(c, "dhts_bcf_open not called");
+    if (c->vcf_text) return fail(c, "index build: VCF text needs a tabix index (not written by this build)");
+    if (c->bcf_rg_active || c->shard_b0 != 0 || c->shard_b1 != c->n_blocks) return fail(c, "index build needs a whole-file scan (no region or shard)");
+    if (min_shift <= 0) min_shift = 14;
+    int64_t max_len = 0; int nids = 0;
+    for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i]) { nids++; if (i < c->bh.ctg_len.size() && c->bh.ctg_len[i] > max_len) max_len = c->bh.ctg_len[i]; }
+    if (!max_len) max_len = (1ll << 31) - 1;
+    int n_lvls = 0;
+    {
+        const int64_t need = max_len + 256;
+        if (need <= (1ll << (min_shift + 27))) { int64_t maxpos = 1ll << min_shift; while (need > maxpos) { ++n_lvls; maxpos *= 8; } }
+        else { n_lvls = 9; int64_t maxpos = 1ll << (min_shift + 27); while (need > maxpos) { ++min_shift; maxpos *= 2; } }
+    }
+    const std::vector<int32_t> saved_proj = c->bcf_proj;
+    const int32_t none = 0;
+    if (dhts_bcf_set_projection(c, &none, 0) || dhts_bcf_rewind(c)) return -1;
+    const int64_t nb = c->n_blocks;
+    auto tell = [&](uint64_t u) -> uint64_t {
+        const uint64_t *uo = c->h_uoff.data();
+        int64_t lo = 0, hi = nb + 1;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (uo[mid] < u) lo = mid + 1; else hi = mid; }
+        if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
+        return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
+    };
+    BaiBuild ib; ib.set_csi(min_shift, n_lvls); ib.init(nids, tell(c->first_rec_uoff));
+    bool ok = true; int rc = 0;
+    std::vector<uint32_t> ro; std::vector<uint8_t> core;
+    for (;;) {
+        dhts_bcf_batch b;
+        if (dhts_bcf_next_batch(c, 0, &b)) { rc = -1; break; }
+        const int64_t n = b.n_rows / (c->bsch.tidy && c->bsch.n_samples > 0 ? c->bsch.n_samples : 1);
+        if (n > 0) {
+            // rid / pos / rlen sit in the 32-byte head of every record: offsets from the batch, the heads gathered by one strided copy
+            ro.resize(n); core.resize((size_t)n * 12);
+            HIPCHK(c, hipMemcpyAsync(ro.data(), c->b_rec_off.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            ENSURE(c, c->ix_end, (size_t)n * 12 + 64);
+            hipLaunchKernelGGL(bcf_index_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->last_bcf_u, (const uint32_t *)c->b_rec_off.p, n, (uint32_t *)c->ix_end.p);
+            HIPCHK(c, hipMemcpyAsync(core.data(), c->ix_end.p, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const uint64_t base = b.first_rec_uoff - ro[0];
+            for (int64_t i = 0; i < n && ok; i++) {
+                int32_t rid, pos, rlen; memcpy(&rid, &core[(size_t)i * 12], 4); memcpy(&pos, &core[(size_t)i * 12 + 4], 4); memcpy(&rlen, &core[(size_t)i * 12 + 8], 4);
+                const uint64_t u_end = (i + 1 < n) ? base + ro[i + 1] : b.end_uoff;
+                const int64_t p64 = (uint32_t)pos == 0xffffffffu ? -1 : (int64_t)pos;
+                ok = ib.push(rid, p64, p64 + rlen, tell(u_end), true);
+            }
+            if (!ok) break;
+        }
+        if (b.status != 0) { if (b.status < 0) { rc = fail(c, "index build: the scan ended on an error (status %d)", b.status); } break; }
+    }
+    (void)dhts_bcf_set_projection(c, saved_proj.data(), (int32_t)saved_proj.size());
+    (void)dhts_bcf_rewind(c);
+    if (rc) return -1;
+    if (!ok) return fail(c, "index build: %s", ib.err.c_str());
+    uint64_t fin = c->comp_len;
+    if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
+    ib.finish(fin << 16);
+    ib.save(c->built_index);
+    return (int64_t)c->built_index.size();
+}
+
+// raw bytes -> a valid BGZF file (what hts_idx_save writes a .csi / .tbi through): stored (uncompressed) DEFLATE blocks of up to 65,280
+// bytes with CRC-32 and ISIZE, and the 28-byte EOF block.  Host only.  Returns the size (also when out is NULL or too small: call twice).
+extern "C" int64_t dhts_bgzf_wrap(const void *raw, uint64_t n, void *out, uint64_t cap) {
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint8_t *src = (const uint8_t *)raw; uint8_t *dst = (uint8_t *)out; uint64_t need = 28, at = 0;
+    for (uint64_t p = 0; p < n; p += 65280) need += 18 + 5 + (n - p < 65280 ? n - p : 65280) + 8;
+    if (!dst || cap < need) return (int64_t)need;
+    uint32_t tab[256];
+    for (uint32_t i = 0; i < 256; i++) { uint32_t x = i; for (int k = 0; k < 8; k++) x = (x & 1) ? 0xEDB88320u ^ (x >> 1) : x >> 1; tab[i] = x; }
+    for (uint64_t p = 0; p < n; p += 65280) {
+        const uint32_t l = (uint32_t)(n - p < 65280 ? n - p : 65280), total = 18 + 5 + l + 8;
+        const uint8_t hd[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, (uint8_t)((total - 1) & 0xff), (uint8_t)((total - 1) >> 8)};
+        memcpy(dst + at, hd, 18); at += 18;
+        dst[at++] = 1; dst[at++] = (uint8_t)l; dst[at++] = (uint8_t)(l >> 8); dst[at++] = (uint8_t)~l; dst[at++] = (uint8_t)((~l) >> 8);      // BFINAL = 1, BTYPE = 00, LEN, NLEN
+        memcpy(dst + at, src + p, l); at += l;
+        uint32_t crc = 0xffffffffu; for (uint32_t i = 0; i < l; i++) crc = tab[(crc ^ src[p + i]) & 0xff] ^ (crc >> 8);
+        crc ^= 0xffffffffu;
+        for (int k = 0; k < 4; k++) dst[at++] = (uint8_t)(crc >> (8 * k));
+        for (int k = 0; k < 4; k++) dst[at++] = (uint8_t)(l >> (8 * k));
+    }
+    memcpy(dst + at, eof, 28); at += 28;
+    return (int64_t)at;
 }
 
 // ---- interval overlap join ------------------------------------------------------------------------------------------------
@@ -2755,7 +2873,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
             }
         }
     }
-    out->n_rows = nrec * reps;
+    out->n_rows = nrec * reps; c->last_bcf_u = st.u;
     out->end_uoff = out_base + carry_start;
     out->first_rec_uoff = nrec > 0 ? out_base + rec0_off : NONE64;
     return batch_end(c, B, carry_start, rec_err, shard_finished, &out->status);

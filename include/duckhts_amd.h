@@ -298,6 +298,11 @@ void dhts_release_pools(void);
  * the pool needs the room (least recently used first) or dhts_release_pools.  DHTS_FILE_CACHE=0 disables it. */
 int dhts_resident_from_cache(const dhts_ctx *);
 int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);   /* hipMemGetInfo after a device synchronise */
+/* CSI writer (src/hts_index_builder.c -> bcf_index_build3; htslib vcf.c:4657-4688, hts.c hts_idx_push / hts_idx_finish / idx_save_core):
+ * one scan of the open BCF; the bytes (dhts_bam_index_bytes) are the UNCOMPRESSED index, dhts_bgzf_wrap (host only) turns raw bytes into
+ * a valid BGZF file -- stored DEFLATE blocks + the EOF block -- which is what a .csi on disk is. */
+int64_t dhts_bcf_build_index(dhts_ctx *, int min_shift);          /* min_shift <= 0: 14, the default of bcf_index_build */
+int64_t dhts_bgzf_wrap(const void *raw, uint64_t n, void *out, uint64_t cap);   /* returns the size needed / written */
 /* read_bcf: the room the LAST batch of the context needs, and its read-back: out_cols[b->n_cols] = b->cols with HOST pointers (four queued
  * copies -- validity, fixed payloads, offsets, children / bytes -- and one wait) */
 uint64_t dhts_bcf_batch_host_bytes(const dhts_ctx *);

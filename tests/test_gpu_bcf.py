@@ -207,3 +207,75 @@ def test_format_flag_column_stays_inside_its_payload():
     hdr = bcf_cases.std_header(extra=['##FORMAT=<ID=FLG,Number=0,Type=Flag,Description="d">'])
     _check(W.bcf_bytes(hdr, bcf_cases.basic_records() * 300))
     _check(W.bcf_bytes(hdr, bcf_cases.basic_records() * 300), tidy=True)
+
+
+def _parse_csi(d):
+    import struct
+    assert d[:4] == b"CSI\x01"
+    min_shift, depth, l_aux = struct.unpack_from("<iii", d, 4)
+    p = 16 + l_aux
+    (n_ref,) = struct.unpack_from("<i", d, p); p += 4
+    refs = []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", d, p); p += 4
+        bins = {}
+        for _b in range(n_bin):
+            bin_, loff, n_chunk = struct.unpack_from("<IQi", d, p); p += 16
+            bins[bin_] = (loff, [struct.unpack_from("<QQ", d, p + 16 * k) for k in range(n_chunk)]); p += 16 * n_chunk
+        refs.append(bins)
+    (n_no_coor,) = struct.unpack_from("<Q", d, p) if p + 8 <= len(d) else (0,)
+    return min_shift, depth, l_aux, refs, n_no_coor
+
+
+def test_csi_writer_equals_the_reference_index(tmp_path):
+    """dhts_bcf_build_index on the reference's vcf_file.bcf against its golden vcf_file.bcf.csi (written by htslib's bcf_index_build): same
+    parameters, bins, loffsets, chunks and counts (the file order of bins is khash's and is not part of the format); the wrapped file is
+    valid BGZF and serves region queries"""
+    import ctypes as C
+    import gzip
+    import duckhts_amd
+    data = _gold("vcf_file.bcf")
+    gold = _parse_csi(gzip.decompress(_gold("vcf_file.bcf.csi")))
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(data); ctx.bgzf_index()
+        duckhts_amd.BcfScan(ctx)
+        L = duckhts_amd.lib()
+        L.dhts_bcf_build_index.restype = C.c_int64
+        L.dhts_bcf_build_index.argtypes = [C.c_void_p, C.c_int]
+        n = L.dhts_bcf_build_index(ctx.h, 14)
+        assert n > 0, L.dhts_error(ctx.h)
+        raw = np.zeros(n, np.uint8)
+        assert L.dhts_bam_index_bytes(ctx.h, raw.ctypes.data, n) == 0
+    finally:
+        ctx.close()
+    mine = _parse_csi(raw.tobytes())
+    assert mine[:3] == gold[:3] == (14, 5, 0) and mine[4] == gold[4]
+    assert mine[3] == gold[3]
+    L.dhts_bgzf_wrap.restype = C.c_int64
+    L.dhts_bgzf_wrap.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    need = L.dhts_bgzf_wrap(raw.ctypes.data, n, None, 0)
+    out = np.zeros(need, np.uint8)
+    assert L.dhts_bgzf_wrap(raw.ctypes.data, n, out.ctypes.data, need) == need
+    assert gzip.decompress(out.tobytes()) == raw.tobytes() and out[-28:].tobytes() == _gold("vcf_file.bcf.csi")[-28:]
+    # the written index narrows a region query exactly like the golden one
+    for region in ("1:3000150-3000151", "1:3062915-3062915", "4:1-10000000"):
+        a = duckhts_amd.read_bcf(data, region=region, index=out.tobytes())
+        b = duckhts_amd.read_bcf(data, region=region, index=_gold("vcf_file.bcf.csi"))
+        assert orc.bcf_cols_diff(a, b) is None and a["n_rows"] == b["n_rows"]
+    # a larger synthetic file: written index vs no index, random regions
+    from duckhts_amd import synth
+    big = synth.bcf_file(20000, seed=5)
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(big); ctx.bgzf_index(); duckhts_amd.BcfScan(ctx)
+        n = L.dhts_bcf_build_index(ctx.h, 0)
+        assert n > 0, L.dhts_error(ctx.h)
+        raw = np.zeros(n, np.uint8); L.dhts_bam_index_bytes(ctx.h, raw.ctypes.data, n)
+    finally:
+        ctx.close()
+    need = L.dhts_bgzf_wrap(raw.ctypes.data, n, None, 0); out = np.zeros(need, np.uint8); L.dhts_bgzf_wrap(raw.ctypes.data, n, out.ctypes.data, need)
+    for region in ("chr1:1-2000000", "chr2:100000-100500", "chrX", "chr5:1-1"):
+        a = duckhts_amd.read_bcf(big, region=region, index=out.tobytes())
+        b = duckhts_amd.read_bcf(big, region=region)
+        assert orc.bcf_cols_diff(a, b) is None
