@@ -659,9 +659,9 @@ struct BcfBind {
     std::string path, region;
     std::vector<std::string> regions;    // comma split, empty tokens dropped (parse_regions_duckdb, bcf_reader.c:423-446)
     std::string index_file; std::vector<uint8_t> index_bytes;
-    dhts_ctx *ctx = nullptr;
-    dhts_bcf_info inf;
-    int has_index = 0;
+    dhts_ctx *ctx = nullptr;             // bind-time context: holds only the head of the file (header, dictionaries, schema)
+    dhts_bcf_info inf;                   // schema of the bind context (column names / types live there)
+    int has_index = 0, tidy = 0, device = 0;
 };
 // ---- scan pipeline, as for read_bam: a producer thread drives the device and reads every batch back into a pinned arena (four queued
 // copies, dhts_bcf_batch_fetch); the scan callbacks fill DataChunks from those arenas while the device works on the next batch.
@@ -683,11 +683,14 @@ struct BcfScan {
     std::mutex mu; std::condition_variable cv_ready, cv_free;
     std::deque<BcfHostBatch *> ready; std::vector<BcfHostBatch *> free_slots, all;
     std::thread th; bool done = false, cancel = false; std::string error;
+    dhts_ctx *ctx = nullptr;             // the scan's own context (the producer stages the file into it); lives until the chunks are filled:
+    dhts_bcf_info inf;                   // its name tables -- a text scan adds the names records use without a header definition
     ~BcfScan() {
         { std::lock_guard<std::mutex> lk(mu); cancel = true; }
         cv_free.notify_all(); cv_ready.notify_all();
         if (th.joinable()) th.join();
         for (auto hb : all) { dhts_host_free(hb->arena); delete hb; }
+        if (ctx) dhts_destroy(ctx);
     }
 };
 struct BcfLocal {
@@ -727,13 +730,23 @@ static void bcf_read_bind(duckdb_bind_info info) {
         set_error(info, err); delete b; return;
     }
     int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
-    b->ctx = dhts_create(dev);
+    b->ctx = dhts_create(dev); b->tidy = tidy; b->device = dev;
     if (!b->ctx) { set_error(info, "read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); destroy_bcf_bind(b); return; }
-    if (dhts_open_path(b->ctx, b->path.c_str()) != 0) {
-        snprintf(err, sizeof(err), "Failed to open BCF/VCF file: %s", b->path.c_str());
-        set_error(info, err); destroy_bcf_bind(b); return;
+    // like the reference, bind reads the header only (bcf_open + bcf_hdr_read, bcf_reader.c:480-505): the head of the file is staged, four
+    // times more whenever the header turns out to be longer; every scan stages the file in its own context (bcf_read_global_init)
+    bool hdr_ok = false;
+    for (uint64_t head = 1u << 20;; head *= 4) {
+        if (dhts_open_path_range(b->ctx, b->path.c_str(), 0, head) != 0) {
+            snprintf(err, sizeof(err), "Failed to open BCF/VCF file: %s", b->path.c_str());
+            set_error(info, err); destroy_bcf_bind(b); return;
+        }
+        const bool whole = dhts_resident_bytes(b->ctx) < head;
+        if (dhts_bgzf_index(b->ctx) > 0 && dhts_bcf_open(b->ctx, tidy) == 0 && dhts_bcf_info_get(b->ctx, &b->inf) == 0) { hdr_ok = true; break; }
+        if (whole || head >= (1ull << 34)) break;
+        const char *m0 = dhts_error(b->ctx);
+        if (m0 && strncmp(m0, "read_bcf:", 9) == 0) break;                   // a refusal, not a header that is merely longer than the head
     }
-    if (dhts_bgzf_index(b->ctx) <= 0 || dhts_bcf_open(b->ctx, tidy) != 0 || dhts_bcf_info_get(b->ctx, &b->inf) != 0) {
+    if (!hdr_ok) {
         const char *m = dhts_error(b->ctx);
         set_error(info, (m && strncmp(m, "read_bcf:", 9) == 0) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505 (or what this build does not read yet)
         destroy_bcf_bind(b); return;
@@ -759,11 +772,11 @@ static void bcf_read_bind(duckdb_bind_info info) {
 }
 
 // chained single-region iterators (bcf_reader.c:1327-1345): the next region that yields an iterator; false when none is left
-static bool bcf_next_region(BcfBind *bind, size_t *next_region) {
+static bool bcf_next_region(BcfBind *bind, dhts_ctx *c, size_t *next_region) {
     while (*next_region < bind->regions.size()) {
         const std::string &rg = bind->regions[(*next_region)++];
-        if (dhts_bcf_set_region(bind->ctx, rg.c_str()) == 0) {                  // unknown contig / malformed: skipped (bcf_reader.c:944-953)
-            if (!bind->index_bytes.empty()) (void)dhts_bcf_load_index(bind->ctx, bind->index_bytes.data(), bind->index_bytes.size());   // window only: a failure keeps the full scan
+        if (dhts_bcf_set_region(c, rg.c_str()) == 0) {                          // unknown contig / malformed: skipped (bcf_reader.c:944-953)
+            if (!bind->index_bytes.empty()) (void)dhts_bcf_load_index(c, bind->index_bytes.data(), bind->index_bytes.size());   // window only: a failure keeps the full scan
             return true;
         }
     }
@@ -771,15 +784,20 @@ static bool bcf_next_region(BcfBind *bind, size_t *next_region) {
 }
 
 static void bcf_producer_main(BcfScan *g) {
-    BcfBind *bind = g->bind; dhts_ctx *c = bind->ctx;
+    BcfBind *bind = g->bind;
     auto finish = [&](const std::string &err) {
         std::lock_guard<std::mutex> lk(g->mu);
         if (!err.empty() && g->error.empty()) g->error = err;
         g->done = true; g->cv_ready.notify_all();
     };
+    dhts_ctx *c = g->ctx = dhts_create(bind->device);
+    if (!c) { finish("read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
+    if (dhts_open_path(c, bind->path.c_str()) != 0 || dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
+        finish(std::string("Failed to open BCF/VCF file: ") + bind->path); return;
+    }
     if (dhts_bcf_set_projection(c, g->proj.data(), (int32_t)g->proj.size()) != 0 || dhts_bcf_set_region(c, nullptr) != 0) { finish("Failed to open BCF/VCF file"); return; }
     size_t next_region = 0;
-    if (!bind->regions.empty() && !bcf_next_region(bind, &next_region)) { finish(""); return; }     // no region produced an iterator: zero rows (bcf_reader.c:955-959)
+    if (!bind->regions.empty() && !bcf_next_region(bind, c, &next_region)) { finish(""); return; }     // no region produced an iterator: zero rows (bcf_reader.c:955-959)
     static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;
     for (;;) {
@@ -817,7 +835,7 @@ static void bcf_producer_main(BcfScan *g) {
             g->cv_ready.notify_all();
         }
         if (b.status != 0) {                                     // EOF, or the silent stop at the first bad record (bcf_reader.c:1319-1349)
-            if (!bind->regions.empty() && bcf_next_region(bind, &next_region)) continue;
+            if (!bind->regions.empty() && bcf_next_region(bind, c, &next_region)) continue;
             break;
         }
         { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
@@ -906,8 +924,8 @@ static void bcf_fill(const BcfBind *bind, const BcfScan *g, const BcfHostBatch *
         const dhts_bcf_col &h = hb->cols[g->slot[ci]];
         const dhts_bcf_colinfo &inf = bind->inf.cols[h.col];
         duckdb_vector vec = get_vec(output, ci);
-        const char *const *names = inf.encoding == DHTS_ENC_CONTIG ? bind->inf.contig_name : inf.encoding == DHTS_ENC_DICT ? bind->inf.dict_name :
-                                   inf.encoding == DHTS_ENC_SAMPLE ? bind->inf.sample_name : nullptr;
+        const char *const *names = inf.encoding == DHTS_ENC_CONTIG ? g->inf.contig_name : inf.encoding == DHTS_ENC_DICT ? g->inf.dict_name :
+                                   inf.encoding == DHTS_ENC_SAMPLE ? g->inf.sample_name : nullptr;      // (the SCAN's tables: a text scan may have added names)
         auto name_of = [&](int32_t id) -> const char * { if (id < 0) return "PASS"; const char *nm = names[id]; return nm ? nm : "."; };
         if (!inf.is_list) {
             const size_t w = bcf_fixed_width(inf);
