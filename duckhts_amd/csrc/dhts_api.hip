@@ -2632,6 +2632,7 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
             }
             HIPCHK(c, hipMemcpy((uint8_t *)c->v_out.p + x.dst, &bits, 4, hipMemcpyHostToDevice));
         }
+        HIPCHK(c, hipDeviceSynchronize());                   // (small pageable uploads: make sure they have landed before the record stage reads the records)
     }
     HIPCHK(c, hipMemcpyAsync(&rec0_text, c->v_line_off.p, 4, hipMemcpyDeviceToHost, c->stream));
     st.u = (const uint8_t *)c->v_out.p; st.ulen = total;
