@@ -100,3 +100,27 @@ def test_extension_footer_on_the_built_library(tmp_path):
     # still a loadable shared object (dlopen ignores trailing bytes) exporting the entrypoint DuckDB looks up: <name>_init_c_api
     L = ctypes.CDLL(str(out))
     assert hasattr(L, "duckhts_init_c_api")
+
+
+def test_bgzf_wrap_is_valid_bgzf_without_a_gpu():
+    """dhts_bgzf_wrap (host only): stored-block BGZF with CRC-32 / ISIZE per block and htslib's EOF block; any gzip reader inflates it"""
+    import ctypes as C
+    import gzip
+    import numpy as np
+    L = duckhts_amd.lib()
+    L.dhts_bgzf_wrap.restype = C.c_int64
+    L.dhts_bgzf_wrap.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    rng = np.random.RandomState(3)
+    for n in (0, 1, 65279, 65280, 65281, 200000):
+        raw = rng.randint(0, 256, n).astype(np.uint8)
+        need = L.dhts_bgzf_wrap(raw.ctypes.data, n, None, 0)
+        out = np.zeros(need, np.uint8)
+        assert L.dhts_bgzf_wrap(raw.ctypes.data, n, out.ctypes.data, need) == need
+        b = out.tobytes()
+        assert gzip.decompress(b) == raw.tobytes()
+        assert b[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+        p, blocks = 0, 0                                    # the BSIZE chain covers the file exactly
+        while p < len(b):
+            assert b[p:p + 4] == b"\x1f\x8b\x08\x04" and b[p + 12:p + 16] == b"BC\x02\x00"
+            p += int.from_bytes(b[p + 16:p + 18], "little") + 1; blocks += 1
+        assert p == len(b) and blocks == (n + 65279) // 65280 + 1
