@@ -189,6 +189,13 @@ class Context:
     def bgzf_index(self):
         return self._chk(self.L.dhts_bgzf_index(self.h))
 
+    def scan_window_stats(self):
+        """(index windows, BGZF blocks) of the current scan range (the whole file without an index)"""
+        w, b = C.c_int64(0), C.c_int64(0)
+        self.L.dhts_scan_window_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._chk(self.L.dhts_scan_window_stats(self.h, C.byref(w), C.byref(b)))
+        return w.value, b.value
+
     def bgzf_table(self, n):
         coff = np.zeros(n, np.uint64)
         clen = np.zeros(n, np.uint32)
@@ -462,9 +469,10 @@ class BcfScan:
         return self.ctx._chk(self.ctx.L.dhts_bcf_set_region(self.ctx.h, region.encode() if region else None)) == 0
 
     def load_index(self, index_bytes):
-        """CSI bytes: narrows the scan window of the region set last (call after set_region)"""
+        """CSI / TBI bytes: narrows the scan window of the region set last (call after set_region)"""
         buf = np.frombuffer(index_bytes, dtype=np.uint8)
-        self.ctx._chk(self.ctx.L.dhts_bcf_load_index(self.ctx.h, buf.ctypes.data, buf.nbytes))
+        # VCF text: the region names a sequence of the tabix index, so it is resolved here; False = the index does not know it (region skipped)
+        return self.ctx._chk(self.ctx.L.dhts_bcf_load_index(self.ctx.h, buf.ctypes.data, buf.nbytes)) == 0
 
     def next_batch(self, max_blocks=0):
         b = BcfBatch()
@@ -594,8 +602,8 @@ def read_bcf(src, tidy=False, columns=None, device=0, max_blocks=0, block_range=
         for rg in passes:
             if rg is not None and not sc.set_region(rg):
                 continue
-            if rg is not None and index is not None:
-                sc.load_index(index)
+            if rg is not None and index is not None and not sc.load_index(index):
+                continue
             while True:
                 b = sc.next_batch(max_blocks)
                 if b.n_rows:

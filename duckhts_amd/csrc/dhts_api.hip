@@ -218,6 +218,8 @@ struct dhts_ctx {
     std::vector<int32_t> bcf_proj; std::vector<dhts_bcf_col> bcf_out;
     struct Arena { const uint8_t *p = nullptr; uint64_t n = 0; } bcf_ar[4];      // device arenas of the last batch's columns: validity, fixed payloads, offsets, children / bytes
     bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
+    // VCF text: a region names a sequence of the tabix index (tbx_name2id), so it is resolved when the index arrives (dhts_bcf_load_index)
+    bool bcf_rg_pending = false; std::string bcf_rg_tok; int32_t bcf_rg_itid = -1; std::vector<std::string> tbx_names;
     DevBuf b_keep, b_map, b_sel;
     DevBuf d_ctg_ok, d_id_ok, d_info_slot, d_fmt_slot, b_rec_off, b_dir, b_lens, b_offs, b_partial, b_total, b_coldev, b_fixed, b_valid, b_var;
     // scan position
@@ -1268,9 +1270,9 @@ int dhts_bam_set_regions(dhts_ctx *c, const char *regions) {
 struct QIv { int32_t tid; int64_t beg, end; };
 struct IdxWindow { bool any = false; uint64_t vmin = ~0ull, vmax = 0, last_end = 0; std::vector<std::pair<uint64_t, uint64_t>> chunks; };   // chunks: (begin, end) virtual offsets of every bin chunk the query touches
 
-static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::vector<QIv> &q, bool whole, IdxWindow &w) {
-    std::vector<uint8_t> inflated;
-    if (n >= 18 && d[0] == 0x1f && d[1] == 0x8b) {                       // BGZF: inflate on the device
+// the index bytes as stored in memory: a BGZF file (.csi, .tbi) is inflated on the device through a scratch context
+static int index_plain(dhts_ctx *c, const uint8_t *&d, uint64_t &n, std::vector<uint8_t> &inflated) {
+    if (n >= 18 && d[0] == 0x1f && d[1] == 0x8b) {
         dhts_ctx *t = dhts_create(c->device);
         if (!t) return fail(c, "cannot create a scratch context for the index");
         int64_t nb = -1;
@@ -1286,11 +1288,33 @@ static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::ve
         for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) return fail(c, "index inflate failed (block %lld)", (long long)k);
         d = inflated.data(); n = tot;
     }
+    return 0;
+}
+// the tabix header of an index (TBI: behind n_ref; CSI: the aux block), tbx.c:552-597: preset + the sequence names in index order.
+// Returns 0, 1 when the index carries no tabix header, <0 on a malformed one.
+static int tabix_header(dhts_ctx *c, const uint8_t *d, uint64_t n, int32_t &preset, std::vector<std::string> &names) {
+    const uint8_t *m = nullptr; uint64_t lm = 0;
+    if (n >= 8 && memcmp(d, "TBI\1", 4) == 0) { m = d + 8; lm = n - 8; }
+    else if (n >= 16 && memcmp(d, "CSI\1", 4) == 0) { lm = hle32(d + 12); if (lm > n - 16) return fail(c, "bad CSI header"); m = d + 16; }
+    else return 1;
+    if (lm < 28) return 1;
+    preset = (int32_t)hle32(m);
+    const uint32_t l_nm = hle32(m + 24);
+    if (l_nm > lm - 28) return fail(c, "Invalid index header");
+    names.clear();
+    for (uint32_t p = 0; p < l_nm;) { uint32_t e = p; while (e < l_nm && m[28 + e]) e++; names.emplace_back((const char *)m + 28 + p, e - p); p = e + 1; }
+    return 0;
+}
+
+static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::vector<QIv> &q, bool whole, IdxWindow &w) {
+    std::vector<uint8_t> inflated;
+    if (index_plain(c, d, n, inflated)) return -1;
     uint64_t p = 0;
     auto need = [&](uint64_t k) { return p + k <= n; };
     auto hle64 = [&](const uint8_t *x) { return (uint64_t)hle32(x) | ((uint64_t)hle32(x + 4) << 32); };
-    int min_shift = 14, depth = 5; bool csi = false;
+    int min_shift = 14, depth = 5; bool csi = false; bool tbi = false;
     if (need(8) && memcmp(d, "BAI\1", 4) == 0) p = 4;
+    else if (need(36) && memcmp(d, "TBI\1", 4) == 0) { p = 4; tbi = true; }         // BAI's body behind n_ref + the tabix header
     else if (need(16) && memcmp(d, "CSI\1", 4) == 0) {
         csi = true; min_shift = (int32_t)hle32(d + 4); depth = (int32_t)hle32(d + 8); const uint32_t l_aux = hle32(d + 12); p = 16;
         if (min_shift < 0 || depth < 0 || depth > 10 || !need(l_aux)) return fail(c, "bad CSI header");
@@ -1298,6 +1322,7 @@ static int index_window(dhts_ctx *c, const uint8_t *d, uint64_t n, const std::ve
     } else return fail(c, "index is neither BAI nor CSI");
     if (!need(4)) return fail(c, "truncated index");
     const int32_t n_ref = (int32_t)hle32(d + p); p += 4;
+    if (tbi) { const uint64_t l_nm = hle32(d + p + 24); if (!need(28 + l_nm)) return fail(c, "truncated index"); p += 28 + l_nm; }
     const uint32_t meta_bin = (uint32_t)(((1ull << (depth * 3 + 3)) - 1) / 7 + 1);
     const int maxs = min_shift + 3 * depth;
     for (int32_t t = 0; t < n_ref; t++) {
@@ -1458,11 +1483,48 @@ int dhts_bam_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     return dhts_bam_rewind(c);
 }
 
+static int bcf_upload_dicts(dhts_ctx *c);
+// VCF text (tbx_index_load3 + vcf_hdr_read's "add the missing contigs", vcf.c:2649-2668; tbx_itr_querys): the index names its sequences
+// itself.  Returns 1 when the pending region names none of them (no iterator: the reference skips the region).
+static int bcf_text_index(dhts_ctx *c, const uint8_t *d, uint64_t n) {
+    std::vector<uint8_t> inflated;
+    if (index_plain(c, d, n, inflated)) return -1;
+    int32_t preset = 0; std::vector<std::string> names;
+    const int rc = tabix_header(c, d, n, preset, names);
+    if (rc < 0) return -1;
+    if (rc == 1) return fail(c, "read_bcf: the index of a VCF text file has no tabix header");
+    if ((preset & 0xffff) != 2) return fail(c, "read_bcf: the tabix index was not built with the VCF preset");
+    bool added = false;
+    for (auto &nm : names) {
+        bool have = false;
+        for (size_t i = 0; i < c->bh.ctg.size() && !have; i++) have = c->bh.ctg_present[i] && c->bh.ctg[i] == nm;
+        if (have) continue;
+        if (nm.find('\n') != std::string::npos || !dhts::bcf_header_add_line(c->bh, ("##contig=<ID=" + nm + ">").c_str())) return fail(c, "read_bcf: cannot add contig '%s' of the index to the header", nm.c_str());
+        added = true;
+    }
+    if (added && bcf_upload_dicts(c)) return -1;
+    c->tbx_names = names;
+    if (c->bcf_rg_pending) {
+        int tid; int64_t b, e;
+        if (!parse_region_token(names, c->bcf_rg_tok, tid, b, e)) { c->bcf_rg_pending = false; c->bcf_rg_active = false; c->rg_empty_window = true; (void)dhts_bcf_rewind(c); return 1; }
+        int32_t rid = -1;
+        for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i] && c->bh.ctg[i] == names[tid]) { rid = (int32_t)i; break; }
+        if (rid < 0) return fail(c, "internal: index sequence without a header id");
+        c->bcf_rg_pending = false; c->bcf_rg_itid = tid; c->bcf_rg_tid = rid; c->bcf_rg_beg = b; c->bcf_rg_end = e;
+    }
+    return 0;
+}
+
 int dhts_bcf_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     if (!c || !c->bcf_open) return -1;
+    if (c->vcf_text) {
+        if (c->plain_text) return fail(c, "read_bcf: an uncompressed VCF has no index");
+        const int rc = bcf_text_index(c, (const uint8_t *)bytes, n);
+        if (rc) return rc;
+    }
     std::vector<QIv> q;
     const bool whole = !c->bcf_rg_active || c->bcf_rg_all;
-    if (!whole) q.push_back({c->bcf_rg_tid, c->bcf_rg_beg, c->bcf_rg_end});
+    if (!whole) q.push_back({c->vcf_text ? c->bcf_rg_itid : c->bcf_rg_tid, c->bcf_rg_beg, c->bcf_rg_end});
     IdxWindow w;
     if (index_window(c, (const uint8_t *)bytes, n, q, whole, w)) return -1;
     if (apply_window(c, w, whole, false)) return -1;
@@ -1556,6 +1618,7 @@ static int bam_aux_map(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam
 namespace {
 struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_finish / idx_save_core build it: BAI (min_shift 14, 5 levels) or CSI
     int n_ref = 0; int min_shift = 14, n_lvls = 5; uint32_t n_bins = ((1u << (3 * 5 + 3)) - 1) / 7; bool csi = false;
+    bool tbi = false; std::vector<uint8_t> aux;                             // tabix: "TBI\1" instead of "BAI\1" / the CSI aux block = tbx_set_meta's header (tbx.c:375-407); the index grows with the names met
     std::vector<std::map<uint32_t, uint64_t>> loff;                        // CSI: per bin, the linear-index offset of its first window (update_loff, hts.c:2426-2455)
     void set_csi(int ms, int lv) { csi = true; min_shift = ms; n_lvls = lv; n_bins = (uint32_t)((((uint64_t)1 << (3 * lv + 3)) - 1) / 7); }
     struct Ch { uint64_t u, v; };
@@ -1574,7 +1637,7 @@ struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_fin
         if (tid < 0) { beg = -1; end = 0; }
         const int64_t maxpos = 1ll << (min_shift + 3 * n_lvls);
         if (tid >= 0 && !(beg <= maxpos && end <= maxpos)) { err = csi ? "Region cannot be stored in a csi index with these parameters. Please use a larger min_shift or depth" : "Region cannot be stored in a bai index. Try using a csi index"; return false; }
-        if (tid >= n_ref) { if (!csi) { err = "record refers to a reference beyond the header"; return false; } n_ref = tid + 1; bidx.resize(n_ref); has_b.resize(n_ref, 0); lidx.resize(n_ref); loff.resize(n_ref); }   // (hts_idx_push enlarges the index)
+        if (tid >= n_ref) { if (!csi && !tbi) { err = "record refers to a reference beyond the header"; return false; } n_ref = tid + 1; bidx.resize(n_ref); has_b.resize(n_ref, 0); lidx.resize(n_ref); loff.resize(n_ref); }   // (hts_idx_push enlarges the index)
         if (last_tid != tid || (last_tid >= 0 && tid < 0)) {
             if (tid >= 0 && n_no_coor) { err = "NO_COOR reads not in a single block at the end"; return false; }
             if (tid >= 0 && has_b[tid]) { err = "Chromosome blocks not continuous"; return false; }
@@ -1661,7 +1724,8 @@ struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_fin
         o.clear();
         if (csi) {                                                                   // hts_idx_save_as CSI (hts.c:2820-2900): magic, min_shift, depth, l_aux = 0
             o.push_back('C'); o.push_back('S'); o.push_back('I'); o.push_back(1);
-            w32((uint32_t)min_shift); w32((uint32_t)n_lvls); w32(0);
+            w32((uint32_t)min_shift); w32((uint32_t)n_lvls); w32((uint32_t)aux.size());
+            o.insert(o.end(), aux.begin(), aux.end());
             w32((uint32_t)n_ref);
             for (int i = 0; i < n_ref; i++) {
                 w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
@@ -1670,8 +1734,9 @@ struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_fin
             w64(n_no_coor);
             return;
         }
-        o.push_back('B'); o.push_back('A'); o.push_back('I'); o.push_back(1);
+        o.push_back(tbi ? 'T' : 'B'); o.push_back(tbi ? 'B' : 'A'); o.push_back('I'); o.push_back(1);
         w32((uint32_t)n_ref);
+        if (tbi) o.insert(o.end(), aux.begin(), aux.end());
         for (int i = 0; i < n_ref; i++) {
             w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
             if (has_b[i]) for (auto &kv : bidx[i]) { w32(kv.first); w32((uint32_t)kv.second.size()); for (auto &ch : kv.second) { w64(ch.u); w64(ch.v); } }
@@ -1752,17 +1817,24 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->bcf_open) return fail(c, "dhts_bcf_open not called");
-    if (c->vcf_text) return fail(c, "index build: VCF text needs a tabix index (not written by this build)");
+    if (c->vcf_text && c->plain_text) return fail(c, "index build: an uncompressed VCF cannot be indexed (tabix needs BGZF)");
     if (c->bcf_rg_active || c->shard_b0 != 0 || c->shard_b1 != c->n_blocks) return fail(c, "index build needs a whole-file scan (no region or shard)");
+    const bool text = c->vcf_text, tbi = text && min_shift <= 0;
     if (min_shift <= 0) min_shift = 14;
     int64_t max_len = 0; int nids = 0;
     for (size_t i = 0; i < c->bh.ctg.size(); i++) if (c->bh.ctg_present[i]) { nids++; if (i < c->bh.ctg_len.size() && c->bh.ctg_len[i] > max_len) max_len = c->bh.ctg_len[i]; }
-    if (!max_len) max_len = (1ll << 31) - 1;
     int n_lvls = 0;
-    {
-        const int64_t need = max_len + 256;
-        if (need <= (1ll << (min_shift + 27))) { int64_t maxpos = 1ll << min_shift; while (need > maxpos) { ++n_lvls; maxpos *= 8; } }
+    auto adjust = [&](int64_t len) {                                                 // hts_adjust_csi_settings (hts.c:2367-2400)
+        const int64_t need = len + 256;
+        if (need <= (1ll << (min_shift + 27))) { int64_t maxpos = 1ll << (min_shift + 3 * n_lvls); while (need > maxpos) { ++n_lvls; maxpos *= 8; } }
         else { n_lvls = 9; int64_t maxpos = 1ll << (min_shift + 27); while (need > maxpos) { ++min_shift; maxpos *= 2; } }
+    };
+    if (!text) { if (!max_len) max_len = (1ll << 31) - 1; adjust(max_len); }        // idx_calc_n_lvls_ids
+    else if (tbi) n_lvls = 5;
+    else {                                                                           // tbx_index (tbx.c:451-484): TBX_MAX_SHIFT 31; the ##contig lengths, or a generous default
+        n_lvls = (31 - min_shift + 2) / 3;
+        if (max_len) adjust(max_len);
+        else n_lvls = min_shift < 10 ? 9 : min_shift < 25 ? 9 - (min_shift - 10) / 3 : 4;
     }
     const std::vector<int32_t> saved_proj = c->bcf_proj;
     const int32_t none = 0;
@@ -1775,7 +1847,10 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
         if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
         return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
     };
-    BaiBuild ib; ib.set_csi(min_shift, n_lvls); ib.init(nids, tell(c->first_rec_uoff));
+    BaiBuild ib;
+    if (tbi) ib.tbi = true; else ib.set_csi(min_shift, n_lvls);
+    ib.init(text ? 0 : nids, tell(c->first_rec_uoff));
+    std::vector<int32_t> tid_of; std::vector<std::string> tnames;                    // text: sequence ids in the order of first appearance (get_tid, tbx.c:82-107)
     bool ok = true; int rc = 0;
     std::vector<uint32_t> ro; std::vector<uint8_t> core;
     for (;;) {
@@ -1785,7 +1860,7 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
         if (n > 0) {
             // rid / pos / rlen sit in the 32-byte head of every record: offsets from the batch, the heads gathered by one strided copy
             ro.resize(n); core.resize((size_t)n * 12);
-            HIPCHK(c, hipMemcpyAsync(ro.data(), c->b_rec_off.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(ro.data(), text ? c->v_line_off.p : c->b_rec_off.p, n * 4, hipMemcpyDeviceToHost, c->stream));   // (text: a line ends where the next one starts)
             HIPCHK(c, hipStreamSynchronize(c->stream));
             ENSURE(c, c->ix_end, (size_t)n * 12 + 64);
             hipLaunchKernelGGL(bcf_index_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->last_bcf_u, (const uint32_t *)c->b_rec_off.p, n, (uint32_t *)c->ix_end.p);
@@ -1796,6 +1871,12 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
                 int32_t rid, pos, rlen; memcpy(&rid, &core[(size_t)i * 12], 4); memcpy(&pos, &core[(size_t)i * 12 + 4], 4); memcpy(&rlen, &core[(size_t)i * 12 + 8], 4);
                 const uint64_t u_end = (i + 1 < n) ? base + ro[i + 1] : b.end_uoff;
                 const int64_t p64 = (uint32_t)pos == 0xffffffffu ? -1 : (int64_t)pos;
+                if (text) {
+                    if (rid < 0 || rid >= (int32_t)c->bh.ctg.size()) { ok = false; ib.err = "record without a sequence name"; break; }
+                    if ((int32_t)tid_of.size() < (int32_t)c->bh.ctg.size()) tid_of.resize(c->bh.ctg.size(), -1);
+                    if (tid_of[rid] < 0) { tid_of[rid] = (int32_t)tnames.size(); tnames.push_back(c->bh.ctg[rid]); }
+                    ok = ib.push(tid_of[rid], p64 < 0 ? 0 : p64, p64 + rlen, tell(u_end), true);       // the interval of tbx_parse1: rlen of a text record is its tabix END - pos
+                } else
                 ok = ib.push(rid, p64, p64 + rlen, tell(u_end), true);
             }
             if (!ok) break;
@@ -1809,6 +1890,14 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
     uint64_t fin = c->comp_len;
     if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
     ib.finish(fin << 16);
+    if (text) {                                                                      // tbx_set_meta: the VCF preset {TBX_VCF, 1, 2, 0, '#', 0}, l_nm, names
+        const uint32_t conf[6] = {2, 1, 2, 0, '#', 0}; uint32_t l_nm = 0;
+        for (auto &nm : tnames) l_nm += (uint32_t)nm.size() + 1;
+        auto w32 = [&](uint32_t x) { for (int k = 0; k < 4; k++) ib.aux.push_back((uint8_t)(x >> (8 * k))); };
+        for (uint32_t x : conf) w32(x);
+        w32(l_nm);
+        for (auto &nm : tnames) { ib.aux.insert(ib.aux.end(), nm.begin(), nm.end()); ib.aux.push_back(0); }
+    }
     ib.save(c->built_index);
     return (int64_t)c->built_index.size();
 }
@@ -2460,11 +2549,15 @@ int dhts_bcf_set_projection(dhts_ctx *c, const int32_t *col_ids, int32_t n) {
 // Returns 0, 1 when the region yields no iterator (unknown contig / malformed: the reference skips it, bcf_reader.c:935-953), <0 on error.
 int dhts_bcf_set_region(dhts_ctx *c, const char *region) {
     if (!c || !c->bcf_open) return -1;
-    c->bcf_rg_active = false; c->bcf_rg_all = false; c->rg_empty_window = false;
+    c->bcf_rg_active = false; c->bcf_rg_all = false; c->rg_empty_window = false; c->bcf_rg_pending = false;
     c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1; c->scan_first_uoff = c->first_rec_uoff;
     if (!region || !*region) return dhts_bcf_rewind(c);
     std::string tok(region);
     if (tok == ".") { c->bcf_rg_active = true; c->bcf_rg_all = true; return dhts_bcf_rewind(c); }
+    if (c->vcf_text) {                                                          // names are the index's (tbx_itr_querys): resolved by dhts_bcf_load_index
+        c->bcf_rg_active = true; c->bcf_rg_pending = true; c->bcf_rg_tok = tok; c->bcf_rg_tid = c->bcf_rg_itid = -1;
+        return dhts_bcf_rewind(c);
+    }
     std::vector<std::string> names;
     for (size_t i = 0; i < c->bh.ctg.size(); i++) names.push_back(c->bh.ctg_present[i] ? c->bh.ctg[i] : std::string("\x01"));
     int tid; int64_t b, e;
@@ -2511,7 +2604,9 @@ extern "C" int64_t dhts_debug_vcf_records(dhts_ctx *c, uint8_t *dst, uint64_t ca
 // ---- VCF text batches (vcf_text.hip): the lines of the batch become BCF2 records in v_out; rec_off / dir as for binary input ----------
 // out: nrec, carry_start (start of the incomplete last line), rec_err (a line failed: the scan ends before it), rec0_text (text offset of
 // the first line), st re-pointed at the records.  Names without a definition are added to the header and the batch is measured again.
-static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t &nrec, uint64_t &carry_start, bool &rec_err, uint32_t &rec0_text, uint32_t &stride, unsigned long long &bad_rec) {
+// lim: lines that start at or behind this text offset belong to the next shard / lie behind the index window (finished = one was met).
+static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t &nrec, uint64_t &carry_start, bool &rec_err, uint32_t &rec0_text, uint32_t &stride, unsigned long long &bad_rec,
+                            uint64_t lim, bool &finished) {
     const uint8_t *u = B.u; const uint64_t ulen = B.ulen, out_base = B.out_base;
     uint64_t t0 = 0;
     if (c->first_batch) { if (c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch"); t0 = c->scan_first_uoff - out_base; }
@@ -2531,6 +2626,14 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     int64_t nlines = (int64_t)nl; int last_open = 0;
     carry_start = last_start;
     if (B.final_batch && last_start < ulen) { nlines++; last_open = 1; carry_start = ulen; }     // the last line of the file need not end in a newline
+    if (lim < ulen) {
+        std::vector<uint32_t> lo_(nlines + 1);
+        HIPCHK(c, hipMemcpy(lo_.data(), c->v_line_off.p, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost));
+        int64_t lo = 0, hi = nlines;                                                            // first line that starts at or behind lim
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (lo_[mid] < lim) lo = mid + 1; else hi = mid; }
+        if (lo < nlines) { finished = true; carry_start = lo_[lo]; nlines = lo; last_open = 0; }
+        else if (carry_start >= lim) finished = true;
+    }
     if (nlines == 0) return 0;
     ENSURE(c, c->v_rec_len, (size_t)(nlines + 1) * 4 + 64); ENSURE(c, c->b_rec_off, (size_t)(nlines + 1) * 4 + 64); ENSURE(c, c->v_ctr, 64);
     const uint32_t UCAP = 65536, PCAP = 1u << 20;
@@ -2697,9 +2800,11 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     unsigned long long bad = ~0ull;
     uint32_t stride = 64;
     if (c->vcf_text) {
-        if (c->shard_world > 1 || c->bcf_rg_active) return fail(c, "read_bcf: block-range shards and region queries are not supported on VCF text input yet");
+        if (c->bcf_rg_pending) return fail(c, "read_bcf: a region query on VCF text needs the tabix index (dhts_bcf_load_index) before the scan");
+        if (c->shard_rank != 0) return fail(c, "read_bcf: block-range shards that start inside the file are not supported on VCF text input yet");
         uint32_t rec0_text = 0;
-        if (vcf_text_records(c, B, st, nrec, carry_start, rec_err, rec0_text, stride, bad)) return -1;
+        const uint64_t lim = (B.sharded_tail && out_base + ulen > shard_end_u) ? shard_end_u - out_base : ~0ull;
+        if (vcf_text_records(c, B, st, nrec, carry_start, rec_err, rec0_text, stride, bad, lim, shard_finished)) return -1;
         rec0_off = rec0_text;
     } else
     for (;;) {
@@ -2752,7 +2857,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     }
     if (nrec > 0) {
         if (bad < (unsigned long long)nrec) { nrec = (int64_t)bad; rec_err = true; }    // the first bad record ends the scan (bcf_reader.c:1319-1349)
-        if (nrec > 0 && B.sharded_tail && out_base + ulen > shard_end_u) {
+        if (nrec > 0 && !c->vcf_text && B.sharded_tail && out_base + ulen > shard_end_u) {
             std::vector<uint32_t> ro(nrec);
             HIPCHK(c, hipMemcpyAsync(ro.data(), c->b_rec_off.p, nrec * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));

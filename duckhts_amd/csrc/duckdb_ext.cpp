@@ -753,7 +753,7 @@ static void bcf_read_bind(duckdb_bind_info info) {
     }
     for (const std::string &f : {idx, b->path + ".csi", b->path + ".tbi"}) if (!f.empty() && file_exists(f)) { b->index_file = f; break; }
     b->has_index = !b->index_file.empty();
-    if (b->has_index && !b->regions.empty() && (b->index_file.size() < 4 || b->index_file.compare(b->index_file.size() - 4, 4, ".tbi") != 0)) {
+    if (b->has_index && !b->regions.empty()) {
         FILE *f = fopen(b->index_file.c_str(), "rb");
         if (f) { uint8_t tmp[65536]; size_t k; while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) b->index_bytes.insert(b->index_bytes.end(), tmp, tmp + k); fclose(f); }
     }
@@ -776,7 +776,9 @@ static bool bcf_next_region(BcfBind *bind, dhts_ctx *c, size_t *next_region) {
     while (*next_region < bind->regions.size()) {
         const std::string &rg = bind->regions[(*next_region)++];
         if (dhts_bcf_set_region(c, rg.c_str()) == 0) {                          // unknown contig / malformed: skipped (bcf_reader.c:944-953)
-            if (!bind->index_bytes.empty()) (void)dhts_bcf_load_index(c, bind->index_bytes.data(), bind->index_bytes.size());   // window only: a failure keeps the full scan
+            // BCF: the index only narrows the window, a failure keeps the full scan.  VCF text: the region names a sequence of the tabix
+            // index (tbx_itr_querys), 1 = the index does not know it; a failure surfaces with the first batch
+            if (!bind->index_bytes.empty() && dhts_bcf_load_index(c, bind->index_bytes.data(), bind->index_bytes.size()) == 1) continue;
             return true;
         }
     }

@@ -168,6 +168,97 @@ __device__ __forceinline__ int vcf_str2dbl_fast(const uint8_t *s, uint32_t l, do
     return 0;
 }
 
+// ---- the interval of a VCF line as tabix sees it (tbx_parse1, htslib tbx.c:96-312): what region queries on text are tested against --------
+// strtoll(s, &e, base) over u[p, e): white space, sign, base 0 = 0x.. hex / 0.. octal / decimal; saturating.  *adv = characters consumed.
+__device__ __forceinline__ long long vcf_strtoll(const uint8_t *u, uint32_t p, uint32_t e, int base, uint32_t *adv) {
+    uint32_t v = p;
+    while (v < e && vcf_isspace(u[v])) v++;
+    bool neg = false;
+    if (v < e && (u[v] == '-' || u[v] == '+')) { neg = u[v] == '-'; v++; }
+    int b = base;
+    if (b == 0) {
+        if (v + 2 < e + 0 && u[v] == '0' && (u[v + 1] == 'x' || u[v + 1] == 'X') && v + 2 < e && ((u[v + 2] >= '0' && u[v + 2] <= '9') || ((u[v + 2] | 32) >= 'a' && (u[v + 2] | 32) <= 'f'))) { b = 16; v += 2; }
+        else if (v < e && u[v] == '0') b = 8;
+        else b = 10;
+    }
+    unsigned long long n = 0; bool any = false, over = false; const unsigned long long lim = neg ? 0x8000000000000000ull : 0x7fffffffffffffffull;
+    for (; v < e; v++) {
+        const uint8_t c = u[v]; int d = (c >= '0' && c <= '9') ? c - '0' : ((c | 32) >= 'a' && (c | 32) <= 'z') ? (c | 32) - 'a' + 10 : 99;
+        if (d >= b) break;
+        any = true;
+        if (over) continue;
+        if (n > (lim - (unsigned)d) / (unsigned)b) { over = true; n = lim; } else n = n * (unsigned)b + (unsigned)d;
+    }
+    if (adv) *adv = any ? v - p : 0;
+    return neg ? (long long)(0ull - n) : (long long)n;
+}
+__device__ __forceinline__ uint32_t vcf_find(const uint8_t *u, uint32_t a, uint32_t b, const char *pat, uint32_t pl) {      // strstr over u[a, b)
+    for (uint32_t i = a; i + pl <= b; i++) { uint32_t k = 0; while (k < pl && u[i + k] == (uint8_t)pat[k]) k++; if (k == pl) return i; }
+    return 0xffffffffu;
+}
+__device__ __forceinline__ bool vcf_svlen_alt(const uint8_t *u, uint32_t a, uint32_t l) {                                    // svlen_on_ref_for_vcf_alt
+    if (l < 5 || u[a] != '<') return false;
+    if (u[a + 4] != '>' && u[a + 4] != ':') return false;
+    const uint8_t c1 = u[a + 1], c2 = u[a + 2], c3 = u[a + 3];
+    if (!((c1 == 'C' && c2 == 'N' && c3 == 'V') || (c1 == 'D' && c2 == 'E' && c3 == 'L') || (c1 == 'D' && c2 == 'U' && c3 == 'P') || (c1 == 'I' && c2 == 'N' && c3 == 'V'))) return false;
+    return u[a + l - 1] == '>';
+}
+// end of the line's interval; beg = POS - 1 clamped at 0; [r0,r1) REF, [a0,a1) ALT, [i0,i1) INFO, [x0,x1) FORMAT + samples (x0 == x1: none)
+__device__ __forceinline__ long long vcf_tabix_end(const uint8_t *u, long long beg, uint32_t r0, uint32_t r1, uint32_t a0, uint32_t a1, uint32_t i0, uint32_t i1, uint32_t x0, uint32_t x1) {
+    if (beg < 0) beg = 0;
+    const long long reflen = (long long)(r1 - r0);
+    long long end = 1, svlen = 0, fmtlen = 0;
+    if (reflen > 0) end = beg + reflen;
+    // ALT alleles numbered from 1; which of the first 64 are <DEL>/<DUP>/<CNV>/<INV> (more symbolic alleles than that: ignored)
+    unsigned long long svmask = 0; int alcnt = 1; bool getlen = false;
+    for (uint32_t s0 = a0;;) {
+        uint32_t t = s0; while (t < a1 && u[t] != ',') t++;
+        ++alcnt;
+        if (vcf_svlen_alt(u, s0, t - s0)) { if (alcnt - 1 < 64) svmask |= 1ull << (alcnt - 1); }
+        else if ((t - s0 == 3 && u[s0] == '<' && u[s0 + 1] == '*' && u[s0 + 2] == '>') || (t - s0 == 9 && vcf_find(u, s0, t, "<NON_REF>", 9) == s0)) getlen = true;
+        if (t >= a1 || alcnt >= 65536) break;
+        s0 = t + 1;
+    }
+    uint32_t s = vcf_find(u, i0, i1, "END=", 4);
+    if (s == i0) s += 4; else if (s != 0xffffffffu) { s = vcf_find(u, i0, i1, ";END=", 5); if (s != 0xffffffffu) s += 5; }
+    if (s != 0xffffffffu && !(s < i1 && u[s] == '.')) { const long long v = vcf_strtoll(u, s, i1, 0, nullptr); if (v > beg) end = v; }
+    s = vcf_find(u, i0, i1, "SVLEN=", 6);
+    if (s == i0) s += 6; else if (s != 0xffffffffu) { s = vcf_find(u, i0, i1, ";SVLEN=", 7); if (s != 0xffffffffu) s += 7; }
+    for (int d = 1; s != 0xffffffffu && d < alcnt; ++d) {
+        uint32_t t = s; while (t < i1 && u[t] != ',') t++;
+        long long tmp = 1;
+        if (d < 64 && ((svmask >> d) & 1ull)) { tmp = vcf_strtoll(u, s, i1, 10, nullptr); if (tmp < 0) tmp = -tmp; }
+        if (svlen < tmp) svlen = tmp;
+        s = t < i1 ? t + 1 : 0xffffffffu;
+    }
+    if (getlen && x1 > x0) {                                                    // FORMAT/LEN of the samples (gVCF blocks)
+        uint32_t fq = x0; while (fq < x1 && u[fq] != '\t') fq++;
+        int lenpos = -1, pos = 0;
+        for (uint32_t a = x0;; pos++) {
+            uint32_t b2 = a; while (b2 < fq && u[b2] != ':') b2++;
+            if (b2 - a == 3 && u[a] == 'L' && u[a + 1] == 'E' && u[a + 2] == 'N') { lenpos = pos; break; }
+            if (b2 >= fq) break;
+            a = b2 + 1;
+        }
+        for (uint32_t sm = fq < x1 ? fq + 1 : x1; lenpos >= 0 && sm <= x1;) {
+            uint32_t se = sm; while (se < x1 && u[se] != '\t') se++;
+            uint32_t f = sm; long long tmp = 0;
+            for (int d = 0; d <= lenpos; ++d) {
+                if (d == lenpos) { tmp = vcf_strtoll(u, f, se, 10, nullptr); break; }
+                uint32_t c = f; while (c < se && u[c] != ':') c++;
+                if (c >= se) break;
+                f = c + 1;
+            }
+            if (fmtlen < tmp) fmtlen = tmp;
+            if (se >= x1) break;
+            sm = se + 1;
+        }
+    }
+    long long m = reflen; if (svlen > m) m = svlen; if (fmtlen > m) m = fmtlen;
+    if (end < beg + m) end = beg + m;
+    return end;
+}
+
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
 #define VCF_MAXF 32
@@ -232,7 +323,9 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         // ID
         if (fe[2] - fs[2] == 1 && u[fs[2]] == '.') o.size(0, 7); else o.vchar(u + fs[2], fe[2] - fs[2]);
         // REF, ALT
-        o.vchar(u + fs[3], fe[3] - fs[3]); rlen = (int32_t)(fe[3] - fs[3]);
+        o.vchar(u + fs[3], fe[3] - fs[3]);
+        // rlen: pos + rlen = the END the tabix iterator tests regions with (text carries no rlen; see vcf_tabix_end)
+        rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1) - pos);
         if (!(fe[4] - fs[4] == 1 && u[fs[4]] == '.')) {
             uint32_t t = fs[4];
             for (uint32_t r = fs[4];; r++) {

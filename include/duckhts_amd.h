@@ -198,6 +198,11 @@ int dhts_bam_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
 /* the scan range the regions + index produced: number of disjoint windows (the merged chunk list of hts_itr_multi_bam, hts.c:3597-3739;
  * chunks closer than DHTS_WINDOW_GAP_MB, default 32, are scanned as one window) and the BGZF blocks they cover */
 int dhts_scan_window_stats(const dhts_ctx *, int64_t *n_windows, int64_t *n_blocks);
+/* BCF: CSI bytes, narrows the window as above (optional).  bgzipped VCF TEXT: TBI, or CSI with a tabix header (tbx_index_load3, tbx.c:552-597)
+ * -- REQUIRED for a region other than ".": the region names a sequence of the INDEX (tbx_itr_querys -> tbx_name2id), so it is resolved here;
+ * the index's sequences missing from the header become ##contig lines as in vcf_hdr_read (vcf.c:2649-2668).  Rows are decided on the
+ * device by the interval tbx_parse1 gives a line (tbx.c:96-312: REF length, SVLEN of <DEL>/<DUP>/<CNV>/<INV>, FORMAT/LEN, INFO/END).
+ * Returns 0, 1 = the index does not know the region's sequence (no iterator: the reference skips the region), <0 on error.            */
 int dhts_bcf_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
 /* standard_tags := true (src/bam_reader.c:54-70, 920-966): the reference's 56-entry tag table, in its order */
 int dhts_bam_std_tag_count(void);
@@ -277,7 +282,8 @@ int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /*
 int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);
 /* ONE region of read_bcf(region := 'a,b,...'): the reference chains single-region iterators in the order given (src/bcf_reader.c:
  * 1327-1345; overlapping regions repeat rows).  bcf_itr_querys + the overlap test of hts_itr_next (hts.c:4287-4300) over bcf_readrec
- * (vcf.c:2267-2276).  0 = set, 1 = no iterator for this region (unknown contig: skipped by the reference), NULL/"" clears.       */
+ * (vcf.c:2267-2276).  0 = set, 1 = no iterator for this region (unknown contig: skipped by the reference), NULL/"" clears.
+ * On VCF text the name is resolved by dhts_bcf_load_index (see there), which must follow before the scan.                          */
 int dhts_bcf_set_region(dhts_ctx *, const char *region);
 int dhts_bcf_rewind(dhts_ctx *);
 int dhts_bcf_next_batch(dhts_ctx *, int64_t max_blocks, dhts_bcf_batch *out);
@@ -302,6 +308,9 @@ int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes
  * one scan of the open BCF; the bytes (dhts_bam_index_bytes) are the UNCOMPRESSED index, dhts_bgzf_wrap (host only) turns raw bytes into
  * a valid BGZF file -- stored DEFLATE blocks + the EOF block -- which is what a .csi on disk is. */
 int64_t dhts_bcf_build_index(dhts_ctx *, int min_shift);          /* min_shift <= 0: 14, the default of bcf_index_build */
+/* On bgzipped VCF text the same call is the tabix writer (tbx_index_build3 with tbx_conf_vcf, tbx.c:437-510): min_shift <= 0 writes a TBI
+ * (14 / 5 levels), > 0 a CSI whose depth follows the ##contig lengths (hts_adjust_csi_settings) and whose aux block is the tabix header;
+ * sequence ids in the order of first appearance, intervals by the tbx_parse1 rule above. */
 int64_t dhts_bgzf_wrap(const void *raw, uint64_t n, void *out, uint64_t cap);   /* returns the size needed / written */
 /* read_bcf: the room the LAST batch of the context needs, and its read-back: out_cols[b->n_cols] = b->cols with HOST pointers (four queued
  * copies -- validity, fixed payloads, offsets, children / bytes -- and one wait) */

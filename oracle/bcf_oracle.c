@@ -880,6 +880,69 @@ static int hdr_add_dummy(hdr_t *h, const char *fmt, const char *name)          /
     return rc < 0 ? -1 : 0;
 }
 
+/* The END of a VCF line as the tabix iterator sees it (tbx_parse1, htslib tbx.c:96-312, VCF preset) -- the reference serves
+ * read_bcf(region := ...) on text through tbx_itr_next, whose overlap test uses this interval, not get_rlen's: beg = POS - 1 (>= 0),
+ * end = beg + max(len(REF), SVLEN of <DEL>/<DUP>/<CNV>/<INV> alleles, FORMAT/LEN of gVCF blocks), or INFO/END when that is larger. */
+static int svlen_alt(const char *alt, size_t sz)                               /* svlen_on_ref_for_vcf_alt, hts_internal.h:181-197 */
+{
+    if (sz < 5 || alt[0] != '<') return 0;
+    if (alt[4] != '>' && alt[4] != ':') return 0;
+    if (memcmp(alt, "<CNV", 4) && memcmp(alt, "<DEL", 4) && memcmp(alt, "<DUP", 4) && memcmp(alt, "<INV", 4)) return 0;
+    return alt[sz - 1] == '>';
+}
+static int64_t tbx_vcf_end(int64_t beg, const char *ref, const char *alt, const char *info, const char *rest)
+{
+    int64_t end = 1, reflen = (int64_t)strlen(ref), svlen = 0, fmtlen = 0;
+    if (beg < 0) beg = 0;
+    if (reflen > 0) end = beg + reflen;
+    uint8_t svl[8192]; memset(svl, 0, sizeof svl);
+    int alcnt = 1, use_svlen = 0, getlen = 0;
+    for (const char *s = alt;;) {                                              /* every ALT allele (also of "."), numbered from 1 */
+        const char *t = strchr(s, ',');
+        size_t l = t ? (size_t)(t - s) : strlen(s);
+        ++alcnt;
+        if (svlen_alt(s, l)) { svl[(alcnt - 1) >> 3] |= (uint8_t)(1 << ((alcnt - 1) & 7)); use_svlen = 1; }
+        else if ((l == 3 && !memcmp(s, "<*>", 3)) || (l == 9 && !memcmp(s, "<NON_REF>", 9))) getlen = 1;
+        if (!t || alcnt >= 65536) break;
+        s = t + 1;
+    }
+    const char *s = strstr(info, "END=");
+    if (s == info) s += 4; else if (s) { s = strstr(info, ";END="); if (s) s += 5; }
+    if (s && *s != '.') { char *e; long long v = strtoll(s, &e, 0); if (v > beg) end = v; }
+    s = strstr(info, "SVLEN=");
+    if (s == info) s += 6; else if (s) { s = strstr(info, ";SVLEN="); if (s) s += 7; }
+    for (int d = 1; s && d < alcnt; ++d) {
+        const char *t = strchr(s, ','); long long tmp = 1;
+        if (use_svlen && (svl[d >> 3] & (1 << (d & 7)))) { tmp = atoll(s); if (tmp < 0) tmp = -tmp; }
+        if (svlen < tmp) svlen = tmp;
+        s = t ? t + 1 : NULL;
+    }
+    if (getlen && rest) {                                                      /* FORMAT/LEN of the samples */
+        const char *fq = strchr(rest, '\t'); size_t fl = fq ? (size_t)(fq - rest) : strlen(rest);
+        int lenpos = -1, pos = 0;
+        for (size_t a = 0;; pos++) {
+            size_t b2 = a; while (b2 < fl && rest[b2] != ':') b2++;
+            if (b2 - a == 3 && !memcmp(rest + a, "LEN", 3)) { lenpos = pos; break; }
+            if (b2 >= fl) break;
+            a = b2 + 1;
+        }
+        for (const char *sm = fq ? fq + 1 : NULL; sm && lenpos >= 0;) {
+            const char *se = strchr(sm, '\t'); const char *f = sm; int d = 0; long long tmp = 0;
+            for (; d <= lenpos; ++d) {
+                if (d == lenpos) { tmp = atoll(f); break; }
+                const char *c = (const char *)memchr(f, ':', se ? (size_t)(se - f) : strlen(f));
+                if (!c) break;
+                f = c + 1;
+            }
+            if (fmtlen < tmp) fmtlen = tmp;
+            sm = se ? se + 1 : NULL;
+        }
+    }
+    int64_t m = reflen; if (svlen > m) m = svlen; if (fmtlen > m) m = fmtlen;
+    if (end < beg + m) end = beg + m;
+    return end;
+}
+
 /* FORMAT column + sample columns -> the indiv block (vcf_parse_format vcf.c:3686-3742 and its seven steps 3137-3684).
  * rest = "FORMAT\tsample1\tsample2..." (NUL-terminated, modified in place).  Integers and genotypes are written as int32 vectors. */
 typedef struct { int key, ht, is_gt, max_l, max_m, max_g, size, skip; uint8_t *buf; } fmtaux_t;
@@ -1073,6 +1136,8 @@ static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
             if (*r == 0) break;
         }
     }
+    /* rlen: what makes pos + rlen the END the tabix iterator tests regions with (text has no stored rlen; get_rlen's value is not observable) */
+    rlen = (int32_t)(tbx_vcf_end(pos, f[3], f[4], f[7], rest) - pos);
     /* QUAL: atof */
     uint32_t qbits = 0x7F800001u;
     if (strcmp(f[5], ".")) { float q = (float)atof(f[5]); memcpy(&qbits, &q, 4); }

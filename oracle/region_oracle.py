@@ -179,6 +179,54 @@ def bcf_region_rows(table, contigs, region_string, tidy_reps=1):
     return out
 
 
+def tabix_names(index_bytes):
+    """sequence names of a tabix index in index order (tbx.c:552-597 index_load: the 28-byte header + names behind n_ref of a .tbi,
+    or in the aux block of a .csi); None when the index has no tabix header"""
+    import gzip
+    import struct
+    d = gzip.decompress(index_bytes) if index_bytes[:2] == b"\x1f\x8b" else bytes(index_bytes)
+    if d[:4] == b"TBI\x01":
+        m = d[8:]
+    elif d[:4] == b"CSI\x01":
+        (l_aux,) = struct.unpack_from("<i", d, 12)
+        m = d[16:16 + l_aux]
+    else:
+        return None
+    if len(m) < 28:
+        return None
+    (l_nm,) = struct.unpack_from("<i", m, 24)
+    return [x.decode() for x in m[28:28 + l_nm].split(b"\x00")[:-1]]
+
+
+def vcf_text_region_rows(table, chrom, names, region_string, tidy_reps=1):
+    """read_bcf(region := ...) on bgzipped VCF TEXT: tbx_itr_querys per region token (src/bcf_reader.c:938-939, 1327-1345) -- the name is
+    looked up among the INDEX's sequences (tbx_name2id), unknown ones give no iterator and are skipped -- then hts_itr_next's test on the
+    interval tbx_parse1 computes for the line (tbx.c:96-312): same sequence and end > beg_q and end_q > beg, beg = POS - 1 clamped at 0,
+    end = what bcf_oracle.c tbx_vcf_end returns (stored by the oracle as pos0 + rlen of the text record).
+    chrom = CHROM per RECORD (bytes); names = tabix_names(index)."""
+    rec = table["rec"]
+    out = []
+    if not any(region_string.split(",")):
+        return list(range(len(rec["rid"]) * tidy_reps))
+    chrom = np.array([c if c is not None else b"" for c in chrom], dtype=object)
+    for tok in region_string.split(","):
+        if tok == "":
+            continue
+        if tok == ".":
+            idx = np.arange(len(rec["rid"]))
+        else:
+            r = parse_region(names, tok)
+            if r is None:
+                continue
+            tid, b, e = r
+            beg, end = np.maximum(rec["pos0"], 0), rec["pos0"] + rec["rlen"]
+            same = np.array([c == names[tid].encode() for c in chrom], bool) if len(chrom) else np.zeros(0, bool)
+            idx = np.nonzero(same & (end > b) & (e > beg))[0]
+        for i in idx:
+            out.extend(range(int(i) * tidy_reps, int(i) * tidy_reps + tidy_reps))
+    return out
+
+
 def overlap_join(table, tid, beg, end):
     """Interval overlap join of read_bam rows with intervals (tid, beg, end) (half-open, 0-based, tid = header index).
     Semantics = cgranges cr_overlap (ref: third_party/cgranges/cgranges.c:255-297): interval i of the read's contig is reported iff

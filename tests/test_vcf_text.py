@@ -202,7 +202,7 @@ def test_gpu_vcf_text_through_the_table_function(tmp_path):
 @pytest.mark.gpu
 def test_gpu_region_on_vcf_text_through_the_table_function(tmp_path):
     """duckhts.test:399-403: a region naming a contig nobody knows yields no iterator, i.e. zero rows; without an index the reference's
-    message; a region that would need the text scan's own predicate is refused for now"""
+    message; a region the index knows is served (more in tests/test_vcf_region.py)"""
     import shutil
     from test_duckdb_surface import run_host
     fn = os.path.join(str(tmp_path), "no_contig.vcf.gz")
@@ -214,3 +214,7 @@ def test_gpu_region_on_vcf_text_through_the_table_function(tmp_path):
     assert rc == 0 and "rows=0 " in out                                              # duckhts.test:401-403
     rc, out, _ = run_host(fn, fn="read_bcf")
     assert rc == 0 and "rows=1 " in out                                              # duckhts.test:395-397
+    rc, out, _ = run_host(fn, named=[("region", "chr1:1-1000")], fn="read_bcf")      # chr1 has no ##contig line: the tabix index names it
+    assert rc == 0 and "rows=1 " in out
+    rc, out, _ = run_host(fn, named=[("region", "chr1:2-3,no_such_contig")], fn="read_bcf")
+    assert rc == 0 and "rows=0 " in out
