@@ -1149,8 +1149,12 @@ int dhts_bam_set_shard(dhts_ctx *c, int rank, int world) {
 // a scan that starts at the top of the file begins with the block that holds the first record (headers may span many blocks)
 static void skip_header_blocks(dhts_ctx *c) {
     if (c->shard_rank != 0 || c->n_blocks <= 0) return;
-    int64_t lo = 0, hi = c->n_blocks;                       // last block b with uoff[b] <= scan_first_uoff
-    while (hi - lo > 1) { int64_t mid = (lo + hi) / 2; if (c->h_uoff[mid] <= c->scan_first_uoff) lo = mid; else hi = mid; }
+    // the first block that ends behind scan_first_uoff; blocks that declare no bytes (ISIZE 0) at that position are not skipped: a damaged
+    // ISIZE of 0 on the block that holds the first record has to be seen by the inflate stage (round-2 soak, seed 2001161)
+    int64_t lo = 0, hi = c->n_blocks;
+    while (lo < hi) { int64_t mid = (lo + hi) / 2; if (c->h_uoff[mid + 1] > c->scan_first_uoff) hi = mid; else lo = mid + 1; }
+    while (lo > 0 && c->h_uoff[lo - 1] >= c->scan_first_uoff && c->h_isize[lo - 1] == 0) lo--;
+    if (lo >= c->n_blocks) { lo = c->n_blocks - 1; while (lo > 0 && c->h_uoff[lo] >= c->scan_first_uoff && c->h_uoff[lo - 1] >= c->scan_first_uoff) lo--; }
     if (lo >= c->shard_b0 && lo < c->shard_b1) c->next_block = lo;
 }
 

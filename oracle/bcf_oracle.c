@@ -1273,7 +1273,7 @@ int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, ui
         if (n_rows) *n_rows = s.n_rows;
         if (blob && materialise) {
             buf_t o = { 0 };
-            uint32_t nc = (uint32_t)s.ncol; uint64_t nr = (uint64_t)s.n_rows, fr = 0; int32_t st = status; uint32_t ns = 0;
+            uint32_t nc = (uint32_t)s.ncol; uint64_t nr = (uint64_t)s.n_rows, fr = 0; int32_t st = status; uint32_t ns = (uint32_t)s.h.n_smp;
             buf_push(&o, &nc, 4); buf_push(&o, &nr, 8); buf_push(&o, &st, 4); buf_push(&o, &fr, 8); buf_push(&o, &ns, 4);
             for (int i = 0; i < s.ncol; i++) ser_col(&o, &s.col[i], s.n_rows);
             { uint64_t nrec = (uint64_t)s.n_recs; buf_push(&o, &nrec, 8); buf_push(&o, s.rec_rid.p, s.rec_rid.n); buf_push(&o, s.rec_pos.p, s.rec_pos.n); buf_push(&o, s.rec_rlen.p, s.rec_rlen.n); }

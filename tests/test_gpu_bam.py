@@ -423,6 +423,28 @@ def test_wrong_isize_is_a_block_error_rows_before_kept(bogus):
             assert list(got[c]) == list(clean[c][:n]), c
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["first_record_block", "middle"])
+def test_an_isize_of_zero_on_a_data_block_is_reported(which):
+    """a block that declares no bytes takes no room in the inflated stream: when it is the block that holds the first record, the jump over
+    the header blocks used to jump over it as well (0 rows, clean end; round-2 soak seed 2001161)"""
+    data = bytearray(cases.case_basic(payload=65280 if which == "first_record_block" else 777, level=1, n=50 if which == "first_record_block" else 200, seed=2001161))
+    clean = orc.bam_read(bytes(data))
+    p, blocks = 0, []
+    while p + 18 <= len(data) and data[p:p + 4] == b"\x1f\x8b\x08\x04":
+        bl = struct.unpack_from("<H", data, p + 16)[0] + 1
+        blocks.append((p, bl)); p += bl
+    k = 1 if which == "first_record_block" else len(blocks) // 2
+    struct.pack_into("<I", data, blocks[k][0] + blocks[k][1] - 4, 0)
+    for mb in (0, 1, 2):
+        got = duckhts_amd.read_bam(bytes(data), max_blocks=mb)
+        assert got["status"] < 0 and got["n_rows"] < clean["n_rows"], (mb, got["status"], got["n_rows"])
+        if which == "first_record_block":
+            assert got["n_rows"] == 0
+        for c in COLS:
+            assert list(got[c]) == list(clean[c][:got["n_rows"]]), c
+
+
 # ---- next-batch prefetch: a caller that changes the batch size invalidates the prefetched phase B ---------------------------
 @pytest.mark.gpu
 def test_varying_batch_sizes_discard_the_prefetch():

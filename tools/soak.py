@@ -74,15 +74,15 @@ def main():
             while p + 18 <= len(data) and data[p:p + 4] == b"\x1f\x8b\x08\x04":
                 bl = struct.unpack_from("<H", data, p + 16)[0] + 1
                 blocks.append((p, bl)); p += bl
-            hit = []
+            orig = {}
             for _ in range(rnd.randint(1, 3)):
                 k = rnd.randrange(1, len(blocks))
                 at = blocks[k][0] + blocks[k][1] - 4
                 old = struct.unpack_from("<I", data, at)[0]
+                orig.setdefault(k, old)
                 new = rnd.choice([old ^ (1 << rnd.randrange(32)), 0xFFFF0000 + old, 0xFFFFFFFF, 0x80000000 | old, 65537, 65536, old + 1, rnd.getrandbits(32)])
                 struct.pack_into("<I", data, at, new & 0xFFFFFFFF)
-                if (new & 0xFFFFFFFF) != old:
-                    hit.append(k)
+            hit = [k for k, o in orig.items() if struct.unpack_from("<I", data, blocks[k][0] + blocks[k][1] - 4)[0] != o]   # (a second hit may restore the value)
             mb = rnd.choice([0, 1, 2, 5])
             got = {}
             try:
