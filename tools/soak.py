@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--regions", action="store_true", help="random (mostly malformed) region strings against the restatement of hts_parse_region / sam_itr_regarray")
     ap.add_argument("--surface", action="store_true", help="per seed: the DuckDB table functions through the mini host, random projections, chunk-exact against the oracle")
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
+    ap.add_argument("--vcfregions", action="store_true", help="per seed: a sorted bgzipped VCF with symbolic alleles / SVLEN / END / gVCF LEN, the tabix writer (TBI or CSI), random region queries vs the oracle's tabix interval rule")
     ap.add_argument("--isize", action="store_true", help="per seed: hostile ISIZE trailer values (bit flips, 0xFFFFxxxx, > 64 KiB) on random blocks: the scan must end at that block with the rows before it intact")
     ap.add_argument("--vcf", action="store_true", help="per seed: a VCF TEXT file (sites-only or with samples, plain or BGZF) of lines made from a grammar and then damaged character by character, wide or tidy, random batch sizes")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
@@ -238,6 +239,68 @@ def main():
                 msgs.append(f"vcf text: {type(e).__name__} {str(e)[:200]}")
             done += 1
             print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (vcf text: {len(lines)} lines{' samples' if smp else ''}{' tidy' if tidy else ''}, {exp['n_rows'] if 'exp' in dir() else '?'} rows)", flush=True)
+            bad += bool(msgs)
+            continue
+        if args.vcfregions:
+            # sorted bgzipped VCF text with every form the tabix interval rule looks at (symbolic alleles, SVLEN, END, gVCF LEN) -> the index
+            # writer (TBI or CSI) -> random regions: rows vs the oracle's tabix rule
+            import test_vcf_region as TR
+            import vcf_text_cases as V
+            hdr = V.SHDR[:-1] + ['##INFO=<ID=END,Number=1,Type=Integer,Description="d">', '##INFO=<ID=SVLEN,Number=.,Type=Integer,Description="d">',
+                                 '##FORMAT=<ID=LEN,Number=1,Type=Integer,Description="d">'] + (["##contig=<ID=chr3,length=%d>" % rnd.choice([5000, 10 ** 7, 3 * 10 ** 9])] if rnd.random() < 0.5 else []) + [V.SHDR[-1]]
+            names = rnd.sample(["chr1", "chr2", "chrUn", "chr3", "1", "HLA-A*01:01"], rnd.randint(1, 4))
+            lines = []
+            per = rnd.choice([30, 400, 3000])
+            for chrom in names:
+                pos = rnd.choice([0, 1, 1000])
+                for _ in range(per):
+                    pos += rnd.choice([0, 1, 1, rnd.randint(1, 50), rnd.randint(1, 20000)])
+                    alt = rnd.choice(["T", "T", "T,C", "<DEL>", "<DUP>", "<DUP:TANDEM>", "<INV>", "<CNV>", "<INS>", "<DELX>", "<*>", "T,<NON_REF>", "<DEL>,T,<DUP>", "."])
+                    inf = []
+                    if rnd.random() < 0.3:
+                        inf.append("SVLEN=" + ",".join(rnd.choice([".", "", str(rnd.randint(-30000, 30000)), "5x"]) for _ in range(rnd.randint(1, 3))))
+                    if rnd.random() < 0.3:
+                        inf.append(rnd.choice(["END=", "XEND=", "END=", "END="]) + rnd.choice([".", str(pos + rnd.randint(-5, 40000)), str(rnd.randint(0, 100)), "0x10", "12abc"]))
+                    if rnd.random() < 0.3:
+                        inf.append("DP=%d" % rnd.randint(0, 99))
+                    rnd.shuffle(inf)
+                    fmt = rnd.choice(["GT", "GT:LEN", "LEN:GT", "GT:GQ:LEN"])
+                    def smp():
+                        v = {"GT": "0/0", "GQ": str(rnd.randint(0, 99)), "LEN": rnd.choice([".", str(rnd.randint(0, 30000)), str(rnd.randint(0, 50))])}
+                        ks = fmt.split(":")
+                        return ":".join(v[k] for k in ks[:rnd.randint(1, len(ks))])
+                    lines.append("\t".join([chrom, str(pos), ".", rnd.choice(["A", "ACGT", "ACGTACGTACGTACGTAC"]), alt, ".", ".", ";".join(inf) or ".", fmt, smp(), smp(), smp()]))
+            data = bw.bgzf_file(V.text(lines, hdr=hdr), payload=rnd.choice([500, 3000, 65280]), level=rnd.choice([0, 1, 6]))
+            try:
+                ms = rnd.choice([0, 0, 14, 10, 16])
+                raw, index = TR.build_index(data, ms)
+                tidy = rnd.random() < 0.2
+                exp = orc.bcf_read(data, tidy)
+                reps = exp["n_samples"] if tidy else 1
+                chrom = orc.bcf_col_py(exp["by_name"]["CHROM"])[::reps]
+                if exp["status"] != 0 or exp["n_rows"] != len(lines) * reps:
+                    msgs.append(f"generator: oracle status {exp['status']} rows {exp['n_rows']}")
+                t = TR.parse_tabix(raw)
+                if [x.decode() for x in t["names"]] != names:
+                    msgs.append(f"index names {t['names']} vs {names}")
+                for _ in range(4):
+                    toks = []
+                    for _k in range(rnd.randint(1, 3)):
+                        nm = rnd.choice(names + ["nosuch"])
+                        if ":" in nm or rnd.random() < 0.1:
+                            nm = "{" + nm + "}"
+                        b = rnd.randint(1, 300000)
+                        toks.append(rnd.choice([nm, "%s:%d-%d" % (nm, b, b + rnd.choice([0, 10, 5000, 10 ** 6])), "%s:%d" % (nm, b), "%s:-%d" % (nm, b), "."]))
+                    rg = ",".join(toks)
+                    rows = ro.vcf_text_region_rows(exp, chrom, names, rg, reps)
+                    got = duckhts_amd.read_bcf(data, tidy=tidy, region=rg, index=index, max_blocks=rnd.choice([0, 1, 3]))
+                    d = orc.bcf_cols_diff(orc.bcf_take_rows(exp, rows), got)
+                    if d is not None:
+                        msgs.append(f"region {rg}: {d}")
+            except Exception as e:
+                msgs.append(f"vcf regions: {type(e).__name__} {str(e)[:200]}")
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs[:3])}  (vcf regions: {len(lines)} lines on {names}, index min_shift {ms})", flush=True)
             bad += bool(msgs)
             continue
         if args.surface:
