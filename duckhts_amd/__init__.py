@@ -78,7 +78,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
-           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_bcf_build_index", "dhts_bgzf_wrap", "dhts_bcf_batch_host_bytes", "dhts_bcf_batch_fetch", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
+           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_bcf_build_index", "dhts_bgzf_wrap", "dhts_bgzf_compress", "dhts_bgzip_file", "dhts_bgunzip_file", "dhts_bcf_batch_host_bytes", "dhts_bcf_batch_fetch", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
 
 
 def lib():
@@ -188,6 +188,29 @@ class Context:
     # ---- BGZF ----
     def bgzf_index(self):
         return self._chk(self.L.dhts_bgzf_index(self.h))
+
+    def bgzf_compress(self, raw, level=-1):
+        """bgzip on the device: raw bytes -> the bytes of a BGZF file (EOF block included)"""
+        buf = np.frombuffer(raw, dtype=np.uint8) if len(raw) else np.zeros(0, np.uint8)
+        f = self.L.dhts_bgzf_compress
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+        bound = self._chk(f(self.h, buf.ctypes.data, buf.nbytes, level, None, 0))
+        out = np.empty(bound, np.uint8)
+        n = self._chk(f(self.h, buf.ctypes.data, buf.nbytes, level, out.ctypes.data, bound))
+        return out[:n].tobytes()
+
+    def bgzip_file(self, src, dst, level=-1):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.L.dhts_bgzip_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._chk(self.L.dhts_bgzip_file(self.h, os.fsencode(src), os.fsencode(dst), level, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def bgunzip_file(self, src, dst):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.L.dhts_bgunzip_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._chk(self.L.dhts_bgunzip_file(self.h, os.fsencode(src), os.fsencode(dst), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def scan_window_stats(self):
         """(index windows, BGZF blocks) of the current scan range (the whole file without an index)"""

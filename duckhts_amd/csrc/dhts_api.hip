@@ -9,8 +9,10 @@
 #include "bcf_records.hip"
 #include "vcf_text.hip"
 #include "bam_tags.hip"
+#include "bgzf_deflate.hip"
 #include "bcf_header.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -219,6 +221,7 @@ struct dhts_ctx {
     struct Arena { const uint8_t *p = nullptr; uint64_t n = 0; } bcf_ar[4];      // device arenas of the last batch's columns: validity, fixed payloads, offsets, children / bytes
     bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
     // VCF text: a region names a sequence of the tabix index (tbx_name2id), so it is resolved when the index arrives (dhts_bcf_load_index)
+    DevBuf z_in, z_slots, z_sizes, z_offs, z_out;                           // bgzip: raw chunk, per-block slots / sizes / offsets, packed blocks
     bool bcf_rg_pending = false; std::string bcf_rg_tok; int32_t bcf_rg_itid = -1; std::vector<std::string> tbx_names;
     DevBuf b_keep, b_map, b_sel;
     DevBuf d_ctg_ok, d_id_ok, d_info_slot, d_fmt_slot, b_rec_off, b_dir, b_lens, b_offs, b_partial, b_total, b_coldev, b_fixed, b_valid, b_var;
@@ -1904,6 +1907,138 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
     }
     ib.save(c->built_index);
     return (int64_t)c->built_index.size();
+}
+
+// ---- bgzip / bgunzip (src/bgzip.c: bgzf_write / bgzf_read loops, htslib bgzf.c) ----------------------------------------------------------
+static const uint8_t BGZF_EOF_BLOCK[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// raw bytes already in z_in (n of them, padded) -> packed BGZF blocks in z_out; *out_len = their size
+static int bgzf_compress_device(dhts_ctx *c, uint64_t n, int level, uint64_t *out_len) {
+    const int64_t nblk = (int64_t)((n + DFL_IN - 1) / DFL_IN);
+    *out_len = 0;
+    if (nblk == 0) return 0;
+    ENSURE(c, c->z_slots, (size_t)nblk * DFL_SLOT + 64); ENSURE(c, c->z_sizes, (size_t)(nblk + 1) * 4 + 64); ENSURE(c, c->z_offs, (size_t)(nblk + 2) * 8 + 64);
+    hipLaunchKernelGGL(bgzf_deflate_blocks, dim3((unsigned)nblk), dim3(64), DFL_LDS_BYTES, c->stream, (const uint8_t *)c->z_in.p, n, nblk, level, (uint8_t *)c->z_slots.p, (uint32_t *)c->z_sizes.p);
+    HIPCHK(c, hipGetLastError());
+    const uint32_t *in1[1] = {(const uint32_t *)c->z_sizes.p}; uint64_t *o64[1] = {(uint64_t *)c->z_offs.p}; uint64_t total = 0;
+    if (run_scan(c, 1, in1, nullptr, o64, nblk, &total)) return -1;
+    ENSURE(c, c->z_out, total + 64);
+    hipLaunchKernelGGL(bgzf_pack_blocks, dim3((unsigned)nblk), dim3(64), 0, c->stream, (const uint8_t *)c->z_slots.p, (const uint32_t *)c->z_sizes.p, (const uint64_t *)c->z_offs.p, nblk, (uint8_t *)c->z_out.p);
+    HIPCHK(c, hipGetLastError());
+    *out_len = total;
+    return 0;
+}
+// GPU bgzip of a host buffer: one BGZF block per 0xff00 input bytes + the EOF block.  Returns the file size; with out == NULL or cap too small
+// nothing is written and the return value is an upper bound (call twice).  level 0 stores, 1..9 (and -1) compress (one setting).
+extern "C" int64_t dhts_bgzf_compress(dhts_ctx *c, const void *raw, uint64_t n, int level, void *out, uint64_t cap) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nblk = (n + DFL_IN - 1) / DFL_IN, bound = n + nblk * 31 + 28;
+    if (!out || cap < bound) return (int64_t)bound;
+    if (n >= (1ull << 40)) return fail(c, "input too large");
+    uint64_t done = 0, at = 0;
+    const uint64_t CH = (uint64_t)DFL_IN * 8192;                                  // 535 MB of input per launch
+    while (done < n) {
+        const uint64_t m = n - done < CH ? n - done : CH;
+        ENSURE(c, c->z_in, m + PAD_BYTES);
+        HIPCHK(c, hipMemcpyAsync(c->z_in.p, (const uint8_t *)raw + done, m, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync((uint8_t *)c->z_in.p + m, 0, PAD_BYTES, c->stream));
+        uint64_t ol = 0;
+        if (bgzf_compress_device(c, m, level, &ol)) return -1;
+        if (at + ol + 28 > cap) return fail(c, "internal: compressed size above its bound");
+        HIPCHK(c, hipMemcpyAsync((uint8_t *)out + at, c->z_out.p, ol, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        at += ol; done += m;
+    }
+    memcpy((uint8_t *)out + at, BGZF_EOF_BLOCK, 28);
+    return (int64_t)(at + 28);
+}
+// bgzip(path): file -> BGZF file (bgzip.c:231-293).  Returns 0, -2 input cannot be opened, -3 output cannot be opened, -4 read error, -5 write error.
+extern "C" int dhts_bgzip_file(dhts_ctx *c, const char *in_path, const char *out_path, int level, int64_t *bytes_in, int64_t *bytes_out) {
+    if (!c || !in_path || !out_path) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) { fail(c, "bgzip: cannot open input %s: %s", in_path, strerror(errno)); return -2; }
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) { close(fd); fail(c, "bgzip: cannot open output %s", out_path); return -3; }
+    const uint64_t CH = (uint64_t)DFL_IN * 4096;                                  // 267 MB of input per launch
+    uint8_t *pin = (uint8_t *)dhts_host_alloc(CH + CH / 1024 + (1u << 20));
+    int rc = 0; int64_t nin = 0, nout = 0;
+    if (!pin) { rc = -1; fail(c, "bgzip: out of pinned memory"); }
+    if (level < 0 || level > 9) level = -1;
+    while (rc == 0) {
+        size_t got = 0;
+        while (got < CH) { const ssize_t r = read(fd, pin + got, CH - got); if (r < 0) { rc = -4; fail(c, "bgzip: read error"); break; } if (r == 0) break; got += (size_t)r; }
+        if (rc || got == 0) break;
+        uint64_t ol = 0;
+        if (c->z_in.ensure(got + PAD_BYTES)) { rc = -1; fail(c, "hipMalloc failed"); break; }
+        if (hipMemcpyAsync(c->z_in.p, pin, got, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemsetAsync((uint8_t *)c->z_in.p + got, 0, PAD_BYTES, c->stream) != hipSuccess ||
+            bgzf_compress_device(c, got, level == 0 ? 0 : 6, &ol) || hipMemcpyAsync(pin, c->z_out.p, ol, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = -1; if (!*dhts_error(c)) fail(c, "bgzip: device error"); break;
+        }
+        if (fwrite(pin, 1, ol, fo) != ol) { rc = -5; fail(c, "bgzip: write error"); break; }
+        nin += (int64_t)got; nout += (int64_t)ol;
+        if (got < CH) break;
+    }
+    if (rc == 0 && fwrite(BGZF_EOF_BLOCK, 1, 28, fo) != 28) { rc = -5; fail(c, "bgzip: write error"); }
+    if (rc == 0) nout += 28;
+    if (pin) dhts_host_free(pin);
+    close(fd);
+    if (fclose(fo) != 0 && rc == 0) { rc = -5; fail(c, "bgzip: close error"); }
+    if (bytes_in) *bytes_in = nin;
+    if (bytes_out) *bytes_out = nout;
+    return rc;
+}
+// bgunzip(path): BGZF file -> the bytes it holds (bgzip.c:167-230: bgzf_read until 0).  Blocks are inflated on the device in batches.
+// Returns 0, -2 input cannot be opened / is not BGZF, -3 output cannot be opened, -4 a block failed (the reference: "bgunzip: read error"), -5 write error.
+extern "C" int dhts_bgunzip_file(dhts_ctx *c, const char *in_path, const char *out_path, int64_t *bytes_in, int64_t *bytes_out) {
+    if (!c || !in_path || !out_path) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    {
+        // a file that is not gzip at all is handed through as it is (bgzf_open "r" reads such a file transparently, bgzf.c:412-450, so the
+        // reference's bgunzip copies it): nothing to inflate, the copy is plain file I/O
+        const int fd = open(in_path, O_RDONLY);
+        if (fd < 0) { fail(c, "bgunzip: cannot open input %s", in_path); return -2; }
+        uint8_t magic[2] = {0, 0}; const ssize_t got = pread(fd, magic, 2, 0);
+        if (got == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            FILE *fo = fopen(out_path, "wb");
+            if (!fo) { close(fd); fail(c, "bgunzip: cannot open output %s: %s", out_path, strerror(errno)); return -3; }
+            std::vector<uint8_t> buf(1u << 20); int rc = 0; int64_t n = 0;
+            for (;;) { const ssize_t r = read(fd, buf.data(), buf.size()); if (r < 0) { rc = -4; fail(c, "bgunzip: read error"); break; } if (r == 0) break;
+                       if (fwrite(buf.data(), 1, (size_t)r, fo) != (size_t)r) { rc = -5; fail(c, "bgunzip: write error"); break; } n += r; }
+            close(fd);
+            if (fclose(fo) != 0 && rc == 0) { rc = -5; fail(c, "bgunzip: write error"); }
+            if (bytes_in) *bytes_in = n;
+            if (bytes_out) *bytes_out = n;
+            return rc;
+        }
+        close(fd);
+    }
+    if (dhts_open_path(c, in_path) != 0) return -2;
+    const int64_t nb = dhts_bgzf_index(c);
+    if (nb < 0 || (nb == 0 && c->comp_len > 0)) { if (nb == 0) fail(c, "bgunzip: %s is gzip but not BGZF (plain gzip is not read by this build)", in_path); return -2; }
+    if (c->bgzf_status != 0) { fail(c, "bgunzip: read error"); return -4; }
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) { fail(c, "bgunzip: cannot open output %s: %s", out_path, strerror(errno)); return -3; }
+    const int64_t B = 4096;
+    uint64_t cap = 0;
+    for (int64_t b = 0; b < nb; b += B) { const int64_t e = b + B < nb ? b + B : nb; if (c->h_uoff[e] - c->h_uoff[b] > cap) cap = c->h_uoff[e] - c->h_uoff[b]; }
+    uint8_t *pin = (uint8_t *)dhts_host_alloc(cap + 64);
+    std::vector<int32_t> bs(B);
+    int rc = pin ? 0 : -1; int64_t nout = 0;
+    for (int64_t b = 0; b < nb && rc == 0; b += B) {
+        const int64_t k = b + B < nb ? B : nb - b;
+        const int64_t got = dhts_bgzf_inflate_to_host(c, b, k, pin, cap, bs.data());
+        if (got < 0) { rc = -1; break; }
+        for (int64_t i = 0; i < k; i++) if (bs[i] != 0) { rc = -4; fail(c, "bgunzip: read error"); break; }
+        if (rc) break;
+        if (got > 0 && fwrite(pin, 1, (size_t)got, fo) != (size_t)got) { rc = -5; fail(c, "bgunzip: write error"); break; }
+        nout += got;
+    }
+    if (pin) dhts_host_free(pin);
+    if (fclose(fo) != 0 && rc == 0) { rc = -5; fail(c, "bgunzip: write error"); }
+    if (bytes_in) *bytes_in = (int64_t)c->file_size;
+    if (bytes_out) *bytes_out = nout;
+    return rc;
 }
 
 // raw bytes -> a valid BGZF file (what hts_idx_save writes a .csi / .tbi through): stored (uncompressed) DEFLATE blocks of up to 65,280

@@ -307,6 +307,15 @@ int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes
 /* CSI writer (src/hts_index_builder.c -> bcf_index_build3; htslib vcf.c:4657-4688, hts.c hts_idx_push / hts_idx_finish / idx_save_core):
  * one scan of the open BCF; the bytes (dhts_bam_index_bytes) are the UNCOMPRESSED index, dhts_bgzf_wrap (host only) turns raw bytes into
  * a valid BGZF file -- stored DEFLATE blocks + the EOF block -- which is what a .csi on disk is. */
+/* bgzip / bgunzip (src/bgzip.c:88-293 -> bgzf_write / bgzf_read, htslib bgzf.c): DEFLATE *compression* on the device, one wave per BGZF block
+ * (0xff00 input bytes each; fixed-Huffman code, hash-table match finder; a block that does not shrink is stored), CRC-32 and ISIZE included,
+ * EOF block appended.  level 0 stores; -1 and 1..9 all select the one compressing setting.  The bytes are not zlib's bytes (no two DEFLATE
+ * implementations agree); every reader returns the input.
+ * dhts_bgzf_compress: host buffer -> host buffer; returns the size, or an upper bound when out is NULL / cap is below that bound.
+ * dhts_bgzip_file / dhts_bgunzip_file: 0, -2 cannot open input (or not BGZF), -3 cannot open output, -4 read / block error, -5 write error. */
+int64_t dhts_bgzf_compress(dhts_ctx *, const void *raw, uint64_t n, int level, void *out, uint64_t cap);
+int dhts_bgzip_file(dhts_ctx *, const char *in_path, const char *out_path, int level, int64_t *bytes_in, int64_t *bytes_out);
+int dhts_bgunzip_file(dhts_ctx *, const char *in_path, const char *out_path, int64_t *bytes_in, int64_t *bytes_out);
 int64_t dhts_bcf_build_index(dhts_ctx *, int min_shift);          /* min_shift <= 0: 14, the default of bcf_index_build */
 /* On bgzipped VCF text the same call is the tabix writer (tbx_index_build3 with tbx_conf_vcf, tbx.c:437-510): min_shift <= 0 writes a TBI
  * (14 / 5 levels), > 0 a CSI whose depth follows the ##contig lengths (hts_adjust_csi_settings) and whose aux block is the tabix header;
