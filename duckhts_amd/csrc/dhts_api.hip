@@ -221,7 +221,7 @@ struct dhts_ctx {
     struct Arena { const uint8_t *p = nullptr; uint64_t n = 0; } bcf_ar[4];      // device arenas of the last batch's columns: validity, fixed payloads, offsets, children / bytes
     bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
     // VCF text: a region names a sequence of the tabix index (tbx_name2id), so it is resolved when the index arrives (dhts_bcf_load_index)
-    DevBuf z_in, z_slots, z_sizes, z_offs, z_out;                           // bgzip: raw chunk, per-block slots / sizes / offsets, packed blocks
+    DevBuf z_in, z_slots, z_sizes, z_offs, z_out, z_tok;                           // bgzip: raw chunk, per-block slots / sizes / offsets, packed blocks
     bool bcf_rg_pending = false; std::string bcf_rg_tok; int32_t bcf_rg_itid = -1; std::vector<std::string> tbx_names;
     DevBuf b_keep, b_map, b_sel;
     DevBuf d_ctg_ok, d_id_ok, d_info_slot, d_fmt_slot, b_rec_off, b_dir, b_lens, b_offs, b_partial, b_total, b_coldev, b_fixed, b_valid, b_var;
@@ -1917,7 +1917,9 @@ static int bgzf_compress_device(dhts_ctx *c, uint64_t n, int level, uint64_t *ou
     *out_len = 0;
     if (nblk == 0) return 0;
     ENSURE(c, c->z_slots, (size_t)nblk * DFL_SLOT + 64); ENSURE(c, c->z_sizes, (size_t)(nblk + 1) * 4 + 64); ENSURE(c, c->z_offs, (size_t)(nblk + 2) * 8 + 64);
-    hipLaunchKernelGGL(bgzf_deflate_blocks, dim3((unsigned)nblk), dim3(64), DFL_LDS_BYTES, c->stream, (const uint8_t *)c->z_in.p, n, nblk, level, (uint8_t *)c->z_slots.p, (uint32_t *)c->z_sizes.p);
+    if (level != 0) ENSURE(c, c->z_tok, (size_t)nblk * DFL_IN * 4 + 64);                  // the parse of every block: one word per token
+    hipLaunchKernelGGL(bgzf_deflate_blocks, dim3((unsigned)nblk), dim3(64), DFL_LDS_BYTES, c->stream, (const uint8_t *)c->z_in.p, n, nblk, level, (uint8_t *)c->z_slots.p, (uint32_t *)c->z_sizes.p,
+                       (uint32_t *)c->z_tok.p);
     HIPCHK(c, hipGetLastError());
     const uint32_t *in1[1] = {(const uint32_t *)c->z_sizes.p}; uint64_t *o64[1] = {(uint64_t *)c->z_offs.p}; uint64_t total = 0;
     if (run_scan(c, 1, in1, nullptr, o64, nblk, &total)) return -1;
@@ -1936,7 +1938,7 @@ extern "C" int64_t dhts_bgzf_compress(dhts_ctx *c, const void *raw, uint64_t n, 
     if (!out || cap < bound) return (int64_t)bound;
     if (n >= (1ull << 40)) return fail(c, "input too large");
     uint64_t done = 0, at = 0;
-    const uint64_t CH = (uint64_t)DFL_IN * 8192;                                  // 535 MB of input per launch
+    const uint64_t CH = (uint64_t)DFL_IN * 4096;                                  // 267 MB of input per launch
     while (done < n) {
         const uint64_t m = n - done < CH ? n - done : CH;
         ENSURE(c, c->z_in, m + PAD_BYTES);
