@@ -1756,7 +1756,12 @@ struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_fin
 }  // namespace
 
 // Builds a BAI for the open BAM with one full scan (the scan state is rewound before and after).  Returns the index size.
-int64_t dhts_bam_build_index(dhts_ctx *c) {
+static int64_t bam_build_index_impl(dhts_ctx *c, int min_shift);
+int64_t dhts_bam_build_index(dhts_ctx *c) { return bam_build_index_impl(c, 0); }
+// min_shift > 0: CSI with that min_shift, the depth from the longest reference (sam_index, htslib sam.c:989-1007: hts_adjust_csi_settings
+// from n_lvls = 0); min_shift <= 0: BAI
+extern "C" int64_t dhts_bam_build_index_csi(dhts_ctx *c, int min_shift) { return bam_build_index_impl(c, min_shift); }
+static int64_t bam_build_index_impl(dhts_ctx *c, int min_shift) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->bam_open) return fail(c, "dhts_bam_open not called");
@@ -1770,7 +1775,16 @@ int64_t dhts_bam_build_index(dhts_ctx *c) {
         if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
         return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
     };
-    BaiBuild ib; ib.init((int)c->ref_name.size(), tell(c->first_rec_uoff));
+    BaiBuild ib;
+    if (min_shift > 0) {
+        int64_t max_len = 0; for (uint32_t l : c->ref_len) if ((int64_t)l > max_len) max_len = l;
+        int n_lvls = 0;                                                              // hts_adjust_csi_settings (hts.c:2367-2400) from n_lvls = 0
+        const int64_t need = max_len + 256;
+        if (need <= (1ll << (min_shift + 27))) { int64_t maxpos = 1ll << min_shift; while (need > maxpos) { ++n_lvls; maxpos *= 8; } }
+        else { n_lvls = 9; int64_t maxpos = 1ll << (min_shift + 27); while (need > maxpos) { ++min_shift; maxpos *= 2; } }
+        ib.set_csi(min_shift, n_lvls);
+    }
+    ib.init((int)c->ref_name.size(), tell(c->first_rec_uoff));
     std::vector<int32_t> tid; std::vector<int64_t> pos, endp; std::vector<uint16_t> flag; std::vector<uint32_t> ro;
     dhts_bam_batch b;
     bool ok = true;
@@ -2668,6 +2682,7 @@ int dhts_bcf_open(dhts_ctx *c, int tidy_format) {
     return dhts_bcf_rewind(c);
 }
 
+extern "C" int dhts_bcf_is_text(const dhts_ctx *c) { return (!c || !c->bcf_open || !c->vcf_text) ? 0 : c->plain_text ? 2 : 1; }
 int dhts_bcf_info_get(const dhts_ctx *c, dhts_bcf_info *out) {
     if (!c || !c->bcf_open || !out) return -1;
     out->n_cols = (int32_t)c->bcf_colinfo.size(); out->cols = c->bcf_colinfo.data();

@@ -1034,6 +1034,8 @@ extern "C" __attribute__((visibility("default"), weak)) bool duckhts_init_c_api(
     }
     register_read_bcf_function(conn);                     // registration order of src/duckhts.c:54-71
     register_read_bam_function(conn);
+    register_bgzip_function(conn); register_bgunzip_function(conn);           // (the readers between them in src/duckhts.c are not on this path)
+    register_bam_index_function(conn); register_bcf_index_function(conn); register_tabix_index_function(conn);
     API(void, duckdb_disconnect, duckdb_connection *)(&conn);
     return true;
 }

@@ -214,6 +214,7 @@ int dhts_bam_rewind(dhts_ctx *);
  * hts_idx_push / hts_idx_finish / idx_save_core hts.c:2315-2818).  One whole-file scan of the open BAM; returns the size of the
  * index (bytes of a .bai file) kept in the context, or <0 (unsorted input, a record beyond 2^29, ... as in hts_idx_push).       */
 int64_t dhts_bam_build_index(dhts_ctx *);
+int64_t dhts_bam_build_index_csi(dhts_ctx *, int min_shift);   /* sam_index_build3(fn, fnidx, min_shift): > 0 writes a CSI (depth from the longest @SQ), <= 0 the BAI */
 int dhts_bam_index_bytes(dhts_ctx *, uint8_t *out, uint64_t cap);
 /* Interval overlap join on the scan (SURVEY 8(f) item 1 / BASELINE config 5).  The reference vendors cgranges
  * (third_party/cgranges, cr_add / cr_index / cr_overlap cgranges.c:255-297) as the model for joining read_bam rows with
@@ -278,6 +279,7 @@ typedef struct {
 
 int dhts_bcf_open(dhts_ctx *, int tidy_format);                      /* header + dictionaries + schema; positions the scan at the first record */
 int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
+int dhts_bcf_is_text(const dhts_ctx *);                              /* after dhts_bcf_open: 0 binary BCF, 1 bgzipped VCF text, 2 plain VCF text */
 int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /* default: every schema column */
 int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);
 /* ONE region of read_bcf(region := 'a,b,...'): the reference chains single-region iterators in the order given (src/bcf_reader.c:

@@ -39,7 +39,7 @@ typedef struct Bind { TF *tf; const char *path; char names[16][32]; char vals[16
 typedef struct Init { Bind *b; idx_t proj[1024]; idx_t nproj; void *data; duckdb_delete_callback_t del; idx_t max_threads; char err[1024]; int has_err; } Init;
 typedef struct Func { Bind *b; Init *g, *l; char err[1024]; int has_err; } Func;
 
-static TF g_tfs[8]; static int g_ntf = 0;
+static TF g_tfs[16]; static int g_ntf = 0;
 static void *g_api[DUCKDB_ABI_V120_NSLOTS];
 
 static void *h_malloc(size_t n) { return malloc(n); }
@@ -53,6 +53,7 @@ static duckdb_logical_type h_create_map_type(duckdb_logical_type k, duckdb_logic
 static void h_destroy_logical_type(duckdb_logical_type *t) { if (t && *t) { free(((LType *)*t)->child); free(*t); *t = NULL; } }
 static char *h_get_varchar(duckdb_value v) { Value *x = v; if (!x || !x->s) return NULL; char *r = malloc(strlen(x->s) + 1); strcpy(r, x->s); return r; }
 static bool h_get_bool(duckdb_value v) { Value *x = v; return x && x->b; }
+static int64_t h_get_int64(duckdb_value v) { Value *x = v; return (x && x->s) ? strtoll(x->s, NULL, 10) : 0; }
 static bool h_is_null_value(duckdb_value v) { Value *x = v; return !x || x->is_null; }
 static void h_destroy_value(duckdb_value *v) { if (v && *v) { Value *x = *v; free(x->s); free(x); *v = NULL; } }
 
@@ -237,7 +238,7 @@ int main(int argc, char **argv) {
 #define SET(name, fn) g_api[SLOT_##name] = (void *)(fn)
     SET(duckdb_malloc, h_malloc); SET(duckdb_free, h_free); SET(duckdb_vector_size, h_vector_size); SET(duckdb_connect, h_connect); SET(duckdb_disconnect, h_disconnect);
     SET(duckdb_create_logical_type, h_create_logical_type); SET(duckdb_create_list_type, h_create_list_type); SET(duckdb_create_map_type, h_create_map_type);
-    SET(duckdb_destroy_logical_type, h_destroy_logical_type); SET(duckdb_get_varchar, h_get_varchar); SET(duckdb_get_bool, h_get_bool); SET(duckdb_is_null_value, h_is_null_value);
+    SET(duckdb_destroy_logical_type, h_destroy_logical_type); SET(duckdb_get_varchar, h_get_varchar); SET(duckdb_get_bool, h_get_bool); SET(duckdb_get_int64, h_get_int64); SET(duckdb_is_null_value, h_is_null_value);
     SET(duckdb_destroy_value, h_destroy_value); SET(duckdb_create_table_function, h_create_table_function); SET(duckdb_destroy_table_function, h_destroy_table_function);
     SET(duckdb_table_function_set_name, h_tf_set_name); SET(duckdb_table_function_add_parameter, h_tf_add_parameter); SET(duckdb_table_function_add_named_parameter, h_tf_add_named);
     SET(duckdb_table_function_set_bind, h_tf_set_bind); SET(duckdb_table_function_set_init, h_tf_set_init); SET(duckdb_table_function_set_local_init, h_tf_set_local_init);
@@ -265,6 +266,8 @@ int main(int argc, char **argv) {
         memcpy(tab, g_api, sizeof(g_api));                 /* duckdb_ext_api = *res */
         duckdb_connection conn = NULL; h_connect(g_db, &conn);
         reg_bcf(conn); reg_bam(conn);                      /* src/duckhts.c:54-55 */
+        static const char *more[] = {"register_bgzip_function", "register_bgunzip_function", "register_bam_index_function", "register_bcf_index_function", "register_tabix_index_function"};
+        for (int k = 0; k < 5; k++) { void (*reg)(duckdb_connection) = dlsym(so, more[k]); if (reg) reg(conn); }     /* src/duckhts.c:61-65 */
         h_disconnect(&conn);
     } else {
         bool (*entry)(duckdb_extension_info, struct duckdb_extension_access *) = dlsym(so, "duckhts_init_c_api");

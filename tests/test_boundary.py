@@ -48,8 +48,13 @@ def test_direct_registration_without_the_entrypoint():
     """src/duckhts.c:54-55 order (read_bcf, then read_bam), names, named parameters (VARCHAR=17, BOOLEAN=1), pushdown"""
     want = ["TF read_bcf pushdown=1 bind=1 init=1 local_init=1 func=1 named=region:17,index_path:17,tidy_format:1",
             "TF read_bam pushdown=1 bind=1 init=1 local_init=1 func=1 named=region:17,index_path:17,reference:17,standard_tags:1,auxiliary_tags:1"]
+    want += ["TF bgzip pushdown=0 bind=1 init=1 local_init=0 func=1 named=output_path:17,threads:4,level:4,keep:1,overwrite:1",            # src/bgzip.c:336-357
+             "TF bgunzip pushdown=0 bind=1 init=1 local_init=0 func=1 named=output_path:17,threads:4,keep:1,overwrite:1",                 # :359-380
+             "TF bam_index pushdown=0 bind=1 init=1 local_init=0 func=1 named=index_path:17,min_shift:4,threads:4",                        # src/hts_index_builder.c:326-344
+             "TF bcf_index pushdown=0 bind=1 init=1 local_init=0 func=1 named=index_path:17,min_shift:4,threads:4",                        # :346-364
+             "TF tabix_index pushdown=0 bind=1 init=1 local_init=0 func=1 named=preset:17,index_path:17,min_shift:4,threads:4,seq_col:4,start_col:4,end_col:4,comment_char:17,skip_lines:4"]   # :366-390
     assert catalog(["--direct"]) == want
-    assert catalog([]) == want                              # the entrypoint registers the same two
+    assert catalog([]) == want                              # the entrypoint registers the same seven, in src/duckhts.c's order
 
 
 def test_direct_registration_binds_like_the_entrypoint():
@@ -58,6 +63,14 @@ def test_direct_registration_binds_like_the_entrypoint():
     assert host("--direct", duckhts_amd.LIB_PATH, "read_bam", "/no/such.bam") == (3, "ERROR bind: Failed to open SAM/BAM/CRAM file: /no/such.bam")
     assert host("--direct", duckhts_amd.LIB_PATH, "read_bcf", "") == (3, "ERROR bind: read_bcf requires a file path")
     assert host("--direct", duckhts_amd.LIB_PATH, "read_bcf", "/no/such.bcf") == (3, "ERROR bind: Failed to open BCF/VCF file: /no/such.bcf")
+    # src/bgzip.c:101-105,139-150; src/hts_index_builder.c:121-125,232-239
+    assert host(duckhts_amd.LIB_PATH, "bgzip", "") == (3, "ERROR bind: bgzip requires a file path")
+    assert host(duckhts_amd.LIB_PATH, "bgunzip", "") == (3, "ERROR bind: bgunzip requires a file path")
+    assert host(duckhts_amd.LIB_PATH, "bgzip", __file__, "-n", "output_path=" + __file__) == (3, f"ERROR bind: bgzip: output '{__file__}' already exists (use overwrite := TRUE to replace)")
+    assert host(duckhts_amd.LIB_PATH, "bam_index", "") == (3, "ERROR bind: bam_index requires a file path")
+    assert host(duckhts_amd.LIB_PATH, "bcf_index", "") == (3, "ERROR bind: bcf_index requires a file path")
+    assert host(duckhts_amd.LIB_PATH, "tabix_index", "") == (3, "ERROR bind: tabix_index requires a file path")
+    assert host(duckhts_amd.LIB_PATH, "tabix_index", "x.gz", "-n", "preset=bam") == (3, "ERROR bind: tabix_index: preset must be one of vcf, bed, gff, sam")
 
 
 @pytest.mark.gpu
