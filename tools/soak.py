@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--regions", action="store_true", help="random (mostly malformed) region strings against the restatement of hts_parse_region / sam_itr_regarray")
     ap.add_argument("--surface", action="store_true", help="per seed: the DuckDB table functions through the mini host, random projections, chunk-exact against the oracle")
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
+    ap.add_argument("--bgzip", action="store_true", help="per seed: an input of random texture and size through the device compressor; every member checked with zlib, the whole with the library's own inflate")
     ap.add_argument("--vcfregions", action="store_true", help="per seed: a sorted bgzipped VCF with symbolic alleles / SVLEN / END / gVCF LEN, the tabix writer (TBI or CSI), random region queries vs the oracle's tabix interval rule")
     ap.add_argument("--isize", action="store_true", help="per seed: hostile ISIZE trailer values (bit flips, 0xFFFFxxxx, > 64 KiB) on random blocks: the scan must end at that block with the rows before it intact")
     ap.add_argument("--vcf", action="store_true", help="per seed: a VCF TEXT file (sites-only or with samples, plain or BGZF) of lines made from a grammar and then damaged character by character, wide or tidy, random batch sizes")
@@ -239,6 +240,70 @@ def main():
                 msgs.append(f"vcf text: {type(e).__name__} {str(e)[:200]}")
             done += 1
             print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}  (vcf text: {len(lines)} lines{' samples' if smp else ''}{' tidy' if tidy else ''}, {exp['n_rows'] if 'exp' in dir() else '?'} rows)", flush=True)
+            bad += bool(msgs)
+            continue
+        if args.bgzip:
+            # bgzip on the device: inputs of every texture (random, runs, periodic, text, mixed; sizes around the block boundaries) must come back
+            # from zlib unchanged, block by block, with the container fields right; bgunzip of the result through the library's own inflate too
+            import gzip
+            import zlib
+            import struct
+            kind = rnd.choice(["random", "runs", "period", "text", "mixed", "lowent"])
+            size = rnd.choice([0, 1, 2, 3, 4, 5, 63, 64, 65, 257, 258, 259, 4000, 65279, 65280, 65281, 130560, 130561, rnd.randint(0, 400000), rnd.randint(0, 3000000)])
+            def gen(k, m):
+                if k == "random":
+                    return rnd.randbytes(m)
+                if k == "runs":
+                    out = bytearray()
+                    while len(out) < m:
+                        out += bytes([rnd.randrange(256)]) * rnd.choice([1, 2, 3, 4, 5, 257, 258, 259, 300, 1000, 70000])
+                    return bytes(out[:m])
+                if k == "period":
+                    per = rnd.choice([1, 2, 3, 4, 5, 7, 8, 255, 256, 32767, 32768, 32769, 40000])
+                    return (rnd.randbytes(per) * (m // per + 1))[:m]
+                if k == "text":
+                    words = [rnd.randbytes(rnd.randint(1, 12)).hex().encode() for _ in range(rnd.choice([5, 50, 2000]))]
+                    out = bytearray()
+                    while len(out) < m:
+                        out += rnd.choice(words) + rnd.choice([b" ", b"\t", b"\n", b"="])
+                    return bytes(out[:m])
+                if k == "lowent":
+                    return bytes(rnd.choice(b"\x00\x00\x00\x01\xff\x90") for _ in range(m))
+                out = bytearray()
+                while len(out) < m:
+                    out += gen(rnd.choice(["random", "runs", "period", "text", "lowent"]), rnd.randint(1, 70000))
+                return bytes(out[:m])
+            raw = gen(kind, size)
+            level = rnd.choice([-1, -1, 6, 1, 9, 0])
+            try:
+                ctx = duckhts_amd.Context(0)
+                try:
+                    z = ctx.bgzf_compress(raw, level)
+                    if z[-28:] != bw.EOF_BLOCK:
+                        msgs.append("no EOF block")
+                    p, at = 0, 0
+                    while p < len(z) - 28 and not msgs:
+                        bs = struct.unpack_from("<H", z, p + 16)[0] + 1
+                        if z[p:p + 4] != b"\x1f\x8b\x08\x04" or z[p + 10:p + 16] != b"\x06\x00BC\x02\x00" or bs > 65536:
+                            msgs.append(f"bad member header at {p}"); break
+                        piece = zlib.decompress(z[p + 18:p + bs - 8], -15)
+                        crc, isz = struct.unpack_from("<II", z, p + bs - 8)
+                        if piece != raw[at:at + 65280] or isz != len(piece) or crc != zlib.crc32(piece):
+                            msgs.append(f"member at {p}: payload / CRC / ISIZE differ"); break
+                        at += isz; p += bs
+                    if not msgs and (at != len(raw) or p != len(z) - 28):
+                        msgs.append(f"covered {at} of {len(raw)} bytes")
+                    if not msgs and len(raw):
+                        ctx.open(z); nb = ctx.bgzf_index()
+                        out, bst = ctx.bgzf_inflate(0, nb, len(raw))
+                        if bytes(out) != raw or any(bst):
+                            msgs.append("the library's own inflate disagrees")
+                finally:
+                    ctx.close()
+            except Exception as e:
+                msgs.append(f"bgzip: {type(e).__name__} {str(e)[:200]}")
+            done += 1
+            print(f"seed {seed}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs[:3])}  (bgzip {kind} {size} bytes level {level})", flush=True)
             bad += bool(msgs)
             continue
         if args.vcfregions:
