@@ -2309,6 +2309,123 @@ static int batch_end(dhts_ctx *c, const Batch &B, uint64_t carry_start, bool rec
     return 0;
 }
 
+// ---- tabix index of a bgzipped line format other than VCF (tbx_index_build3 / tbx_index, tbx.c:437-541, with tbx_conf_bed / _gff / _sam or
+// custom columns): the device finds the lines and their intervals (tabix_intervals), the host numbers the sequence names in order of first
+// appearance and feeds hts_idx_push.  min_shift <= 0: TBI.  The context needs dhts_open_path + dhts_bgzf_index only.
+extern "C" int64_t dhts_tabix_build_index(dhts_ctx *c, int preset, int sc, int bc, int ec, int meta_char, int line_skip, int min_shift) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_blocks <= 0 || c->plain_text) return fail(c, "tabix_index: the file is not BGZF");
+    if ((preset & 0xffff) == 2) return fail(c, "tabix_index: the vcf preset goes through dhts_bcf_build_index");
+    if ((preset & 0xffff) > 2) return fail(c, "tabix_index: preset not supported");
+    discard_prefetch(c);
+    c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1; c->wins.clear(); c->win_cur = 0; c->scan_end_uoff = ~0ull; c->rg_empty_window = false;
+    c->next_block = 0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0; c->huff_b0 = c->huff_nb = 0; c->scan_first_uoff = 0;
+    const bool tbi = min_shift <= 0;
+    if (tbi) min_shift = 14;
+    const int64_t nb = c->n_blocks;
+    auto tell = [&](uint64_t u) -> uint64_t {
+        const uint64_t *uo = c->h_uoff.data();
+        int64_t lo = 0, hi = nb + 1;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (uo[mid] < u) lo = mid + 1; else hi = mid; }
+        if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
+        return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
+    };
+    BaiBuild ib; bool inited = false; uint64_t last_off = tell(0); int64_t lineno = 0, max_ref_len = 0;
+    auto init_index = [&]() {
+        if (tbi) ib.tbi = true;
+        else {
+            int n_lvls = (31 - min_shift + 2) / 3;
+            if (max_ref_len) {
+                const int64_t need = max_ref_len + 256;
+                if (need <= (1ll << (min_shift + 27))) { int64_t maxpos = 1ll << (min_shift + 3 * n_lvls); while (need > maxpos) { ++n_lvls; maxpos *= 8; } }
+                else { n_lvls = 9; int64_t maxpos = 1ll << (min_shift + 27); while (need > maxpos) { ++min_shift; maxpos *= 2; } }
+            } else n_lvls = min_shift < 10 ? 9 : min_shift < 25 ? 9 - (min_shift - 10) / 3 : 4;
+            ib.set_csi(min_shift, n_lvls);
+        }
+        ib.init(0, last_off); inited = true;
+    };
+    std::vector<std::string> names; std::map<std::string, int32_t> tid_of; int32_t last_tid = -1;
+    std::vector<TbxLine> rows; std::vector<uint32_t> lo; std::string nm;
+    TbxConf cf = {preset, sc, bc, ec, meta_char, line_skip};
+    int rc = 0; std::string err;
+    for (;;) {
+        Batch B;
+        if (batch_begin(c, 0, B)) return -1;
+        const uint8_t *u = B.u; const uint64_t ulen = B.ulen, out_base = B.out_base;
+        uint64_t carry_start = ulen; int64_t nlines = 0; int last_open = 0;
+        if (ulen > 0) {
+            const int64_t nchunks = (int64_t)((ulen + VCF_CHUNK - 1) / VCF_CHUNK);
+            ENSURE(c, c->v_cnt, (size_t)nchunks * 4 + 64); ENSURE(c, c->v_base, (size_t)(nchunks + 1) * 4 + 64);
+            hipLaunchKernelGGL(vcf_line_count, dim3((unsigned)nchunks), dim3(256), 0, c->stream, u, (uint64_t)0, ulen, (uint32_t *)c->v_cnt.p, nchunks);
+            const uint32_t *kin[1] = {(const uint32_t *)c->v_cnt.p}; uint32_t *kout[1] = {(uint32_t *)c->v_base.p}; uint64_t nl = 0;
+            if (run_scan(c, 1, kin, kout, nullptr, nchunks, &nl)) return -1;
+            if (nl + 2 >= (1ull << 32)) return fail(c, "batch too large");
+            ENSURE(c, c->v_line_off, (size_t)(nl + 2) * 4 + 64);
+            hipLaunchKernelGGL(vcf_line_fill, dim3((unsigned)nchunks), dim3(256), 0, c->stream, u, (uint64_t)0, ulen, (const uint32_t *)c->v_base.p, (uint32_t *)c->v_line_off.p, nchunks);
+            lo.resize((size_t)nl + 2);
+            HIPCHK(c, hipMemcpyAsync(lo.data(), c->v_line_off.p, (size_t)(nl + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            nlines = (int64_t)nl; carry_start = lo[nl];
+            if (B.final_batch && lo[nl] < ulen) { nlines++; last_open = 1; carry_start = ulen; lo[nl + 1] = (uint32_t)ulen; }
+        }
+        if (nlines > 0) {
+            ENSURE(c, c->v_undef, (size_t)nlines * sizeof(TbxLine) + 64);
+            hipLaunchKernelGGL(tabix_intervals, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, c->stream, u, (const uint32_t *)c->v_line_off.p, nlines, ulen, last_open, cf, (TbxLine *)c->v_undef.p);
+            rows.resize((size_t)nlines);
+            HIPCHK(c, hipMemcpyAsync(rows.data(), c->v_undef.p, (size_t)nlines * sizeof(TbxLine), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < nlines && rc == 0; i++) {
+                const TbxLine &r = rows[(size_t)i];
+                ++lineno;
+                const uint64_t after = tell(out_base + ((last_open && i + 1 == nlines) ? ulen : (uint64_t)lo[(size_t)i + 1]));
+                if (lineno <= line_skip || r.flag == 1) {
+                    if (r.flag == 1 && !tbi && (preset & 0xffff) == 1) {                   // adjust_max_ref_len_sam (tbx.c:425-435): @SQ ... LN:
+                        const uint32_t l0 = lo[(size_t)i], l1 = (last_open && i + 1 == nlines) ? (uint32_t)ulen : lo[(size_t)i + 1] - 1u;
+                        std::string line(l1 - l0, '\0');
+                        if (l1 > l0) HIPCHK(c, hipMemcpy(&line[0], u + l0, l1 - l0, hipMemcpyDeviceToHost));
+                        if (line.compare(0, 3, "@SQ") == 0) { const size_t q = line.find("\tLN:", 3); if (q != std::string::npos) { const long long len = strtoll(line.c_str() + q + 4, nullptr, 10); if (len > max_ref_len) max_ref_len = len; } }
+                    }
+                    last_off = after; continue;
+                }
+                if (!inited) init_index();
+                if (r.flag == 2) { rc = -1; err = "Failed to parse the line (was the wrong preset used?)"; break; }
+                int32_t tid = last_tid;
+                if (!r.same || last_tid < 0) {
+                    nm.assign(r.name_len, '\0');
+                    if (r.name_len) HIPCHK(c, hipMemcpy(&nm[0], u + r.name_off, r.name_len, hipMemcpyDeviceToHost));
+                    auto it = tid_of.find(nm);
+                    if (it == tid_of.end()) { tid = (int32_t)names.size(); tid_of[nm] = tid; names.push_back(nm); } else tid = it->second;
+                    last_tid = tid;
+                }
+                if (!ib.push(tid, r.beg, r.end, after, true)) { rc = -1; err = ib.err; }
+            }
+        }
+        if (rc) break;
+        int32_t status = 0;
+        if (batch_end(c, B, carry_start, false, false, &status)) return -1;
+        if (status == 1) break;
+        if (status < 0) { rc = -1; err = "the BGZF stream ended on an error"; break; }
+    }
+    discard_prefetch(c);
+    c->next_block = 0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+    if (rc) return fail(c, "tabix_index: %s", err.c_str());
+    if (!inited) init_index();
+    uint64_t fin = c->comp_len;
+    if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
+    ib.finish(fin << 16);
+    {
+        const uint32_t conf[6] = {(uint32_t)preset, (uint32_t)sc, (uint32_t)bc, (uint32_t)ec, (uint32_t)meta_char, (uint32_t)line_skip}; uint32_t l_nm = 0;
+        for (auto &x : names) l_nm += (uint32_t)x.size() + 1;
+        auto w32 = [&](uint32_t x) { for (int k = 0; k < 4; k++) ib.aux.push_back((uint8_t)(x >> (8 * k))); };
+        for (uint32_t x : conf) w32(x);
+        w32(l_nm);
+        for (auto &x : names) { ib.aux.insert(ib.aux.end(), x.begin(), x.end()); ib.aux.push_back(0); }
+    }
+    ib.save(c->built_index);
+    return (int64_t)c->built_index.size();
+}
+
 static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out);
 int dhts_bam_next_batch(dhts_ctx *c, int64_t max_blocks, uint32_t colmask, dhts_bam_batch *out) {
     if (!c || !out) return -1;

@@ -121,12 +121,17 @@ void bgunzip_bind(duckdb_bind_info info) { bgzip_bind_common(info, true); }
 // ---- index builders (src/hts_index_builder.c:111-325) ----
 // kind 0: sam_index_build3 (sam.c:1029-1069), 1: bcf_index_build3 (vcf.c:4700-4742), 2: tbx_index_build3 with the VCF preset (tbx.c:526-541).
 // Returns htslib's code: 0, -1 indexing failed, -2 cannot open, -3 format not indexable, -4 the index could not be saved.
-int build_index_file(int kind, const std::string &path, const std::string &index_path, int min_shift, bool *wrote_csi) {
+struct TbxConfHost { int preset, sc, bc, ec, meta, skip; };
+int build_index_file(int kind, const std::string &path, const std::string &index_path, int min_shift, bool *wrote_csi, const TbxConfHost *conf = nullptr) {
     dhts_ctx *c = dhts_create(device_id());
     if (!c) return -1;
     int rc = 0; int64_t n = -1; bool csi = false, compressed = false;
     if (dhts_open_path(c, path.c_str()) != 0) rc = kind == 2 ? -1 : -2;
     else if (dhts_bgzf_index(c) <= 0) rc = kind == 0 ? -3 : kind == 1 ? -3 : -2;       // not BGZF
+    else if (kind == 2 && conf && (conf->preset & 0xffff) != 2) {                           // bed / gff / sam / custom columns: lines, not VCF records
+        n = dhts_tabix_build_index(c, conf->preset, conf->sc, conf->bc, conf->ec, conf->meta, conf->skip, min_shift);
+        csi = min_shift > 0; compressed = true; if (n < 0) rc = -1;
+    }
     else if (kind == 0) {
         if (dhts_bam_open(c) != 0) rc = -3;                                                // SAM / CRAM: not read by this build
         else { n = dhts_bam_build_index_csi(c, min_shift); csi = min_shift > 0; compressed = csi; if (n < 0) rc = -1; }
@@ -167,23 +172,29 @@ void index_bind_common(duckdb_bind_info info, int kind) {
     if (path.empty()) { bind_error(info, std::string(fn) + " requires a file path"); return; }
     int64_t min_shift = kind == 1 && ends_with(path, ".bcf") ? 14 : 0, threads = 4, v = 0;
     std::string index_path = take(named_varchar(info, "index_path"));
+    TbxConfHost conf = {2, 1, 2, 0, '#', 0};                                           // tbx_conf_vcf (tbx.c:55)
     if (kind == 2) {
         const std::string preset = take(named_varchar(info, "preset"));
-        if (!preset.empty() && preset != "vcf" && preset != "bed" && preset != "gff" && preset != "sam") { bind_error(info, "tabix_index: preset must be one of vcf, bed, gff, sam"); return; }
-        bool custom = false;
-        custom |= named_int(info, "seq_col", &v) && v != 1; custom |= named_int(info, "start_col", &v) && v != 2; custom |= named_int(info, "end_col", &v) && v != 0;
-        custom |= named_int(info, "skip_lines", &v) && v != 0;
+        if (preset.empty() || preset == "vcf") {}
+        else if (preset == "bed") conf = {0x10000, 1, 2, 3, '#', 0};                   // tbx_conf_bed / _gff / _sam (tbx.c:43-52)
+        else if (preset == "gff") conf = {0, 1, 4, 5, '#', 0};
+        else if (preset == "sam") conf = {1, 3, 4, 0, '@', 0};
+        else { bind_error(info, "tabix_index: preset must be one of vcf, bed, gff, sam"); return; }
+        if (named_int(info, "seq_col", &v)) conf.sc = (int)v;                           // hts_index_builder.c:264-287
+        if (named_int(info, "start_col", &v)) conf.bc = (int)v;
+        if (named_int(info, "end_col", &v)) conf.ec = (int)v;
         const std::string cc = take(named_varchar(info, "comment_char"));
-        custom |= !cc.empty() && cc[0] != '#';
-        if ((!preset.empty() && preset != "vcf") || custom) {
-            bind_error(info, "tabix_index: this build indexes the vcf preset only (the files read_bcf reads); bed / gff / sam and custom columns are not on its path"); return;
+        if (!cc.empty()) conf.meta = (unsigned char)cc[0];
+        if (named_int(info, "skip_lines", &v)) conf.skip = (int)v;
+        if ((conf.preset & 0xffff) == 2 && (conf.sc != 1 || conf.bc != 2 || conf.ec != 0 || conf.meta != '#' || conf.skip != 0)) {
+            bind_error(info, "tabix_index: the vcf preset with other columns / comment character / skipped lines is not supported by this build"); return;
         }
     }
     if (named_int(info, "min_shift", &v)) min_shift = v;
     (void)named_int(info, "threads", &threads);
     const bool cram = kind == 0 && ends_with(path, ".cram");
     const std::string target = !index_path.empty() ? index_path : path + (cram ? ".crai" : min_shift > 0 ? ".csi" : kind == 0 ? ".bai" : ".tbi");
-    const int rc = build_index_file(kind, path, target, (int)min_shift, nullptr);
+    const int rc = build_index_file(kind, path, target, (int)min_shift, nullptr, kind == 2 ? &conf : nullptr);
     if (rc != 0) {
         char err[1024]; snprintf(err, sizeof(err), "%s: failed to build index for %s (error %d)", fn, path.c_str(), rc);
         bind_error(info, err); return;

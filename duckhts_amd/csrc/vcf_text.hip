@@ -259,6 +259,61 @@ __device__ __forceinline__ long long vcf_tabix_end(const uint8_t *u, long long b
     return end;
 }
 
+// ---- tabix_index for the line formats other than VCF (tbx_parse1 with the generic / UCSC / SAM presets, tbx.c:96-178, 300-312) --------------------
+// One lane per line: flag 1 = a meta line (first byte == meta) -- skipped by the indexer --, 2 = the line does not parse, 0 = interval
+// [beg, end) on the sequence named by u[name_off, name_off + name_len); same = the name equals the previous line's (so that the host looks at
+// a name only where it changes).
+struct TbxLine { uint32_t name_off, name_len; long long beg, end; uint32_t flag, same; };
+struct TbxConf { int32_t preset, sc, bc, ec, meta, skip; };
+extern "C" __global__ void __launch_bounds__(256)
+tabix_intervals(const uint8_t *__restrict__ u, const uint32_t *__restrict__ line_off, int64_t nlines, uint64_t text_end, int32_t last_open, TbxConf cf, TbxLine *__restrict__ out) {
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nlines) return;
+    const uint32_t l0 = line_off[li];
+    uint32_t l1 = (li + 1 < nlines || !last_open) ? line_off[li + 1] - 1u : (uint32_t)text_end;
+    if (l1 > l0 && u[l1 - 1] == '\r') l1--;                                      // bgzf_getline drops a CR in front of the newline (bgzf.c:2328)
+    TbxLine r; r.name_off = l0; r.name_len = 0; r.beg = -1; r.end = -1; r.flag = 0; r.same = 0;
+    if (l1 > l0 && u[l0] == (uint8_t)cf.meta) { r.flag = 1; out[li] = r; return; }
+    bool have_name = false, bad = false;
+    int id = 1; uint32_t b = l0;
+    for (uint32_t i = l0; i <= l1 && !bad; i++) {
+        if (i < l1 && u[i] != '\t' && u[i] != 0) continue;                       // (a NUL ends the line for tbx_parse1's C strings)
+        if (id == cf.sc) { r.name_off = b; r.name_len = i - b; have_name = true; }
+        else if (id == cf.bc) {
+            uint32_t adv = 0; r.beg = vcf_strtoll(u, b, i, 0, &adv);
+            if (cf.bc <= cf.ec) r.end = r.beg;
+            if (adv == 0) { bad = true; break; }
+            if (!(cf.preset & 0x10000)) --r.beg; else if (cf.bc <= cf.ec) ++r.end;
+            if (r.beg < 0) r.beg = 0;
+            if (r.end < 1) r.end = 1;
+        } else if ((cf.preset & 0xffff) == 0) {
+            if (id == cf.ec) { uint32_t adv = 0; r.end = vcf_strtoll(u, b, i, 0, &adv); if (adv == 0) { bad = true; break; } }
+        } else if ((cf.preset & 0xffff) == 1 && id == 6) {                       // SAM: reference length of the CIGAR
+            long long l = 0;
+            for (uint32_t s = b; s < i;) {
+                uint32_t adv = 0; const long long x = vcf_strtoll(u, s, i, 10, &adv);
+                const uint32_t t = s + adv; const uint8_t op = t < i ? (u[t] & 0xdf) : 0;
+                if (op == 'M' || op == 'D' || op == 'N') l += (int)x;
+                s = t + 1;
+            }
+            if (l == 0) l = 1;
+            r.end = r.beg + l;
+        }
+        if (i < l1 && u[i] == 0) break;
+        b = i + 1; ++id;
+    }
+    if (bad || !have_name || r.beg < 0 || r.end < 0) r.flag = 2;
+    if (r.flag == 0 && li > 0) {
+        // the previous line's name: parsed again (cheap: the name column is among the first)
+        const uint32_t p0 = line_off[li - 1]; uint32_t p1 = line_off[li] - 1u; if (p1 > p0 && u[p1 - 1] == '\r') p1--;
+        int pid = 1; uint32_t pb = p0, pn0 = 0, pn1 = 0; bool got = false;
+        if (!(p1 > p0 && u[p0] == (uint8_t)cf.meta))
+            for (uint32_t i = p0; i <= p1; i++) { if (i < p1 && u[i] != '\t' && u[i] != 0) continue; if (pid == cf.sc) { pn0 = pb; pn1 = i; got = true; break; } if (i < p1 && u[i] == 0) break; pb = i + 1; ++pid; }
+        if (got && pn1 - pn0 == r.name_len) { uint32_t k = 0; while (k < r.name_len && u[pn0 + k] == u[r.name_off + k]) k++; r.same = k == r.name_len ? 1u : 0u; }
+    }
+    out[li] = r;
+}
+
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
 #define VCF_MAXF 32

@@ -309,6 +309,12 @@ int dhts_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes
 /* CSI writer (src/hts_index_builder.c -> bcf_index_build3; htslib vcf.c:4657-4688, hts.c hts_idx_push / hts_idx_finish / idx_save_core):
  * one scan of the open BCF; the bytes (dhts_bam_index_bytes) are the UNCOMPRESSED index, dhts_bgzf_wrap (host only) turns raw bytes into
  * a valid BGZF file -- stored DEFLATE blocks + the EOF block -- which is what a .csi on disk is. */
+/* tabix index of a bgzipped line format other than VCF (tbx_index_build3 with tbx_conf_bed / _gff / _sam or custom columns, tbx.c:437-541):
+ * preset = TBX_GENERIC 0 | TBX_SAM 1 (| TBX_UCSC 0x10000 for 0-based half-open coordinates), sc / bc / ec = 1-based sequence, begin and end
+ * columns, meta_char / line_skip = lines the indexer passes over.  The context needs dhts_open_path + dhts_bgzf_index only.  The device finds
+ * the lines and their intervals (tbx_parse1), the host numbers the names in order of first appearance.  min_shift <= 0: TBI, else CSI.
+ * Returns the size of the (uncompressed) index, fetched with dhts_bam_index_bytes. */
+int64_t dhts_tabix_build_index(dhts_ctx *, int preset, int sc, int bc, int ec, int meta_char, int line_skip, int min_shift);
 /* bgzip / bgunzip (src/bgzip.c:88-293 -> bgzf_write / bgzf_read, htslib bgzf.c): DEFLATE *compression* on the device, one wave per BGZF block
  * (0xff00 input bytes each; fixed-Huffman code, hash-table match finder; a block that does not shrink is stored), CRC-32 and ISIZE included,
  * EOF block appended.  level 0 stores; -1 and 1..9 all select the one compressing setting.  The bytes are not zlib's bytes (no two DEFLATE

@@ -90,8 +90,27 @@ def test_gpu_index_table_functions(tmp_path):
     assert mine == ref
     assert one_row("tabix_index", vz, named=[("min_shift", "14"), ("index_path", os.path.join(d, "x.csi"))])[1] == [1, os.path.join(d, "x.csi"), "CSI"]
     assert TR.parse_tabix(open(os.path.join(d, "x.csi"), "rb").read()) == TR.parse_tabix(open(os.path.join(GOLD, "index.vcf.gz.csi"), "rb").read())
-    rc, out, _ = run_host(vz, named=[("preset", "bed")], fn="tabix_index")
-    assert rc == 3 and "vcf preset only" in out
+    # the other presets and custom columns: the reference's own tabix fixtures (gff: generic 1/4/5; two TSVs with custom columns, a skipped
+    # header line and '#' lines; bgzipped SAM with the sam preset: interval end from the CIGAR)
+    for data, gold, named in (("gff_file.gff.gz", "gff_file.gff.gz.tbi", [("preset", "gff")]),
+                              ("header_tabix.tsv.gz", "header_tabix.tsv.gz.tbi", [("preset", "gff"), ("seq_col", "1"), ("start_col", "2"), ("end_col", "2"), ("skip_lines", "1")]),
+                              ("meta_tabix.tsv.gz", "meta_tabix.tsv.gz.tbi", [("preset", "gff"), ("seq_col", "1"), ("start_col", "2"), ("end_col", "2"), ("skip_lines", "1"), ("comment_char", "#")]),
+                              ("rg.sam.gz", "rg.sam.gz.tbi", [("preset", "sam")])):
+        f = os.path.join(d, data); shutil.copy(os.path.join(GOLD, data), f)
+        assert one_row("tabix_index", f, named=named)[1] == [1, f + ".tbi", "TBI"]
+        mine, ref = TR.parse_tabix(open(f + ".tbi", "rb").read()), TR.parse_tabix(open(os.path.join(GOLD, gold), "rb").read())
+        assert mine == ref, (data, mine, ref)
+    bed = os.path.join(d, "t.bed")
+    open(bed, "wb").write(b"#track\nchrA\t0\t10\tx\nchrA\t5\t300000\ty\nchrB\t7\t8\tz\n")
+    one_row("bgzip", bed)
+    assert one_row("tabix_index", bed + ".gz", named=[("preset", "bed"), ("min_shift", "12")])[1] == [1, bed + ".gz.csi", "CSI"]
+    t = TR.parse_tabix(open(bed + ".gz.csi", "rb").read())
+    assert t["conf"] == (0x10000, 1, 2, 3, ord("#"), 0) and t["names"] == [b"chrA", b"chrB"] and t["min_shift"] == 12
+    assert [t["refs"][k][(1 << (3 * t["depth"] + 3)) // 7 + 1][1][1] for k in range(2)] == [(2, 0), (1, 0)]          # the pseudo-bin: records per sequence
+    open(bed, "wb").write(b"chrA\tx\t10\n")
+    one_row("bgzip", bed, named=[("overwrite", "true")])
+    rc, out, _ = run_host(bed + ".gz", named=[("preset", "bed")], fn="tabix_index")
+    assert rc == 3 and out == f"ERROR bind: tabix_index: failed to build index for {bed}.gz (error -1)"              # "expected int" (tbx.c:136)
     # bam_index: BAI equal to the golden one; CSI serves region queries like the BAI
     bam = os.path.join(d, "range.bam"); shutil.copy(os.path.join(GOLD, "range.bam"), bam)
     assert one_row("bam_index", bam)[1] == [1, bam + ".bai", "BAI"]
