@@ -866,6 +866,10 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
     return launch_lz(c, b0, nb, out, out_base, c->stream);
 }
 
+// how many blocks phase A may decode ahead of the batch that needs them (default 524,288: a whole 10 GB file in one launch, 67 GB of token /
+// literal scratch).  A caller that serves many queries from one process wants a scratch the device pool can keep: 196,608 blocks = two full
+// rounds of the 1,536 resident waves, 29 GB.
+extern "C" void dhts_set_super_blocks(dhts_ctx *c, int64_t n) { if (c && n >= 16384) c->super_blocks = n; }
 int64_t dhts_bgzf_inflate_to_host(dhts_ctx *c, int64_t blk0, int64_t nblk, uint8_t *out, uint64_t cap, int32_t *blk_status) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));

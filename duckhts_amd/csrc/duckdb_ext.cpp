@@ -291,6 +291,7 @@ static void producer_main(BamScan *g, Producer *p) {
     };
     dhts_ctx *c = dhts_create(p->device);
     if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
+    dhts_set_super_blocks(c, 196608);                    // a scratch the device pool keeps from query to query (29 GB instead of 67 GB for a 10 GB file)
     const double t_created = now_s() - t_start; double t_staged = 0;
     int rc;
     // a plain whole-file scan on one device starts decoding while the file is still being staged: the block table is built over the
@@ -794,6 +795,7 @@ static void bcf_producer_main(BcfScan *g) {
     };
     dhts_ctx *c = g->ctx = dhts_create(bind->device);
     if (!c) { finish("read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
+    dhts_set_super_blocks(c, 196608);
     if (dhts_open_path(c, bind->path.c_str()) != 0 || dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
         finish(std::string("Failed to open BCF/VCF file: ") + bind->path); return;
     }

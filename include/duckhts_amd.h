@@ -279,6 +279,7 @@ typedef struct {
 
 int dhts_bcf_open(dhts_ctx *, int tidy_format);                      /* header + dictionaries + schema; positions the scan at the first record */
 int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
+void dhts_set_super_blocks(dhts_ctx *, int64_t n_blocks);             /* phase A look-ahead (default 524,288 blocks = 67 GB of scratch for a 10 GB file); the table functions use 196,608 */
 int dhts_bcf_is_text(const dhts_ctx *);                              /* after dhts_bcf_open: 0 binary BCF, 1 bgzipped VCF text, 2 plain VCF text */
 int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /* default: every schema column */
 int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);
