@@ -2,10 +2,10 @@
 // bgzf_compress, htslib bgzf.c:509-620: every 0xff00 input bytes become one gzip member with the BC extra field, CRC-32 and ISIZE).
 //
 // One wave per BGZF block, three stages in one kernel:
-//   1. LZ77 parse.  64 consecutive input positions per step; lane i hashes the 4 bytes at its position into a 2^13-entry table of last
-//      positions in LDS (read the candidate, then insert) and verifies the candidate byte for byte (8 bytes per compare, up to 258): greedy,
-//      one candidate per position.  The greedy parse of the step is a walk over the lanes' step lengths (a wave-uniform loop over v_readlane,
-//      one iteration per token).  Tokens (literal, or length + distance) go to a per-block scratch in HBM; their symbols are counted in LDS.
+//   1. LZ77 parse.  64 consecutive input positions per step; lane i hashes the 4 bytes at its position into a table of 2^12 buckets of the two
+//      last positions in LDS (read the candidates, then insert) and verifies both byte for byte (8 bytes per compare, up to 258); the longer
+//      wins.  The parse of the step is a walk over the lanes' step lengths (a wave-uniform loop over v_readlane, one iteration per token) with
+//      zlib's one-position lazy evaluation: a match gives way to a literal when the next position holds a longer one (not at level 1).  Tokens (literal, or length + distance) go to a per-block scratch in HBM; their symbols are counted in LDS.
 //   2. Code construction.  Code lengths from the counts: len = ceil(log2(total / count)) capped at 15 (a Shannon code: satisfies Kraft by
 //      construction), then codes are shortened, most frequent symbol first, until the code is complete (Kraft sum exactly 1: inflate
 //      rejects incomplete literal/length codes).  The same for the 19-symbol code-length alphabet (cap 7).  Code lengths are sent with zero
@@ -163,34 +163,41 @@ bgzf_deflate_blocks(const uint8_t *__restrict__ in, uint64_t n_in, int64_t nblk,
             const bool hashable = p + 4 <= n;
             uint32_t v = 0;
             if (p < n) __builtin_memcpy(&v, src + p, 4);          // (the input buffer is padded: reading up to 3 bytes past n is safe)
-            const uint32_t h = (v * 2654435761u) >> (32 - DFL_HASH_BITS);
-            const uint32_t cand = hashable ? tab[h] : DFL_NONE;
-            __syncthreads();                                       // every lane has its candidate before the step's positions are entered
-            if (hashable) tab[h] = (uint16_t)p;
-            uint32_t len = 0;
-            if (cand != DFL_NONE && p - cand <= 32768u) {
-                uint32_t cv; __builtin_memcpy(&cv, src + cand, 4);
-                if (cv == v) {
-                    const uint32_t maxl = n - p < 258u ? n - p : 258u;
-                    len = 4;
-                    while (len < maxl) {
-                        uint64_t a, b; __builtin_memcpy(&a, src + p + len, 8); __builtin_memcpy(&b, src + cand + len, 8);
-                        const uint64_t x = a ^ b;
-                        if (x) { len += (uint32_t)(__builtin_ctzll(x) >> 3); break; }
-                        len += 8;
-                    }
-                    len = len > maxl ? maxl : len;
+            // buckets of two: [0] the most recent position with this hash, [1] the one before
+            const uint32_t h = ((v * 2654435761u) >> (32 - DFL_HASH_BITS + 1)) * 2u;
+            const uint32_t c0 = hashable ? tab[h] : DFL_NONE, c1 = hashable ? tab[h + 1] : DFL_NONE;
+            __syncthreads();                                       // every lane has its candidates before the step's positions are entered
+            if (hashable) { tab[h + 1] = (uint16_t)c0; tab[h] = (uint16_t)p; }      // (lanes of one bucket write the same [1]; one of them wins [0])
+            uint32_t len = 0, cand = DFL_NONE;
+            const uint32_t maxl = n - p < 258u ? n - p : 258u;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t cc = k ? c1 : c0;
+                if (cc == DFL_NONE || p - cc > 32768u || (k && cc == c0)) continue;
+                uint32_t cv; __builtin_memcpy(&cv, src + cc, 4);
+                if (cv != v) continue;
+                uint32_t l = 4;
+                while (l < maxl) {
+                    uint64_t a, b; __builtin_memcpy(&a, src + p + l, 8); __builtin_memcpy(&b, src + cc + l, 8);
+                    const uint64_t x = a ^ b;
+                    if (x) { l += (uint32_t)(__builtin_ctzll(x) >> 3); break; }
+                    l += 8;
                 }
+                l = l > maxl ? maxl : l;
+                if (l > len) { len = l; cand = cc; }                // (the nearer candidate wins a tie: shorter distance code)
             }
             const uint32_t step = len >= 4u ? len : 1u;
-            // greedy parse: walk the step lengths from the first uncovered position
+            // greedy parse with one step of look-ahead (zlib's lazy evaluation, deflate.c deflate_slow): a match gives way to a literal when the
+            // next position holds a longer one.  A walk over the step lengths from the first uncovered position, wave-uniform.
+            const uint32_t step_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)step, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane i gets lane i+1 (0 for lane 63)
+            const uint32_t eff = (step > 1u && step_next > step && level != 1) ? 1u : step;
             uint64_t sel = 0; uint32_t q = skip;
             const uint32_t lim = n - base < 64u ? n - base : 64u;
-            while (q < lim) { sel |= 1ull << q; q += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)q); }
+            while (q < lim) { sel |= 1ull << q; q += (uint32_t)__builtin_amdgcn_readlane((int)eff, (int)q); }
             skip = q - lim;                                        // (only meaningful when lim == 64; the last step ends the loop)
             if ((sel >> lane) & 1ull) {
                 const uint32_t idx = ntok + (uint32_t)__popcll(sel & ((1ull << lane) - 1ull));
-                if (step == 1u) { tok[idx] = v & 0xffu; atomicAdd(&cnt_l[v & 0xffu], 1u); }
+                if (eff == 1u) { tok[idx] = v & 0xffu; atomicAdd(&cnt_l[v & 0xffu], 1u); }
                 else {
                     uint32_t lc, leb, lev, dc, deb, dev;
                     dfl_len_code(len, lc, leb, lev); dfl_dist_code(p - cand - 1u, dc, deb, dev);
