@@ -1538,7 +1538,7 @@ int dhts_bcf_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     if (!whole) q.push_back({c->vcf_text ? c->bcf_rg_itid : c->bcf_rg_tid, c->bcf_rg_beg, c->bcf_rg_end});
     IdxWindow w;
     if (index_window(c, (const uint8_t *)bytes, n, q, whole, w)) return -1;
-    if (apply_window(c, w, whole, false)) return -1;
+    if (apply_window(c, w, whole, false, true)) return -1;         // disjoint windows, each cut exactly at its end (as for read_bam)
     return dhts_bcf_rewind(c);
 }
 
@@ -2827,6 +2827,7 @@ int dhts_bcf_set_projection(dhts_ctx *c, const int32_t *col_ids, int32_t n) {
 int dhts_bcf_set_region(dhts_ctx *c, const char *region) {
     if (!c || !c->bcf_open) return -1;
     c->bcf_rg_active = false; c->bcf_rg_all = false; c->rg_empty_window = false; c->bcf_rg_pending = false;
+    c->wins.clear(); c->win_cur = 0; c->scan_end_uoff = ~0ull;
     c->shard_b0 = 0; c->shard_b1 = c->n_blocks; c->shard_rank = 0; c->shard_world = 1; c->scan_first_uoff = c->first_rec_uoff;
     if (!region || !*region) return dhts_bcf_rewind(c);
     std::string tok(region);
@@ -2852,6 +2853,8 @@ int dhts_bcf_set_block_range(dhts_ctx *c, int64_t b0, int64_t b1, int speculativ
 
 int dhts_bcf_rewind(dhts_ctx *c) {
     if (!c) return -1;
+    discard_prefetch(c);
+    if (!c->wins.empty()) enter_window(c, 0);
     c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = c->rg_empty_window; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;
     skip_header_blocks(c);
@@ -3032,7 +3035,23 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     return 0;
 }
 
+static int bcf_next_batch_one(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out);
 int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
+    if (!c || !out) return -1;
+    for (;;) {
+        if (bcf_next_batch_one(c, max_blocks, out)) return -1;
+        // a region query with several index windows: the end of one window is the start of the next, not the end of the scan
+        if (out->status == 1 && c->win_cur + 1 < c->wins.size()) {
+            enter_window(c, c->win_cur + 1);
+            discard_prefetch(c);
+            c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = false; c->first_batch = true; c->ucur = 0;
+            out->status = 0;
+            if (out->n_rows == 0) continue;
+        }
+        return 0;
+    }
+}
+static int bcf_next_batch_one(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     if (!c || !out) return -1;
     memset(out, 0, sizeof(*out));
     for (auto &a : c->bcf_ar) { a.p = nullptr; a.n = 0; }
@@ -3069,7 +3088,11 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     const bool speculative = (start0 == NONE64);
     uint64_t first0 = NONE64, spec_from = 0; int spec_tries = 0; bool restoring = false;
     int64_t nrec = 0; uint64_t carry_start = 0; bool rec_err = false;
-    const uint64_t shard_end_u = B.sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
+    // the scan range ends with its last block (later shards / the rest of the file exist) or, for one of several index windows, exactly
+    // at the window's end: windows are disjoint, so no record is delivered twice
+    uint64_t shard_end_u = B.sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
+    if (c->scan_end_uoff < shard_end_u) shard_end_u = c->scan_end_uoff;
+    const bool cut_tail = B.sharded_tail || c->scan_end_uoff != ~0ull;
     bool shard_finished = false;
     const int reps = c->bsch.tidy ? c->bsch.n_samples : 1;
     const int D = 2 + st.n_info_f + st.n_fmt_f;
@@ -3080,7 +3103,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
         if (c->bcf_rg_pending) return fail(c, "read_bcf: a region query on VCF text needs the tabix index (dhts_bcf_load_index) before the scan");
         if (c->shard_rank != 0) return fail(c, "read_bcf: block-range shards that start inside the file are not supported on VCF text input yet");
         uint32_t rec0_text = 0;
-        const uint64_t lim = (B.sharded_tail && out_base + ulen > shard_end_u) ? shard_end_u - out_base : ~0ull;
+        const uint64_t lim = (cut_tail && out_base + ulen > shard_end_u) ? shard_end_u - out_base : ~0ull;
         if (vcf_text_records(c, B, st, nrec, carry_start, rec_err, rec0_text, stride, bad, lim, shard_finished)) return -1;
         rec0_off = rec0_text;
     } else
@@ -3134,7 +3157,7 @@ int dhts_bcf_next_batch(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *out) {
     }
     if (nrec > 0) {
         if (bad < (unsigned long long)nrec) { nrec = (int64_t)bad; rec_err = true; }    // the first bad record ends the scan (bcf_reader.c:1319-1349)
-        if (nrec > 0 && !c->vcf_text && B.sharded_tail && out_base + ulen > shard_end_u) {
+        if (nrec > 0 && !c->vcf_text && cut_tail && out_base + ulen > shard_end_u) {
             std::vector<uint32_t> ro(nrec);
             HIPCHK(c, hipMemcpyAsync(ro.data(), c->b_rec_off.p, nrec * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));

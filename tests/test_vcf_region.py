@@ -283,3 +283,47 @@ def test_gpu_region_on_vcf_text_through_the_table_function(tmp_path):
             rc, out, _ = run_host(fn, named=[("region", rg)], fn="read_bcf")
             assert rc == 0 and ("rows=%d " % want) in out, (rg, want, out)
         os.remove(fn + ext)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gap_mb", ["0", "0.01"])
+def test_gpu_disjoint_index_windows(gap_mb, monkeypatch):
+    """DHTS_WINDOW_GAP_MB=0 makes every merged index chunk a window of its own (the default, 32 MB, merges everything in files this small):
+    each window is cut exactly at its end, so no row comes twice, and the rows are the oracle's -- text and binary"""
+    import duckhts_amd
+    from duckhts_amd import synth
+    monkeypatch.setenv("DHTS_WINDOW_GAP_MB", gap_mb)
+    data = sv_text(450000, seed=9, payload=65280)                  # (large enough that bins keep their own chunks: compress_binning folds a bin of < 64 KiB into its parent)
+    for ms in (0, 10):
+        _, idx = build_index(data, ms)
+        ctx = duckhts_amd.Context(0)
+        nws = []
+        try:
+            ctx.open(data); ctx.bgzf_index()
+            sc = duckhts_amd.BcfScan(ctx)
+            for rg in ("chr1:1000000-1000100", "chr2:2000000-2000500", "chrUn:50000-51000", "chr1:3900000-3900010"):
+                assert sc.set_region(rg) and sc.load_index(idx)
+                nws.append(ctx.scan_window_stats()[0])
+        finally:
+            ctx.close()
+        print("index windows", gap_mb, ms, nws)
+        if gap_mb == "0":
+            assert max(nws) > 1, nws                                                    # long intervals sit in high bins: several chunks
+        for k, rg in enumerate(("chr1:1000000-1250000", "chr2:1-50,chr2:4200000-", "chrUn:1000000-1000100", "chr2:1500000-1500001,chr1:1500000-1500001")):
+            region_check(data, rg, idx, max_blocks=(0, 1, 5)[(k + ms) % 3])
+    import test_gpu_bcf as TB
+    big = synth.bcf_file(40000, seed=11, payload=2000)
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(big); ctx.bgzf_index(); duckhts_amd.BcfScan(ctx)
+        import ctypes as C
+        L = duckhts_amd.lib()
+        L.dhts_bcf_build_index.restype = C.c_int64; L.dhts_bcf_build_index.argtypes = [C.c_void_p, C.c_int]
+        n = L.dhts_bcf_build_index(ctx.h, 12)
+        raw = np.zeros(n, np.uint8); L.dhts_bam_index_bytes(ctx.h, raw.ctypes.data, n)
+        csi = ctx.bgzf_compress(raw.tobytes())
+    finally:
+        ctx.close()
+    for rg in ("chr1:1-3000000", "chr2:100000-5000000,chr1:1-10", "chrX", "chr5:1000000-1000001"):
+        for mb in (0, 2):
+            TB._region_check(big, rg, index=csi, max_blocks=mb)
