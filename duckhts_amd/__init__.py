@@ -78,7 +78,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
-           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_bcf_build_index", "dhts_bgzf_wrap", "dhts_bgzf_compress", "dhts_bgzip_file", "dhts_bgunzip_file", "dhts_bcf_is_text", "dhts_set_super_blocks", "dhts_bam_build_index_csi", "dhts_tabix_build_index", "dhts_bcf_batch_host_bytes", "dhts_bcf_batch_fetch", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
+           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_bcf_build_index", "dhts_bgzf_wrap", "dhts_bgzf_compress", "dhts_bgzip_file", "dhts_bgunzip_file", "dhts_bcf_is_text", "dhts_bcf_header_bytes", "dhts_bcf_region_segments", "dhts_set_super_blocks", "dhts_bam_build_index_csi", "dhts_tabix_build_index", "dhts_bcf_batch_host_bytes", "dhts_bcf_batch_fetch", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch"]
 
 
 def lib():
@@ -364,6 +364,16 @@ class Context:
         self.L.dhts_bam_region_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         self._chk(self.L.dhts_bam_region_segments(self.h, buf.ctypes.data, buf.nbytes, beg.ctypes.data, end.ctypes.data, cap, C.byref(n)))
         return None if n.value < 0 else (beg[:n.value].copy(), end[:n.value].copy())
+
+    def bcf_region_segments(self, regions, index_bytes, cap=4096):
+        """(header bytes, beg[], end[]) a read_bcf region query stages instead of the whole file, or None (dhts_bcf_region_segments)"""
+        buf = np.frombuffer(index_bytes, dtype=np.uint8)
+        beg, end, n = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64), C.c_int64(0)
+        self.L.dhts_bcf_header_bytes.restype = C.c_uint64
+        self.L.dhts_bcf_header_bytes.argtypes = [C.c_void_p]
+        self.L.dhts_bcf_region_segments.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        self._chk(self.L.dhts_bcf_region_segments(self.h, regions.encode(), buf.ctypes.data, buf.nbytes, beg.ctypes.data, end.ctypes.data, cap, C.byref(n)))
+        return None if n.value < 0 else (int(self.L.dhts_bcf_header_bytes(self.h)), beg[:n.value].copy(), end[:n.value].copy())
 
     def open_segments(self, path, header_bytes, beg, end):
         beg, end = np.ascontiguousarray(beg, np.uint64), np.ascontiguousarray(end, np.uint64)

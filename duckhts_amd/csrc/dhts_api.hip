@@ -221,6 +221,7 @@ struct dhts_ctx {
     struct Arena { const uint8_t *p = nullptr; uint64_t n = 0; } bcf_ar[4];      // device arenas of the last batch's columns: validity, fixed payloads, offsets, children / bytes
     bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
     // VCF text: a region names a sequence of the tabix index (tbx_name2id), so it is resolved when the index arrives (dhts_bcf_load_index)
+    std::vector<uint8_t> idx_cache; uint64_t idx_cache_len = 0, idx_cache_n = 0; const uint8_t *idx_cache_src = nullptr; uint8_t idx_cache_key[128] = {0};   // the last BGZF index, inflated
     DevBuf z_in, z_slots, z_sizes, z_offs, z_out, z_tok;                           // bgzip: raw chunk, per-block slots / sizes / offsets, packed blocks
     bool bcf_rg_pending = false; std::string bcf_rg_tok; int32_t bcf_rg_itid = -1; std::vector<std::string> tbx_names;
     DevBuf b_keep, b_map, b_sel;
@@ -1284,6 +1285,12 @@ struct IdxWindow { bool any = false; uint64_t vmin = ~0ull, vmax = 0, last_end =
 // the index bytes as stored in memory: a BGZF file (.csi, .tbi) is inflated on the device through a scratch context
 static int index_plain(dhts_ctx *c, const uint8_t *&d, uint64_t &n, std::vector<uint8_t> &inflated) {
     if (n >= 18 && d[0] == 0x1f && d[1] == 0x8b) {
+        // the same index comes back for every region of a query (and twice per region on text: names, then windows): inflate it once per
+        // context.  Identity = address, length and the bytes at both ends.
+        uint8_t key[128]; const uint64_t kn = n < 64 ? n : 64;
+        memset(key, 0, sizeof(key)); memcpy(key, d, kn); memcpy(key + 64, d + n - kn, kn);
+        if (c->idx_cache_src == d && c->idx_cache_n == n && memcmp(c->idx_cache_key, key, 128) == 0 && !c->idx_cache.empty()) { d = c->idx_cache.data(); n = c->idx_cache_len; return 0; }
+        const uint8_t *src0 = d; const uint64_t n0 = n;
         dhts_ctx *t = dhts_create(c->device);
         if (!t) return fail(c, "cannot create a scratch context for the index");
         int64_t nb = -1;
@@ -1297,7 +1304,8 @@ static int index_plain(dhts_ctx *c, const uint8_t *&d, uint64_t &n, std::vector<
         HIPCHK(c, hipSetDevice(c->device));
         if (got < 0) return fail(c, "index inflate failed");
         for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) return fail(c, "index inflate failed (block %lld)", (long long)k);
-        d = inflated.data(); n = tot;
+        c->idx_cache.swap(inflated); c->idx_cache_len = tot; c->idx_cache_src = src0; c->idx_cache_n = n0; memcpy(c->idx_cache_key, key, 128);
+        d = c->idx_cache.data(); n = tot;
     }
     return 0;
 }
@@ -1540,6 +1548,56 @@ int dhts_bcf_load_index(dhts_ctx *c, const void *bytes, uint64_t n) {
     if (index_window(c, (const uint8_t *)bytes, n, q, whole, w)) return -1;
     if (apply_window(c, w, whole, false, true)) return -1;         // disjoint windows, each cut exactly at its end (as for read_bam)
     return dhts_bcf_rewind(c);
+}
+
+// compressed bytes of the blocks that hold the header of the open BCF / VCF: what a region query stages in front of its index windows
+extern "C" uint64_t dhts_bcf_header_bytes(const dhts_ctx *c) {
+    if (!c || !c->bcf_open || c->n_blocks <= 0 || c->plain_text) return 0;
+    int64_t k = 0;
+    while (k + 1 < c->n_blocks && c->h_uoff[k + 1] < c->first_rec_uoff) k++;
+    return c->h_coff[k] + c->h_clen[k];
+}
+// The byte ranges of the file the regions of read_bcf(region := 'a,b,...') need, from a context that holds the header (dhts_bcf_open done;
+// the bind context of the table function): the union of every region's index windows, as dhts_bam_region_segments returns them.
+// *count = -1: the query needs the whole file (a "." region, or no usable index).  Regions the index does not know contribute nothing.
+extern "C" int dhts_bcf_region_segments(dhts_ctx *c, const char *regions, const void *index_bytes, uint64_t n, uint64_t *beg, uint64_t *end, int64_t cap, int64_t *count) {
+    if (!c || !c->bcf_open || !count || !regions) return -1;
+    *count = -1;
+    if (c->plain_text) return 0;
+    IdxWindow all; bool whole = false;
+    std::string csv(regions); size_t p = 0;
+    while (p <= csv.size() && !whole) {
+        size_t q = csv.find(',', p); if (q == std::string::npos) q = csv.size();
+        const std::string tok = csv.substr(p, q - p); p = q + 1;
+        if (tok.empty()) continue;
+        if (dhts_bcf_set_region(c, tok.c_str()) != 0) continue;                 // unknown contig: skipped by the scan as well
+        if (c->bcf_rg_all) { whole = true; break; }
+        if (c->vcf_text) { const int rc = bcf_text_index(c, (const uint8_t *)index_bytes, n); if (rc == 1) continue; if (rc < 0) return -1; }
+        std::vector<QIv> qv; qv.push_back({c->vcf_text ? c->bcf_rg_itid : c->bcf_rg_tid, c->bcf_rg_beg, c->bcf_rg_end});
+        IdxWindow w;
+        if (index_window(c, (const uint8_t *)index_bytes, n, qv, false, w)) return -1;
+        if (!w.any) continue;
+        all.any = true;
+        for (auto &x : merged_windows(w, true)) all.chunks.push_back(x);         // exactly the windows dhts_bcf_load_index will ask for
+    }
+    (void)dhts_bcf_set_region(c, nullptr);
+    if (whole) return 0;
+    std::vector<std::pair<uint64_t, uint64_t>> sg;
+    if (all.any) {
+        // (the union of the regions' windows: they may overlap; sorted and merged like one region's chunks)
+        std::sort(all.chunks.begin(), all.chunks.end());
+        std::vector<std::pair<uint64_t, uint64_t>> mg;
+        const uint64_t gap_bytes = (uint64_t)(getenv("DHTS_WINDOW_GAP_MB") ? atof(getenv("DHTS_WINDOW_GAP_MB")) : 32.0) * (1u << 20);
+        for (auto &x : all.chunks) {
+            if (!mg.empty() && (x.first >> 16) <= (mg.back().second >> 16) + gap_bytes) { if (x.second > mg.back().second) mg.back().second = x.second; }
+            else mg.push_back(x);
+        }
+        for (auto &x : mg) sg.push_back({x.first >> 16, x.second >> 16});
+    }
+    *count = (int64_t)sg.size();
+    if ((int64_t)sg.size() > cap) { *count = -1; return 0; }                     // too many ranges for the caller's room: the whole file
+    for (size_t k = 0; k < sg.size(); k++) { beg[k] = sg[k].first; end[k] = sg[k].second; }
+    return 0;
 }
 
 // the scan range becomes window k of a multi-window region query

@@ -660,6 +660,7 @@ struct BcfBind {
     std::string path, region;
     std::vector<std::string> regions;    // comma split, empty tokens dropped (parse_regions_duckdb, bcf_reader.c:423-446)
     std::string index_file; std::vector<uint8_t> index_bytes;
+    uint64_t header_bytes = 0; std::vector<uint64_t> seg_beg, seg_end; int64_t seg_count = -1;     // region query: header blocks + index windows are all that is staged
     dhts_ctx *ctx = nullptr;             // bind-time context: holds only the head of the file (header, dictionaries, schema)
     dhts_bcf_info inf;                   // schema of the bind context (column names / types live there)
     int has_index = 0, tidy = 0, device = 0;
@@ -758,6 +759,16 @@ static void bcf_read_bind(duckdb_bind_info info) {
         FILE *f = fopen(b->index_file.c_str(), "rb");
         if (f) { uint8_t tmp[65536]; size_t k; while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) b->index_bytes.insert(b->index_bytes.end(), tmp, tmp + k); fclose(f); }
     }
+    {
+        // only the header blocks and the index windows of the regions are staged (the reference seeks to the chunks): byte ranges from this
+        // context, which holds the header.  DHTS_SPARSE=0 stages the whole file.
+        static const bool env_nosparse = getenv("DHTS_SPARSE") && atoi(getenv("DHTS_SPARSE")) == 0;
+        if (!b->index_bytes.empty() && !b->regions.empty() && !env_nosparse) {
+            b->header_bytes = dhts_bcf_header_bytes(b->ctx);
+            b->seg_beg.resize(4096); b->seg_end.resize(4096);
+            if (b->header_bytes == 0 || dhts_bcf_region_segments(b->ctx, b->region.c_str(), b->index_bytes.data(), b->index_bytes.size(), b->seg_beg.data(), b->seg_end.data(), 4096, &b->seg_count) != 0) b->seg_count = -1;
+        }
+    }
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
     auto mklist = API(duckdb_logical_type, duckdb_create_list_type, duckdb_logical_type);
     auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);
@@ -796,7 +807,9 @@ static void bcf_producer_main(BcfScan *g) {
     dhts_ctx *c = g->ctx = dhts_create(bind->device);
     if (!c) { finish("read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);
-    if (dhts_open_path(c, bind->path.c_str()) != 0 || dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
+    const int orc = bind->seg_count >= 0 ? dhts_open_path_segments(c, bind->path.c_str(), bind->header_bytes, bind->seg_beg.data(), bind->seg_end.data(), bind->seg_count)
+                                         : dhts_open_path(c, bind->path.c_str());
+    if (orc != 0 || dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
         finish(std::string("Failed to open BCF/VCF file: ") + bind->path); return;
     }
     if (dhts_bcf_set_projection(c, g->proj.data(), (int32_t)g->proj.size()) != 0 || dhts_bcf_set_region(c, nullptr) != 0) { finish("Failed to open BCF/VCF file"); return; }

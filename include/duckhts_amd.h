@@ -204,6 +204,11 @@ int dhts_scan_window_stats(const dhts_ctx *, int64_t *n_windows, int64_t *n_bloc
  * device by the interval tbx_parse1 gives a line (tbx.c:96-312: REF length, SVLEN of <DEL>/<DUP>/<CNV>/<INV>, FORMAT/LEN, INFO/END).
  * Returns 0, 1 = the index does not know the region's sequence (no iterator: the reference skips the region), <0 on error.            */
 int dhts_bcf_load_index(dhts_ctx *, const void *index_bytes, uint64_t n);
+/* What a region query of read_bcf has to stage instead of the whole file (the reference seeks to the index chunks): the compressed bytes of
+ * the header blocks, and the union of the index windows of every region of 'a,b,...' as file byte ranges for dhts_open_path_segments
+ * (same conventions as dhts_bam_region_segments; *count = -1: stage the whole file).  Both on a context that holds the header. */
+uint64_t dhts_bcf_header_bytes(const dhts_ctx *);
+int dhts_bcf_region_segments(dhts_ctx *, const char *regions, const void *index_bytes, uint64_t n, uint64_t *beg, uint64_t *end, int64_t cap, int64_t *count);
 /* standard_tags := true (src/bam_reader.c:54-70, 920-966): the reference's 56-entry tag table, in its order */
 int dhts_bam_std_tag_count(void);
 int dhts_bam_std_tag_info(int idx, char name[3], char *type, char *subtype);   /* type: 'i' BIGINT, 'Z'/'A' VARCHAR, 'B' LIST(BIGINT) */

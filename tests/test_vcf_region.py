@@ -327,3 +327,65 @@ def test_gpu_disjoint_index_windows(gap_mb, monkeypatch):
     for rg in ("chr1:1-3000000", "chr2:100000-5000000,chr1:1-10", "chrX", "chr5:1000000-1000001"):
         for mb in (0, 2):
             TB._region_check(big, rg, index=csi, max_blocks=mb)
+
+
+@pytest.mark.gpu
+def test_gpu_region_queries_stage_only_their_windows(tmp_path, monkeypatch):
+    """read_bcf(region := ...) through the table function stages the header blocks and the regions' index windows, not the file (the reference
+    seeks to the chunks): same rows as with DHTS_SPARSE=0, a fraction of the bytes resident; text and binary"""
+    import duckhts_amd
+    from duckhts_amd import synth
+    from test_duckdb_surface import run_host
+    L = duckhts_amd.lib()
+    monkeypatch.setenv("DHTS_WINDOW_GAP_MB", "0.05")             # (the default, 32 MB, would merge every window of files this small)
+    data = sv_text(450000, seed=9, payload=65280)
+    _, tbi = build_index(data, 0)
+    big = synth.bcf_file(60000, seed=11)
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(big); ctx.bgzf_index(); duckhts_amd.BcfScan(ctx)
+        import ctypes as C
+        L.dhts_bcf_build_index.restype = C.c_int64; L.dhts_bcf_build_index.argtypes = [C.c_void_p, C.c_int]
+        n = L.dhts_bcf_build_index(ctx.h, 14)
+        raw = np.zeros(n, np.uint8); L.dhts_bam_index_bytes(ctx.h, raw.ctypes.data, n)
+        csi = ctx.bgzf_compress(raw.tobytes())
+    finally:
+        ctx.close()
+    for name, blob, index, ext, regions in (("t.vcf.gz", data, tbi, ".tbi", "chr1:1000000-1000100,chrUn:50000-51000,nosuch,chr2:4000000-"), ("b.bcf", big, csi, ".csi", "chr2:100000-5000000,chr1:1-10,chrX:1-3000000")):
+        fn = os.path.join(str(tmp_path), name)
+        open(fn, "wb").write(blob); open(fn + ext, "wb").write(index)
+        # C ABI: segments from a header context, a second context that holds only them
+        hdr = duckhts_amd.Context(0)
+        try:
+            hdr.open(fn); hdr.bgzf_index(); duckhts_amd.BcfScan(hdr)
+            seg = hdr.bcf_region_segments(regions, index)
+            assert seg is not None and len(seg[1]) >= 2
+            assert hdr.bcf_region_segments("chr1,.", index) is None                    # "." needs the whole file
+        finally:
+            hdr.close()
+        c2 = duckhts_amd.Context(0)
+        try:
+            c2.open_segments(fn, *seg); c2.bgzf_index()
+            assert L.dhts_resident_bytes(c2.h) < len(blob) // 3, (L.dhts_resident_bytes(c2.h), len(blob))
+            sc = duckhts_amd.BcfScan(c2)
+            total = 0
+            for rg in regions.split(","):
+                if not sc.set_region(rg) or not sc.load_index(index):
+                    continue
+                while True:
+                    b = sc.next_batch(3)
+                    total += b.n_rows
+                    if b.status != 0:
+                        assert b.status == 1, b.status
+                        break
+        finally:
+            c2.close()
+        want = duckhts_amd.read_bcf(blob, region=regions, index=index)["n_rows"]
+        assert total == want and want > 0
+        # the table function: same rows with and without sparse staging
+        outs = []
+        for env in ({}, {"DHTS_SPARSE": "0"}):
+            rc, out, _ = run_host(fn, named=[("region", regions)], fn="read_bcf", env=env)
+            assert rc == 0, out
+            outs.append(out.split("rows=")[1].split()[0])
+        assert outs[0] == outs[1] == str(want), (outs, want)
