@@ -732,7 +732,10 @@ static void bcf_read_bind(duckdb_bind_info info) {
         set_error(info, err); delete b; return;
     }
     int dev = getenv("DHTS_DEVICE") ? atoi(getenv("DHTS_DEVICE")) : 0;
+    static const bool trace_bcf_bind = getenv("DHTS_TRACE") != nullptr;
+    const double tb0 = now_s();
     b->ctx = dhts_create(dev); b->tidy = tidy; b->device = dev;
+    const double tb1 = now_s();
     if (!b->ctx) { set_error(info, "read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); destroy_bcf_bind(b); return; }
     // like the reference, bind reads the header only (bcf_open + bcf_hdr_read, bcf_reader.c:480-505): the head of the file is staged, four
     // times more whenever the header turns out to be longer; every scan stages the file in its own context (bcf_read_global_init)
@@ -753,6 +756,7 @@ static void bcf_read_bind(duckdb_bind_info info) {
         set_error(info, (m && strncmp(m, "read_bcf:", 9) == 0) ? m : "Failed to read BCF/VCF header");       // bcf_reader.c:505 (or what this build does not read yet)
         destroy_bcf_bind(b); return;
     }
+    const double tb2 = now_s();
     for (const std::string &f : {idx, b->path + ".csi", b->path + ".tbi"}) if (!f.empty() && file_exists(f)) { b->index_file = f; break; }
     b->has_index = !b->index_file.empty();
     if (b->has_index && !b->regions.empty()) {
@@ -769,6 +773,7 @@ static void bcf_read_bind(duckdb_bind_info info) {
             if (b->header_bytes == 0 || dhts_bcf_region_segments(b->ctx, b->region.c_str(), b->index_bytes.data(), b->index_bytes.size(), b->seg_beg.data(), b->seg_end.data(), 4096, &b->seg_count) != 0) b->seg_count = -1;
         }
     }
+    if (trace_bcf_bind) fprintf(stderr, "[dhts] read_bcf bind: context %.4f s, head of the file + block table + header %.4f s, index file + windows %.4f s (%lld byte ranges)\n", tb1 - tb0, tb2 - tb1, now_s() - tb2, (long long)b->seg_count);
     auto mk = API(duckdb_logical_type, duckdb_create_logical_type, int);
     auto mklist = API(duckdb_logical_type, duckdb_create_list_type, duckdb_logical_type);
     auto add = API(void, duckdb_bind_add_result_column, duckdb_bind_info, const char *, duckdb_logical_type);
@@ -804,17 +809,24 @@ static void bcf_producer_main(BcfScan *g) {
         if (!err.empty() && g->error.empty()) g->error = err;
         g->done = true; g->cv_ready.notify_all();
     };
+    static const bool trace = getenv("DHTS_TRACE") != nullptr;       // stage timings on stderr
+    const double t_start = now_s();
     dhts_ctx *c = g->ctx = dhts_create(bind->device);
     if (!c) { finish("read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);
+    const double t_ctx = now_s() - t_start;
     const int orc = bind->seg_count >= 0 ? dhts_open_path_segments(c, bind->path.c_str(), bind->header_bytes, bind->seg_beg.data(), bind->seg_end.data(), bind->seg_count)
                                          : dhts_open_path(c, bind->path.c_str());
     if (orc != 0 || dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
         finish(std::string("Failed to open BCF/VCF file: ") + bind->path); return;
     }
+    const double t_open = now_s() - t_start;
     if (dhts_bcf_set_projection(c, g->proj.data(), (int32_t)g->proj.size()) != 0 || dhts_bcf_set_region(c, nullptr) != 0) { finish("Failed to open BCF/VCF file"); return; }
     size_t next_region = 0;
     if (!bind->regions.empty() && !bcf_next_region(bind, c, &next_region)) { finish(""); return; }     // no region produced an iterator: zero rows (bcf_reader.c:955-959)
+    const double t_region = now_s() - t_start;
+    if (trace) fprintf(stderr, "[dhts] read_bcf producer dev %d: context %.4f s, staged + block table + header at %.4f s (%s, %llu bytes resident), first region set at %.4f s\n", bind->device, t_ctx, t_open,
+                       bind->seg_count >= 0 ? "header + index windows" : "whole file", (unsigned long long)dhts_resident_bytes(c), t_region);
     static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;
     for (;;) {
