@@ -2916,6 +2916,7 @@ int dhts_bcf_rewind(dhts_ctx *c) {
     c->next_block = c->shard_b0; c->carry_len = 0; c->stream_done = c->rg_empty_window; c->first_batch = true; c->ucur = 0;
     c->huff_b0 = c->huff_nb = 0;
     skip_header_blocks(c);
+    if (c->vcf_text && c->shard_rank != 0 && c->shard_b0 > 0 && c->wins.empty()) c->next_block = c->shard_b0 - 1;   // (the byte in front of the shard: see vcf_text_records)
     return 0;
 }
 
@@ -2947,8 +2948,29 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
                             uint64_t lim, bool &finished) {
     const uint8_t *u = B.u; const uint64_t ulen = B.ulen, out_base = B.out_base;
     uint64_t t0 = 0;
-    if (c->first_batch) { if (c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch"); t0 = c->scan_first_uoff - out_base; }
+    if (c->first_batch && c->shard_rank == 0) { if (c->scan_first_uoff < out_base) return fail(c, "internal: header beyond first batch"); t0 = c->scan_first_uoff - out_base; }
+    else if (c->first_batch) {
+        // a block-range shard that starts inside the file owns the lines that START at or behind its first block: lines synchronise on the
+        // newline, so the start is the byte behind the first newline at or after (shard start - 1); the batch begins one block early for that byte
+        const uint64_t U0 = c->h_uoff[c->shard_b0];
+        uint64_t q = U0 > out_base ? U0 - 1 - out_base : 0; bool found = U0 <= out_base;
+        std::vector<uint8_t> piece(1u << 16);
+        while (!found && q < ulen) {
+            const uint64_t k = ulen - q < piece.size() ? ulen - q : piece.size();
+            HIPCHK(c, hipMemcpy(piece.data(), u + q, k, hipMemcpyDeviceToHost));
+            const void *nl = memchr(piece.data(), '\n', k);
+            if (nl) { q += (uint64_t)((const uint8_t *)nl - piece.data()) + 1; found = true; } else q += k;
+        }
+        t0 = found ? q : ulen;
+        if (c->first_rec_uoff > out_base + t0) t0 = c->first_rec_uoff - out_base;     // (a shard that starts inside the header)
+    }
     nrec = 0; carry_start = ulen; rec_err = false; rec0_text = (uint32_t)t0; bad_rec = ~0ull;
+    if (c->first_batch) {
+        // a scan range that ends before its first line starts (a shard inside the header, a shard swallowed by one long line) owns no line
+        uint64_t end_abs = c->shard_b1 < c->n_blocks ? c->h_uoff[c->shard_b1] : ~0ull;
+        if (c->scan_end_uoff < end_abs) end_abs = c->scan_end_uoff;
+        if (out_base + t0 >= end_abs) { finished = true; carry_start = t0 < ulen ? t0 : ulen; return 0; }
+    }
     if (t0 >= ulen) { carry_start = ulen; return 0; }
     const int64_t nchunks = (int64_t)((ulen - (t0 & ~(uint64_t)15) + VCF_CHUNK - 1) / VCF_CHUNK);
     ENSURE(c, c->v_cnt, (size_t)nchunks * 4 + 64); ENSURE(c, c->v_base, (size_t)(nchunks + 1) * 4 + 64);
@@ -3159,7 +3181,6 @@ static int bcf_next_batch_one(dhts_ctx *c, int64_t max_blocks, dhts_bcf_batch *o
     uint32_t stride = 64;
     if (c->vcf_text) {
         if (c->bcf_rg_pending) return fail(c, "read_bcf: a region query on VCF text needs the tabix index (dhts_bcf_load_index) before the scan");
-        if (c->shard_rank != 0) return fail(c, "read_bcf: block-range shards that start inside the file are not supported on VCF text input yet");
         uint32_t rec0_text = 0;
         const uint64_t lim = (cut_tail && out_base + ulen > shard_end_u) ? shard_end_u - out_base : ~0ull;
         if (vcf_text_records(c, B, st, nrec, carry_start, rec_err, rec0_text, stride, bad, lim, shard_finished)) return -1;

@@ -218,3 +218,35 @@ def test_gpu_region_on_vcf_text_through_the_table_function(tmp_path):
     assert rc == 0 and "rows=1 " in out
     rc, out, _ = run_host(fn, named=[("region", "chr1:2-3,no_such_contig")], fn="read_bcf")
     assert rc == 0 and "rows=0 " in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["many_bgzf", "many_plain", "samples_many_bgzf", "undefined_names_bgzf_small_blocks"])
+def test_gpu_block_range_shards_of_text_concatenate(name):
+    """block-range shards on VCF text: a shard that starts inside the file owns the lines that START in its blocks (lines synchronise on the
+    newline; the line that runs out of a shard is finished from the next shard's blocks) -- every way of cutting reproduces the whole scan"""
+    import duckhts_amd
+    data = dict(CASES)[name]
+    exp = orc.bcf_read(data)
+    ctx = duckhts_amd.Context(0)
+    ctx.open(data)
+    nb = ctx.bgzf_index()
+    ctx.close()
+    if nb < 3:
+        pytest.skip("a single block")
+    for ways in (2, 3, min(7, nb), nb):
+        cuts = [nb * k // ways for k in range(ways + 1)]
+        spans, parts = [], []
+        for r in range(ways):
+            got = duckhts_amd.read_bcf(data, block_range=(cuts[r], cuts[r + 1], r > 0), max_blocks=(0, 1, 2)[r % 3])
+            if exp["status"] == 0:
+                assert got["status"] == 1, (name, ways, r, got["status"])
+            spans.append((got["first_rec_uoff"], got["end_uoff"], got["n_rows"]))
+            parts.append(got)
+        if exp["status"] == 0:
+            assert sum(p["n_rows"] for p in parts) == exp["n_rows"], (name, ways, [p["n_rows"] for p in parts])
+            for col in ("POS", "REF"):
+                key = "fixed" if col == "POS" else "sbytes"
+                assert np.array_equal(np.concatenate([p["by_name"][col][key] for p in parts if p["n_rows"]]), exp["by_name"][col][key]), (name, ways, col)
+            nonempty = [s for s in spans if s[2]]
+            assert duckhts_amd.check_handoff(nonempty) == exp["n_rows"]

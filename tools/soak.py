@@ -236,6 +236,21 @@ def main():
                     msgs.append("vcf text: " + d)
                 elif (got["status"] == 1) != (exp["status"] == 0):
                     msgs.append(f"vcf text status {got['status']} vs {exp['status']}")
+                if not msgs and exp["status"] == 0 and exp["n_rows"] > 0:
+                    # block-range shards of the text: every cut reproduces the scan (lines synchronise on the newline)
+                    c0 = duckhts_amd.Context(0); c0.open(data); nblk = c0.bgzf_index(); c0.close()
+                    if nblk >= 2:
+                        ways = rnd.randint(2, min(nblk, 6))
+                        cuts = sorted(rnd.sample(range(1, nblk), ways - 1)) if nblk > ways else list(range(1, nblk))
+                        cuts = [0] + cuts + [nblk]
+                        parts = [duckhts_amd.read_bcf(data, tidy=tidy, block_range=(cuts[r], cuts[r + 1], r > 0), max_blocks=rnd.choice([0, 1, 3])) for r in range(len(cuts) - 1)]
+                        if sum(p["n_rows"] for p in parts) != exp["n_rows"] or any(p["status"] != 1 for p in parts):
+                            msgs.append(f"text shards {cuts}: rows {[p['n_rows'] for p in parts]} status {[p['status'] for p in parts]} vs {exp['n_rows']}")
+                        else:
+                            import numpy as np
+                            pos = np.concatenate([p["by_name"]["POS"]["fixed"] for p in parts if p["n_rows"]])
+                            if not np.array_equal(pos, exp["by_name"]["POS"]["fixed"]):
+                                msgs.append(f"text shards {cuts}: POS differs")
             except Exception as e:
                 msgs.append(f"vcf text: {type(e).__name__} {str(e)[:200]}")
             done += 1
