@@ -815,9 +815,26 @@ static void bcf_producer_main(BcfScan *g) {
     if (!c) { finish("read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);
     const double t_ctx = now_s() - t_start;
-    const int orc = bind->seg_count >= 0 ? dhts_open_path_segments(c, bind->path.c_str(), bind->header_bytes, bind->seg_beg.data(), bind->seg_end.data(), bind->seg_count)
-                                         : dhts_open_path(c, bind->path.c_str());
-    if (orc != 0 || dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
+    // a plain whole-file scan starts decoding while the file is still being staged (as read_bam does): the block table is built over the
+    // resident prefix and extended as more bytes arrive.  DHTS_STREAM=0, region queries and uncompressed text stage first.
+    static const bool env_nostream = getenv("DHTS_STREAM") && atoi(getenv("DHTS_STREAM")) == 0;
+    const bool streaming = bind->regions.empty() && !env_nostream && bind->seg_count < 0 && dhts_bcf_is_text(bind->ctx) != 2;
+    int staged_all = 1;
+    int orc = bind->seg_count >= 0 ? dhts_open_path_segments(c, bind->path.c_str(), bind->header_bytes, bind->seg_beg.data(), bind->seg_end.data(), bind->seg_count)
+              : streaming ? dhts_open_path_async(c, bind->path.c_str()) : dhts_open_path(c, bind->path.c_str());
+    if (orc == 0 && !streaming && (dhts_bgzf_index(c) <= 0 || dhts_bcf_open(c, bind->tidy) != 0)) orc = -1;
+    if (orc == 0 && streaming) {
+        // the header needs the first blocks only: 32 MiB to start with, four times more whenever that is not enough
+        uint64_t want = 32u << 20;
+        for (;;) {
+            const int64_t f = dhts_stage_wait(c, want, &staged_all);
+            if (f < 0) { orc = -1; break; }
+            if (dhts_bgzf_index_staged(c) > 0 && dhts_bcf_open(c, bind->tidy) == 0) break;
+            if (staged_all) { orc = -1; break; }
+            want *= 4;
+        }
+    }
+    if (orc != 0 || dhts_bcf_info_get(c, &g->inf) != 0) {
         finish(std::string("Failed to open BCF/VCF file: ") + bind->path); return;
     }
     const double t_open = now_s() - t_start;
@@ -826,11 +843,17 @@ static void bcf_producer_main(BcfScan *g) {
     if (!bind->regions.empty() && !bcf_next_region(bind, c, &next_region)) { finish(""); return; }     // no region produced an iterator: zero rows (bcf_reader.c:955-959)
     const double t_region = now_s() - t_start;
     if (trace) fprintf(stderr, "[dhts] read_bcf producer dev %d: context %.4f s, staged + block table + header at %.4f s (%s, %llu bytes resident), first region set at %.4f s\n", bind->device, t_ctx, t_open,
-                       bind->seg_count >= 0 ? "header + index windows" : "whole file", (unsigned long long)dhts_resident_bytes(c), t_region);
+                       bind->seg_count >= 0 ? "header + index windows" : streaming ? "streaming" : "whole file", (unsigned long long)dhts_resident_bytes(c), t_region);
     static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;
     for (;;) {
         dhts_bcf_batch b;
+        if (streaming && !staged_all && dhts_blocks_ahead(c) < max_blocks) {
+            // not enough known blocks for a full batch: wait for (at least) another 128 MiB of the file, then extend the block table
+            int64_t f = dhts_stage_wait(c, 0, &staged_all);
+            if (f >= 0 && !staged_all) f = dhts_stage_wait(c, (uint64_t)f + (128u << 20), &staged_all);
+            if (f < 0 || dhts_bgzf_index_staged(c) < 0) { finish(dhts_error(c)); return; }
+        }
         if (dhts_bcf_next_batch(c, max_blocks, &b) != 0) { finish(dhts_error(c)); return; }
         if (b.n_rows > 0) {
             BcfHostBatch *hb = nullptr;

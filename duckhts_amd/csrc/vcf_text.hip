@@ -219,11 +219,28 @@ __device__ __forceinline__ long long vcf_tabix_end(const uint8_t *u, long long b
         if (t >= a1 || alcnt >= 65536) break;
         s0 = t + 1;
     }
-    uint32_t s = vcf_find(u, i0, i1, "END=", 4);
-    if (s == i0) s += 4; else if (s != 0xffffffffu) { s = vcf_find(u, i0, i1, ";END=", 5); if (s != 0xffffffffu) s += 5; }
+    // strstr(info, "END=") at the start of INFO, else strstr(info, ";END=") (tbx.c:213-233) = the first ';'-separated field that starts
+    // with "END="; the same for "SVLEN=".  One walk over the fields, the ';' found eight bytes at a time.  SVLEN can only matter when an
+    // allele is symbolic or REF is empty (its contribution is otherwise 1 <= reflen).
+    uint32_t pe = 0xffffffffu, ps = 0xffffffffu;
+    const bool want_sv = svmask != 0 || reflen < 1;
+    for (uint32_t f = i0; f < i1;) {
+        if (pe == 0xffffffffu && f + 4 <= i1 && u[f] == 'E' && u[f + 1] == 'N' && u[f + 2] == 'D' && u[f + 3] == '=') pe = f + 4;
+        else if (want_sv && ps == 0xffffffffu && f + 6 <= i1 && u[f] == 'S' && u[f + 1] == 'V' && u[f + 2] == 'L' && u[f + 3] == 'E' && u[f + 4] == 'N' && u[f + 5] == '=') ps = f + 6;
+        if (pe != 0xffffffffu && (ps != 0xffffffffu || !want_sv)) break;
+        uint32_t t = f;
+        for (; t + 8 <= i1; t += 8) {
+            uint64_t v; __builtin_memcpy(&v, u + t, 8); v ^= 0x3b3b3b3b3b3b3b3bull;
+            const uint64_t z = (v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull;
+            if (z) { t += (uint32_t)(__builtin_ctzll(z) >> 3); goto semi; }
+        }
+        while (t < i1 && u[t] != ';') t++;
+    semi:
+        f = t + 1;
+    }
+    uint32_t s = pe;
     if (s != 0xffffffffu && !(s < i1 && u[s] == '.')) { const long long v = vcf_strtoll(u, s, i1, 0, nullptr); if (v > beg) end = v; }
-    s = vcf_find(u, i0, i1, "SVLEN=", 6);
-    if (s == i0) s += 6; else if (s != 0xffffffffu) { s = vcf_find(u, i0, i1, ";SVLEN=", 7); if (s != 0xffffffffu) s += 7; }
+    s = ps;
     for (int d = 1; s != 0xffffffffu && d < alcnt; ++d) {
         uint32_t t = s; while (t < i1 && u[t] != ',') t++;
         long long tmp = 1;
@@ -380,7 +397,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         // REF, ALT
         o.vchar(u + fs[3], fe[3] - fs[3]);
         // rlen: pos + rlen = the END the tabix iterator tests regions with (text carries no rlen; see vcf_tabix_end)
-        rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1) - pos);
+        if (WRITE) rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1) - pos);
         if (!(fe[4] - fs[4] == 1 && u[fs[4]] == '.')) {
             uint32_t t = fs[4];
             for (uint32_t r = fs[4];; r++) {
