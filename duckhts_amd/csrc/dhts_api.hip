@@ -148,6 +148,9 @@ struct dhts_ctx {
     hipStream_t stream = nullptr;
     // phase B of the NEXT batch runs on a second stream while this batch's record stage (latency-bound, mostly idle SIMDs) runs on `stream`
     hipStream_t stream_b = nullptr; hipEvent_t pf_done = nullptr;
+    // overlapped read-back (dhts_bam_batch_fetch_begin / _wait): a batch's columns are gathered into one of two snapshots on the scan
+    // stream and leave for the host on a copy stream while the next batch is computed
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}; DevBuf snap[2];
     struct Prefetch { bool valid = false; int64_t b0 = 0, nb = 0; uint64_t carry = 0; int ucur = 0; } pf;
     std::string err;
     // resident compressed bytes
@@ -282,6 +285,9 @@ int dhts_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess
 // milliseconds, which is most of what a query on a small file or a narrow region spends in dhts_create.
 namespace {
 struct StreamSet { int dev; hipStream_t s, sb; hipEvent_t ev; };
+struct CopySet { int dev; hipStream_t s; hipEvent_t snap[2], done[2]; };
+std::mutex g_cs_mu;
+std::vector<CopySet> g_cs;
 std::mutex g_ss_mu;
 std::vector<StreamSet> g_ss;
 }
@@ -325,6 +331,15 @@ void dhts_destroy(dhts_ctx *c) {
     const bool clean = hipStreamSynchronize(c->stream_b) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
     timing_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->copy_stream) {
+        const bool cclean = hipStreamSynchronize(c->copy_stream) == hipSuccess;
+        std::lock_guard<std::mutex> lk(g_cs_mu);
+        static bool cs_at_exit = false;
+        if (!cs_at_exit) { cs_at_exit = true; std::atexit([]() { std::lock_guard<std::mutex> lk2(g_cs_mu); for (auto &x : g_cs) { if (hipSetDevice(x.dev) != hipSuccess) continue; for (int k = 0; k < 2; k++) { (void)hipEventDestroy(x.snap[k]); (void)hipEventDestroy(x.done[k]); } (void)hipStreamDestroy(x.s); } g_cs.clear(); }); }
+        if (cclean && g_cs.size() < 32) g_cs.push_back({c->device, c->copy_stream, {c->ev_snap[0], c->ev_snap[1]}, {c->ev_done[0], c->ev_done[1]}});
+        else { for (int k = 0; k < 2; k++) { (void)hipEventDestroy(c->ev_snap[k]); (void)hipEventDestroy(c->ev_done[k]); } (void)hipStreamDestroy(c->copy_stream); }
+        c->copy_stream = nullptr;
+    }
     bool kept = false;
     if (clean) {
         std::lock_guard<std::mutex> lk(g_ss_mu);
@@ -3475,6 +3490,75 @@ int dhts_bam_batch_fetch(dhts_ctx *c, const dhts_bam_batch *b, uint32_t m, void 
         if (!oc[k]->off || !oc[k]->len || !oc[k]->bytes) return fail(c, "hipMemcpyAsync failed");
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The same read-back, overlapped with the next batch: the columns are gathered into snapshot `slot` (0 / 1) on the scan stream -- device to
+// device, in the layout of the host arena -- and ONE copy takes the snapshot to the host on a copy stream; the call returns at once, `out`
+// already points into dst.  dhts_bam_batch_fetch_wait(slot) returns when the bytes have landed.  The scan may go on to the next batch in
+// between: its kernels are ordered behind the gather on the scan stream and never touch the snapshot.
+static int copy_set_acquire(dhts_ctx *c) {
+    if (c->copy_stream) return 0;
+    {
+        std::lock_guard<std::mutex> lk(g_cs_mu);
+        for (size_t i = 0; i < g_cs.size(); i++) if (g_cs[i].dev == c->device) {
+            c->copy_stream = g_cs[i].s; for (int k = 0; k < 2; k++) { c->ev_snap[k] = g_cs[i].snap[k]; c->ev_done[k] = g_cs[i].done[k]; }
+            g_cs[i] = g_cs.back(); g_cs.pop_back();
+            return 0;
+        }
+    }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { c->copy_stream = nullptr; return fail(c, "hipStreamCreate failed"); }
+    for (int k = 0; k < 2; k++)
+        if (hipEventCreateWithFlags(&c->ev_snap[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) != hipSuccess) return fail(c, "hipEventCreate failed");
+    return 0;
+}
+extern "C" int dhts_bam_batch_fetch_begin(dhts_ctx *c, const dhts_bam_batch *b, uint32_t m, void *dst, uint64_t cap, dhts_bam_batch *out, int slot) {
+    if (!c || !b || !out || slot < 0 || slot > 1) return -1;
+    *out = *b;
+    if (b->n_rows <= 0) return 0;
+    const uint64_t need = dhts_bam_batch_host_bytes(b, m);
+    if (need > cap || (need && !dst)) return fail(c, "host arena too small for the batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (copy_set_acquire(c)) return -1;
+    // (the snapshot may still be on its way to the host from two batches ago)
+    HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
+    if (c->snap[slot].ensure(need + 64)) return fail(c, "hipMalloc failed");
+    const uint64_t n = (uint64_t)b->n_rows; uint8_t *h = (uint8_t *)dst, *sp = (uint8_t *)c->snap[slot].p; uint64_t at = 0;
+    auto put = [&](const void *src, uint64_t bytes) -> const void * {
+        void *d = h + at;
+        if (bytes && hipMemcpyAsync(sp + at, src, bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return nullptr;
+        at += al64(bytes);
+        return d;
+    };
+#define DHTS_FETCH(field, type, bitno, bytes) do { if (m & (1u << (bitno))) { out->field = (const type *)put(b->field, (bytes)); if (!out->field) return fail(c, "hipMemcpyAsync failed"); } else out->field = nullptr; } while (0)
+    DHTS_FETCH(flag, uint16_t, DHTS_BAM_FLAG, n * 2); DHTS_FETCH(pos, int64_t, DHTS_BAM_POS, n * 8); DHTS_FETCH(mapq, int32_t, DHTS_BAM_MAPQ, n * 4);
+    DHTS_FETCH(pnext, int64_t, DHTS_BAM_PNEXT, n * 8); DHTS_FETCH(tlen, int64_t, DHTS_BAM_TLEN, n * 8); DHTS_FETCH(tid, int32_t, DHTS_BAM_RNAME, n * 4);
+    DHTS_FETCH(mtid, int32_t, DHTS_BAM_RNEXT, n * 4); DHTS_FETCH(rg_idx, int32_t, DHTS_BAM_SAMPLE_ID, n * 4);
+#undef DHTS_FETCH
+    if (m & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) { out->rg_valid = (const uint64_t *)put(b->rg_valid, ((n + 63) / 64) * 8); if (!out->rg_valid) return fail(c, "hipMemcpyAsync failed"); }
+    else out->rg_valid = nullptr;
+    const dhts_strcol *sc[5] = {&b->qname, &b->cigar, &b->seq, &b->qual, &b->rg};
+    dhts_strcol *oc[5] = {&out->qname, &out->cigar, &out->seq, &out->qual, &out->rg};
+    const int bit[5] = {DHTS_BAM_QNAME, DHTS_BAM_CIGAR, DHTS_BAM_SEQ, DHTS_BAM_QUAL, DHTS_BAM_READ_GROUP_ID};
+    for (int k = 0; k < 5; k++) {
+        if (!(m & (1u << bit[k]))) { oc[k]->off = oc[k]->len = nullptr; oc[k]->bytes = nullptr; oc[k]->nbytes = 0; continue; }
+        oc[k]->off = (const uint32_t *)put(sc[k]->off, (n + 1) * 4); oc[k]->len = (const uint32_t *)put(sc[k]->len, n * 4);
+        const uint64_t at0 = at;
+        oc[k]->bytes = (const uint8_t *)put(sc[k]->bytes, sc[k]->nbytes);
+        at = at0 + al64(sc[k]->nbytes + 1);                             // (one readable byte behind the heap, as in the size formula)
+        if (!oc[k]->off || !oc[k]->len || !oc[k]->bytes) return fail(c, "hipMemcpyAsync failed");
+    }
+    HIPCHK(c, hipEventRecord(c->ev_snap[slot], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_snap[slot], 0));
+    HIPCHK(c, hipMemcpyAsync(dst, sp, at, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_done[slot], c->copy_stream));
+    return 0;
+}
+extern "C" int dhts_bam_batch_fetch_wait(dhts_ctx *c, int slot) {
+    if (!c || slot < 0 || slot > 1) return -1;
+    if (!c->copy_stream) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
     return 0;
 }
 

@@ -337,6 +337,13 @@ static void producer_main(BamScan *g, Producer *p) {
     if (rc != 0) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
     static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;       // ~270 MB of inflated stream per batch: the engine gets its first chunk early and the stages overlap
+    HostBatch *pending = nullptr; int pending_slot = 0, slot_no = 0;
+    auto publish = [&](HostBatch *hb, int sl) -> bool {
+        if (dhts_bam_batch_fetch_wait(c, sl) != 0) return false;
+        { std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
+        g->cv_ready.notify_all();
+        return true;
+    };
     for (;;) {
         dhts_bam_batch b;
         if (streaming && !staged_all && dhts_blocks_ahead(c) < max_blocks) {
@@ -362,19 +369,27 @@ static void producer_main(BamScan *g, Producer *p) {
             const double tb2 = now_s(); t_slot += tb2 - tb1;
             const uint64_t need = dhts_bam_batch_host_bytes(&b, g->colmask);
             if (need > hb->cap) { dhts_host_free(hb->arena); hb->arena = dhts_host_alloc(need); hb->cap = hb->arena ? need : 0; }
-            if ((need && !hb->arena) || dhts_bam_batch_fetch(c, &b, g->colmask, hb->arena, hb->cap, &hb->b) != 0 || fetch_optional(c, g, b, hb) != 0) {
+            // the read-back of this batch runs on a copy stream while the next batch is scanned: the batch is handed to the fill threads one
+            // turn later, when its bytes have had a whole scan's time to cross PCIe (DHTS_OVERLAP_READBACK=0: copy, wait, hand over)
+            static const bool env_serial = getenv("DHTS_OVERLAP_READBACK") && atoi(getenv("DHTS_OVERLAP_READBACK")) == 0;
+            const int frc = env_serial ? dhts_bam_batch_fetch(c, &b, g->colmask, hb->arena, hb->cap, &hb->b) : dhts_bam_batch_fetch_begin(c, &b, g->colmask, hb->arena, hb->cap, &hb->b, slot_no);
+            if ((need && !hb->arena) || frc != 0 || fetch_optional(c, g, b, hb) != 0) {
                 std::string m = hb->arena || !need ? dhts_error(c) : "read_bam: out of pinned host memory"; dhts_destroy(c); fail_with(m); return;
             }
-            t_fetch += now_s() - tb2;
             hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false;
             if (!p->has_rows) { p->has_rows = true; p->first_v = dhts_voffset(c, b.first_rec_uoff); }
             p->end_v = dhts_voffset(c, b.end_uoff);
-            { std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
-            g->cv_ready.notify_all();
+            if (pending && !publish(pending, pending_slot)) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
+            pending = nullptr;
+            if (env_serial) { std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
+            else { pending = hb; pending_slot = slot_no; slot_no ^= 1; }
+            if (env_serial) g->cv_ready.notify_all();
+            t_fetch += now_s() - tb2;
         }
         if (b.status != 0) { p->clean_end = b.status == 1; break; }       // end of the stream, or the silent stop at the first bad block / record (bam_reader.c:754-766)
         { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
     }
+    if (pending && !publish(pending, pending_slot)) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
     dhts_destroy(c);
     if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: context %.4f s, staged at %.4f s%s, block table %.4f s, header %.4f s, open+index+header %.4f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
                        p->rank, p->world, p->device, t_created, t_staged, from_cache ? " (file still resident in HBM)" : "", t_idx, t_hdr, t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);

@@ -341,6 +341,11 @@ uint64_t dhts_bcf_batch_host_bytes(const dhts_ctx *);
 int dhts_bcf_batch_fetch(dhts_ctx *, const dhts_bcf_batch *b, void *dst, uint64_t cap, dhts_bcf_col *out_cols);
 uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
 int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);
+/* the same read-back overlapped with the next batch: the columns are gathered into one of two device snapshots (slot 0 / 1) and leave for
+ * the host as ONE copy on a separate stream; _begin returns at once (out points into dst), _wait(slot) when the bytes have landed.  Call
+ * dhts_bam_next_batch in between: PCIe and the scan of the next batch then run side by side. */
+int dhts_bam_batch_fetch_begin(dhts_ctx *, const dhts_bam_batch *dev_batch, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *host_batch, int slot);
+int dhts_bam_batch_fetch_wait(dhts_ctx *, int slot);
 
 /* ---- utilities ------------------------------------------------------------------------------ */
 int dhts_memcpy_d2h(dhts_ctx *, void *dst, const void *src_dev, uint64_t n);
