@@ -3599,6 +3599,45 @@ int dhts_bcf_batch_fetch(dhts_ctx *c, const dhts_bcf_batch *b, void *dst, uint64
     return 0;
 }
 
+// read_bcf's read-back overlapped with the next batch (see dhts_bam_batch_fetch_begin): the four arenas are gathered into snapshot `slot`
+// on the scan stream and leave as one copy on the copy stream; out_cols point into dst at once, the bytes are there after _wait(slot).
+extern "C" int dhts_bcf_batch_fetch_begin(dhts_ctx *c, const dhts_bcf_batch *b, void *dst, uint64_t cap, dhts_bcf_col *out_cols, int slot) {
+    if (!c || !b || (b->n_cols > 0 && !out_cols) || slot < 0 || slot > 1) return -1;
+    for (int i = 0; i < b->n_cols; i++) out_cols[i] = b->cols[i];
+    if (b->n_rows <= 0 || b->n_cols <= 0) return 0;
+    const uint64_t need = dhts_bcf_batch_host_bytes(c);
+    if (need > cap || (need && !dst)) return fail(c, "host arena too small for the batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (copy_set_acquire(c)) return -1;
+    HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
+    if (c->snap[slot].ensure(need + 64)) return fail(c, "hipMalloc failed");
+    uint8_t *h = (uint8_t *)dst, *sp = (uint8_t *)c->snap[slot].p; uint64_t at = 0; const uint8_t *hb[4];
+    for (int k = 0; k < 4; k++) {
+        hb[k] = h + at;
+        if (c->bcf_ar[k].n) HIPCHK(c, hipMemcpyAsync(sp + at, c->bcf_ar[k].p, c->bcf_ar[k].n, hipMemcpyDeviceToDevice, c->stream));
+        at += al64(c->bcf_ar[k].n);
+    }
+    auto rebase = [&](const void *p) -> const void * {
+        if (!p) return nullptr;
+        const uint8_t *q = (const uint8_t *)p;
+        for (int k = 0; k < 4; k++) if (c->bcf_ar[k].p && q >= c->bcf_ar[k].p && q <= c->bcf_ar[k].p + c->bcf_ar[k].n) return hb[k] + (q - c->bcf_ar[k].p);
+        return nullptr;
+    };
+    for (int i = 0; i < b->n_cols; i++) {
+        dhts_bcf_col &o = out_cols[i]; const dhts_bcf_col &d = b->cols[i];
+        o.valid = (const uint8_t *)rebase(d.valid); o.fixed = rebase(d.fixed); o.off = (const uint32_t *)rebase(d.off); o.bytes = (const uint8_t *)rebase(d.bytes);
+        o.child_fixed = (const uint32_t *)rebase(d.child_fixed); o.child_off = (const uint32_t *)rebase(d.child_off); o.child_valid = (const uint8_t *)rebase(d.child_valid);
+        if ((d.valid && !o.valid) || (d.fixed && !o.fixed) || (d.off && !o.off) || (d.bytes && !o.bytes) || (d.child_fixed && !o.child_fixed) || (d.child_off && !o.child_off) || (d.child_valid && !o.child_valid))
+            return fail(c, "batch column outside the batch arenas");
+    }
+    HIPCHK(c, hipEventRecord(c->ev_snap[slot], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_snap[slot], 0));
+    if (at) HIPCHK(c, hipMemcpyAsync(dst, sp, at, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_done[slot], c->copy_stream));
+    return 0;
+}
+extern "C" int dhts_bcf_batch_fetch_wait(dhts_ctx *c, int slot) { return dhts_bam_batch_fetch_wait(c, slot); }
+
 int dhts_memcpy_d2h(dhts_ctx *c, void *dst, const void *src_dev, uint64_t n) {
     if (!c) return -1;
     if (n == 0) return 0;

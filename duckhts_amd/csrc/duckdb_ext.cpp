@@ -688,7 +688,7 @@ struct BcfHostBatch {
     void *arena = nullptr; uint64_t cap = 0;
     std::vector<dhts_bcf_col> cols;                 // HOST pointers, projection order (deduplicated)
     std::vector<std::vector<uint32_t>> conv;        // per column: DHTS_ENC_FLOAT_TEXT children converted to float bits
-    int64_t n = 0; int status = 0;
+    int64_t n = 0; int status = 0; int ncols_fetched = 0;
     int64_t next = 0; int readers = 0; bool retired = false;
 };
 struct BcfScan {
@@ -861,6 +861,28 @@ static void bcf_producer_main(BcfScan *g) {
                        bind->seg_count >= 0 ? "header + index windows" : streaming ? "streaming" : "whole file", (unsigned long long)dhts_resident_bytes(c), t_region);
     static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;
+    BcfHostBatch *pending = nullptr; int pending_slot = 0, slot_no = 0;
+    auto publish = [&](BcfHostBatch *hb, int sl) -> bool {          // sl < 0: the bytes are already there
+        if (sl >= 0 && dhts_bcf_batch_fetch_wait(c, sl) != 0) return false;
+        hb->conv.assign((size_t)hb->ncols_fetched, std::vector<uint32_t>());
+        for (int i = 0; i < hb->ncols_fetched; i++) {
+            const dhts_bcf_col &h = hb->cols[i];
+            if (bind->inf.cols[h.col].encoding != DHTS_ENC_FLOAT_TEXT) continue;
+            // Float fields of a transcript arrive as text: (float)strtod, NaN unless the whole token converts (vep_parse_float, src/vep_parser.c:222-235)
+            std::vector<uint32_t> &cv = hb->conv[i]; cv.assign(h.child_n + 1, 0);
+            std::string tok;
+            for (uint64_t k = 0; k < h.child_n; k++) {
+                if (h.child_valid && !h.child_valid[k]) continue;
+                tok.assign((const char *)h.bytes + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
+                char *end = nullptr; const double v = strtod(tok.c_str(), &end);
+                const float f = (end == tok.c_str() || *end) ? NAN : (float)v;
+                memcpy(&cv[k], &f, 4);
+            }
+        }
+        { std::lock_guard<std::mutex> lk(g->mu); g->ready.push_back(hb); }
+        g->cv_ready.notify_all();
+        return true;
+    };
     for (;;) {
         dhts_bcf_batch b;
         if (streaming && !staged_all && dhts_blocks_ahead(c) < max_blocks) {
@@ -881,25 +903,15 @@ static void bcf_producer_main(BcfScan *g) {
             const uint64_t need = dhts_bcf_batch_host_bytes(c);
             if (need > hb->cap) { dhts_host_free(hb->arena); hb->arena = dhts_host_alloc(need); hb->cap = hb->arena ? need : 0; }
             hb->cols.assign((size_t)b.n_cols, dhts_bcf_col());
-            if ((need && !hb->arena) || dhts_bcf_batch_fetch(c, &b, hb->arena, hb->cap, hb->cols.data()) != 0) { finish(hb->arena || !need ? dhts_error(c) : "read_bcf: out of pinned host memory"); return; }
-            hb->conv.assign((size_t)b.n_cols, std::vector<uint32_t>());
-            for (int i = 0; i < b.n_cols; i++) {
-                const dhts_bcf_col &h = hb->cols[i];
-                if (bind->inf.cols[h.col].encoding != DHTS_ENC_FLOAT_TEXT) continue;
-                // Float fields of a transcript arrive as text: (float)strtod, NaN unless the whole token converts (vep_parse_float, src/vep_parser.c:222-235)
-                std::vector<uint32_t> &cv = hb->conv[i]; cv.assign(h.child_n + 1, 0);
-                std::string tok;
-                for (uint64_t k = 0; k < h.child_n; k++) {
-                    if (h.child_valid && !h.child_valid[k]) continue;
-                    tok.assign((const char *)h.bytes + h.child_off[k], h.child_off[k + 1] - h.child_off[k]);
-                    char *end = nullptr; const double v = strtod(tok.c_str(), &end);
-                    const float f = (end == tok.c_str() || *end) ? NAN : (float)v;
-                    memcpy(&cv[k], &f, 4);
-                }
-            }
-            hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false;
-            { std::lock_guard<std::mutex> lk(g->mu); g->ready.push_back(hb); }
-            g->cv_ready.notify_all();
+            static const bool env_serial = getenv("DHTS_OVERLAP_READBACK") && atoi(getenv("DHTS_OVERLAP_READBACK")) == 0;
+            const int frc = env_serial ? dhts_bcf_batch_fetch(c, &b, hb->arena, hb->cap, hb->cols.data()) : dhts_bcf_batch_fetch_begin(c, &b, hb->arena, hb->cap, hb->cols.data(), slot_no);
+            if ((need && !hb->arena) || frc != 0) { finish(hb->arena || !need ? dhts_error(c) : "read_bcf: out of pinned host memory"); return; }
+            hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false; hb->ncols_fetched = b.n_cols;
+            // the previous batch has had this batch's scan to cross PCIe: finish it (text floats) and hand it to the fill threads
+            if (pending && !publish(pending, pending_slot)) { finish(dhts_error(c)); return; }
+            pending = nullptr;
+            if (env_serial) { if (!publish(hb, -1)) { finish(dhts_error(c)); return; } }
+            else { pending = hb; pending_slot = slot_no; slot_no ^= 1; }
         }
         if (b.status != 0) {                                     // EOF, or the silent stop at the first bad record (bcf_reader.c:1319-1349)
             if (!bind->regions.empty() && bcf_next_region(bind, c, &next_region)) continue;
@@ -907,9 +919,9 @@ static void bcf_producer_main(BcfScan *g) {
         }
         { std::lock_guard<std::mutex> lk(g->mu); if (g->cancel) break; }
     }
+    if (pending && !publish(pending, pending_slot)) { finish(dhts_error(c)); return; }
     finish("");
 }
-
 static void bcf_read_global_init(duckdb_init_info info) {
     BcfBind *bind = (BcfBind *)API(void *, duckdb_init_get_bind_data, duckdb_init_info)(info);
     if (!bind->regions.empty() && !bind->has_index) {

@@ -339,6 +339,8 @@ int64_t dhts_bgzf_wrap(const void *raw, uint64_t n, void *out, uint64_t cap);   
  * copies -- validity, fixed payloads, offsets, children / bytes -- and one wait) */
 uint64_t dhts_bcf_batch_host_bytes(const dhts_ctx *);
 int dhts_bcf_batch_fetch(dhts_ctx *, const dhts_bcf_batch *b, void *dst, uint64_t cap, dhts_bcf_col *out_cols);
+int dhts_bcf_batch_fetch_begin(dhts_ctx *, const dhts_bcf_batch *dev_batch, void *dst, uint64_t cap, dhts_bcf_col *host_cols, int slot);   /* overlapped, as dhts_bam_batch_fetch_begin */
+int dhts_bcf_batch_fetch_wait(dhts_ctx *, int slot);
 uint64_t dhts_bam_batch_host_bytes(const dhts_bam_batch *b, uint32_t colmask);
 int dhts_bam_batch_fetch(dhts_ctx *, const dhts_bam_batch *b, uint32_t colmask, void *dst, uint64_t cap, dhts_bam_batch *out);
 /* the same read-back overlapped with the next batch: the columns are gathered into one of two device snapshots (slot 0 / 1) and leave for
