@@ -24,6 +24,7 @@ struct BamStream {
     uint64_t ulen;         // valid bytes
     int32_t n_ref;
     int32_t final_batch;   // 1: no more data follows (an incomplete tail is a truncation)
+    int32_t seq_packed;    // 1: the SEQ heap keeps the file's 4-bit codes ((l_seq + 1) / 2 bytes per row; the consumer expands them)
 };
 
 __device__ __forceinline__ uint32_t ldu32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -287,6 +288,7 @@ struct BamStrOut {
     const uint32_t *off_qname, *off_cigar, *off_seq, *off_qual, *off_rg;
     uint8_t *qname, *cigar, *seq, *qual, *rg;
     uint32_t *alen_qual;     // actual QUAL length (the reference assigns through a NUL-terminated API: byte 223 (+33 == 0) truncates)
+    uint32_t *seq_chars;     // packed SEQ: bases per row (0: the row's SEQ is "*"); NULL otherwise
 };
 
 // SEQ: 16 bases (8 packed bytes p0,p1) -> 16 chars; "=ACMGRSVTWYHKDBN" (hts.c:260), high nibble first (sam.h:325).

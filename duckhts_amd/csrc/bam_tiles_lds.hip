@@ -325,7 +325,7 @@ template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &s
     c.cig_rel[row] = (uint32_t)(r.cig_off - o); c.ncig_eff[row] = r.n_cigar_eff;
     const uint64_t seq = o + 36 + r.l_qname + 4ull * r.n_cigar;
     const uint64_t qual = seq + (((uint64_t)r.l_seq + 1) >> 1);
-    c.len_seq[row] = r.l_seq > 0 ? (uint32_t)r.l_seq : 1;
+    c.len_seq[row] = r.l_seq > 0 ? (st.seq_packed ? ((uint32_t)r.l_seq + 1u) >> 1 : (uint32_t)r.l_seq) : 1;
     c.len_qual[row] = (r.l_seq > 0 && s.u8(qual) != 255) ? (uint32_t)r.l_seq : 1;
     const uint64_t aux = qual + (uint64_t)r.l_seq, end = o + 4ull + r.block_len;
     bool bad; const uint64_t rg = aux_find_t(s, aux, end, 'R', 'G', &bad, r.cg_beg, r.cg_end);
@@ -413,8 +413,13 @@ struct TsSrc {                 // bytes of the inflated stream by absolute offse
         return v;
     }
 };
-__device__ __forceinline__ void ts_seq_chunk(const TsSrc &src, uint64_t seq, uint32_t l_seq, uint32_t k, uint8_t *d) {
+__device__ __forceinline__ void ts_seq_chunk(const TsSrc &src, uint64_t seq, uint32_t l_seq, uint32_t k, uint8_t *d, int packed) {
     const uint64_t p = src.u64(seq + 8ull * k);
+    if (packed) {                                           // the 8 source bytes of this chunk as they are (16 bases)
+        const uint32_t nb = ((l_seq + 1u) >> 1) - 8u * k, w[4] = {(uint32_t)p, (uint32_t)(p >> 32), 0u, 0u};
+        store_n16(d + 8u * k, w, nb < 8u ? nb : 8u);
+        return;
+    }
     uint32_t w[4]; seq16((uint32_t)p, (uint32_t)(p >> 32), w);
     store_n16(d + 16u * k, w, l_seq - 16u * k);
 }
@@ -507,7 +512,7 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
             if (ch < T) {
                 const uint32_t j = cmap[ch], k = ch - r_c0[j], ls = r_lseq[j], lq = ls & 0x7fffffffu;
                 const uint64_t sq = tb + r_seq[j];
-                if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + r_oseq[j]);
+                if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + r_oseq[j], st.seq_packed);
                 if (w_qual && !(ls >> 31)) {
                     const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + r_oqual[j]);
                     if (fz != 0xffffffffu) atomicMin(&r_nul[j], fz);
@@ -516,7 +521,7 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
         }
         // ---- per-row pieces (wave 0) ----
         if (ok) {
-            if (w_seq && l_seq == 0) s.seq[off_seq] = '*';
+            if (w_seq && l_seq == 0) s.seq[off_seq] = st.seq_packed ? 0 : '*';
             if (w_qual && star) s.qual[off_qual] = '*';
             for (uint32_t b = 0; w_qn && b < len_qn; b += 16) {
                 const uint64_t a = src.u64(o + 36 + b), e = src.u64(o + 36 + b + 8);
@@ -551,7 +556,7 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
                 const uint64_t sq = ((uint64_t)RDLANE((uint32_t)(seq >> 32), i) << 32) | RDLANE((uint32_t)seq, i);
                 uint32_t fzm = 0xffffffffu;
                 for (uint32_t k = lane; k < (lq + 15u) >> 4; k += 64) {
-                    if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + os);
+                    if (w_seq) ts_seq_chunk(src, sq, lq, k, s.seq + os, st.seq_packed);
                     if (w_qual && !st_i) { const uint32_t fz = ts_qual_chunk(src, sq + (((uint64_t)lq + 1) >> 1), lq, k, s.qual + oq); fzm = fz < fzm ? fz : fzm; }
                 }
                 if (fzm != 0xffffffffu) atomicMin(&r_nul[i], fzm);
@@ -559,6 +564,7 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
         }
         __syncthreads();
         if (ok && w_qual) { const uint32_t fz = r_nul[lane]; s.alen_qual[d] = star ? 1u : (fz != 0xffffffffu ? fz : l_seq); }
+        if (act && w_seq && s.seq_chars) s.seq_chars[d] = ok ? l_seq : 0u;
         __syncthreads();
     }
 }

@@ -13,6 +13,7 @@
 #include "bcf_header.h"
 
 #include <errno.h>
+#include <time.h>
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -96,6 +97,8 @@ void pool_give(void *p, size_t cap, const std::string &tag = std::string(), uint
     for (void *q : drop) (void)hipFree(q);
 }
 }
+static std::atomic<uint64_t> g_malloc_calls{0}, g_malloc_bytes{0}, g_malloc_ns{0};     // hipMalloc calls the pool could not serve (DHTS_TRACE reports them)
+extern "C" void dhts_debug_malloc_stats(uint64_t *calls, uint64_t *bytes, double *seconds) { if (calls) *calls = g_malloc_calls; if (bytes) *bytes = g_malloc_bytes; if (seconds) *seconds = 1e-9 * (double)g_malloc_ns; }
 // Owning device allocation: returned to the pool by its destructor, so deleting a context gives back every byte of HBM it held.
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
@@ -119,6 +122,8 @@ struct DevBuf {
         release();
         size_t want = n + n / 8 + 4096, got = 0;
         if (void *q = pool_take(want, &got)) { p = q; cap = got; return 0; }
+        struct timespec t0_, t1_; clock_gettime(CLOCK_MONOTONIC, &t0_);
+        struct Tick { struct timespec &a, &b; size_t w; ~Tick() { clock_gettime(CLOCK_MONOTONIC, &b); g_malloc_calls++; g_malloc_bytes += w; g_malloc_ns += (uint64_t)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)); } } tick_{t0_, t1_, want};
         if (hipMalloc(&p, want) != hipSuccess) {
             // out of memory: drop what the pool holds on to and try once more
             { std::lock_guard<std::mutex> lk(g_pool_mu); for (auto &b : g_pool) (void)hipFree(b.p); g_pool.clear(); g_pool_bytes = 0; }
@@ -225,6 +230,7 @@ struct dhts_ctx {
     bool bcf_rg_active = false, bcf_rg_all = false; int32_t bcf_rg_tid = -1; int64_t bcf_rg_beg = 0, bcf_rg_end = 0;
     // VCF text: a region names a sequence of the tabix index (tbx_name2id), so it is resolved when the index arrives (dhts_bcf_load_index)
     std::vector<uint8_t> idx_cache; uint64_t idx_cache_len = 0, idx_cache_n = 0; const uint8_t *idx_cache_src = nullptr; uint8_t idx_cache_key[128] = {0};   // the last BGZF index, inflated
+    bool seq_packed = false; DevBuf seq_chars;
     DevBuf z_in, z_slots, z_sizes, z_offs, z_out, z_tok;                           // bgzip: raw chunk, per-block slots / sizes / offsets, packed blocks
     bool bcf_rg_pending = false; std::string bcf_rg_tok; int32_t bcf_rg_itid = -1; std::vector<std::string> tbx_names;
     DevBuf b_keep, b_map, b_sel;
@@ -886,6 +892,9 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
 // literal scratch).  A caller that serves many queries from one process wants a scratch the device pool can keep: 196,608 blocks = two full
 // rounds of the 1,536 resident waves, 29 GB.
 extern "C" void dhts_set_super_blocks(dhts_ctx *c, int64_t n) { if (c && n >= 16384) c->super_blocks = n; }
+// SEQ as the file's 4-bit codes: seq.bytes holds (l + 1) / 2 bytes per row at seq.off, seq.len the number of bases (0: "*"); the batch says so
+// in seq_packed.  Saves 18 % of an all-column read-back; the consumer expands with "=ACMGRSVTWYHKDBN" (high nibble first).
+extern "C" void dhts_bam_set_seq_packed(dhts_ctx *c, int on) { if (c) c->seq_packed = on != 0; }
 int64_t dhts_bgzf_inflate_to_host(dhts_ctx *c, int64_t blk0, int64_t nblk, uint8_t *out, uint64_t cap, int32_t *blk_status) {
     if (!c) return -1;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2529,7 +2538,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
     if (batch_begin(c, max_blocks, B)) return -1;
     const bool sharded_tail = B.sharded_tail, final_batch = B.final_batch;
     uint8_t *u = B.u; uint64_t ulen = B.ulen; const uint64_t out_base = B.out_base;
-    BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0;
+    BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0; st.seq_packed = c->seq_packed ? 1 : 0;
     c->last_stream = st;
 
     // ---- tiles ----
@@ -2707,6 +2716,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
         uint64_t tot[5] = {0, 0, 0, 0, 0};
         BamStrOut so; memset(&so, 0, sizeof(so));
         so.off_qname = o32[0]; so.off_cigar = o32[1]; so.off_seq = o32[2]; so.off_qual = o32[3]; so.off_rg = o32[4]; so.alen_qual = (uint32_t *)c->alen_qual.p;
+        if (c->seq_packed && (colmask & (1u << DHTS_BAM_SEQ))) { ENSURE(c, c->seq_chars, (size_t)nrows * 4 + 64); so.seq_chars = (uint32_t *)c->seq_chars.p; }
         const uint32_t str_cols = (1u << DHTS_BAM_QNAME) | (1u << DHTS_BAM_CIGAR) | (1u << DHTS_BAM_SEQ) | (1u << DHTS_BAM_QUAL) | (1u << DHTS_BAM_READ_GROUP_ID);
         if (colmask & str_cols) {      // projection pushdown: with no string column projected the whole string pass is skipped
             const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
@@ -2728,7 +2738,8 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
         out->rg_idx = bc.rg_idx; out->rg_valid = bc.rg_valid;
         out->qname = {o32[0], bc.len_qname, so.qname, tot[0]};
         out->cigar = {o32[1], bc.len_cigar, so.cigar, tot[1]};
-        out->seq = {o32[2], bc.len_seq, so.seq, tot[2]};
+        out->seq = {o32[2], so.seq_chars ? so.seq_chars : bc.len_seq, so.seq, tot[2]};
+        out->seq_packed = so.seq_chars ? 1 : 0;
         out->qual = {o32[3], so.alen_qual, so.qual, tot[3]};
         out->rg = {o32[4], bc.len_rg, so.rg, tot[4]};
     }
@@ -3507,7 +3518,11 @@ static int copy_set_acquire(dhts_ctx *c) {
             return 0;
         }
     }
-    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { c->copy_stream = nullptr; return fail(c, "hipStreamCreate failed"); }
+    // (highest priority: the runtime maps streams onto a handful of hardware queues, and a copy stream that lands on the scan stream's queue
+    //  serialises behind its kernels -- every other query of a process did, when the two pooled stream sets swapped roles; the high-priority
+    //  streams have queues of their own)
+    int pr_lo = 0, pr_hi = 0; (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+    if (hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, pr_hi) != hipSuccess) { c->copy_stream = nullptr; return fail(c, "hipStreamCreate failed"); }
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&c->ev_snap[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) != hipSuccess) return fail(c, "hipEventCreate failed");
     return 0;

@@ -44,6 +44,7 @@ extern "C" __attribute__((visibility("default"))) void dhts_set_duckdb_api(const
     if (api_table) memcpy((void *)duckdb_ext_api, api_table, sizeof(void *) * DUCKDB_ABI_V120_NSLOTS);
 }
 
+extern "C" void dhts_debug_malloc_stats(uint64_t *calls, uint64_t *bytes, double *seconds);
 static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static inline void set_null(duckdb_vector vec, idx_t row) {           // src/bam_reader.c:38-42
@@ -108,6 +109,7 @@ struct BamScan {
     }
 };
 struct BamLocal {
+    std::vector<char> seq_tmp;         // packed SEQ expands here before it is assigned
     bool done = false;
     HostBatch *cur = nullptr; Producer *cur_owner = nullptr; int64_t pos = 0, end = 0;     // rows [pos, end) of `cur` are this worker's
 };
@@ -142,6 +144,23 @@ static inline bool inl_string(duckdb_string_t *d, const char *s, size_t len) {
     if (len > 12) return false;
     memset(d, 0, sizeof(*d)); d->value.inlined.length = (uint32_t)len; memcpy(d->value.inlined.inlined, s, len);
     return true;
+}
+// 4-bit base codes -> text, high nibble first ("=ACMGRSVTWYHKDBN", htslib hts.c:260, sam.h:325): 16 bases per step through pshufb
+// (the table is the shuffle's own 16-byte lookup), a 512-byte pair table for the tail.  out must have room for n + 16 bytes.
+#include <immintrin.h>
+static const char kSeqNt16[] = "=ACMGRSVTWYHKDBN";
+static uint16_t g_seq_pair[256];
+static const bool g_seq_pair_init = [] { for (int b = 0; b < 256; b++) { const uint8_t p[2] = {(uint8_t)kSeqNt16[b >> 4], (uint8_t)kSeqNt16[b & 15]}; uint16_t v; memcpy(&v, p, 2); g_seq_pair[b] = v; } return true; }();
+__attribute__((target("ssse3"))) static inline void expand_seq(const uint8_t *src, uint32_t n, char *out) {
+    const __m128i tab = _mm_loadu_si128((const __m128i *)kSeqNt16), lo_mask = _mm_set1_epi8(0x0f);
+    uint32_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_loadl_epi64((const __m128i *)(src + i / 2));             // 8 bytes = 16 bases
+        const __m128i hi = _mm_and_si128(_mm_srli_epi16(v, 4), lo_mask), lo = _mm_and_si128(v, lo_mask);
+        _mm_storeu_si128((__m128i *)(out + i), _mm_shuffle_epi8(tab, _mm_unpacklo_epi8(hi, lo)));
+    }
+    for (; i < n; i += 2) { const uint16_t v = g_seq_pair[src[i / 2]]; memcpy(out + i, &v, 2); }    // (may write one byte past an odd n: room is there)
+    (void)g_seq_pair_init;
 }
 
 static void bam_read_bind(duckdb_bind_info info) {
@@ -292,6 +311,7 @@ static void producer_main(BamScan *g, Producer *p) {
     dhts_ctx *c = dhts_create(p->device);
     if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);                    // a scratch the device pool keeps from query to query (29 GB instead of 67 GB for a 10 GB file)
+    { static const bool env_unpacked = getenv("DHTS_SEQ_PACKED") && atoi(getenv("DHTS_SEQ_PACKED")) == 0; dhts_bam_set_seq_packed(c, env_unpacked ? 0 : 1); }   // SEQ crosses PCIe as 4-bit codes, the fill threads expand it
     const double t_created = now_s() - t_start; double t_staged = 0;
     int rc;
     // a plain whole-file scan on one device starts decoding while the file is still being staged: the block table is built over the
@@ -391,6 +411,7 @@ static void producer_main(BamScan *g, Producer *p) {
     }
     if (pending && !publish(pending, pending_slot)) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
     dhts_destroy(c);
+    if (trace) { uint64_t mc = 0, mb = 0; double ms = 0; dhts_debug_malloc_stats(&mc, &mb, &ms); fprintf(stderr, "[dhts] hipMalloc calls the pool could not serve so far in this process: %llu, %.2f GB, %.3f s\n", (unsigned long long)mc, 1e-9 * (double)mb, ms); }
     if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: context %.4f s, staged at %.4f s%s, block table %.4f s, header %.4f s, open+index+header %.4f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
                        p->rank, p->world, p->device, t_created, t_staged, from_cache ? " (file still resident in HBM)" : "", t_idx, t_hdr, t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
     { std::lock_guard<std::mutex> lk(g->mu); p->done = true; }
@@ -571,7 +592,19 @@ static void bam_read_function(duckdb_function_info info, duckdb_data_chunk outpu
             case DHTS_BAM_RNEXT: put_name(b.mtid); break;
             case DHTS_BAM_PNEXT: memcpy((int64_t *)get_data(vec) + row_count, b.pnext + s, take * 8); break;
             case DHTS_BAM_TLEN: memcpy((int64_t *)get_data(vec) + row_count, b.tlen + s, take * 8); break;
-            case DHTS_BAM_SEQ: put_str(b.seq); break;
+            case DHTS_BAM_SEQ:
+                if (!b.seq_packed) { put_str(b.seq); break; }
+                {   // the batch carries the file's 4-bit codes: expand here (seq_to_string, bam_reader.c:560-575; "*" for an empty SEQ)
+                    duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;
+                    for (idx_t r = 0; r < take; r++) {
+                        const uint32_t n = b.seq.len[s + r];
+                        if (n == 0) { inl_string(d + r, "*", 1); continue; }
+                        if (l->seq_tmp.size() < (size_t)n + 32) l->seq_tmp.resize((size_t)n + 32 + n / 2);
+                        expand_seq(b.seq.bytes + b.seq.off[s + r], n, l->seq_tmp.data());
+                        if (!inl_string(d + r, l->seq_tmp.data(), n)) assign_len(vec, row_count + r, l->seq_tmp.data(), n);
+                    }
+                }
+                break;
             case DHTS_BAM_QUAL: put_str(b.qual); break;
             case DHTS_BAM_READ_GROUP_ID: {
                 duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;

@@ -91,7 +91,7 @@ typedef struct {
     int32_t status;          /* 0 = more data may follow, 1 = end of stream reached cleanly,
                                 <0 = the stream ended on an error after these rows (the
                                 reference ends the scan silently: bam_reader.c:754-766)        */
-    int32_t reserved;
+    int32_t seq_packed;      /* 1: seq.bytes holds the file's 4-bit base codes, seq.len the number of bases (dhts_bam_set_seq_packed) */
     const uint16_t *flag;    /* FLAG  USMALLINT */
     const int64_t *pos;      /* POS   BIGINT (1-based) */
     const int32_t *mapq;     /* MAPQ  INTEGER */
@@ -284,6 +284,7 @@ typedef struct {
 
 int dhts_bcf_open(dhts_ctx *, int tidy_format);                      /* header + dictionaries + schema; positions the scan at the first record */
 int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
+void dhts_bam_set_seq_packed(dhts_ctx *, int on);                    /* SEQ stays 4 bits per base in the batch: (l + 1) / 2 bytes per row, high nibble first, "=ACMGRSVTWYHKDBN"; len = bases, 0 = "*" */
 void dhts_set_super_blocks(dhts_ctx *, int64_t n_blocks);             /* phase A look-ahead (default 524,288 blocks = 67 GB of scratch for a 10 GB file); the table functions use 196,608 */
 int dhts_bcf_is_text(const dhts_ctx *);                              /* after dhts_bcf_open: 0 binary BCF, 1 bgzipped VCF text, 2 plain VCF text */
 int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /* default: every schema column */
