@@ -415,6 +415,14 @@ struct PinBuf { void *p; size_t cap; bool busy; };
 std::mutex g_pin_mu;
 std::vector<PinBuf> g_pin;
 }
+// streams of the staging threads (host -> device copies).  DHTS_STAGE_PRIO: 0 normal (default), 1 highest, 2 lowest -- which hardware queue
+// class the copies share (see the copy stream of the read-back)
+static hipError_t stage_stream_create(hipStream_t *st) {
+    static const int prio = getenv("DHTS_STAGE_PRIO") ? atoi(getenv("DHTS_STAGE_PRIO")) : 0;
+    if (prio == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio == 1 ? hi : lo);
+}
 extern "C" void *dhts_host_alloc(uint64_t n) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     int best = -1;
@@ -463,7 +471,7 @@ static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uin
         if (hipSetDevice(dev) != hipSuccess) { rc = -1; return; }
         hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; void *pin[2] = {dhts_host_alloc(CH), dhts_host_alloc(CH)}; bool used[2] = {false, false};
         uint64_t piece_of[2] = {0, 0};
-        if (!pin[0] || !pin[1] || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        if (!pin[0] || !pin[1] || stage_stream_create(&st) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = -2;
         int k = 0;
         while (rc == 0) {
@@ -514,7 +522,7 @@ static int stage_file_pieces(dhts_ctx *c, int fd, const std::vector<StagePiece> 
     auto worker = [&]() {
         if (hipSetDevice(dev) != hipSuccess) { rc = -1; return; }
         hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; void *pin[2] = {dhts_host_alloc(CH), dhts_host_alloc(CH)}; bool used[2] = {false, false};
-        if (!pin[0] || !pin[1] || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        if (!pin[0] || !pin[1] || stage_stream_create(&st) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = -2;
         int k = 0;
         while (rc == 0) {
