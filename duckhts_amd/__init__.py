@@ -212,6 +212,11 @@ class Context:
         self._chk(self.L.dhts_bgunzip_file(self.h, os.fsencode(src), os.fsencode(dst), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_seq_packed(self, on=True):
+        self.L.dhts_bam_set_seq_packed.argtypes = [C.c_void_p, C.c_int]
+        self.L.dhts_bam_set_seq_packed.restype = None
+        self.L.dhts_bam_set_seq_packed(self.h, int(on))
+
     def scan_window_stats(self):
         """(index windows, BGZF blocks) of the current scan range (the whole file without an index)"""
         w, b = C.c_int64(0), C.c_int64(0)
@@ -438,7 +443,15 @@ class Context:
         valid = [(int(words[i >> 6]) >> (i & 63)) & 1 for i in range(n)]
         res["QNAME"] = strs(b.qname)
         res["CIGAR"] = strs(b.cigar)
-        res["SEQ"] = strs(b.seq)
+        if b.seq_packed:                               # dhts_bam_set_seq_packed: 4-bit codes, len = bases (0: "*")
+            off = self.d2h(b.seq.off, n + 1, np.uint32); ln = self.d2h(b.seq.len, n, np.uint32)
+            data = self.d2h(b.seq.bytes, int(b.seq.nbytes), np.uint8)
+            lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+            both = np.empty(2 * len(data), np.uint8); both[0::2] = lut[data >> 4]; both[1::2] = lut[data & 15]
+            txt = both.tobytes()
+            res["SEQ"] = [b"*" if ln[i] == 0 else txt[2 * int(off[i]):2 * int(off[i]) + int(ln[i])] for i in range(n)]
+        else:
+            res["SEQ"] = strs(b.seq)
         res["QUAL"] = strs(b.qual)
         res["READ_GROUP_ID"] = strs(b.rg, valid)
         rgi = self.d2h(b.rg_idx, n, np.int32)

@@ -445,6 +445,68 @@ def test_an_isize_of_zero_on_a_data_block_is_reported(which):
             assert list(got[c]) == list(clean[c][:got["n_rows"]]), c
 
 
+@pytest.mark.gpu
+def test_packed_seq_and_overlapped_fetch_at_the_c_abi():
+    """dhts_bam_set_seq_packed: the batch carries 4-bit codes, len = bases, "*" = 0 bases; dhts_bam_batch_fetch_begin / _wait deliver the
+    same bytes as dhts_bam_batch_fetch while the next batch is already being scanned"""
+    import ctypes as C
+    data = cases.case_basic(payload=777, n=3000, seed=12)
+    for extra in (cases.case_error_midfile("cigar_qlen"), read_golden("range.bam")):
+        exp = orc.bam_read(extra)
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(extra); ctx.bgzf_index(); hdr = ctx.bam_open(); ctx.set_seq_packed(True)
+            b = ctx.next_batch(0)
+            assert b.seq_packed == 1
+            got = ctx.batch_to_host(b, hdr)
+            assert got["SEQ"] == list(exp["SEQ"][:b.n_rows]) and got["QUAL"] == list(exp["QUAL"][:b.n_rows])
+        finally:
+            ctx.close()
+    exp = orc.bam_read(data)
+    L = duckhts_amd.lib()
+    L.dhts_bam_batch_host_bytes.restype = C.c_uint64; L.dhts_bam_batch_host_bytes.argtypes = [C.c_void_p, C.c_uint32]
+    L.dhts_host_alloc.restype = C.c_void_p; L.dhts_host_alloc.argtypes = [C.c_uint64]; L.dhts_host_free.argtypes = [C.c_void_p]
+    L.dhts_bam_batch_fetch_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.dhts_bam_batch_fetch_wait.argtypes = [C.c_void_p, C.c_int]
+    ctx = duckhts_amd.Context(0)
+    try:
+        ctx.open(data); ctx.bgzf_index(); ctx.bam_open(); ctx.set_seq_packed(True)
+        arenas, hosts, slot, rows, seqs = [], [], 0, 0, []
+        pending = None
+        while True:
+            b = ctx.next_batch(3)
+            if b.n_rows:
+                need = L.dhts_bam_batch_host_bytes(C.byref(b), 0x1FFF)
+                arena = L.dhts_host_alloc(need); arenas.append(arena)
+                hb = duckhts_amd.BamBatch()
+                assert L.dhts_bam_batch_fetch_begin(ctx.h, C.byref(b), 0x1FFF, arena, need, C.byref(hb), slot) == 0, ctx.L.dhts_error(ctx.h)
+                if pending is not None:
+                    assert L.dhts_bam_batch_fetch_wait(ctx.h, pending[1]) == 0
+                    hosts.append(pending[0])
+                pending = (hb, slot); slot ^= 1
+            if b.status != 0:
+                break
+        if pending is not None:
+            assert L.dhts_bam_batch_fetch_wait(ctx.h, pending[1]) == 0
+            hosts.append(pending[0])
+        lut = b"=ACMGRSVTWYHKDBN"
+        for hb in hosts:
+            n = hb.n_rows
+            off = np.ctypeslib.as_array(C.cast(hb.seq.off, C.POINTER(C.c_uint32)), (n + 1,)); ln = np.ctypeslib.as_array(C.cast(hb.seq.len, C.POINTER(C.c_uint32)), (n,))
+            raw = np.ctypeslib.as_array(C.cast(hb.seq.bytes, C.POINTER(C.c_uint8)), (int(hb.seq.nbytes),))
+            pos = np.ctypeslib.as_array(C.cast(hb.pos, C.POINTER(C.c_int64)), (n,))
+            assert list(pos) == list(exp["POS"][rows:rows + n])
+            for i in range(n):
+                s_ = bytes(lut[(raw[off[i] + (k >> 1)] >> (0 if k & 1 else 4)) & 15] for k in range(int(ln[i]))) or b"*"
+                seqs.append(s_)
+            rows += n
+        assert rows == exp["n_rows"] and seqs == list(exp["SEQ"])
+        for a in arenas:
+            L.dhts_host_free(a)
+    finally:
+        ctx.close()
+
+
 # ---- next-batch prefetch: a caller that changes the batch size invalidates the prefetched phase B ---------------------------
 @pytest.mark.gpu
 def test_varying_batch_sizes_discard_the_prefetch():
