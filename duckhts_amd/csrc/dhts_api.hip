@@ -138,6 +138,7 @@ struct DevBuf {
 struct StageProg {
     std::mutex mu; std::condition_variable cv;
     std::vector<uint8_t> piece_done; uint64_t next_piece = 0, frontier = 0, len = 0; bool finished = false; int rc = 0;
+    std::atomic<bool> cancel{false};          // the context is being closed: nobody will read the rest of the file (a LIMIT query, an error)
     void mark(uint64_t pi, uint64_t ch) {
         std::lock_guard<std::mutex> lk(mu);
         piece_done[pi] = 1;
@@ -362,7 +363,8 @@ void dhts_destroy(dhts_ctx *c) {
 const char *dhts_error(const dhts_ctx *c) { return c ? c->err.c_str() : "no context (no MI355X device or code object)"; }
 
 static void stop_stager(dhts_ctx *c) {
-    if (c->stager.joinable()) c->stager.join();            // (a staging run always terminates: it only reads a file)
+    if (c->prog && c->stager.joinable()) c->prog->cancel.store(true);     // whoever closes the context does not want the rest of the file: the readers stop after their current piece
+    if (c->stager.joinable()) c->stager.join();
     if (c->prog && !c->pending_tag.empty() && c->prog->finished && c->prog->rc == 0 && c->prog->frontier == c->prog->len) { c->comp.tag = c->pending_tag; c->comp.tag_len = c->prog->len; }
     c->pending_tag.clear();
     delete c->prog; c->prog = nullptr; c->growing = false;
@@ -475,6 +477,7 @@ static int stage_file_range(dhts_ctx *c, int fd, uint64_t off, uint64_t len, uin
             hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = -2;
         int k = 0;
         while (rc == 0) {
+            if (prog && prog->cancel.load()) { rc = -9; break; }                      // (the caller is closing the context: stop reading)
             const uint64_t pi = next.fetch_add(1);
             if (pi >= npieces) break;
             const uint64_t o = pi * CH; const size_t want = (size_t)(len - o < CH ? len - o : CH);

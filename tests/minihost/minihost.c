@@ -191,6 +191,7 @@ static void write_chunk(FILE *fo, Chunk *cp, uint64_t n) {
 
 static void vec_release(Vec *v) { for (size_t h = 0; h < v->nheap; h++) free(v->heap[h]); free(v->heap); v->heap = NULL; v->nheap = 0; v->heap_used = v->heap_cap = 0; }
 
+static uint64_t g_limit = 0;          /* -l N: stop after N rows (what a LIMIT does to a table function) */
 static void *worker_main(void *arg) {
     Worker *w = arg; Bind *b = w->b; Init *g = w->g; TF *tf = w->tf;
     memset(&w->l, 0, sizeof(w->l)); w->l.b = b; memcpy(w->l.proj, g->proj, sizeof(g->proj)); w->l.nproj = g->nproj;
@@ -220,6 +221,7 @@ static void *worker_main(void *arg) {
             if (v->child) { v->list_size = 0; if (v->child->type == DUCKDB_TYPE_STRUCT) { for (int q = 0; q < 2; q++) vec_release(v->child->kids[q]); } else { vec_release(v->child); free(v->child->validity); v->child->validity = NULL; } }
         }
         if (n == 0) break;
+        if (g_limit && (w->rows + n) >= g_limit) { w->rows += n; w->chunks++; break; }      /* LIMIT: the engine stops pulling and tears the scan down */
         w->rows += n; w->chunks++;
     }
     for (size_t k = 0; k < c.ncol; k++) {
@@ -299,6 +301,7 @@ int main(int argc, char **argv) {
         } else if (!strcmp(argv[i], "-p") && i + 1 < argc) proj = argv[++i];
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
         else if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);       /* worker threads offered to the scan (<= max_threads it asks for) */
+        else if (!strcmp(argv[i], "-l") && i + 1 < argc) g_limit = strtoull(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "-r") && i + 1 < argc) repeat = atoi(argv[++i]);        /* run the query this many times in one process (warm runs) */
     }
     for (int rep = 0; rep < repeat; rep++) {

@@ -527,3 +527,21 @@ def test_read_bcf_parallel_fill(tmp_path):
                 want_cols.append([int(c["fixed"][i]) if c["valid"][i] else None for i in range(exp["n_rows"])])
         want = list(zip(*want_cols))
         assert sorted(got, key=repr) == sorted(want, key=repr)
+
+
+@pytest.mark.gpu
+def test_a_scan_that_is_abandoned_early_closes_cleanly(tmp_path):
+    """what LIMIT does to a table function: the engine takes one chunk and tears the scan down while the file is still being staged -- the
+    readers stop after their current piece (the context used to read the rest of the file first), the partly staged file is not kept as the
+    resident copy, and the next full scan of the same process is complete"""
+    from duckhts_amd import synth
+    fn = os.path.join(str(tmp_path), "big.bam")
+    synth.bam_segment(3_000_000, seed=8)[0].tofile(fn)
+    for env in ({"DHTS_FILE_CACHE": "0"}, {}):
+        r = subprocess.run([HOST, duckhts_amd.LIB_PATH, "read_bam", fn, "-l", "10", "-r", "3"], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "OK rows=2048 chunks=1 " in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([HOST, duckhts_amd.LIB_PATH, "read_bam", fn, "-t", "4", "-r", "2"], capture_output=True, text=True, env=dict(os.environ, DHTS_THREADS="4"))
+    assert r.returncode == 0 and "OK rows=3000000 " in r.stdout, r.stdout + r.stderr
+    # one process: LIMIT first, then everything
+    r = subprocess.run([HOST, duckhts_amd.LIB_PATH, "read_bcf", os.path.join(os.path.dirname(__file__), "golden", "vcf_file.bcf"), "-l", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK rows=15 " in r.stdout                                   # (a file smaller than one chunk)
