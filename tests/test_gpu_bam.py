@@ -873,3 +873,49 @@ def test_whole_file_stays_resident_for_the_next_query(tmp_path):
     hit, names = scan(False)
     assert hit == 1
     L.dhts_release_pools()
+
+
+@pytest.mark.gpu
+def test_concurrent_contexts_in_one_process():
+    """an engine runs several table functions at once (a join of two read_bam calls, a UNION of files): contexts are independent, the device /
+    pinned / stream pools are shared -- four threads scanning BAM, BCF, VCF text and compressing at the same time get what they get alone"""
+    import threading
+    import gzip
+    import vep_cases
+    bam = cases.case_basic(payload=4000, n=20000, seed=31)
+    bcf = read_golden("vcf_file.bcf")
+    txt = vep_cases.fixture_text().encode()
+    want_bam, want_bcf, want_txt = orc.bam_read(bam), orc.bcf_read(bcf), orc.bcf_read(txt)
+    errs = []
+
+    def run_bam():
+        for _ in range(4):
+            got = duckhts_amd.read_bam(bam, max_blocks=7)
+            if got["n_rows"] != want_bam["n_rows"] or list(got["POS"]) != list(want_bam["POS"]) or got["SEQ"] != list(want_bam["SEQ"]):
+                errs.append("bam")
+
+    def run_bcf():
+        for _ in range(6):
+            if orc.bcf_cols_diff(want_bcf, duckhts_amd.read_bcf(bcf)) is not None:
+                errs.append("bcf")
+
+    def run_txt():
+        for _ in range(4):
+            if orc.bcf_cols_diff(want_txt, duckhts_amd.read_bcf(txt, max_blocks=2)) is not None:
+                errs.append("txt")
+
+    def run_zip():
+        ctx = duckhts_amd.Context(0)
+        try:
+            for _ in range(4):
+                if gzip.decompress(ctx.bgzf_compress(txt)) != txt:
+                    errs.append("bgzip")
+        finally:
+            ctx.close()
+
+    th = [threading.Thread(target=f) for f in (run_bam, run_bcf, run_txt, run_zip, run_bam)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
