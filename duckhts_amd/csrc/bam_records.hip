@@ -25,6 +25,7 @@ struct BamStream {
     int32_t n_ref;
     int32_t final_batch;   // 1: no more data follows (an incomplete tail is a truncation)
     int32_t seq_packed;    // 1: the SEQ heap keeps the file's 4-bit codes ((l_seq + 1) / 2 bytes per row; the consumer expands them)
+    int32_t want_rg;       // 0: neither READ_GROUP_ID nor SAMPLE_ID is projected: the walk over the auxiliary fields to RG is skipped
 };
 
 __device__ __forceinline__ uint32_t ldu32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }

@@ -328,7 +328,9 @@ template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &s
     c.len_seq[row] = r.l_seq > 0 ? (st.seq_packed ? ((uint32_t)r.l_seq + 1u) >> 1 : (uint32_t)r.l_seq) : 1;
     c.len_qual[row] = (r.l_seq > 0 && s.u8(qual) != 255) ? (uint32_t)r.l_seq : 1;
     const uint64_t aux = qual + (uint64_t)r.l_seq, end = o + 4ull + r.block_len;
-    bool bad; const uint64_t rg = aux_find_t(s, aux, end, 'R', 'G', &bad, r.cg_beg, r.cg_end);
+    // (bam_read1 does not look at the auxiliary fields: the walk serves the two read-group columns only -- a chain of dependent reads per
+    //  record that a projection without them does not pay)
+    bool bad = false; const uint64_t rg = st.want_rg ? aux_find_t(s, aux, end, 'R', 'G', &bad, r.cg_beg, r.cg_end) : NONE64;
     uint32_t rl = 0; int32_t rgi = -1; uint8_t rgv = 0;
     if (rg != NONE64 && (s.u8(rg) == 'Z' || s.u8(rg) == 'H')) {
         rgv = 1;

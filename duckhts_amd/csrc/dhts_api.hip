@@ -2550,6 +2550,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
     const bool sharded_tail = B.sharded_tail, final_batch = B.final_batch;
     uint8_t *u = B.u; uint64_t ulen = B.ulen; const uint64_t out_base = B.out_base;
     BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0; st.seq_packed = c->seq_packed ? 1 : 0;
+    st.want_rg = (colmask & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) ? 1 : 0;
     c->last_stream = st;
 
     // ---- tiles ----
