@@ -1,30 +1,29 @@
 // bgzf_huff_wave.hip -- phase A of the BGZF inflate, ONE WAVE PER BGZF BLOCK (gfx950), written from RFC 1951.
 //
 // Replaces the Huffman-decoding half of htslib bgzf.c:762-824 (bgzf_uncompress / inflate_block over zlib's inflate).
-// Produces exactly what bgzf_huff_decode (bgzf_inflate.hip, one LANE per block) produces -- the literal bytes, one u32 token per
-// LZ77 match and the InflateMeta record that bgzf_lz_resolve consumes -- so the two kernels are interchangeable and each is the
-// other's cross-check (tests/test_gpu_bam.py, tools/hostsim/sim_wave.cpp).
+// Produces what bgzf_lz_resolve consumes: the literal bytes, one u32 token per LZ77 match and the InflateMeta record of every block
+// (the same words the one-lane-per-block kernel of bgzf_inflate.hip produces: each is the other's cross-check in the tests and in
+// tools/hostsim/sim_wave.cpp).
 //
-// Why a second kernel: with one lane per block a symbol costs ~250 wave instructions per 64 symbols, but a launch can never
-// finish faster than ONE lane decodes ONE whole block (~22 k symbols, 13-15 ms), which is the floor of every small file, index
-// window or LIMIT query.  Here the 64 lanes of a wave share one block:
-//   * the code-length section of a dynamic block is decoded once, wave-uniformly (scalar unit + a 128-entry table held in two
-//     VGPRs and read with v_readlane), and the canonical tables are built by all lanes: ranks by ballot/mbcnt, then a direct
-//     lookup table of up to 2^12 u16 entries (literal/length) and 2^9 u32 entries (distance) in LDS, filled in code order so
-//     that every lane writes a contiguous range of codes;
-//   * the symbol stream [p0, end of payload) is cut into 64 equal bit ranges.  DEFLATE symbols are self-delimiting, so a decoder
-//     started at a wrong bit falls into step with the true symbol sequence after a few dozen symbols: every lane first decodes
-//     only the last SYNC_W bits before its right neighbour's range to PROPOSE where that neighbour starts (pass 0), then decodes
-//     its own range from its proposed start, counting what it will emit (pass 1).  Lane 0 starts at the true position; lane i is
-//     CONFIRMED when lane i-1 is confirmed and ends exactly where lane i started.  Lanes behind a broken link restart from their
-//     predecessor's end until the chain holds: by induction the confirmed chain IS the serial decode -- nothing is probabilistic
-//     about the result, only about how many rounds it takes (one, almost always);
-//   * exclusive prefix sums over the per-lane counts give every lane its place in the literal and token streams, and pass 2
-//     decodes the ranges once more, storing literals and tokens (same token format as the lane-per-block kernel: a literal run
-//     that crosses lane boundaries is carried into the lane that holds the next match).
-// A block costs ~2.2 decodes of each symbol at ~45 instructions per 64 symbols, a fraction of the canonical-arithmetic loop, and
-// its latency is microseconds.  LDS per wave: 8 KB, so 20 waves share a CU (five per SIMD): the loop is a chain of dependent
-// operations with two LDS lookups in it, and what hides that latency is the number of resident waves.
+// Round 3 structure (every symbol is decoded ~1.3 times instead of 3.4):
+//   * the kernel is PERSISTENT: a workgroup (one wave) takes BGZF blocks from an atomic counter until none is left, and owns a staging
+//     area in global memory (64 lanes x {352 tokens, 1 KiB of literals}) that it reuses for every block, so it stays in the caches;
+//   * the code-length section of a dynamic block is decoded once, wave-uniformly, and both alphabets become direct lookup tables in LDS
+//     (u16 literal/length entries under an 11-bit root, u32 distance entries under an 8-bit root; longer codes by canonical arithmetic);
+//   * the symbol stream [p0, end of payload) is cut into 64 equal bit ranges.  DEFLATE symbols are self-delimiting, so a decoder started
+//     at a wrong bit falls into step with the true sequence after a few dozen symbols: PASS 0 decodes only the last HW_SYNC_W bits in
+//     front of every range boundary (a loop that tracks nothing but the bit position) and PROPOSES where the next range starts;
+//   * PASS 1 decodes every range from its proposed start and EMITS WHILE IT COUNTS: literal bytes and tokens go through small per-lane
+//     rings in LDS (one unconditional ds_write each per symbol; the cursor only advances when the symbol was a literal / a distance) and
+//     leave for the lane's staging slice in 16-byte stores.  Lane 0 starts at the true position; lane i is CONFIRMED when lane i-1 is
+//     confirmed and ended exactly where lane i started.  Lanes behind a broken link start again from their predecessor's end (a few
+//     percent of the 64-range segments need that second round): by induction the confirmed chain IS the serial decode;
+//   * wave scans over the per-lane counts place every lane's literals and tokens in the block's scratch slot, and every lane copies its
+//     own staging slice there (16 bytes per step); the literal run that crosses lane boundaries is added to the first match token of
+//     the lane that holds the next match (plus "511 literals, no match" tokens when it overflows the 9-bit field);
+//   * a lane whose staging slice is too small (never on real data: a slice holds 4x the average) sends the segment through lane 0
+//     alone, which then appends directly to the block's slot.
+// Distances are checked against the output position by bgzf_lz_resolve (the first kernel that knows absolute positions).
 #ifndef BGZF_HUFF_WAVE_HIP
 #define BGZF_HUFF_WAVE_HIP
 #ifndef HOSTSIM_W
@@ -68,7 +67,7 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 
 // ---- geometry --------------------------------------------------------------------------------------------------------------------
 #ifndef HW_RLL
-#define HW_RLL 11u                 /* root bits of the literal/length table (u16 entries: 4 KB) */
+#define HW_RLL 12u                 /* root bits of the literal/length table (u16 entries: 8 KB) */
 #endif
 #ifndef HW_RD
 #define HW_RD 8u                   /* root bits of the distance table (u32 entries: 1 KB) */
@@ -78,16 +77,27 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 #endif
 #define HW_MIN_S 256u              /* a sub-stream is at least this many bits (short tails use fewer lanes) */
 #define HW_STAGE 1024u             /* bytes of compressed data staged for the wave-uniform header reader */
+// staging slice of one lane in global memory (per workgroup: 64 slices of each)
+#define HW_LANE_TOK 352u           /* tokens  (64 x 352 = DHTS_TOK_STRIDE) */
+#define HW_LANE_LIT 1024u          /* literal bytes */
+#define HW_STAGE_TOK_WORDS (64u * HW_LANE_TOK)
+#define HW_STAGE_LIT_BYTES (64u * HW_LANE_LIT)
+// per-lane rings in LDS: literal bytes (32 per lane, stride 36), tokens [8][64]
+#define HW_LRING_BYTES 2304u
+#define HW_TRING_BYTES 2048u
 // LDS image of one wave
-#define HW_OFF_LL 0u                                     /* u16 [4096] */
-#define HW_OFF_D (HW_OFF_LL + (2u << HW_RLL))            /* u32 [512]  */
-#define HW_OFF_STAGE (HW_OFF_D + (4u << HW_RD))          /* u8 [1024 + 8] header bytes; the lane exchange arrays reuse this space once the header is read */
-#define HW_OFF_LENS (HW_OFF_STAGE + 6u * 256u)           /* u8 [320] code lengths: literal/length then distance */
-#define HW_OFF_SLL (HW_OFF_LENS + 320u)                  /* u16 [288] literal/length entries (without the code length) in canonical order */
+#define HW_OFF_LL 0u                                     /* u16 [2^HW_RLL] */
+#define HW_OFF_D (HW_OFF_LL + (2u << HW_RLL))            /* u32 [2^HW_RD]  */
+#define HW_OFF_SLL (HW_OFF_D + (4u << HW_RD))            /* u16 [288] literal/length entries (without the code length) in canonical order */
 #define HW_OFF_SD (HW_OFF_SLL + 576u)                    /* u32 [32]  distance entries in canonical order */
 #define HW_OFF_TAB (HW_OFF_SD + 128u)                    /* u32 [2][3][16]: per alphabet limit15 / first / offs by code length */
-#define HW_OFF_X HW_OFF_STAGE                            /* u32 [6][64] lane exchange arrays */
-#define HW_LDS_BYTES (HW_OFF_TAB + 384u)
+#define HW_OFF_X (HW_OFF_TAB + 384u)                     /* u32 [6][64] lane exchange arrays */
+#define HW_OFF_LRING (HW_OFF_X + 1536u)                  /* literal ring; while the header is read: u8 [1024 + 8] staged header bytes */
+#define HW_OFF_TRING (HW_OFF_LRING + HW_LRING_BYTES)     /* token ring;   while the tables are built: u8 [320] code lengths */
+#define HW_OFF_IRING (HW_OFF_TRING + HW_TRING_BYTES)      /* input ring: 64 bytes per lane */
+#define HW_OFF_STAGE HW_OFF_LRING
+#define HW_OFF_LENS HW_OFF_TRING
+#define HW_LDS_BYTES (HW_OFF_IRING + 4096u)
 // exchange arrays
 #define HX_START 0
 #define HX_END 1
@@ -98,7 +108,7 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 
 // literal/length entry (u16): [3:0] code length (0 = no symbol: bit 4 set -> code longer than the root, else invalid), [6:4] extra bits,
 //   bit 7 = length code, [15:8] literal byte or length base - 3; end of block = length code with extra-bit count 7 (0x00F0)
-// distance entry (u32): [3:0] code length (0 as above), [7:4] extra bits, [31:16] base
+// distance entry (u32): [3:0] code length (0 as above), [7:4] extra bits, [31:16] base - 1
 // (the two formats share the positions of the code length and of the extra-bit count, so one extraction serves both alphabets)
 #define HW_LONG 0x10u
 #define HW_EOB 0x00F0u
@@ -115,18 +125,18 @@ W_DEV uint32_t hw_ll_entry(uint32_t sym) {
 }
 W_DEV uint32_t hw_d_entry(uint32_t sym) {
     if (sym >= 30u) return 0xffffffffu;                    // 30, 31: never valid
-    if (sym < 4u) return (sym + 1u) << 16;
+    if (sym < 4u) return sym << 16;
     const uint32_t x = (sym >> 1) - 1u;
     const uint32_t base = 1u + ((2u | (sym & 1u)) << x);
-    return (base << 16) | (x << 4);
+    return ((base - 1u) << 16) | (x << 4);
 }
 
 #if defined(HOSTSIM_W) && defined(HW_STATS)
-static unsigned long long g_hw_stat_p1[8], g_hw_stat_dirty, g_hw_stat_seg;
+static unsigned long long g_hw_stat_p1[8], g_hw_stat_dirty, g_hw_stat_seg, g_hw_stat_fallback;
 #endif
 // -DHW_DIAG (device builds for tools/dbg/hw_diag.py): cycles per phase, summed over blocks by lane 0
 #if defined(HW_DIAG) && !defined(HOSTSIM_W)
-__device__ unsigned long long g_hw_diag[16];   // 0 header 1 tables 2 pass0 3 pass1 4 scans 5 pass2 6 total 7 blocks 8 segments 9 pass-1 rounds 10 stored
+__device__ unsigned long long g_hw_diag[16];   // 0 header 1 tables 2 pass0 3 pass1 4 scans 5 copy 6 total 7 blocks 8 segments 9 pass-1 rounds 10 fallbacks
 #define HWD_T(v) const unsigned long long v = clock64()
 #define HWD_ADD(i, a, b) do { hwd[i] += (b) - (a); } while (0)
 #define HWD_CNT(i, n) do { hwd[i] += (n); } while (0)
@@ -135,20 +145,24 @@ __device__ unsigned long long g_hw_diag[16];   // 0 header 1 tables 2 pass0 3 pa
 #define HWD_ADD(i, a, b) do { } while (0)
 #define HWD_CNT(i, n) do { } while (0)
 #endif
-// per-lane results of the counting pass
+// per-lane results of the decoding pass
 struct HwLane {
     uint32_t start, end;       // bit positions (relative to the aligned payload base): first unit / one past the last unit of this lane
-    uint32_t flags;            // 1 = ended on the end-of-block symbol, 2 = invalid code / ran past the payload
-    uint32_t nlit, nmatch, lead, tail, pint, outb;
+    uint32_t flags;            // HWF_*
+    uint32_t nlit, ntok;       // literal bytes / tokens (matches + the lane's own "511 literals" tokens) in the lane's slice
+    uint32_t run, outb;        // literals since the lane's last token; inflated bytes of the lane's units
 };
-#define HWF_EOB 1u
-#define HWF_BAD 2u
+#define HWF_EOB 1u             /* ended on the end-of-block symbol */
+#define HWF_BAD 2u             /* invalid code / ran past the payload */
+#define HWF_OVF 4u             /* the lane's staging slice is full (the counts stay exact) */
 
 // (hi:lo) >> n for n < 32
 #ifdef HOSTSIM_W
 static inline uint32_t hw_shr64lo(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> n); }
+static inline uint32_t hw_bfe(uint32_t v, uint32_t off, uint32_t width) { return width ? (v >> off) & (0xffffffffu >> (32u - width)) : 0u; }
 #else
 __device__ __forceinline__ uint32_t hw_shr64lo(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
+__device__ __forceinline__ uint32_t hw_bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 #endif
 
 // code longer than the table's root (or no code at all): canonical arithmetic on the left-justified 15-bit prefix; 0 = invalid
@@ -178,108 +192,165 @@ W_DEV uint32_t hw_long_ll(const uint8_t *smem, uint32_t bits, const HwLong q) {
     return v == 0xffffu ? 0u : (v | L);
 }
 
-// One lane decodes the units that START in [start, stop) with the tables in LDS: ONE Huffman symbol of either alphabet per iteration
-// (a wave always holds lanes in both states), written as straight-line selects: the only branches are the refill of the bit buffer,
-// the rare long code, and -- in the emitting pass -- the stores.
-// PASS 0: nothing is counted (proposal of the neighbour's start);  PASS 1: counts;  PASS 2: emits literals and tokens.
+// ---- the lane's output streams: LDS rings -> 16-byte stores into the lane's slice ----------------------------------------------------
+// literal ring: 32 bytes per lane at a stride of 36 bytes (nine banks: the 32 lanes of a group hit 32 different banks when they are at the
+// same ring position); token ring: [8][64] words (every lane owns one bank)
+#define HW_LRING_AT(smem, lane, k) ((smem) + HW_OFF_LRING + (uint32_t)(lane) * 36u + ((k) & 31u))
+#define HW_TRING_AT(smem, lane, k) ((uint32_t *)((smem) + HW_OFF_TRING) + ((k) & 7u) * 64u + (uint32_t)(lane))
+W_DEV uint4 hw_lring_chunk(const uint8_t *smem, int lane, uint32_t k) {     // the 16 literal bytes [k, k + 16), k a multiple of 16
+    const uint32_t *p = (const uint32_t *)(smem + HW_OFF_LRING + (uint32_t)lane * 36u + (k & 16u));
+    return make_uint4(p[0], p[1], p[2], p[3]);
+}
+W_DEV uint4 hw_tring_chunk(const uint8_t *smem, int lane, uint32_t k) {     // the 4 tokens [k, k + 4), k a multiple of 4
+    const uint32_t *p = (const uint32_t *)(smem + HW_OFF_TRING) + (k & 4u) * 64u + (uint32_t)lane;
+    return make_uint4(p[0], p[64], p[128], p[192]);
+}
+
+// input ring: 64 bytes per lane, [16 words][64 lanes]
+#define HW_IRING_AT(smem, lane, k) ((uint32_t *)((smem) + HW_OFF_IRING) + ((k) & 15u) * 64u + (uint32_t)(lane))
+// The next 16 input bytes of a lane travel global memory -> four VGPRs -> LDS ring WITHOUT the compiler's knowledge (a load the compiler
+// sees is waited for where its result is copied, i.e. right behind the load: every iteration of the loop then costs a memory latency):
+// HW_LOAD16 issues the load, HW_LOAD16_WAIT is the wait; both sit in ONE straight-line loop body (no back edge between them, so the four
+// registers cannot be moved in between) with four units of decoding in the middle.
+#ifdef HOSTSIM_W
+typedef struct { uint32_t x, y, z, w; } hw_u32x4;
+#define HW_LOAD16(dst, ptr) do { uint32_t t_[4]; __builtin_memcpy(t_, (ptr), 16); (dst).x = t_[0]; (dst).y = t_[1]; (dst).z = t_[2]; (dst).w = t_[3]; } while (0)
+#define HW_LOAD16_WAIT(dst) do { } while (0)
+#else
+typedef uint32_t hw_u32x4 __attribute__((ext_vector_type(4)));
+#define HW_LOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define HW_LOAD16_WAIT(dst) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory")
+#endif
+
+// One lane decodes the units that START in [start, stop) with the tables in LDS: ONE UNIT per step -- a literal, or a length with
+// its distance (the distance half runs under the execution mask of the lanes that decoded a length) -- so a range boundary always lies
+// between units and no lane carries an alphabet state.  Straight-line arithmetic (masks instead of selects); the branches are the refill
+// of the bit buffer (from the lane's input ring in LDS), the rare code above the table's root, the end-of-block symbol, a literal run
+// of 511 or more in front of a match.  The loop body is four units between two "stage points": the top one requests the lane's next
+// 16 input bytes, the bottom one parks them in the input ring and moves full 16-byte pieces of the output rings to the lane's slice.
+// PASS 0: nothing is counted or emitted (proposal of the neighbour's start);  PASS 1: counts and emits into the lane's slice.
 template <int PASS>
-W_DEV void hw_span(const uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t stop, uint32_t limit_bits, uint32_t mask_ll, uint32_t mask_d, uint32_t rll, uint32_t rd, const HwLong lq,
-                   HwLane &r, uint8_t *lit, uint32_t *tok, uint32_t lit_at, uint32_t tok_at, uint32_t out_at, uint32_t run_in, int32_t &status) {
+W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t stop, uint32_t limit_bits, uint32_t mask_ll, uint32_t mask_d, uint32_t rll, uint32_t rd, const HwLong lq,
+                   int lane, HwLane &r, uint8_t *lit_out, uint32_t *tok_out, uint32_t lit_cap, uint32_t tok_cap, uint32_t run_in) {
     const uint16_t *lut_ll = (const uint16_t *)(smem + HW_OFF_LL);
     const uint32_t *lut_d = (const uint32_t *)(smem + HW_OFF_D);
-    // input: the lane reads its range 16 bytes at a time (each 64-byte line is fetched by four loads instead of sixteen), one chunk
-    // ahead of the chunk it is consuming, so a load has four refills (~16 symbols) to arrive before anything waits for it
-    uint32_t lo, hi = 0, cnt, q0, q1, q2, left;
-    uint4 nx;                                                 // the chunk in flight
-    const uint32_t *qp;
+    // input: words [.., wcommit) of the lane's stream are in the ring (word k at ring position k & 15); widx = the next word to enter the
+    // bit buffer, nw = that word (read one refill ahead, so the LDS latency overlaps the decoding of 32 bits)
+    uint32_t lo, hi = 0, cnt, widx, nw, gnext, wcommit;
     {
-        const uint32_t w = start >> 5, o = start & 31u;
-        uint4 c0; __builtin_memcpy(&c0, in32 + w, 16);
-        lo = c0.x >> o; cnt = 32u - o; q0 = c0.y; q1 = c0.z; q2 = c0.w; left = 3;
-        qp = in32 + w + 4; __builtin_memcpy(&nx, qp, 16);
+        const uint32_t w = start >> 5, o = start & 31u, g0 = w >> 2;
+        for (uint32_t g = g0; g < g0 + 4u; g++) {
+            uint4 c; __builtin_memcpy(&c, in32 + 4u * g, 16);
+            *HW_IRING_AT(smem, lane, 4u * g) = c.x; *HW_IRING_AT(smem, lane, 4u * g + 1u) = c.y; *HW_IRING_AT(smem, lane, 4u * g + 2u) = c.z; *HW_IRING_AT(smem, lane, 4u * g + 3u) = c.w;
+        }
+        gnext = g0 + 4u; wcommit = 4u * gnext;
+        lo = *HW_IRING_AT(smem, lane, w) >> o; cnt = 32u - o; widx = w + 1u; nw = *HW_IRING_AT(smem, lane, widx);
     }
-    uint32_t pos = start, mode = 0, want = 0, flags = 0;
-    uint32_t nlit = 0, nmatch = 0, lead = 0, run = (PASS == 2) ? run_in : 0u, pint = 0, outb = 0;
-    uint32_t litw = 0, l0 = 0, l1 = 0, l2 = 0;               // PASS 2: literal bytes not yet stored: (nlit >> 2) & 3 whole words, then the low (nlit & 3) bytes of litw
-    uint32_t ntk = 0, t0 = 0, t1 = 0, t2 = 0;                // PASS 2: tokens of this lane so far; the last ntk & 3 are not yet stored
-    bool live = pos < stop;
-    while (live) {
-        if (cnt < 32u) {
-            if (left == 0u) { q0 = nx.x; q1 = nx.y; q2 = nx.z; const uint32_t q3 = nx.w; qp += 4; __builtin_memcpy(&nx, qp, 16); lo |= q0 << cnt; hi |= (q0 >> 1) >> (31u - cnt); q0 = q1; q1 = q2; q2 = q3; left = 3; }
-            else { lo |= q0 << cnt; hi |= (q0 >> 1) >> (31u - cnt); q0 = q1; q1 = q2; left--; }
-            cnt += 32u;
+    // (the bit buffer holds fewer than 32 bits here, all of them in lo: hi is zero)
+#define HW_REFILL() do {                                                                                                                              \
+        if (cnt < 32u) { lo |= nw << cnt; hi = (nw >> 1) >> (31u - cnt); cnt += 32u; widx++; nw = *HW_IRING_AT(smem, lane, widx); }                       \
+    } while (0)
+#define HW_TAKE(n_) do { const uint32_t u_ = (n_); lo = hw_shr64lo(hi, lo, u_); hi >>= u_; cnt -= u_; pos += u_; } while (0)
+#define HW_PUSH_TOK(v_) do { *HW_TRING_AT(smem, lane, ntok) = (v_); ntok++; } while (0)
+#define HW_FLUSH_TOK() do {                                                                                                                             \
+        if (tfl + 4u <= tok_cap) { const uint4 v_ = hw_tring_chunk(smem, lane, tfl); __builtin_memcpy(tok_out + tfl, &v_, 16); } else flags |= HWF_OVF;  \
+        tfl += 4u;                                                                                                                                        \
+    } while (0)
+#define HW_FLUSH_LIT() do {                                                                                                                             \
+        if (lfl + 16u <= lit_cap) { const uint4 v_ = hw_lring_chunk(smem, lane, lfl); __builtin_memcpy(lit_out + lfl, &v_, 16); } else flags |= HWF_OVF; \
+        lfl += 16u;                                                                                                                                       \
+    } while (0)
+    uint32_t pos = start, flags = 0;
+    uint32_t nlit = 0, ntok = 0, run = (PASS == 1) ? run_in : 0u, mbytes = 0;
+    uint32_t lfl = 0, tfl = 0;                               // literal bytes / tokens already stored in the slice (multiples of 16 / 4)
+    // a lane that decodes garbage (wrong start, damaged stream) stops at the end of the payload at the latest; a lane that has seen the
+    // end-of-block symbol or an invalid code stops by pulling its limit down to zero
+    uint32_t stopv = stop < limit_bits + 64u ? stop : limit_bits + 64u;
+    // ONE unit
+#define HW_UNIT() do {                                                                                                                                \
+        if (pos < stopv) {                                                                                                                                \
+            HW_REFILL();                                                                                                                                  \
+            uint32_t e = lut_ll[lo & mask_ll];                                                                                                            \
+            if ((e & 15u) == 0u) {                                                                                                                        \
+                /* (a literal/length code above the root can only exist when the root is HW_RLL) */                                                       \
+                e = !(e & HW_LONG) ? 0u : (HW_RLL >= 11u && rll == HW_RLL) ? hw_long_ll(smem, lo, lq) : hw_long_code(smem, lo, 0u, rll);                  \
+                if ((e & 15u) == 0u) { flags |= HWF_BAD; stopv = 0; e = 0x0001u; }                                                                        \
+            }                                                                                                                                             \
+            const uint32_t L = e & 15u, x = (e >> 4) & 7u;                                                                                                \
+            const uint32_t ext = hw_bfe(lo, L, x);               /* (the end-of-block entry asks for 7 bits: given back below) */                         \
+            const uint32_t islen_m = (uint32_t)((int32_t)(e << 24) >> 31);     /* all ones for a length code / end of block */                          \
+            if (PASS == 1) {                                                                                                                              \
+                /* the literal ring is written every time; its cursor moves only when the symbol was a literal */                                         \
+                *HW_LRING_AT(smem, lane, nlit) = (uint8_t)(e >> 8);                                                                                       \
+                nlit += 1u + islen_m; run += 1u + islen_m;                                                                                                \
+            }                                                                                                                                             \
+            HW_TAKE(L + x);                                                                                                                               \
+            if (islen_m) {                                                                                                                                \
+                if ((e & 0x70u) == 0x70u) { flags |= HWF_EOB; stopv = 0; pos -= 7u; }                                                                     \
+                else {                                                                                                                                    \
+                    const uint32_t want3 = (e >> 8) + ext;          /* length - 3 */                                                                      \
+                    HW_REFILL();                                                                                                                          \
+                    uint32_t d = lut_d[lo & mask_d];                                                                                                      \
+                    if ((d & 15u) == 0u) {                                                                                                                \
+                        d = !(d & HW_LONG) ? 0u : hw_long_code(smem, lo, 1u, rd);                                                                         \
+                        if ((d & 15u) == 0u) { flags |= HWF_BAD; stopv = 0; d = 0x0001u; }                                                                \
+                    }                                                                                                                                     \
+                    const uint32_t L2 = d & 15u, x2 = (d >> 4) & 15u;                                                                                     \
+                    const uint32_t dist1 = (d >> 16) + hw_bfe(lo, L2, x2);      /* distance - 1 */                                                        \
+                    HW_TAKE(L2 + x2);                                                                                                                     \
+                    if (PASS == 1) {                                                                                                                      \
+                        while (run >= DHTS_TOK_PURE) {             /* 511 literals or more in front of this match: "511 literals, no match" tokens */     \
+                            HW_PUSH_TOK(DHTS_TOK_PURE << 23); run -= DHTS_TOK_PURE;                                                                       \
+                            if (ntok - tfl >= 4u) HW_FLUSH_TOK();                                                                                         \
+                        }                                                                                                                                 \
+                        HW_PUSH_TOK((run << 23) | (want3 << 15) | dist1);                                                                                 \
+                        run = 0; mbytes += want3 + 3u;                                                                                                    \
+                    }                                                                                                                                     \
+                }                                                                                                                                         \
+            }                                                                                                                                             \
+        }                                                                                                                                                 \
+    } while (0)
+    hw_u32x4 inq; inq.x = 0; inq.y = 0; inq.z = 0; inq.w = 0;
+    while (pos < stopv) {
+        // stage point: four units take at most 24 bytes (6 words) and the refill reads one word ahead: with fewer than 8 words in the ring
+        // beyond widx the lane fetches its next 16 bytes and waits for them (a rare burst of long matches); otherwise it requests
+        // them when the ring has a free slot (the chunks [widx / 4, gnext) are in it or on their way) and collects them four units later
+        if (wcommit - widx < 8u) {
+            const uint32_t *gp = in32 + 4u * gnext; hw_u32x4 now; HW_LOAD16(now, gp); HW_LOAD16_WAIT(now);
+            *HW_IRING_AT(smem, lane, 4u * gnext) = now.x; *HW_IRING_AT(smem, lane, 4u * gnext + 1u) = now.y; *HW_IRING_AT(smem, lane, 4u * gnext + 2u) = now.z; *HW_IRING_AT(smem, lane, 4u * gnext + 3u) = now.w;
+            gnext++; wcommit += 4u;
         }
-        const uint32_t bits = lo;
-        const uint32_t e0 = lut_ll[bits & mask_ll], e1 = lut_d[bits & mask_d];
-        uint32_t e = mode ? e1 : e0;
-        if ((e & 15u) == 0u) {
-            // (a literal/length code above the root can only exist when the root is HW_RLL: four lengths, limits in registers)
-            e = !(e & HW_LONG) ? 0u : mode ? hw_long_code(smem, bits, 1u, rd) : (HW_RLL == 11u && rll == HW_RLL) ? hw_long_ll(smem, bits, lq) : hw_long_code(smem, bits, 0u, rll);
-            if ((e & 15u) == 0u) { flags |= HWF_BAD; e = 0x0001u; }
+        const bool req = gnext - (widx >> 2) < 4u;
+        if (req) { const uint32_t *gp = in32 + 4u * gnext; HW_LOAD16(inq, gp); }
+        HW_UNIT(); HW_UNIT(); HW_UNIT(); HW_UNIT();
+        // stage point: the requested bytes have arrived (the load is four units old; so are the stores of the previous stage point)
+        HW_LOAD16_WAIT(inq);
+        if (req) {
+            *HW_IRING_AT(smem, lane, 4u * gnext) = inq.x; *HW_IRING_AT(smem, lane, 4u * gnext + 1u) = inq.y; *HW_IRING_AT(smem, lane, 4u * gnext + 2u) = inq.z; *HW_IRING_AT(smem, lane, 4u * gnext + 3u) = inq.w;
+            gnext++; wcommit += 4u;
         }
-        const uint32_t L = e & 15u;
-        const uint32_t islen = mode ? 0u : (e >> 7) & 1u;
-        const uint32_t xr = (e >> 4) & (mode ? 15u : 7u);
-        const uint32_t iseob = (islen && xr == 7u) ? 1u : 0u;
-        const uint32_t x = iseob ? 0u : xr;
-        const uint32_t val = (mode ? (e >> 16) : ((e >> 8) & 255u) + 3u) + ((bits >> L) & ((1u << x) - 1u));
-        const uint32_t use = L + x;
-        const uint32_t islit = (mode | islen) ^ 1u;
-        if (PASS == 2) {
-            // literals and tokens leave the lane 16 bytes at a time (one store per 16 literals / 4 matches: stores are counted by the
-            // same vmcnt as the input loads, and a scattered 4-byte store per lane costs the memory pipeline a transaction per lane)
-            if (islit) {
-                litw |= ((e >> 8) & 255u) << (8u * (nlit & 3u));
-                if ((nlit & 3u) == 3u) {
-                    const uint32_t qd = (nlit >> 2) & 3u;
-                    if (qd == 0u) l0 = litw; else if (qd == 1u) l1 = litw; else if (qd == 2u) l2 = litw;
-                    else { const uint4 v16 = make_uint4(l0, l1, l2, litw); __builtin_memcpy(lit + lit_at + nlit - 15u, &v16, 16); }
-                    litw = 0;
-                }
-            }
-            if (mode) {
-                // the stream position of this match is out_at + outb: a distance may not reach before the start of the block
-                if (val > out_at + outb) { status = DHTS_BLK_ERR_INFLATE; flags |= HWF_BAD; }
-                else {
-                    uint32_t tv = DHTS_TOK_PURE << 23;
-                    for (;;) {
-                        const bool pure = run >= DHTS_TOK_PURE;
-                        if (!pure) tv = (run << 23) | ((want - 3u) << 15) | (val - 1u); else run -= DHTS_TOK_PURE;
-                        const uint32_t qd = ntk & 3u;
-                        if (qd == 0u) t0 = tv; else if (qd == 1u) t1 = tv; else if (qd == 2u) t2 = tv;
-                        else { const uint4 v16 = make_uint4(t0, t1, t2, tv); __builtin_memcpy(tok + tok_at + ntk - 3u, &v16, 16); }
-                        ntk++;
-                        if (!pure) break;
-                    }
-                }
-            }
+        if (PASS == 1) {
+            // at most four new entries per ring since the last stage point (a match with a very long literal run flushes for itself)
+            if (ntok - tfl >= 4u) HW_FLUSH_TOK();
+            if (nlit - lfl >= 16u) HW_FLUSH_LIT();
         }
-        if (PASS != 0) {
-            if (PASS == 1 && mode && nmatch && run >= DHTS_TOK_PURE) pint += run / DHTS_TOK_PURE;
-            lead = (mode && nmatch == 0u) ? run : lead;
-            nlit += islit; outb += mode ? want : islit;
-            nmatch += mode; run = mode ? 0u : run + islit;
-        }
-        want = islen ? val : want;
-        mode = islen & (iseob ^ 1u);
-        lo = hw_shr64lo(hi, lo, use); hi >>= use; cnt -= use; pos += use;
-        flags |= iseob ? HWF_EOB : 0u;
-        flags |= (pos > limit_bits + 64u) ? HWF_BAD : 0u;            // ran off the payload (a true stream never does)
-        live = flags == 0u && (mode != 0u || pos < stop);
     }
-    if (PASS == 2) {
-        const uint32_t wq = (nlit >> 2) & 3u, base = lit_at + (nlit & ~15u);
-        if (wq > 0u) __builtin_memcpy(lit + base, &l0, 4);
-        if (wq > 1u) __builtin_memcpy(lit + base + 4u, &l1, 4);
-        if (wq > 2u) __builtin_memcpy(lit + base + 8u, &l2, 4);
-        for (uint32_t k = nlit & ~3u; k < nlit; k++) lit[lit_at + k] = (uint8_t)(litw >> (8u * (k & 3u)));
-        const uint32_t tq = ntk & 3u, tb_ = tok_at + (ntk & ~3u);
-        if (tq > 0u) tok[tb_] = t0;
-        if (tq > 1u) tok[tb_ + 1u] = t1;
-        if (tq > 2u) tok[tb_ + 2u] = t2;
+    if (!(flags & HWF_EOB) && pos > limit_bits) flags |= HWF_BAD;            // ran off the payload (a true stream ends with its end-of-block symbol)
+    if (PASS == 1) {
+        // what is still in the rings: whole pieces first, then single entries (nothing is ever stored beyond the lane's counts)
+        while (ntok - tfl >= 4u) HW_FLUSH_TOK();
+        for (; tfl < ntok; tfl++) { if (tfl < tok_cap) tok_out[tfl] = *HW_TRING_AT(smem, lane, tfl); else flags |= HWF_OVF; }
+        while (nlit - lfl >= 16u) HW_FLUSH_LIT();
+        for (; lfl < nlit; lfl++) { if (lfl < lit_cap) lit_out[lfl] = *HW_LRING_AT(smem, lane, lfl); else flags |= HWF_OVF; }
+        r.nlit = nlit; r.ntok = ntok; r.run = run; r.outb = nlit + mbytes;
     }
     r.end = pos; r.flags = flags;
-    if (PASS == 1) { r.nlit = nlit; r.nmatch = nmatch; r.lead = nmatch ? lead : nlit; r.tail = nmatch ? run : 0u; r.pint = pint; r.outb = outb; }
+#undef HW_UNIT
+#undef HW_REFILL
+#undef HW_TAKE
+#undef HW_PUSH_TOK
+#undef HW_FLUSH_TOK
+#undef HW_FLUSH_LIT
 }
 
 // ---- wave-uniform header reader over the staged bytes ---------------------------------------------------------------------------
@@ -287,22 +358,18 @@ struct HwHdr { uint64_t buf; uint32_t cnt, widx; const uint32_t *words; };
 W_DEV void hw_hdr_fill(HwHdr &h) { if (h.cnt <= 32u) { h.buf |= (uint64_t)W_UNI(h.words[h.widx]) << h.cnt; h.widx++; h.cnt += 32u; } }
 W_DEV uint32_t hw_hdr_take(HwHdr &h, uint32_t n) { hw_hdr_fill(h); const uint32_t v = (uint32_t)h.buf & ((1u << n) - 1u); h.buf >>= n; h.cnt -= n; return v; }
 
+// One BGZF block: block `s` of the launch's range, decoded by the calling wave into slot `s` of the scratch.  `slit` / `stok` are the
+// workgroup's staging slices.
 #ifdef HOSTSIM_W
-static void bgzf_huff_decode_wave_body(uint8_t *smem, int blk_in_grid, const uint8_t *comp, BgzfTable tab, int64_t blk0, int32_t nblk,
-                                       uint8_t *lit_all, uint32_t *tok_all, InflateMeta *meta)
+static void hw_block(uint8_t *smem, int64_t s, const uint8_t *comp, BgzfTable tab, int64_t blk0,
+                     uint8_t *lit_all, uint32_t *tok_all, InflateMeta *meta, uint8_t *slit, uint32_t *stok)
 #else
-extern "C" __global__ void __launch_bounds__(64)
-bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
-                      uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta)
+__device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0,
+                                         uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta,
+                                         uint8_t *__restrict__ slit, uint32_t *__restrict__ stok, unsigned long long *hwd)
 #endif
 {
-#ifndef HOSTSIM_W
-    __shared__ __attribute__((aligned(16))) uint8_t smem[HW_LDS_BYTES];
-    const int blk_in_grid = blockIdx.x;
-#endif
     W_LANE_DECL
-    if (blk_in_grid >= nblk) return;
-    const int64_t s = blk_in_grid;
     const int64_t bi = blk0 + s;
     const uint32_t clen = tab.clen[bi];
     uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
@@ -315,9 +382,8 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
     uint32_t *sd = (uint32_t *)(smem + HW_OFF_SD);
     uint32_t *tb = (uint32_t *)(smem + HW_OFF_TAB);          // [0..15] ll limit15, [16..31] ll first, [32..47] ll offs, [48..] the same for distances
     uint32_t *xch = (uint32_t *)(smem + HW_OFF_X);
-
-#if defined(HW_DIAG) && !defined(HOSTSIM_W)
-    unsigned long long hwd[16]; for (int q_ = 0; q_ < 16; q_++) hwd[q_] = 0;
+#ifndef HOSTSIM_W
+    (void)hwd;
 #endif
     HWD_T(t_begin);
     int32_t status = clen >= 26u ? 0 : DHTS_BLK_ERR_INFLATE;
@@ -343,6 +409,7 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
             }
             W_SYNC();
         }
+        HWD_T(t_hs); HWD_ADD(11, t_h0, t_hs);
         HwHdr h; h.words = (const uint32_t *)stage; h.buf = 0; h.cnt = 0; h.widx = 0;
         { const uint32_t o = pos & 31u; hw_hdr_fill(h); h.buf >>= o; h.cnt -= o; }
         uint32_t hpos = pos;                                 // position of the next unread header bit
@@ -397,6 +464,7 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                 for (int L = 1; L <= 7; L++) { left = (left << 1) - (int)ccount[L]; cfirst[L] = first; coffs[L] = offs; offs += ccount[L]; first = (first + ccount[L]) << 1; }
                 if (left != 0) { status = DHTS_BLK_ERR_INFLATE; break; }      // the code-length code must be complete
             }
+            HWD_T(t_hc0);
             PLD(uint32_t, cl0); PLD(uint32_t, cl1);
             W_LANES {
                 for (int half = 0; half < 2; half++) {
@@ -415,32 +483,64 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                 }
             }
             (void)coffs;
-#ifdef HOSTSIM_W
-#define HW_CL_LOOKUP(i) ((i) < 64u ? cl0[(i)] : cl1[(i) - 64u])
-#else
-#define HW_CL_LOOKUP(i) ((i) < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)cl0, (int)(i)) : (uint32_t)__builtin_amdgcn_readlane((int)cl1, (int)((i) - 64u)))
-#endif
+            // The code-length symbols (RFC 1951 3.2.7) are decoded at EVERY bit position of a 1,024-bit window at once (16 positions per
+            // lane): how far the symbol at that position reaches, how many lengths it stands for and which value -- then a short
+            // wave-uniform walk follows the chain of the positions where symbols really start (one LDS read per symbol instead of a
+            // scalar Huffman decode), and the lanes write the lengths the visited symbols stand for.
+            uint16_t *cltab = (uint16_t *)(smem + HW_OFF_X);                 // u16 [128]: the direct table of the code-length code
+            uint32_t *vis = (uint32_t *)(smem + HW_OFF_X + 256u);            // u32 [320]: visited symbols: first index | count << 9 | value << 17
+            uint32_t *arr = (uint32_t *)(smem + HW_OFF_IRING);               // u32 [1024]: per position: advance | count << 4 | value << 12 (0xff: the previous length)
+            W_LANES { cltab[lane] = (uint16_t)PL(cl0); cltab[64 + lane] = (uint16_t)PL(cl1); }
+            HWD_T(t_hc1); HWD_ADD(12, t_hc0, t_hc1);
             const uint32_t total = nl + nd;
-            uint32_t idx = 0, prev = 0;
-            while (idx < total) {
-                hw_hdr_fill(h);
-                if (hpos > limit_bits) { status = DHTS_BLK_ERR_INFLATE; break; }
-                const uint32_t ent = HW_CL_LOOKUP((uint32_t)h.buf & 127u);
-                const uint32_t L = ent & 7u, sym = ent >> 3;
-                if (L == 0u) { status = DHTS_BLK_ERR_INFLATE; break; }
-                h.buf >>= L; h.cnt -= L; hpos += L;
-                uint32_t val, rep;
-                if (sym < 16u) { val = sym; rep = 1; }
-                else if (sym == 16u) { if (idx == 0u) { status = DHTS_BLK_ERR_INFLATE; break; } val = prev; rep = 3u + hw_hdr_take(h, 2); hpos += 2; }
-                else if (sym == 17u) { val = 0; rep = 3u + hw_hdr_take(h, 3); hpos += 3; }
-                else { val = 0; rep = 11u + hw_hdr_take(h, 7); hpos += 7; }
-                if (idx + rep > total) { status = DHTS_BLK_ERR_INFLATE; break; }
-                prev = val;
-                if (val != 0u) {
-                    // distance lengths live behind the 288 literal/length slots
-                    W_LANES { if ((uint32_t)lane < rep) { const uint32_t i = idx + (uint32_t)lane; lens[i < nl ? i : 288u + (i - nl)] = (uint8_t)val; } }
+            const uint32_t w0s = pos >> 5;                                   // the staged bytes start at this word
+            uint32_t idx = 0, prev = 0, nvis = 0, wbase = hpos, q = 0;
+            while (status == 0) {
+                W_SYNC();
+                W_LANES {
+                    const uint32_t *stw = (const uint32_t *)stage;
+                    for (uint32_t j = 0; j < 16u; j++) {
+                        const uint32_t qq = j * 64u + (uint32_t)lane, bp = wbase + qq, wi = (bp >> 5) - w0s;
+                        uint32_t packed = 0;                                 // advance 0: no symbol can be read here
+                        if (wi + 1u < HW_STAGE / 4u) {
+                            const uint32_t v = hw_shr64lo(stw[wi + 1u], stw[wi], bp & 31u);
+                            const uint32_t ent = cltab[v & 127u], L = ent & 7u, sym = ent >> 3;
+                            const uint32_t xb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+                            const uint32_t ev = (v >> L) & ((1u << xb) - 1u);
+                            const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + ev : 3u + ev;
+                            const uint32_t val = sym < 16u ? sym : sym == 16u ? 0xffu : 0u;
+                            if (L != 0u) packed = (L + xb) | (rep << 4) | (val << 12);
+                        }
+                        arr[qq] = packed;
+                    }
                 }
-                idx += rep;
+                W_SYNC();
+                HWD_T(t_hw0);
+                while (idx < total && q < 1024u) {
+                    const uint32_t a = W_UNI(arr[q]);
+                    const uint32_t adv = a & 15u, rep = (a >> 4) & 255u;
+                    uint32_t val = (a >> 12) & 255u;
+                    if (adv == 0u) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    if (val == 0xffu) { if (idx == 0u) { status = DHTS_BLK_ERR_INFLATE; break; } val = prev; }
+                    if (idx + rep > total) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    prev = val;
+                    W_LANES { if (lane == 0) vis[nvis] = idx | (rep << 9) | (val << 17); }
+                    nvis++; idx += rep; q += adv;
+                }
+                { HWD_T(t_hw1); HWD_ADD(14, t_hw0, t_hw1); }
+                if (status != 0 || idx >= total) break;
+                wbase += q; q = 0;                                           // (a header longer than the window: decode the next one)
+                if ((uint32_t)(wbase - pos) > HW_STAGE * 8u - 64u) { status = DHTS_BLK_ERR_INFLATE; break; }
+            }
+            hpos = wbase + q;
+            if (status != 0) break;
+            W_SYNC();
+            W_LANES {
+                for (uint32_t k = (uint32_t)lane; k < nvis; k += 64u) {
+                    const uint32_t e = vis[k], i0 = e & 511u, rep = (e >> 9) & 255u, val = e >> 17;
+                    // distance lengths live behind the 288 literal/length slots (a value other than zero is repeated six times at most)
+                    if (val != 0u) for (uint32_t rr = 0; rr < rep; rr++) { const uint32_t i = i0 + rr; lens[i < nl ? i : 288u + (i - nl)] = (uint8_t)val; }
+                }
             }
             if (status != 0) break;
             if ((uint32_t)(hpos - pos) > HW_STAGE * 8u - 64u) { status = DHTS_BLK_ERR_INFLATE; break; }     // (cannot happen: a header is < 4,600 bits)
@@ -539,6 +639,7 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
             PLD(HwLane, ln);
             W_LANES {
                 PL(ln).start = p0 + (uint32_t)lane * S; PL(ln).end = 0; PL(ln).flags = 0;
+                PL(ln).nlit = 0; PL(ln).ntok = 0; PL(ln).run = 0; PL(ln).outb = 0;
                 xch[HX_START * 64 + lane] = p0 + (uint32_t)lane * S;
             }
             W_SYNC();
@@ -546,8 +647,8 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                 if ((uint32_t)lane + 1u < nlanes) {
                     const uint32_t bnd = p0 + ((uint32_t)lane + 1u) * S;
                     const uint32_t from = bnd - p0 > HW_SYNC_W + (uint32_t)lane * S ? bnd - HW_SYNC_W : p0 + (uint32_t)lane * S;
-                    HwLane tmp; int32_t st_ = 0;
-                    hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, tmp, nullptr, nullptr, 0, 0, 0, 0, st_);
+                    HwLane tmp;
+                    hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, lane, tmp, nullptr, nullptr, 0, 0, 0);
                     if (tmp.flags == 0u) xch[HX_START * 64 + lane + 1] = tmp.end;
                 }
             }
@@ -564,25 +665,27 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
 #endif
                 W_LANES {
                     if ((dirty >> lane) & 1ull) {
-                        int32_t st_ = 0;
                         const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? p0 + ((uint32_t)lane + 1u) * S : 0xffffffffu;   // the last lane runs to the end-of-block symbol
-                        hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, PL(ln), nullptr, nullptr, 0, 0, 0, 0, st_);
+                        // (lane 0 continues the literal run that is open at the start of the segment)
+                        hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, lane, PL(ln),
+                                   slit + (uint32_t)lane * HW_LANE_LIT, stok + (uint32_t)lane * HW_LANE_TOK, HW_LANE_LIT, HW_LANE_TOK, lane == 0 ? run : 0u);
                         // a range whose first unit starts at or beyond its boundary holds nothing: it ends where it starts
                     }
-                    xch[HX_END * 64 + lane] = PL(ln).end; xch[HX_FLAG * 64 + lane] = PL(ln).flags;
                 }
+                W_SYNC();
+                W_LANES { xch[HX_END * 64 + lane] = PL(ln).end; xch[HX_FLAG * 64 + lane] = PL(ln).flags; }
                 W_SYNC();
                 // link i: lane i starts where lane i-1 ended (and lane i-1 went on: no end-of-block, no error)
                 uint64_t linked, stop;
-                W_BALLOT(linked, lane == 0 || ((uint32_t)lane < nlanes && xch[HX_FLAG * 64 + lane - 1] == 0u && xch[HX_END * 64 + lane - 1] == PL(ln).start));
-                W_BALLOT(stop, (uint32_t)lane < nlanes && PL(ln).flags != 0u);
+                W_BALLOT(linked, lane == 0 || ((uint32_t)lane < nlanes && (xch[HX_FLAG * 64 + lane - 1] & (HWF_EOB | HWF_BAD)) == 0u && xch[HX_END * 64 + lane - 1] == PL(ln).start));
+                W_BALLOT(stop, (uint32_t)lane < nlanes && (PL(ln).flags & (HWF_EOB | HWF_BAD)) != 0u);
                 const uint32_t k_conf = (uint32_t)w_ctz64(~linked);                     // lanes 0 .. k_conf-1 are confirmed
                 const uint64_t conf_mask = k_conf >= 64u ? ~0ull : ((1ull << k_conf) - 1ull);
                 if (stop & conf_mask) { n_ok = (uint32_t)w_ctz64(stop & conf_mask) + 1u; break; }      // the first confirmed lane that stopped ends the segment
                 if (k_conf >= nlanes) { n_ok = nlanes; break; }
                 // restart every lane behind a broken link from its predecessor's end (the first of them becomes confirmed next round)
                 uint64_t nd_;
-                W_BALLOT(nd_, (uint32_t)lane >= k_conf && (uint32_t)lane < nlanes && xch[HX_FLAG * 64 + lane - 1] == 0u && xch[HX_END * 64 + lane - 1] != PL(ln).start);
+                W_BALLOT(nd_, (uint32_t)lane >= k_conf && (uint32_t)lane < nlanes && (xch[HX_FLAG * 64 + lane - 1] & (HWF_EOB | HWF_BAD)) == 0u && xch[HX_END * 64 + lane - 1] != PL(ln).start);
                 W_LANES { if ((nd_ >> lane) & 1ull) PL(ln).start = xch[HX_END * 64 + lane - 1]; }
                 dirty = nd_;
                 if (dirty == 0ull) { status = DHTS_BLK_ERR_INFLATE; break; }            // (cannot happen: lane k_conf's link is broken, so it is dirty)
@@ -597,49 +700,100 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
             eob_seen = (last_flags & HWF_EOB) != 0u;
             if (seg_end > limit_bits) { status = DHTS_BLK_ERR_INFLATE; break; }
             if (!eob_seen && seg_end >= limit_bits) { status = DHTS_BLK_ERR_INFLATE; break; }     // the payload ended without an end-of-block symbol
+            uint64_t ovf;
+            W_BALLOT(ovf, (uint32_t)lane < n_ok && (PL(ln).flags & HWF_OVF) != 0u);
+            if (ovf) {
+                // ---- a staging slice was too small: lane 0 decodes the whole segment and appends to the block's slot itself ----
+                HWD_CNT(10, 1);
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+                g_hw_stat_fallback++;
+#endif
+                const uint32_t lcap = nlit_tot < DHTS_LIT_STRIDE ? DHTS_LIT_STRIDE - nlit_tot : 0u, tcap = ntok_tot + 64u < DHTS_TOK_STRIDE ? DHTS_TOK_STRIDE - 64u - ntok_tot : 0u;
+                W_LANES {
+                    if (lane == 0) hw_span<1>(smem, in32, p0, 0xffffffffu, limit_bits, mask_ll, mask_d, rll, rd, lq, lane, PL(ln), lit + nlit_tot, tok + ntok_tot, lcap, tcap, run);
+                }
+                W_SYNC();
+                W_LANES { if (lane == 0) { xch[HX_END * 64] = PL(ln).end; xch[HX_FLAG * 64] = PL(ln).flags; xch[HX_A * 64] = PL(ln).nlit; xch[HX_B * 64] = PL(ln).ntok; xch[HX_C * 64] = PL(ln).run; xch[HX_START * 64] = PL(ln).outb; } }
+                W_SYNC();
+                const uint32_t f0 = xch[HX_FLAG * 64];
+                if (f0 != HWF_EOB || xch[HX_END * 64] != seg_end) { status = DHTS_BLK_ERR_INFLATE; break; }      // (an overflow here means more output than a block may hold)
+                if (outpos + xch[HX_START * 64] > 65536u) { status = DHTS_BLK_ERR_INFLATE; break; }
+                nlit_tot += xch[HX_A * 64]; ntok_tot += xch[HX_B * 64]; run = xch[HX_C * 64]; outpos += xch[HX_START * 64];
+                p0 = seg_end;
+                W_SYNC();
+                HWD_T(t_sf); HWD_ADD(5, t_s2, t_sf);
+                continue;
+            }
             // ---- places: exclusive sums over the lanes of the segment ----
-            PLD(uint32_t, v_nlit); PLD(uint32_t, v_out); PLD(uint32_t, v_ntok); PLD(uint32_t, o_lit); PLD(uint32_t, o_out); PLD(uint32_t, o_tok); PLD(uint32_t, carry);
-            uint32_t tot_lit, tot_out, tot_tok;
-            W_LANES { const bool in = (uint32_t)lane < n_ok; PL(v_nlit) = in ? PL(ln).nlit : 0u; PL(v_out) = in ? PL(ln).outb : 0u; }
+            PLD(uint32_t, v_nlit); PLD(uint32_t, v_out); PLD(uint32_t, v_run); PLD(uint32_t, v_ntok); PLD(uint32_t, o_lit); PLD(uint32_t, o_out); PLD(uint32_t, o_run); PLD(uint32_t, o_tok);
+            PLD(uint32_t, plead); PLD(uint32_t, extra); PLD(uint32_t, newrun);
+            uint32_t tot_lit, tot_out, tot_run, tot_tok;
+            W_LANES { const bool in = (uint32_t)lane < n_ok; PL(v_nlit) = in ? PL(ln).nlit : 0u; PL(v_out) = in ? PL(ln).outb : 0u; PL(v_run) = in ? PL(ln).run : 0u; }
             W_EXCL_SCAN(o_lit, v_nlit, tot_lit);
             W_EXCL_SCAN(o_out, v_out, tot_out);
+            W_EXCL_SCAN(o_run, v_run, tot_run);
+            (void)o_out;
             if (outpos + tot_out > 65536u) { status = DHTS_BLK_ERR_INFLATE; break; }
+            // the lane's first match token (behind its own "511 literals" tokens, if it has any): read back from the slice
+            W_LANES {
+                uint32_t k = 0; const uint32_t n = (uint32_t)lane < n_ok ? PL(ln).ntok : 0u;
+                const uint32_t *st = stok + (uint32_t)lane * HW_LANE_TOK;
+                while (k < n && st[k] == (DHTS_TOK_PURE << 23)) k++;
+                PL(plead) = k;
+                PL(newrun) = k < n ? st[k] >> 23 : 0u;       // (for now: the token's own literal run)
+            }
             uint64_t has_match;
-            W_BALLOT(has_match, (uint32_t)lane < n_ok && PL(ln).nmatch != 0u);
-            W_LANES { xch[HX_A * 64 + lane] = PL(o_lit); xch[HX_B * 64 + lane] = (uint32_t)lane < n_ok ? PL(ln).tail : 0u; xch[HX_C * 64 + lane] = PL(v_nlit); }
+            W_BALLOT(has_match, (uint32_t)lane < n_ok && PL(plead) < PL(ln).ntok);
+            W_LANES { xch[HX_A * 64 + lane] = PL(o_run); }
             W_SYNC();
             W_LANES {
-                // literals that precede this lane's first unit and follow the last match before it (or the start of the block)
+                // literals that precede this lane's first unit and follow the last token before it: the runs left open by the lanes
+                // from the last one with a match (lane 0's run includes what the previous segment left open)
                 const uint64_t lower = has_match & ((1ull << lane) - 1ull);
-                uint32_t c;
-                if (lower == 0ull) c = run + PL(o_lit);
-                else { const int j = w_msb64(lower); c = xch[HX_B * 64 + j] + PL(o_lit) - (xch[HX_A * 64 + j] + xch[HX_C * 64 + j]); }
-                PL(carry) = c;
-                PL(v_ntok) = ((uint32_t)lane < n_ok && PL(ln).nmatch != 0u) ? PL(ln).nmatch + PL(ln).pint + (c + PL(ln).lead) / DHTS_TOK_PURE : 0u;
+                const uint32_t c = lower == 0ull ? PL(o_run) : PL(o_run) - xch[HX_A * 64 + w_msb64(lower)];
+                const bool hm = ((has_match >> lane) & 1ull) != 0ull;
+                const uint32_t t = c + PL(newrun);
+                PL(extra) = hm ? t / DHTS_TOK_PURE : 0u;
+                PL(newrun) = t % DHTS_TOK_PURE;
+                PL(v_ntok) = (uint32_t)lane < n_ok ? PL(ln).ntok + PL(extra) : 0u;
             }
             W_EXCL_SCAN(o_tok, v_ntok, tot_tok);
+            // the run that is still open behind the segment's last token
+            if (has_match) run = tot_run - xch[HX_A * 64 + w_msb64(has_match)]; else run = tot_run;
+            const uint32_t q_end = run / DHTS_TOK_PURE;
+            if (ntok_tot + tot_tok + q_end + 64u > DHTS_TOK_STRIDE || nlit_tot + tot_lit > DHTS_LIT_STRIDE) { status = DHTS_BLK_ERR_INFLATE; break; }     // (more than a valid block can hold)
             HWD_T(t_s3); HWD_ADD(4, t_s2, t_s3);
-            // ---- pass 2: emit ----
+            // ---- every lane moves its slice to its place in the block's slot ----
             W_LANES {
                 if ((uint32_t)lane < n_ok) {
-                    HwLane chk; int32_t st_ = 0;
-                    const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? p0 + ((uint32_t)lane + 1u) * S : 0xffffffffu;
-                    hw_span<2>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, chk, lit, tok, nlit_tot + PL(o_lit), ntok_tot + PL(o_tok), outpos + PL(o_out), PL(carry), st_);
-                    xch[HX_FLAG * 64 + lane] = (st_ != 0 || chk.end != PL(ln).end) ? 1u : 0u;
-                } else xch[HX_FLAG * 64 + lane] = 0u;
+                    const uint32_t *st = stok + (uint32_t)lane * HW_LANE_TOK;
+                    uint32_t *dt = tok + ntok_tot + PL(o_tok);
+                    for (uint32_t k = 0; k < PL(extra); k++) dt[k] = DHTS_TOK_PURE << 23;
+                    dt += PL(extra);
+                    const uint32_t n = PL(ln).ntok;
+                    uint32_t k = 0;
+                    for (; k + 4u <= n; k += 4u) { uint4 v; __builtin_memcpy(&v, st + k, 16); __builtin_memcpy(dt + k, &v, 16); }
+                    for (; k < n; k++) dt[k] = st[k];
+                    const uint8_t *sl = slit + (uint32_t)lane * HW_LANE_LIT;
+                    uint8_t *dl = lit + nlit_tot + PL(o_lit);
+                    const uint32_t m = PL(ln).nlit;
+                    uint32_t j = 0;
+                    for (; j + 16u <= m; j += 16u) { uint4 v; __builtin_memcpy(&v, sl + j, 16); __builtin_memcpy(dl + j, &v, 16); }
+                    for (; j < m; j++) dl[j] = sl[j];
+                }
             }
             W_SYNC();
-            uint64_t bad2;
-            W_BALLOT(bad2, xch[HX_FLAG * 64 + lane] != 0u);
-            if (bad2) { status = DHTS_BLK_ERR_INFLATE; break; }
-            // the run that is still open: literals after the last match of the segment
-            if (has_match) { const int j = w_msb64(has_match); run = xch[HX_B * 64 + j] + tot_lit - (xch[HX_A * 64 + j] + xch[HX_C * 64 + j]); }
-            else run += tot_lit;
+            W_LANES {
+                // the first match token takes the literals that the lanes in front of it left open
+                if ((uint32_t)lane < n_ok && PL(plead) < PL(ln).ntok) {
+                    const uint32_t t0 = stok[(uint32_t)lane * HW_LANE_TOK + PL(plead)];
+                    tok[ntok_tot + PL(o_tok) + PL(extra) + PL(plead)] = (t0 & 0x007fffffu) | (PL(newrun) << 23);
+                }
+            }
             nlit_tot += tot_lit; ntok_tot += tot_tok; outpos += tot_out;
             {
-                const uint32_t q = run / DHTS_TOK_PURE;
-                W_LANES { for (uint32_t k = (uint32_t)lane; k < q; k += 64u) tok[ntok_tot + k] = DHTS_TOK_PURE << 23; }
-                ntok_tot += q; run -= q * DHTS_TOK_PURE;
+                W_LANES { for (uint32_t k = (uint32_t)lane; k < q_end; k += 64u) tok[ntok_tot + k] = DHTS_TOK_PURE << 23; }
+                ntok_tot += q_end; run -= q_end * DHTS_TOK_PURE;
             }
             p0 = seg_end;
             W_SYNC();
@@ -650,8 +804,35 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
     if (status == 0 && pos > limit_bits) status = DHTS_BLK_ERR_INFLATE;
     InflateMeta m; m.ntok = ntok_tot; m.nlit = nlit_tot; m.outlen = outpos; m.status = status;
     W_LANES { if (lane == 0) meta[s] = m; }
-#if defined(HW_DIAG) && !defined(HOSTSIM_W)
-    { HWD_T(t_end); HWD_ADD(6, t_begin, t_end); HWD_CNT(7, 1); if (lane == 0) for (int q_ = 0; q_ < 16; q_++) if (hwd[q_]) atomicAdd(&g_hw_diag[q_], hwd[q_]); }
+    W_SYNC();
+    { HWD_T(t_end); HWD_ADD(6, t_begin, t_end); HWD_CNT(7, 1); }
+}
+
+#ifndef HOSTSIM_W
+// The launch: `grid` workgroups of one wave; workgroup g starts with block g and then takes blocks from *counter (set to `grid` by the
+// host before the launch) until the range is exhausted -- every wave reaches the exit test after each block.
+extern "C" __global__ void __launch_bounds__(64)
+bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                      uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta,
+                      uint8_t *__restrict__ stage_lit, uint32_t *__restrict__ stage_tok, uint32_t *__restrict__ counter) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[HW_LDS_BYTES];
+    uint8_t *slit = stage_lit + (size_t)blockIdx.x * HW_STAGE_LIT_BYTES;
+    uint32_t *stok = stage_tok + (size_t)blockIdx.x * HW_STAGE_TOK_WORDS;
+#if defined(HW_DIAG)
+    unsigned long long hwd[16]; for (int q_ = 0; q_ < 16; q_++) hwd[q_] = 0;
+#else
+    unsigned long long *hwd = nullptr;
+#endif
+    uint32_t b = blockIdx.x;
+    while (b < (uint32_t)nblk) {
+        hw_block(smem, (int64_t)b, comp, tab, blk0, lit_all, tok_all, meta, slit, stok, hwd);
+        uint32_t nb_ = 0;
+        if (threadIdx.x == 0) nb_ = atomicAdd(counter, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb_);
+    }
+#if defined(HW_DIAG)
+    if (threadIdx.x == 0) for (int q_ = 0; q_ < 16; q_++) if (hwd[q_]) atomicAdd(&g_hw_diag[q_], hwd[q_]);
 #endif
 }
+#endif
 #endif

@@ -737,6 +737,9 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
         const uint32_t tot_adv = RDLANE(adv_i, 63), tot_lit = RDLANE(lit_i, 63);
         const uint32_t dst = outpos + adv_i - (lrun + mlen);       // where this token's literals start
         const uint32_t lsrc = litpos + lit_i - lrun;               // absolute index of its first literal byte
+        // a distance may not reach in front of the block's first byte (RFC 1951 3.2.3): the wave kernel of phase A cannot make this
+        // test (its lanes do not know their output position while they decode), so it is made here, before any source is touched
+        if (__ballot(mlen > 0 && mdist > dst + lrun) != 0ull) { if (lane == 0) blk_status[bi] = DHTS_BLK_ERR_INFLATE; return; }
         DIAG_T(t_a);
         if (tot_adv <= BR_SPAN && tot_lit <= 1024u) {
             DIAG_ADD(0, 1);

@@ -180,6 +180,7 @@ struct dhts_ctx {
     std::vector<uint64_t> h_coff, h_uoff; std::vector<uint32_t> h_clen, h_isize;
     // inflate scratch
     DevBuf lit, tok, meta;
+    DevBuf stg_lit, stg_tok, wave_ctr;             // wave kernel: staging slices of the resident workgroups, block counter
     DevBuf sg_cnt, sg_base, sg_cand, sg_hits;      // block discovery scratch
     // index writer
     std::vector<uint8_t> built_index; DevBuf ix_end; BamStream last_stream;   // last_stream: the inflated buffer of the latest batch
@@ -187,6 +188,7 @@ struct dhts_ctx {
     bool ov_active = false; int64_t ov_n = 0;
     DevBuf ov_beg, ov_end, ov_pmax, ov_bmax, ov_id, ov_first, ov_cnt, ov_off, ov_ids;
     int64_t huff_b0 = 0, huff_nb = 0;     // block range whose tokens are in the scratch
+    int64_t wave_slots = 0;              // workgroups of the wave kernel the device holds at once (occupancy query, first use)
     int64_t super_blocks = 524288;       // phase A runs ahead over up to this many blocks (1,536 waves are resident at once, six per CU;
                                          // a long launch keeps every SIMD backfilled).  Scratch is 152 KiB per block: see inflate_blocks.
     // inflated stream double buffer (carry moves between them)
@@ -841,9 +843,24 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {   
     static const int64_t wave_max = getenv("DHTS_WAVE_MAX_BLOCKS") ? atoll(getenv("DHTS_WAVE_MAX_BLOCKS")) : 65536;
     const bool env_lane = force >= 0 ? force != 2 : env_a ? !strcmp(env_a, "lane") : (nb > wave_max);
     if (!env_lane) {
+        // persistent launch: as many workgroups (one wave each) as the device holds at once, each with its own staging slices; the
+        // workgroups take blocks from a counter that starts behind the blocks they begin with
+        static const int64_t env_wg = getenv("DHTS_WAVE_WG_PER_CU") ? atoll(getenv("DHTS_WAVE_WG_PER_CU")) : 0;      // tuning knob
+        if (c->wave_slots == 0) {
+            int per_cu = 0; hipDeviceProp_t pr;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bgzf_huff_decode_wave, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+            if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) return fail(c, "hipGetDeviceProperties failed");
+            if (env_wg > 0) per_cu = (int)env_wg;
+            c->wave_slots = (int64_t)per_cu * pr.multiProcessorCount;
+        }
+        const int64_t grid = nb < c->wave_slots ? nb : c->wave_slots;
+        ENSURE(c, c->stg_lit, (size_t)grid * HW_STAGE_LIT_BYTES + 64);
+        ENSURE(c, c->stg_tok, (size_t)grid * HW_STAGE_TOK_WORDS * 4 + 64);
+        ENSURE(c, c->wave_ctr, 64);
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->wave_ctr.p, (int)grid, 1, c->stream));
         KTimer tm(c, DHTS_K_HUFF);
-        hipLaunchKernelGGL(bgzf_huff_decode_wave, dim3((unsigned)nb), dim3(64), 0, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
-                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p);
+        hipLaunchKernelGGL(bgzf_huff_decode_wave, dim3((unsigned)grid), dim3(64), 0, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p, (uint8_t *)c->stg_lit.p, (uint32_t *)c->stg_tok.p, (uint32_t *)c->wave_ctr.p);
     } else {
         KTimer tm(c, DHTS_K_HUFF);
         // a launch that six waves per CU can hold at once keeps every symbol in LDS; a longer one runs eight waves per CU

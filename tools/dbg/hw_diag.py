@@ -22,7 +22,7 @@ L.dhts_debug_time_huff.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
 h = L.dhts_create(0)
 L.dhts_open_tiled(C.c_void_p(h), head.ctypes.data, head.nbytes, body.ctypes.data, body.nbytes, int(os.environ.get("REPS", "4")), tail.ctypes.data, tail.nbytes)
 nb = L.dhts_bgzf_index(C.c_void_p(h))
-names = ["header", "tables", "pass0", "pass1", "scans", "pass2", "total", "blocks", "segments", "p1_rounds"]
+names = ["header", "tables", "pass0", "pass1", "scans", "copy", "total", "blocks", "segments", "p1_rounds", "fallbacks"]
 for nblk in (2048, 65536):
     if nblk + 1 > nb:
         continue
@@ -35,5 +35,5 @@ for nblk in (2048, 65536):
         L.dhts_debug_hw_diag(C.c_void_p(h), d, 1)
         v = [int(x) for x in d]
         blocks = max(v[7], 1)
-        line += " | per block (cycles): " + ", ".join(f"{n} {v[i] / blocks:.0f}" for i, n in enumerate(names[:7])) + f" | segments/block {v[8] / blocks:.2f} p1 rounds/block {v[9] / blocks:.2f} (sampled blocks {v[7]})"
+        line += " | per block (cycles): " + ", ".join(f"{n} {v[i] / blocks:.0f}" for i, n in enumerate(names[:7])) + f" | hdr: stage {v[11] / blocks:.0f} cltab {v[12] / blocks:.0f} walk {v[14] / blocks:.0f} | segments/block {v[8] / blocks:.2f} p1 rounds/block {v[9] / blocks:.2f} (sampled blocks {v[7]})"
     print(line, flush=True)
