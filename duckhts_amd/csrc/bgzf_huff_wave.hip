@@ -44,6 +44,9 @@
 #define W_BALLOT(maskvar, expr) do { maskvar = 0; for (int lane = 0; lane < 64; lane++) if (expr) maskvar |= 1ull << lane; } while (0)
 #define W_EXCL_SCAN(dst, src, total) do { uint32_t run_ = 0; for (int lane = 0; lane < 64; lane++) { const uint32_t v_ = src[lane]; dst[lane] = run_; run_ += v_; } total = run_; } while (0)
 #define W_LANE_DECL
+#define W_READLANE(x, i) ((x)[(i)])
+#define W_WRITELANE(x, i, v) do { (x)[(i)] = (v); } while (0)
+#define W_INCL_SCAN_MAX(dst, src) do { uint32_t run_ = 0; for (int lane = 0; lane < 64; lane++) { if (src[lane] > run_) run_ = src[lane]; dst[lane] = run_; } } while (0)
 static inline uint32_t w_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 static inline uint32_t w_popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 static inline int w_ctz64(uint64_t v) { return v ? __builtin_ctzll(v) : 64; }
@@ -58,6 +61,9 @@ static inline int w_msb64(uint64_t v) { return 63 - __builtin_clzll(v); }
 #define W_BALLOT(maskvar, expr) do { maskvar = __ballot(expr); } while (0)
 #define W_EXCL_SCAN(dst, src, total) do { const uint32_t v_ = (src); const uint32_t i_ = wave_incl_scan(v_, lane); dst = i_ - v_; total = RDLANE(i_, 63); } while (0)
 #define W_LANE_DECL const int lane = threadIdx.x;
+#define W_READLANE(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(i)))
+#define W_WRITELANE(x, i, v) do { (x) = (lane == (int)(i)) ? (uint32_t)(v) : (x); } while (0)
+#define W_INCL_SCAN_MAX(dst, src) do { dst = wave_incl_scan_max(src); } while (0)
 __device__ __forceinline__ uint32_t w_brev32(uint32_t v) { return __brev(v); }
 __device__ __forceinline__ uint32_t w_popc64(uint64_t v) { return (uint32_t)__popcll(v); }
 __device__ __forceinline__ int w_ctz64(uint64_t v) { return v ? __ffsll((unsigned long long)v) - 1 : 64; }
@@ -67,7 +73,7 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 
 // ---- geometry --------------------------------------------------------------------------------------------------------------------
 #ifndef HW_RLL
-#define HW_RLL 12u                 /* root bits of the literal/length table (u16 entries: 8 KB) */
+#define HW_RLL 11u                 /* root bits of the literal/length table (u16 entries: 4 KB) */
 #endif
 #ifndef HW_RD
 #define HW_RD 8u                   /* root bits of the distance table (u32 entries: 1 KB) */
@@ -87,14 +93,17 @@ __device__ __forceinline__ int w_msb64(uint64_t v) { return 63 - __clzll((long l
 #define HW_TRING_BYTES 2048u
 // LDS image of one wave
 #define HW_OFF_LL 0u                                     /* u16 [2^HW_RLL] */
-#define HW_OFF_D (HW_OFF_LL + (2u << HW_RLL))            /* u32 [2^HW_RD]  */
+#define HW_SUB_ENTRIES 512u                              /* second-level literal/length entries (u16) */
+#define HW_OFF_SUB (HW_OFF_LL + (2u << HW_RLL))          /* u16 [HW_SUB_ENTRIES] */
+#define HW_OFF_D (HW_OFF_SUB + 2u * HW_SUB_ENTRIES)      /* u32 [2^HW_RD]  */
 #define HW_OFF_SLL (HW_OFF_D + (4u << HW_RD))            /* u16 [288] literal/length entries (without the code length) in canonical order */
 #define HW_OFF_SD (HW_OFF_SLL + 576u)                    /* u32 [32]  distance entries in canonical order */
 #define HW_OFF_TAB (HW_OFF_SD + 128u)                    /* u32 [2][3][16]: per alphabet limit15 / first / offs by code length */
-#define HW_OFF_X (HW_OFF_TAB + 384u)                     /* u32 [6][64] lane exchange arrays */
-#define HW_OFF_LRING (HW_OFF_X + 1536u)                  /* literal ring; while the header is read: u8 [1024 + 8] staged header bytes */
+#define HW_OFF_LRING (HW_OFF_TAB + 384u)                 /* literal ring; while the header is read: u8 [1024 + 8] staged header bytes */
 #define HW_OFF_TRING (HW_OFF_LRING + HW_LRING_BYTES)     /* token ring;   while the tables are built: u8 [320] code lengths */
-#define HW_OFF_IRING (HW_OFF_TRING + HW_TRING_BYTES)      /* input ring: 64 bytes per lane */
+#define HW_OFF_IRING (HW_OFF_TRING + HW_TRING_BYTES)      /* input ring: 64 bytes per lane; between two decoding passes: */
+#define HW_OFF_X HW_OFF_IRING                            /*   u32 [6][64] lane exchange arrays (never touched while a lane decodes) */
+#define HW_OFF_HX (HW_OFF_TRING + 512u)                  /* u32 [64] exchange array of the header reader (the input ring's space holds its position table) */
 #define HW_OFF_STAGE HW_OFF_LRING
 #define HW_OFF_LENS HW_OFF_TRING
 #define HW_LDS_BYTES (HW_OFF_IRING + 4096u)
@@ -178,20 +187,6 @@ W_DEV uint32_t hw_long_code(const uint8_t *smem, uint32_t bits, uint32_t mode, u
     return v == 0xffffu ? 0u : (v | L);
 }
 
-// the four literal/length code lengths above the root (HW_RLL + 1 .. 15 when HW_RLL is 11): limits, first codes and offsets, wave-uniform
-struct HwLong { uint32_t l0, l1, l2, l3, f0, f1, f2, f3, o0, o1, o2, o3; };
-W_DEV uint32_t hw_long_ll(const uint8_t *smem, uint32_t bits, const HwLong q) {
-    const uint32_t w15 = w_brev32(bits) >> 17;
-    const uint32_t c0 = w15 >= q.l0, c1 = w15 >= q.l1, c2 = w15 >= q.l2;
-    if (w15 >= q.l3) return 0u;
-    const uint32_t L = HW_RLL + 1u + c0 + c1 + c2;
-    const uint32_t f = c2 ? q.f3 : c1 ? q.f2 : c0 ? q.f1 : q.f0;
-    const uint32_t o = c2 ? q.o3 : c1 ? q.o2 : c0 ? q.o1 : q.o0;
-    const uint32_t si = o + ((w15 >> (15u - L)) - f);
-    const uint32_t v = si < 288u ? ((const uint16_t *)(smem + HW_OFF_SLL))[si] : 0xffffu;
-    return v == 0xffffu ? 0u : (v | L);
-}
-
 // ---- the lane's output streams: LDS rings -> 16-byte stores into the lane's slice ----------------------------------------------------
 // literal ring: 32 bytes per lane at a stride of 36 bytes (nine banks: the 32 lanes of a group hit 32 different banks when they are at the
 // same ring position); token ring: [8][64] words (every lane owns one bank)
@@ -216,10 +211,14 @@ W_DEV uint4 hw_tring_chunk(const uint8_t *smem, int lane, uint32_t k) {     // t
 typedef struct { uint32_t x, y, z, w; } hw_u32x4;
 #define HW_LOAD16(dst, ptr) do { uint32_t t_[4]; __builtin_memcpy(t_, (ptr), 16); (dst).x = t_[0]; (dst).y = t_[1]; (dst).z = t_[2]; (dst).w = t_[3]; } while (0)
 #define HW_LOAD16_WAIT(dst) do { } while (0)
+#define HW_ANY(c) (c)
 #else
 typedef uint32_t hw_u32x4 __attribute__((ext_vector_type(4)));
 #define HW_LOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #define HW_LOAD16_WAIT(dst) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory")
+// (a wave-level test in front of a rare per-lane case -- __ballot(c) != 0 -- was measured: the compiler then emits both the scalar
+//  branch and the execution-mask branch, 4 % more instructions in all)
+#define HW_ANY(c) (c)
 #endif
 
 // One lane decodes the units that START in [start, stop) with the tables in LDS: ONE UNIT per step -- a literal, or a length with
@@ -230,7 +229,7 @@ typedef uint32_t hw_u32x4 __attribute__((ext_vector_type(4)));
 // 16 input bytes, the bottom one parks them in the input ring and moves full 16-byte pieces of the output rings to the lane's slice.
 // PASS 0: nothing is counted or emitted (proposal of the neighbour's start);  PASS 1: counts and emits into the lane's slice.
 template <int PASS>
-W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t stop, uint32_t limit_bits, uint32_t mask_ll, uint32_t mask_d, uint32_t rll, uint32_t rd, const HwLong lq,
+W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t stop, uint32_t limit_bits, uint32_t mask_ll, uint32_t mask_d, uint32_t rll, uint32_t rd, uint32_t subbits,
                    int lane, HwLane &r, uint8_t *lit_out, uint32_t *tok_out, uint32_t lit_cap, uint32_t tok_cap, uint32_t run_in) {
     const uint16_t *lut_ll = (const uint16_t *)(smem + HW_OFF_LL);
     const uint32_t *lut_d = (const uint32_t *)(smem + HW_OFF_D);
@@ -271,10 +270,13 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
         if (pos < stopv) {                                                                                                                                \
             HW_REFILL();                                                                                                                                  \
             uint32_t e = lut_ll[lo & mask_ll];                                                                                                            \
-            if ((e & 15u) == 0u) {                                                                                                                        \
-                /* (a literal/length code above the root can only exist when the root is HW_RLL) */                                                       \
-                e = !(e & HW_LONG) ? 0u : (HW_RLL >= 11u && rll == HW_RLL) ? hw_long_ll(smem, lo, lq) : hw_long_code(smem, lo, 0u, rll);                  \
-                if ((e & 15u) == 0u) { flags |= HWF_BAD; stopv = 0; e = 0x0001u; }                                                                        \
+            if (HW_ANY((e & 15u) == 0u)) {                                                                                                                \
+                if ((e & 15u) == 0u) {                                                                                                                    \
+                    /* a code longer than the root: second-level table (number in the entry, index = the next stream bits), else canonical arithmetic */\
+                    if (e & 0x20u) e = ((const uint16_t *)(smem + HW_OFF_SUB))[((e >> 6) << subbits) + hw_bfe(lo, rll, subbits)];                          \
+                    else e = (e & HW_LONG) ? hw_long_code(smem, lo, 0u, rll) : 0u;                                                                        \
+                    if ((e & 15u) == 0u) { flags |= HWF_BAD; stopv = 0; e = 0x0001u; }                                                                    \
+                }                                                                                                                                         \
             }                                                                                                                                             \
             const uint32_t L = e & 15u, x = (e >> 4) & 7u;                                                                                                \
             const uint32_t ext = hw_bfe(lo, L, x);               /* (the end-of-block entry asks for 7 bits: given back below) */                         \
@@ -285,27 +287,30 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
                 nlit += 1u + islen_m; run += 1u + islen_m;                                                                                                \
             }                                                                                                                                             \
             HW_TAKE(L + x);                                                                                                                               \
-            if (islen_m) {                                                                                                                                \
-                if ((e & 0x70u) == 0x70u) { flags |= HWF_EOB; stopv = 0; pos -= 7u; }                                                                     \
-                else {                                                                                                                                    \
-                    const uint32_t want3 = (e >> 8) + ext;          /* length - 3 */                                                                      \
-                    HW_REFILL();                                                                                                                          \
-                    uint32_t d = lut_d[lo & mask_d];                                                                                                      \
+            const bool iseob = (e & 0xf0u) == 0xf0u;                                                                                                      \
+            if (HW_ANY(iseob)) { if (iseob) { flags |= HWF_EOB; stopv = 0; pos -= 7u; } }                                                                 \
+            if (islen_m != 0u && !iseob) {                                                                                                                \
+                const uint32_t want3 = (e >> 8) + ext;          /* length - 3 */                                                                          \
+                HW_REFILL();                                                                                                                              \
+                uint32_t d = lut_d[lo & mask_d];                                                                                                          \
+                if (HW_ANY((d & 15u) == 0u)) {                                                                                                            \
                     if ((d & 15u) == 0u) {                                                                                                                \
                         d = !(d & HW_LONG) ? 0u : hw_long_code(smem, lo, 1u, rd);                                                                         \
                         if ((d & 15u) == 0u) { flags |= HWF_BAD; stopv = 0; d = 0x0001u; }                                                                \
                     }                                                                                                                                     \
-                    const uint32_t L2 = d & 15u, x2 = (d >> 4) & 15u;                                                                                     \
-                    const uint32_t dist1 = (d >> 16) + hw_bfe(lo, L2, x2);      /* distance - 1 */                                                        \
-                    HW_TAKE(L2 + x2);                                                                                                                     \
-                    if (PASS == 1) {                                                                                                                      \
+                }                                                                                                                                         \
+                const uint32_t L2 = d & 15u, x2 = (d >> 4) & 15u;                                                                                         \
+                const uint32_t dist1 = (d >> 16) + hw_bfe(lo, L2, x2);      /* distance - 1 */                                                            \
+                HW_TAKE(L2 + x2);                                                                                                                         \
+                if (PASS == 1) {                                                                                                                          \
+                    if (HW_ANY(run >= DHTS_TOK_PURE)) {                                                                                                   \
                         while (run >= DHTS_TOK_PURE) {             /* 511 literals or more in front of this match: "511 literals, no match" tokens */     \
                             HW_PUSH_TOK(DHTS_TOK_PURE << 23); run -= DHTS_TOK_PURE;                                                                       \
                             if (ntok - tfl >= 4u) HW_FLUSH_TOK();                                                                                         \
                         }                                                                                                                                 \
-                        HW_PUSH_TOK((run << 23) | (want3 << 15) | dist1);                                                                                 \
-                        run = 0; mbytes += want3 + 3u;                                                                                                    \
                     }                                                                                                                                     \
+                    HW_PUSH_TOK((run << 23) | (want3 << 15) | dist1);                                                                                     \
+                    run = 0; mbytes += want3 + 3u;                                                                                                        \
                 }                                                                                                                                         \
             }                                                                                                                                             \
         }                                                                                                                                                 \
@@ -465,37 +470,38 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
                 if (left != 0) { status = DHTS_BLK_ERR_INFLATE; break; }      // the code-length code must be complete
             }
             HWD_T(t_hc0);
-            PLD(uint32_t, cl0); PLD(uint32_t, cl1);
-            W_LANES {
-                for (int half = 0; half < 2; half++) {
-                    const uint32_t idx = (uint32_t)lane + 64u * half;        // 7 stream bits, first code bit in bit 0
-                    uint32_t ent = 0, code = 0;
-                    for (uint32_t L = 1; L <= 7u && !ent; L++) {
-                        code = (code << 1) | ((idx >> (L - 1u)) & 1u);
-                        const uint32_t c = code - cfirst[L];
-                        if (code >= cfirst[L] && c < ccount[L]) {
-                            // the c-th symbol (in symbol order) among those of length L
-                            uint32_t seen = 0;
-                            for (uint32_t sy = 0; sy < 19u; sy++) if (((clpack >> (3u * sy)) & 7u) == L) { if (seen == c) { ent = L | (sy << 3); break; } seen++; }
-                        }
-                    }
-                    if (half == 0) PL(cl0) = ent; else PL(cl1) = ent;
-                }
+            // lane s < 19 owns code-length symbol s: its rank among the symbols of its length (ballot per length) gives its canonical code;
+            // then 19 uniform steps drop every symbol into the entries whose low bits are its (bit-reversed) code
+            PLD(uint32_t, cl0); PLD(uint32_t, cl1); PLD(uint32_t, clen_s); PLD(uint32_t, crev_s);
+            W_LANES { PL(clen_s) = lane < 19 ? (uint32_t)(clpack >> (3u * (uint32_t)lane)) & 7u : 0u; PL(crev_s) = 0; PL(cl0) = 0; PL(cl1) = 0; }
+            for (uint32_t L = 1; L <= 7u; L++) {
+                if (ccount[L] == 0u) continue;
+                uint64_t m; W_BALLOT(m, PL(clen_s) == L);
+                W_LANES { if (PL(clen_s) == L) PL(crev_s) = w_brev32(cfirst[L] + w_popc64(m & ((1ull << lane) - 1ull))) >> (32u - L); }
+            }
+            for (int sy = 0; sy < 19; sy++) {
+                const uint32_t L = W_READLANE(clen_s, sy), rv = W_READLANE(crev_s, sy);
+                if (L == 0u) continue;
+                const uint32_t msk = (1u << L) - 1u, ent = L | ((uint32_t)sy << 3);
+                W_LANES { if (((uint32_t)lane & msk) == rv) PL(cl0) = ent; if ((((uint32_t)lane + 64u) & msk) == rv) PL(cl1) = ent; }
             }
             (void)coffs;
             // The code-length symbols (RFC 1951 3.2.7) are decoded at EVERY bit position of a 1,024-bit window at once (16 positions per
-            // lane): how far the symbol at that position reaches, how many lengths it stands for and which value -- then a short
-            // wave-uniform walk follows the chain of the positions where symbols really start (one LDS read per symbol instead of a
-            // scalar Huffman decode), and the lanes write the lengths the visited symbols stand for.
-            uint16_t *cltab = (uint16_t *)(smem + HW_OFF_X);                 // u16 [128]: the direct table of the code-length code
-            uint32_t *vis = (uint32_t *)(smem + HW_OFF_X + 256u);            // u32 [320]: visited symbols: first index | count << 9 | value << 17
+            // lane): how far the symbol at that position reaches, how many lengths it stands for and which value.  A symbol is at most
+            // 14 bits long, so the chain of positions where symbols really start touches every lane's 16 positions: each lane works out
+            // where the chain leaves its positions for each of the 16 offsets at which it can come in (a 16 x 4-bit map, built backwards),
+            // 64 scalar steps push the chain's true entry offset through the maps, and then every lane walks only its own few symbols:
+            // once to count the lengths they stand for (wave scans give each lane its first index and the value a "repeat previous"
+            // symbol copies), once to write them.
+            uint16_t *cltab = (uint16_t *)(smem + HW_OFF_SUB);               // u16 [128]: the direct table of the code-length code (the second-level table's space)
             uint32_t *arr = (uint32_t *)(smem + HW_OFF_IRING);               // u32 [1024]: per position: advance | count << 4 | value << 12 (0xff: the previous length)
             W_LANES { cltab[lane] = (uint16_t)PL(cl0); cltab[64 + lane] = (uint16_t)PL(cl1); }
             HWD_T(t_hc1); HWD_ADD(12, t_hc0, t_hc1);
             const uint32_t total = nl + nd;
             const uint32_t w0s = pos >> 5;                                   // the staged bytes start at this word
-            uint32_t idx = 0, prev = 0, nvis = 0, wbase = hpos, q = 0;
-            while (status == 0) {
+            uint32_t idx0 = 0, prev0 = 16u, wbase = hpos;                    // lengths written so far; the last one (16: there is none); the window's first position (a symbol starts there)
+            bool hdr_done = false;
+            while (status == 0 && !hdr_done) {
                 W_SYNC();
                 W_LANES {
                     const uint32_t *stw = (const uint32_t *)stage;
@@ -516,30 +522,92 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
                 }
                 W_SYNC();
                 HWD_T(t_hw0);
-                while (idx < total && q < 1024u) {
-                    const uint32_t a = W_UNI(arr[q]);
-                    const uint32_t adv = a & 15u, rep = (a >> 4) & 255u;
-                    uint32_t val = (a >> 12) & 255u;
-                    if (adv == 0u) { status = DHTS_BLK_ERR_INFLATE; break; }
-                    if (val == 0xffu) { if (idx == 0u) { status = DHTS_BLK_ERR_INFLATE; break; } val = prev; }
-                    if (idx + rep > total) { status = DHTS_BLK_ERR_INFLATE; break; }
-                    prev = val;
-                    W_LANES { if (lane == 0) vis[nvis] = idx | (rep << 9) | (val << 17); }
-                    nvis++; idx += rep; q += adv;
+                // the lane's map: offset of the chain's first position in the lane's range -> the same for the next lane (15: the chain ends
+                // on an invalid code).  Built from offset 15 down: a symbol either leaves the range or lands on an offset already done.
+                PLD(uint32_t, mlo); PLD(uint32_t, mhi); PLD(uint32_t, ent_o);
+                W_LANES {
+                    uint64_t m = 0;
+                    for (int o = 15; o >= 0; o--) {
+                        const uint32_t a = arr[16u * (uint32_t)lane + (uint32_t)o] & 15u, k = (uint32_t)o + a;
+                        const uint32_t ex = a == 0u ? 15u : k >= 16u ? k - 16u : (uint32_t)(m >> (4u * k)) & 15u;
+                        m |= (uint64_t)ex << (4u * (uint32_t)o);
+                    }
+                    // (an entry offset of 15 can only be the previous lane's "chain ended": a symbol is at most 14 bits long)
+                    m |= 15ull << 60;
+                    PL(mlo) = (uint32_t)m; PL(mhi) = (uint32_t)(m >> 32); PL(ent_o) = 0;
                 }
+                uint32_t e_run = 0;                                          // lane 0 starts on the window's first position
+                for (int i = 0; i < 64; i++) {
+                    W_WRITELANE(ent_o, i, e_run);
+                    const uint32_t lo_ = W_READLANE(mlo, i), hi_ = W_READLANE(mhi, i);
+                    e_run = ((e_run < 8u ? lo_ >> (4u * e_run) : hi_ >> (4u * (e_run - 8u))) & 15u);
+                }
+                // first walk: how many lengths the lane's symbols stand for, and the last value they define (16: none -- only "repeat previous")
+                PLD(uint32_t, nout); PLD(uint32_t, lastv); PLD(uint32_t, o_out);
+                W_LANES {
+                    uint32_t o = PL(ent_o), n = 0, lv = 16u;
+                    if (o == 15u) o = 16u;                                   // the chain ended in front of this lane
+                    while (o < 16u) {
+                        const uint32_t f = arr[16u * (uint32_t)lane + o], a = f & 15u;
+                        if (a == 0u) break;
+                        n += (f >> 4) & 255u;
+                        const uint32_t v = (f >> 12) & 255u;
+                        lv = v == 0xffu ? lv : v;
+                        o += a;
+                    }
+                    PL(nout) = n; PL(lastv) = lv;
+                }
+                uint32_t tot_out;
+                W_EXCL_SCAN(o_out, nout, tot_out);
+                // the value a leading "repeat previous" copies: the last value defined by an earlier lane (or by the previous window)
+                PLD(uint32_t, key); PLD(uint32_t, kmax);
+                W_LANES { PL(key) = PL(lastv) < 16u ? (((uint32_t)lane + 1u) << 8) | PL(lastv) : 0u; }
+                W_INCL_SCAN_MAX(kmax, key);
+                uint32_t *hx = (uint32_t *)(smem + HW_OFF_HX);
+                W_LANES { hx[lane] = PL(kmax); }
+                W_SYNC();
+                // second walk: write the lengths; the lane that meets index `total` knows where the header ends
+                PLD(uint32_t, res);                                          // 0 nothing, 1 error, 0x100 | offset: the header ends at this offset of the lane's range
+                W_LANES {
+                    uint32_t o = PL(ent_o), idx = idx0 + PL(o_out), r_ = 0;
+                    const uint32_t kin = lane == 0 ? 0u : hx[lane - 1];
+                    uint32_t pv = kin ? (kin & 255u) : prev0;
+                    if (PL(ent_o) == 15u) { if (idx < total) r_ = 1u; }       // the chain ended on an invalid code before the last length
+                    else if (idx <= total) {
+                        while (o < 16u) {
+                            if (idx >= total) { r_ = 0x100u | o; break; }
+                            const uint32_t f = arr[16u * (uint32_t)lane + o], a = f & 15u, rep = (f >> 4) & 255u;
+                            if (a == 0u) { r_ = 1u; break; }
+                            uint32_t v = (f >> 12) & 255u;
+                            if (v == 0xffu) { if (pv >= 16u) { r_ = 1u; break; } v = pv; }      // nothing to repeat (RFC 1951 3.2.7)
+                            if (idx + rep > total) { r_ = 1u; break; }
+                            // distance lengths live behind the 288 literal/length slots (a value other than zero is repeated six times at most)
+                            if (v != 0u) for (uint32_t rr = 0; rr < rep; rr++) { const uint32_t i_ = idx + rr; lens[i_ < nl ? i_ : 288u + (i_ - nl)] = (uint8_t)v; }
+                            pv = v; idx += rep; o += a;
+                        }
+                    }
+                    PL(res) = r_;
+                }
+                uint64_t m_err, m_end;
+                W_BALLOT(m_err, PL(res) == 1u);
+                W_BALLOT(m_end, PL(res) >= 0x100u);
                 { HWD_T(t_hw1); HWD_ADD(14, t_hw0, t_hw1); }
-                if (status != 0 || idx >= total) break;
-                wbase += q; q = 0;                                           // (a header longer than the window: decode the next one)
-                if ((uint32_t)(wbase - pos) > HW_STAGE * 8u - 64u) { status = DHTS_BLK_ERR_INFLATE; break; }
-            }
-            hpos = wbase + q;
-            if (status != 0) break;
-            W_SYNC();
-            W_LANES {
-                for (uint32_t k = (uint32_t)lane; k < nvis; k += 64u) {
-                    const uint32_t e = vis[k], i0 = e & 511u, rep = (e >> 9) & 255u, val = e >> 17;
-                    // distance lengths live behind the 288 literal/length slots (a value other than zero is repeated six times at most)
-                    if (val != 0u) for (uint32_t rr = 0; rr < rep; rr++) { const uint32_t i = i0 + rr; lens[i < nl ? i : 288u + (i - nl)] = (uint8_t)val; }
+                // (lanes behind the one that meets `total` see indices >= total at once: the first of them all is the one that counts)
+                if (m_end) {
+                    const int le = w_ctz64(m_end);
+                    if (m_err & ((1ull << le) - 1ull)) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    hpos = wbase + 16u * (uint32_t)le + (W_READLANE(res, le) & 255u);
+                    hdr_done = true;
+                } else {
+                    if (m_err) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    // the window ends before the last length: go on where the chain leaves it
+                    if (e_run == 15u) { status = DHTS_BLK_ERR_INFLATE; break; }
+                    idx0 += tot_out;
+                    const uint32_t klast = W_READLANE(kmax, 63);
+                    prev0 = klast ? (klast & 255u) : prev0;
+                    wbase += 1024u + e_run;
+                    if (idx0 == total) { hpos = wbase; hdr_done = true; }
+                    else if (idx0 > total || (uint32_t)(wbase - pos) > HW_STAGE * 8u - 64u) { status = DHTS_BLK_ERR_INFLATE; break; }
                 }
             }
             if (status != 0) break;
@@ -550,15 +618,29 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
         HWD_T(t_h1); HWD_ADD(0, t_h0, t_h1);
 
         // ---- canonical tables ----
-        // per alphabet: count by length (ballots), limits / first codes / offsets (uniform), rank of every symbol among the symbols of
-        // its length (mbcnt) -> entries in canonical order, then the direct tables in code order.
-        uint32_t rll = 0, rd = 0;
+        // per alphabet: every lane holds K consecutive symbols; the counts by code length travel as 10-bit fields of five words through
+        // five wave scans (totals -> limits / first codes / offsets, prefixes -> rank of every symbol among the symbols of its length)
+        // -> entries in canonical order, then the direct table in code order; literal/length codes longer than the root get a second-level
+        // table of 2^(longest - root) entries per root-bit prefix.
+        uint32_t rll = 0, rd = 0, subbits = 0;
         for (int alpha = 0; alpha < 2 && status == 0; alpha++) {
-            const uint32_t nsym = alpha ? 32u : 288u, base = alpha ? 288u : 0u, rounds = alpha ? 1u : 5u;
-            uint32_t cnt[16]; for (int L = 0; L < 16; L++) cnt[L] = 0;
-            for (uint32_t rr = 0; rr < rounds; rr++) {
-                for (uint32_t L = 1; L <= 15u; L++) { uint64_t m; W_BALLOT(m, (64u * rr + (uint32_t)lane < nsym) && lens[base + 64u * rr + (uint32_t)lane] == L); cnt[L] += w_popc64(m); }
+            const uint32_t nsym = alpha ? 32u : 288u, base = alpha ? 288u : 0u, K = alpha ? 1u : 5u;
+            PLD(uint32_t, lp); PLD(uint32_t, c0); PLD(uint32_t, c1); PLD(uint32_t, c2); PLD(uint32_t, c3); PLD(uint32_t, c4);
+            PLD(uint32_t, e0); PLD(uint32_t, e1); PLD(uint32_t, e2); PLD(uint32_t, e3); PLD(uint32_t, e4);
+            uint32_t tt[5];
+            W_LANES {
+                uint32_t packed = 0, c[5] = {0, 0, 0, 0, 0};
+                for (uint32_t j = 0; j < K; j++) {
+                    const uint32_t sy = K * (uint32_t)lane + j;
+                    const uint32_t L = sy < nsym ? lens[base + sy] : 0u;
+                    packed |= L << (4u * j);
+                    if (L != 0u) { for (uint32_t w = 0; w < 5u; w++) { const uint32_t t = L - 1u - 3u * w; if (t < 3u) c[w] += 1u << (10u * t); } }
+                }
+                PL(lp) = packed; PL(c0) = c[0]; PL(c1) = c[1]; PL(c2) = c[2]; PL(c3) = c[3]; PL(c4) = c[4];
             }
+            W_EXCL_SCAN(e0, c0, tt[0]); W_EXCL_SCAN(e1, c1, tt[1]); W_EXCL_SCAN(e2, c2, tt[2]); W_EXCL_SCAN(e3, c3, tt[3]); W_EXCL_SCAN(e4, c4, tt[4]);
+            uint32_t cnt[16]; cnt[0] = 0;
+            for (uint32_t L = 1; L <= 15u; L++) cnt[L] = (tt[(L - 1u) / 3u] >> (10u * ((L - 1u) % 3u))) & 1023u;
             uint32_t nz = 0, maxlen = 0; int left = 1; uint32_t first = 0, offs = 0;
             uint32_t t_first[16], t_offs[16], t_lim[16];
             t_first[0] = t_offs[0] = t_lim[0] = 0;
@@ -572,41 +654,75 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
             if (!alpha) { if (left < 0 || (left > 0 && nz != 1u) || !has_eob) { status = DHTS_BLK_ERR_INFLATE; break; } }
             else { if (left < 0 || (left > 0 && nz > 1u)) { status = DHTS_BLK_ERR_INFLATE; break; } }
             W_LANES { if (lane < 16) { tb[48 * alpha + lane] = t_lim[lane]; tb[48 * alpha + 16 + lane] = t_first[lane]; tb[48 * alpha + 32 + lane] = t_offs[lane]; } }
+            W_SYNC();
             // ranks -> canonical order
-            uint32_t seen[16]; for (int L = 0; L < 16; L++) seen[L] = 0;
-            for (uint32_t rr = 0; rr < rounds; rr++) {
-                for (uint32_t L = 1; L <= 15u; L++) {
-                    if (cnt[L] == 0u) continue;
-                    uint64_t m; W_BALLOT(m, (64u * rr + (uint32_t)lane < nsym) && lens[base + 64u * rr + (uint32_t)lane] == L);
-                    W_LANES {
-                        if ((m >> lane) & 1ull) {
-                            const uint32_t rank = seen[L] + w_popc64(m & ((1ull << lane) - 1ull));
-                            const uint32_t sym = 64u * rr + (uint32_t)lane;
-                            if (!alpha) sll[t_offs[L] + rank] = (uint16_t)hw_ll_entry(sym); else sd[t_offs[L] + rank] = hw_d_entry(sym);
-                        }
+            W_LANES {
+                const uint32_t ex[5] = {PL(e0), PL(e1), PL(e2), PL(e3), PL(e4)};
+                for (uint32_t j = 0; j < K; j++) {
+                    const uint32_t L = (PL(lp) >> (4u * j)) & 15u;
+                    if (L != 0u) {
+                        uint32_t rank = (ex[(L - 1u) / 3u] >> (10u * ((L - 1u) % 3u))) & 1023u;
+                        for (uint32_t j2 = 0; j2 < j; j2++) rank += ((PL(lp) >> (4u * j2)) & 15u) == L ? 1u : 0u;
+                        const uint32_t sy = K * (uint32_t)lane + j, at = tb[48 * alpha + 32 + L] + rank;
+                        if (!alpha) sll[at] = (uint16_t)hw_ll_entry(sy); else sd[at] = hw_d_entry(sy);
                     }
-                    seen[L] += w_popc64(m);
                 }
             }
             W_SYNC();
-            // direct table: R root bits; lane owns the codes w in [lane * chunk, (lane + 1) * chunk) (MSB-first prefixes), entry index = bit reversal
+            // direct table: R root bits; lane owns the codes w in [lane * chunk, (lane + 1) * chunk) (MSB-first prefixes), entry index = bit
+            // reversal.  Spans of lanes and of symbols are aligned powers of two: a lane's span is one symbol's, or made of whole symbols.
             const uint32_t R = maxlen < (alpha ? HW_RD : HW_RLL) ? (maxlen ? maxlen : 1u) : (alpha ? HW_RD : HW_RLL);
             if (alpha) rd = R; else rll = R;
             const uint32_t size = 1u << R, chunk = size >= 64u ? size >> 6 : 1u;
+            // second level (literal/length only): the prefixes w_long .. of codes longer than the root, 2^sb entries each
+            const uint32_t w_long = t_lim[R] >> (15u - R);
+            uint32_t sb = 0, npref = 0;
+            if (!alpha && maxlen > R) {
+                npref = ((t_lim[15] + (1u << (15u - R)) - 1u) >> (15u - R)) - w_long;
+                sb = maxlen - R;
+                if (sb > 4u || (npref << sb) > HW_SUB_ENTRIES) sb = 0;       // (too many long codes for the second level: canonical arithmetic per symbol)
+                subbits = sb;
+            }
             W_LANES {
                 if ((uint32_t)lane * chunk < size) {
-                    uint32_t L = 1;
-                    for (uint32_t k = 0; k < chunk; k++) {
-                        const uint32_t w = (uint32_t)lane * chunk + k, w15 = w << (15u - R);
-                        while (L <= R && w15 >= tb[48 * alpha + L]) L++;
-                        uint32_t ent;
+                    uint32_t w = (uint32_t)lane * chunk, L = 1;
+                    const uint32_t wend = w + chunk;
+                    uint32_t lim = tb[48 * alpha + 1], fst = tb[48 * alpha + 16 + 1], off = tb[48 * alpha + 32 + 1];
+                    while (w < wend) {
+                        const uint32_t w15 = w << (15u - R);
+                        while (L <= R && w15 >= lim) { L++; if (L <= R) { lim = tb[48 * alpha + L]; fst = tb[48 * alpha + 16 + L]; off = tb[48 * alpha + 32 + L]; } }
+                        uint32_t ent, n;
                         if (L <= R) {
-                            const uint32_t si = tb[48 * alpha + 32 + L] + ((w15 >> (15u - L)) - tb[48 * alpha + 16 + L]);
+                            const uint32_t si = off + ((w15 >> (15u - L)) - fst);
                             if (!alpha) { const uint32_t v = sll[si]; ent = (v == 0xffffu) ? 0u : (v | L); }
                             else { const uint32_t v = sd[si]; ent = (v == 0xffffffffu) ? 0u : (v | L); }
-                        } else ent = (w15 < tb[48 * alpha + 15]) ? HW_LONG : 0u;           // a longer code starts with this prefix / unused code space
-                        const uint32_t ix = w_brev32(w) >> (32u - R);
-                        if (!alpha) lut_ll[ix] = (uint16_t)ent; else lut_d[ix] = ent;
+                            n = 1u << (R - L); if (n > wend - w) n = wend - w;
+                        } else {
+                            // a longer code starts with this prefix (second-level table number w - w_long, or canonical arithmetic) / unused code space
+                            ent = (w15 < tb[48 * alpha + 15]) ? (sb ? (0x30u | ((w - w_long) << 6)) : HW_LONG) : 0u;
+                            n = 1u;
+                        }
+                        for (uint32_t k = 0; k < n; k++) {
+                            const uint32_t ix = w_brev32(w + k) >> (32u - R);
+                            if (!alpha) lut_ll[ix] = (uint16_t)ent; else lut_d[ix] = ent;
+                        }
+                        w += n;
+                    }
+                }
+            }
+            if (sb) {
+                uint16_t *sub = (uint16_t *)(smem + HW_OFF_SUB);
+                const uint32_t nent = npref << sb, M = maxlen;
+                W_LANES {
+                    for (uint32_t t = (uint32_t)lane; t < nent; t += 64u) {
+                        // entry t: prefix w_long + (t >> sb), followed by the sb stream bits (t & mask), i.e. their reversal in code order
+                        const uint32_t w = w_long + (t >> sb), sbits = t & ((1u << sb) - 1u);
+                        const uint32_t cm = (w << sb) | (w_brev32(sbits) >> (32u - sb)), w15 = cm << (15u - M);
+                        uint32_t L = R + 1u;
+                        while (L <= M && w15 >= tb[L]) L++;
+                        uint32_t ent = 0;
+                        if (L <= M) { const uint32_t si = tb[32 + L] + ((w15 >> (15u - L)) - tb[16 + L]); const uint32_t v = si < 288u ? sll[si] : 0xffffu; ent = (v == 0xffffu) ? 0u : (v | L); }
+                        sub[t] = (uint16_t)ent;
                     }
                 }
             }
@@ -614,14 +730,10 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
         }
         if (status != 0) break;
         const uint32_t mask_ll = (1u << rll) - 1u, mask_d = (1u << rd) - 1u;
-        HwLong lq;
-        {
-            const uint32_t a0 = HW_RLL + 1u < 15u ? HW_RLL + 1u : 15u, a1 = HW_RLL + 2u < 15u ? HW_RLL + 2u : 15u, a2 = HW_RLL + 3u < 15u ? HW_RLL + 3u : 15u;
-            lq.l0 = W_UNI(tb[a0]); lq.l1 = W_UNI(tb[a1]); lq.l2 = W_UNI(tb[a2]); lq.l3 = W_UNI(tb[15]);
-            lq.f0 = W_UNI(tb[16 + a0]); lq.f1 = W_UNI(tb[16 + a1]); lq.f2 = W_UNI(tb[16 + a2]); lq.f3 = W_UNI(tb[16 + 15]);
-            lq.o0 = W_UNI(tb[32 + a0]); lq.o1 = W_UNI(tb[32 + a1]); lq.o2 = W_UNI(tb[32 + a2]); lq.o3 = W_UNI(tb[32 + 15]);
-        }
         HWD_T(t_h2); HWD_ADD(1, t_h1, t_h2);
+#ifdef HW_EXP_STOP_AFTER_TABLES          /* instruction-count experiment (tools/dbg/pmc_sq.sh): header and tables only, output invalid */
+        status = DHTS_BLK_ERR_INFLATE; break;
+#endif
 
         // ---- symbols: segments of up to 64 bit ranges until the end-of-block symbol ----
         uint32_t p0 = hpos;
@@ -636,11 +748,11 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
 #endif
             // pass 0: propose the start of lane i + 1 from the last HW_SYNC_W bits of range i
             HWD_T(t_s0); HWD_CNT(8, 1);
-            PLD(HwLane, ln);
+            PLD(HwLane, ln); PLD(uint32_t, prop);
             W_LANES {
                 PL(ln).start = p0 + (uint32_t)lane * S; PL(ln).end = 0; PL(ln).flags = 0;
                 PL(ln).nlit = 0; PL(ln).ntok = 0; PL(ln).run = 0; PL(ln).outb = 0;
-                xch[HX_START * 64 + lane] = p0 + (uint32_t)lane * S;
+                PL(prop) = p0 + ((uint32_t)lane + 1u) * S;          // what lane i proposes for lane i + 1: the nominal boundary unless its decoder finds better
             }
             W_SYNC();
             W_LANES {
@@ -648,12 +760,15 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
                     const uint32_t bnd = p0 + ((uint32_t)lane + 1u) * S;
                     const uint32_t from = bnd - p0 > HW_SYNC_W + (uint32_t)lane * S ? bnd - HW_SYNC_W : p0 + (uint32_t)lane * S;
                     HwLane tmp;
-                    hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, lane, tmp, nullptr, nullptr, 0, 0, 0);
-                    if (tmp.flags == 0u) xch[HX_START * 64 + lane + 1] = tmp.end;
+                    hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, subbits, lane, tmp, nullptr, nullptr, 0, 0, 0);
+                    if (tmp.flags == 0u) PL(prop) = tmp.end;
                 }
             }
             W_SYNC();
-            W_LANES { PL(ln).start = xch[HX_START * 64 + lane]; }
+            W_LANES { xch[HX_START * 64 + lane] = PL(prop); }
+            W_SYNC();
+            W_LANES { if (lane > 0) PL(ln).start = xch[HX_START * 64 + lane - 1]; }
+            W_SYNC();
             HWD_T(t_s1); HWD_ADD(2, t_s0, t_s1);
             // pass 1 until the chain of confirmed lanes reaches the end-of-block symbol or the last lane
             uint64_t dirty = nlanes >= 64u ? ~0ull : ((1ull << nlanes) - 1ull);
@@ -667,7 +782,7 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
                     if ((dirty >> lane) & 1ull) {
                         const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? p0 + ((uint32_t)lane + 1u) * S : 0xffffffffu;   // the last lane runs to the end-of-block symbol
                         // (lane 0 continues the literal run that is open at the start of the segment)
-                        hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, lq, lane, PL(ln),
+                        hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, subbits, lane, PL(ln),
                                    slit + (uint32_t)lane * HW_LANE_LIT, stok + (uint32_t)lane * HW_LANE_TOK, HW_LANE_LIT, HW_LANE_TOK, lane == 0 ? run : 0u);
                         // a range whose first unit starts at or beyond its boundary holds nothing: it ends where it starts
                     }
@@ -710,7 +825,7 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
 #endif
                 const uint32_t lcap = nlit_tot < DHTS_LIT_STRIDE ? DHTS_LIT_STRIDE - nlit_tot : 0u, tcap = ntok_tot + 64u < DHTS_TOK_STRIDE ? DHTS_TOK_STRIDE - 64u - ntok_tot : 0u;
                 W_LANES {
-                    if (lane == 0) hw_span<1>(smem, in32, p0, 0xffffffffu, limit_bits, mask_ll, mask_d, rll, rd, lq, lane, PL(ln), lit + nlit_tot, tok + ntok_tot, lcap, tcap, run);
+                    if (lane == 0) hw_span<1>(smem, in32, p0, 0xffffffffu, limit_bits, mask_ll, mask_d, rll, rd, subbits, lane, PL(ln), lit + nlit_tot, tok + ntok_tot, lcap, tcap, run);
                 }
                 W_SYNC();
                 W_LANES { if (lane == 0) { xch[HX_END * 64] = PL(ln).end; xch[HX_FLAG * 64] = PL(ln).flags; xch[HX_A * 64] = PL(ln).nlit; xch[HX_B * 64] = PL(ln).ntok; xch[HX_C * 64] = PL(ln).run; xch[HX_START * 64] = PL(ln).outb; } }
@@ -772,12 +887,15 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
                     dt += PL(extra);
                     const uint32_t n = PL(ln).ntok;
                     uint32_t k = 0;
+                    // (four 16-byte pieces in flight: the slice was written by this lane a moment ago and comes from the caches)
+                    for (; k + 16u <= n; k += 16u) { uint4 v[4]; for (int u = 0; u < 4; u++) __builtin_memcpy(&v[u], st + k + 4 * u, 16); for (int u = 0; u < 4; u++) __builtin_memcpy(dt + k + 4 * u, &v[u], 16); }
                     for (; k + 4u <= n; k += 4u) { uint4 v; __builtin_memcpy(&v, st + k, 16); __builtin_memcpy(dt + k, &v, 16); }
                     for (; k < n; k++) dt[k] = st[k];
                     const uint8_t *sl = slit + (uint32_t)lane * HW_LANE_LIT;
                     uint8_t *dl = lit + nlit_tot + PL(o_lit);
                     const uint32_t m = PL(ln).nlit;
                     uint32_t j = 0;
+                    for (; j + 64u <= m; j += 64u) { uint4 v[4]; for (int u = 0; u < 4; u++) __builtin_memcpy(&v[u], sl + j + 16 * u, 16); for (int u = 0; u < 4; u++) __builtin_memcpy(dl + j + 16 * u, &v[u], 16); }
                     for (; j + 16u <= m; j += 16u) { uint4 v; __builtin_memcpy(&v, sl + j, 16); __builtin_memcpy(dl + j, &v, 16); }
                     for (; j < m; j++) dl[j] = sl[j];
                 }

@@ -544,6 +544,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_or(uint32_t v) {
     v |= dpp0<0x142, 0xa>(v); v |= dpp0<0x143, 0xc>(v);
     return v;
 }
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v) {      // (lanes without a source read 0: values are unsigned)
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp0<0x138, 0xf>(v); }   // lane i <- lane i-1, lane 0 <- 0
 #define RDLANE(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(i)))
 
