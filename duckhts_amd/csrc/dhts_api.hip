@@ -832,16 +832,13 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {   
     ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
     ENSURE(c, c->meta, (size_t)nb * sizeof(InflateMeta));
     BgzfTable t = dev_table(c);
-    // Two interchangeable kernels fill the scratch (same format, cross-checked by the tests):
-    //   wave: one WAVE per BGZF block, table-driven (bgzf_huff_wave.hip): a block takes well under a millisecond, so short launches --
-    //         index windows, small files, a 1 GB BCF -- no longer pay one lane's serial decode of a whole block (13-15 ms);
-    //   lane: one LANE per block, canonical arithmetic (bgzf_inflate.hip): fewer instructions per symbol once a launch is long enough
-    //         to keep every SIMD backfilled (measured on MI355X per 65,536 blocks: 13.0 ms against 16.3 ms in launches of 131,072;
-    //         launches of 32,768 take 17.6 ms -- one lane's serial decode -- against 8.5 ms).
-    // DHTS_PHASE_A = wave | lane forces one of them; the default switches at DHTS_WAVE_MAX_BLOCKS (65,536: where the two meet).
+    // Two kernels fill the scratch (same format, cross-checked by the tests):
+    //   wave: one WAVE per BGZF block, table-driven, persistent (bgzf_huff_wave.hip): the product path for every launch size since round 3
+    //         (measured on MI355X per 65,536 blocks in launches of 131,072: 9.5 ms; the round-2 version of it took 16.3 ms);
+    //   lane: one LANE per block, canonical arithmetic (bgzf_inflate.hip): 13.0 ms per 65,536 blocks in long launches and never less than one
+    //         lane's serial decode of a whole block (13-15 ms) in short ones; kept as the cross-check of the wave kernel (DHTS_PHASE_A=lane).
     static const char *env_a = getenv("DHTS_PHASE_A");
-    static const int64_t wave_max = getenv("DHTS_WAVE_MAX_BLOCKS") ? atoll(getenv("DHTS_WAVE_MAX_BLOCKS")) : 65536;
-    const bool env_lane = force >= 0 ? force != 2 : env_a ? !strcmp(env_a, "lane") : (nb > wave_max);
+    const bool env_lane = force >= 0 ? force != 2 : (env_a && !strcmp(env_a, "lane"));
     if (!env_lane) {
         // persistent launch: as many workgroups (one wave each) as the device holds at once, each with its own staging slices; the
         // workgroups take blocks from a counter that starts behind the blocks they begin with
