@@ -1,4 +1,4 @@
-import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys, os, ctypes as C; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, duckhts_amd
 from duckhts_amd import synth
 import os
@@ -9,6 +9,8 @@ while True:
     b = ctx.next_batch(16384); rows += b.n_rows
     if b.status != 0: break
 d = (C.c_ulonglong*24)()
+if not hasattr(ctx.L, 'dhts_debug_diag'):
+    print(rows, nb, '(no -DDHTS_DIAG build: counters only)'); sys.exit(0)
 ctx.L.dhts_debug_diag(C.c_void_p(ctx.h), d)
 names=['batches','rounds','easy','hard','lit_iters','far','matches','oversized']
 print(rows, nb, {n:int(v) for n,v in zip(names,d)})
