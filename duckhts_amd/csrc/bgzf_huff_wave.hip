@@ -363,22 +363,19 @@ struct HwHdr { uint64_t buf; uint32_t cnt, widx; const uint32_t *words; };
 W_DEV void hw_hdr_fill(HwHdr &h) { if (h.cnt <= 32u) { h.buf |= (uint64_t)W_UNI(h.words[h.widx]) << h.cnt; h.widx++; h.cnt += 32u; } }
 W_DEV uint32_t hw_hdr_take(HwHdr &h, uint32_t n) { hw_hdr_fill(h); const uint32_t v = (uint32_t)h.buf & ((1u << n) - 1u); h.buf >>= n; h.cnt -= n; return v; }
 
-// One BGZF block: block `s` of the launch's range, decoded by the calling wave into slot `s` of the scratch.  `slit` / `stok` are the
-// workgroup's staging slices.
+// One BGZF block: block `bi` of the table, decoded by the calling wave into `lit` / `tok` (room for DHTS_LIT_STRIDE bytes / DHTS_TOK_STRIDE
+// tokens) and described by `mres`.  `slit` / `stok` are the workgroup's staging slices.
 #ifdef HOSTSIM_W
-static void hw_block(uint8_t *smem, int64_t s, const uint8_t *comp, BgzfTable tab, int64_t blk0,
-                     uint8_t *lit_all, uint32_t *tok_all, InflateMeta *meta, uint8_t *slit, uint32_t *stok)
+static void hw_block(uint8_t *smem, int64_t bi, const uint8_t *comp, BgzfTable tab,
+                     uint8_t *lit, uint32_t *tok, InflateMeta &mres, uint8_t *slit, uint32_t *stok)
 #else
-__device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0,
-                                         uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta,
+__device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_t *__restrict__ comp, BgzfTable tab,
+                                         uint8_t *__restrict__ lit, uint32_t *__restrict__ tok, InflateMeta &mres,
                                          uint8_t *__restrict__ slit, uint32_t *__restrict__ stok, unsigned long long *hwd)
 #endif
 {
     W_LANE_DECL
-    const int64_t bi = blk0 + s;
     const uint32_t clen = tab.clen[bi];
-    uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
-    uint32_t *tok = tok_all + (size_t)s * DHTS_TOK_STRIDE;
     uint16_t *lut_ll = (uint16_t *)(smem + HW_OFF_LL);
     uint32_t *lut_d = (uint32_t *)(smem + HW_OFF_D);
     uint8_t *stage = smem + HW_OFF_STAGE;
@@ -920,15 +917,17 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t s, const uint8_t
         pos = p0;
     }
     if (status == 0 && pos > limit_bits) status = DHTS_BLK_ERR_INFLATE;
-    InflateMeta m; m.ntok = ntok_tot; m.nlit = nlit_tot; m.outlen = outpos; m.status = status;
-    W_LANES { if (lane == 0) meta[s] = m; }
+    mres.ntok = ntok_tot; mres.nlit = nlit_tot; mres.outlen = outpos; mres.status = status;
     W_SYNC();
     { HWD_T(t_end); HWD_ADD(6, t_begin, t_end); HWD_CNT(7, 1); }
 }
 
 #ifndef HOSTSIM_W
-// The launch: `grid` workgroups of one wave; workgroup g starts with block g and then takes blocks from *counter (set to `grid` by the
+// The launches: `grid` workgroups of one wave; workgroup g starts with block g and then takes blocks from *counter (set to `grid` by the
 // host before the launch) until the range is exhausted -- every wave reaches the exit test after each block.
+//
+// bgzf_huff_decode_wave: phase A alone, into the per-block scratch slots that a later bgzf_lz_resolve launch reads (the cross-check path:
+// same scratch format as the one-lane-per-block kernel).
 extern "C" __global__ void __launch_bounds__(64)
 bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                       uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta,
@@ -943,7 +942,44 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
 #endif
     uint32_t b = blockIdx.x;
     while (b < (uint32_t)nblk) {
-        hw_block(smem, (int64_t)b, comp, tab, blk0, lit_all, tok_all, meta, slit, stok, hwd);
+        InflateMeta m;
+        hw_block(smem, blk0 + (int64_t)b, comp, tab, lit_all + (size_t)b * DHTS_LIT_STRIDE, tok_all + (size_t)b * DHTS_TOK_STRIDE, m, slit, stok, hwd);
+        if (threadIdx.x == 0) meta[b] = m;
+        uint32_t nb_ = 0;
+        if (threadIdx.x == 0) nb_ = atomicAdd(counter, 1u);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb_);
+    }
+#if defined(HW_DIAG)
+    if (threadIdx.x == 0) for (int q_ = 0; q_ < 16; q_++) if (hwd[q_]) atomicAdd(&g_hw_diag[q_], hwd[q_]);
+#endif
+}
+
+// bgzf_inflate_fused: the product path.  The wave that decoded a block's Huffman symbols resolves its LZ77 copies right away
+// (lz_block, bgzf_inflate.hip): literals and tokens never leave the workgroup's own 152 KiB area (`wg_lit` / `wg_tok`, reused for every
+// block the workgroup takes, i.e. cache-resident), so the inflate stage reads the compressed block and writes the inflated one -- there
+// is no per-block scratch.  The two phases use the same LDS (phase A's tables are dead when phase B builds its window).
+#define HWF_LDS_BYTES (HW_LDS_BYTES > B_LDS_BYTES ? HW_LDS_BYTES : B_LDS_BYTES)
+extern "C" __global__ void __launch_bounds__(64)
+bgzf_inflate_fused(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                   uint8_t *__restrict__ wg_lit, uint32_t *__restrict__ wg_tok, uint8_t *__restrict__ stage_lit, uint32_t *__restrict__ stage_tok,
+                   uint32_t *__restrict__ counter, uint8_t *__restrict__ out, uint64_t out_base, int32_t *__restrict__ blk_status) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[HWF_LDS_BYTES];
+    uint8_t *slit = stage_lit + (size_t)blockIdx.x * HW_STAGE_LIT_BYTES;
+    uint32_t *stok = stage_tok + (size_t)blockIdx.x * HW_STAGE_TOK_WORDS;
+    uint8_t *lit = wg_lit + (size_t)blockIdx.x * (DHTS_LIT_STRIDE + 64u);
+    uint32_t *tok = wg_tok + (size_t)blockIdx.x * DHTS_TOK_STRIDE;
+#if defined(HW_DIAG)
+    unsigned long long hwd[16]; for (int q_ = 0; q_ < 16; q_++) hwd[q_] = 0;
+#else
+    unsigned long long *hwd = nullptr;
+#endif
+    uint32_t b = blockIdx.x;
+    while (b < (uint32_t)nblk) {
+        InflateMeta m;
+        hw_block(smem, blk0 + (int64_t)b, comp, tab, lit, tok, m, slit, stok, hwd);
+        __syncthreads();                                       // the block's tokens and literals are stored; phase A's LDS is free
+        lz_block(smem, comp, tab, blk0 + (int64_t)b, m, lit, tok, out, out_base, blk_status);
+        __syncthreads();
         uint32_t nb_ = 0;
         if (threadIdx.x == 0) nb_ = atomicAdd(counter, 1u);
         b = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb_);

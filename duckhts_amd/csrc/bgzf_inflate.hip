@@ -664,20 +664,16 @@ __device__ __forceinline__ uint32_t crc_xpow8_tab(uint32_t nbytes) {
     return pw;
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
-                const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
-                const InflateMeta *__restrict__ meta, int64_t scratch_b0, uint8_t *__restrict__ out, uint64_t out_base,
-                int32_t *__restrict__ blk_status) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// One BGZF block: the tokens / literals `tok` / `lit` described by `m` become the block's bytes at out + (uoff[bi] - out_base); the CRC-32 and
+// ISIZE of the trailer are checked (blk_status[bi]).  Called by bgzf_lz_resolve (one workgroup per block, scratch slots written by a
+// phase-A launch) and by bgzf_inflate_fused (bgzf_huff_wave.hip: the wave that decoded the block resolves it right away).
+__device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restrict__ comp, BgzfTable tab, int64_t bi, const InflateMeta m,
+                                         const uint8_t *__restrict__ lit, const uint32_t *__restrict__ tok,
+                                         uint8_t *__restrict__ out, uint64_t out_base, int32_t *__restrict__ blk_status) {
     uint8_t *win = smem + B_WIN;
     uint32_t *crct = (uint32_t *)(smem + B_CRCT);
     uint8_t *ring = smem + B_RING;
     const int lane = threadIdx.x;
-    if ((int64_t)blockIdx.x >= nblk) return;
-    const int64_t bi = blk0 + blockIdx.x;
-    const int64_t s = bi - scratch_b0;            // slot in the phase-A scratch (phase A may run ahead over a larger block range)
-    const InflateMeta m = meta[s];
     const uint32_t isize = tab.isize[bi];
     const uint32_t clen = tab.clen[bi];
     DIAG_DECL;
@@ -694,8 +690,6 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     if (st == 0 && m.outlen != isize) st = DHTS_BLK_ERR_ISIZE;   // htslib does not test ISIZE; we flag it
     if (st != 0) { if (lane == 0) blk_status[bi] = st; return; }
 
-    const uint32_t *tok = tok_all + (size_t)s * DHTS_TOK_STRIDE;
-    const uint8_t *lit = lit_all + (size_t)s * DHTS_LIT_STRIDE;
     uint8_t *dstp = out + (tab.uoff[bi] - out_base);
     uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
     // constants of the flush-chunk CRC: lane's BR_PIECE-byte piece is followed by BR_PIECE*(63-lane) bytes of the chunk
@@ -921,4 +915,16 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     DIAG_TADD(5, t_crc1, t_end);
     DIAG_TADD(6, t_begin, t_end);
     DIAG_FLUSH;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
+                const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
+                const InflateMeta *__restrict__ meta, int64_t scratch_b0, uint8_t *__restrict__ out, uint64_t out_base,
+                int32_t *__restrict__ blk_status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if ((int64_t)blockIdx.x >= nblk) return;
+    const int64_t bi = blk0 + blockIdx.x;
+    const int64_t s = bi - scratch_b0;            // slot in the phase-A scratch (phase A may run ahead over a larger block range)
+    lz_block(smem, comp, tab, bi, meta[s], lit_all + (size_t)s * DHTS_LIT_STRIDE, tok_all + (size_t)s * DHTS_TOK_STRIDE, out, out_base, blk_status);
 }

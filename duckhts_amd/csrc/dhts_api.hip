@@ -181,6 +181,7 @@ struct dhts_ctx {
     // inflate scratch
     DevBuf lit, tok, meta;
     DevBuf stg_lit, stg_tok, wave_ctr;             // wave kernel: staging slices of the resident workgroups, block counter
+    DevBuf wg_lit[2], wg_tok[2], stg2_lit, stg2_tok;  // fused inflate: the workgroups' own literal / token areas ([1], stg2_*: launches on stream_b)
     DevBuf sg_cnt, sg_base, sg_cand, sg_hits;      // block discovery scratch
     // index writer
     std::vector<uint8_t> built_index; DevBuf ix_end; BamStream last_stream;   // last_stream: the inflated buffer of the latest batch
@@ -826,6 +827,20 @@ static BgzfTable dev_table(dhts_ctx *c) {
     t.uoff = (const uint64_t *)c->uoff.p; t.n = c->n_blocks; return t;
 }
 
+// workgroups of the persistent inflate kernels that the device holds at once (occupancy query, first use)
+static int wave_slots(dhts_ctx *c) {
+    if (c->wave_slots == 0) {
+        static const int64_t env_wg = getenv("DHTS_WAVE_WG_PER_CU") ? atoll(getenv("DHTS_WAVE_WG_PER_CU")) : 0;      // tuning knob
+        int per_cu = 0, per_cu2 = 0; hipDeviceProp_t pr;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bgzf_inflate_fused, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void *)bgzf_huff_decode_wave, 64, 0) != hipSuccess || per_cu2 < 1) per_cu2 = 8;
+        if (per_cu2 > per_cu) per_cu = per_cu2;
+        if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) return fail(c, "hipGetDeviceProperties failed");
+        if (env_wg > 0) per_cu = (int)env_wg;
+        c->wave_slots = (int64_t)per_cu * pr.multiProcessorCount;
+    }
+    return 0;
+}
 // phase A over [b0, b0+nb): tokens + literals into the scratch
 static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {      // force: -1 default choice, 0 / 1 lane kernel (all symbols in LDS / far table), 2 wave kernel
     ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 8192);
@@ -842,14 +857,7 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {   
     if (!env_lane) {
         // persistent launch: as many workgroups (one wave each) as the device holds at once, each with its own staging slices; the
         // workgroups take blocks from a counter that starts behind the blocks they begin with
-        static const int64_t env_wg = getenv("DHTS_WAVE_WG_PER_CU") ? atoll(getenv("DHTS_WAVE_WG_PER_CU")) : 0;      // tuning knob
-        if (c->wave_slots == 0) {
-            int per_cu = 0; hipDeviceProp_t pr;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bgzf_huff_decode_wave, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-            if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) return fail(c, "hipGetDeviceProperties failed");
-            if (env_wg > 0) per_cu = (int)env_wg;
-            c->wave_slots = (int64_t)per_cu * pr.multiProcessorCount;
-        }
+        if (wave_slots(c)) return -1;
         const int64_t grid = nb < c->wave_slots ? nb : c->wave_slots;
         ENSURE(c, c->stg_lit, (size_t)grid * HW_STAGE_LIT_BYTES + 64);
         ENSURE(c, c->stg_tok, (size_t)grid * HW_STAGE_TOK_WORDS * 4 + 64);
@@ -882,6 +890,32 @@ static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t
     HIPCHK(c, hipGetLastError());
     return 0;
 }
+// the product path of the inflate stage: ONE persistent launch decodes and resolves blocks [b0, b0+nb) (bgzf_inflate_fused); `alt` selects the
+// second set of workgroup areas (a launch on stream_b may run beside one on the main stream)
+static int launch_fused(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, hipStream_t s, int alt) {
+    if (wave_slots(c)) return -1;
+    const int64_t grid = nb < c->wave_slots ? nb : c->wave_slots;
+    DevBuf &sl = alt ? c->stg2_lit : c->stg_lit, &stk = alt ? c->stg2_tok : c->stg_tok;
+    ENSURE(c, sl, (size_t)grid * HW_STAGE_LIT_BYTES + 64);
+    ENSURE(c, stk, (size_t)grid * HW_STAGE_TOK_WORDS * 4 + 64);
+    ENSURE(c, c->wg_lit[alt], (size_t)grid * (DHTS_LIT_STRIDE + 64) + 8192);
+    ENSURE(c, c->wg_tok[alt], (size_t)grid * DHTS_TOK_STRIDE * 4 + 64);
+    ENSURE(c, c->wave_ctr, 64);
+    uint32_t *ctr = (uint32_t *)c->wave_ctr.p + (alt ? 8 : 0);
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)ctr, (int)grid, 1, s));
+    BgzfTable t = dev_table(c);
+    {
+        KTimer tm(c, DHTS_K_LZ, s);
+        hipLaunchKernelGGL(bgzf_inflate_fused, dim3((unsigned)grid), dim3(64), 0, s, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+                           (uint8_t *)c->wg_lit[alt].p, (uint32_t *)c->wg_tok[alt].p, (uint8_t *)sl.p, (uint32_t *)stk.p, ctr, out, out_base, (int32_t *)c->blk_status.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+static bool inflate_split() {       // DHTS_INFLATE=split: phase A into per-block scratch slots, phase B as its own launch (the round-2 structure)
+    static const bool v = getenv("DHTS_INFLATE") && !strcmp(getenv("DHTS_INFLATE"), "split");
+    return v;
+}
 static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
     if (nb <= 0) return 0;
     if (c->plain_text) {                                     // nothing to inflate: the pieces are copied to their place in the stream
@@ -889,6 +923,7 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
         return 0;
     }
     discard_prefetch(c);                                   // (phase A below may reallocate the scratch a prefetched phase B reads)
+    if (!inflate_split()) return launch_fused(c, b0, nb, out, out_base, c->stream, 0);
     // (a block whose ISIZE field exceeds 64 KiB is recorded and placed as 65,537 bytes -- isize_placed in bam_records.hip -- and fails
     //  phase B's outlen == ISIZE test like any other block with a wrong ISIZE: the stream ends there, rows before it are kept)
     if (!(b0 >= c->huff_b0 && b0 + nb <= c->huff_b0 + c->huff_nb)) {
@@ -2644,7 +2679,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
         const int64_t nb0 = B.b0 + B.nb;
         int64_t nbn = c->shard_b1 - nb0; if (nbn > mb) nbn = mb;
         const bool plain = !no_pf && !rec_err && !B.blk_err && !B.last_of_stream && !B.in_halo && nbn > 0 && !(sharded_tail && out_base + ulen > shard_end_u) &&
-                           nb0 >= c->huff_b0 && nb0 + nbn <= c->huff_b0 + c->huff_nb && !c->pf.valid;
+                           (!inflate_split() || (nb0 >= c->huff_b0 && nb0 + nbn <= c->huff_b0 + c->huff_nb)) && !c->pf.valid;
         if (plain) {
             const uint64_t tail = ulen - carry_start, ulen_n = tail + (c->h_uoff[nb0 + nbn] - c->h_uoff[nb0]);
             bool ok = ulen_n + PAD_BYTES < (1ull << 32);
@@ -2653,7 +2688,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
             if (ok) {
                 uint8_t *un = (uint8_t *)nx.p;
                 if (tail) HIPCHK(c, hipMemcpyAsync(un, u + carry_start, tail, hipMemcpyDeviceToDevice, c->stream_b));
-                if (launch_lz(c, nb0, nbn, un, c->h_uoff[nb0] - tail, c->stream_b)) return -1;
+                if (inflate_split() ? launch_lz(c, nb0, nbn, un, c->h_uoff[nb0] - tail, c->stream_b) : launch_fused(c, nb0, nbn, un, c->h_uoff[nb0] - tail, c->stream_b, 1)) return -1;
                 HIPCHK(c, hipMemsetAsync(un + ulen_n, 0, PAD_BYTES, c->stream_b));
                 HIPCHK(c, hipEventRecord(c->pf_done, c->stream_b));
                 c->pf.valid = true; c->pf.b0 = nb0; c->pf.nb = nbn; c->pf.carry = tail; c->pf.ucur = c->ucur ^ 1;

@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
             // (exact-size LDS image and staging slices: ASAN sees every overrun; the fill pattern shows reads of unwritten bytes)
             std::vector<uint8_t> smem(HW_LDS_BYTES, (uint8_t)(getenv("FILL") ? atoi(getenv("FILL")) : 0xAB));
             std::vector<uint8_t> slit(HW_STAGE_LIT_BYTES, 0xCD); std::vector<uint32_t> stok(HW_STAGE_TOK_WORDS, 0xCDCDCDCDu);
-            hw_block(smem.data(), b, d.data(), t, 0, lit2.data(), tok2.data(), meta2.data(), slit.data(), stok.data());
+            hw_block(smem.data(), b, d.data(), t, lit2.data() + (size_t)b * DHTS_LIT_STRIDE, tok2.data() + (size_t)b * DHTS_TOK_STRIDE, meta2[b], slit.data(), stok.data());
         }
         int bad = 0, mism = 0, differ = 0;
         for (int64_t b = 0; b < nb; b++) {
