@@ -926,12 +926,18 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
 // The launches: `grid` workgroups of one wave; workgroup g starts with block g and then takes blocks from *counter (set to `grid` by the
 // host before the launch) until the range is exhausted -- every wave reaches the exit test after each block.
 //
-// bgzf_huff_decode_wave: phase A alone, into the per-block scratch slots that a later bgzf_lz_resolve launch reads (the cross-check path:
-// same scratch format as the one-lane-per-block kernel).
+// bgzf_huff_decode_wave: phase A.  A block is assembled in the workgroup's own area (`wg_lit` / `wg_tok`, reused for every block the
+// workgroup takes, i.e. cache-resident), then exactly the room it needs -- its literal bytes rounded up to 16 + 4 bytes per token -- is
+// taken from `pool` with one atomic add and the block moves there in coalesced 16-byte pieces: the scratch a later bgzf_lz_resolve launch
+// reads is packed (34 KB per block of a 30x BAM instead of a 152 KiB slot) and is written in whole lines.  blk_off[b] = the block's
+// offset in the pool.  A block that finds the pool exhausted is marked DHTS_BLK_ERR_SCRATCH (the host repeats the range with more room).
+// With pool == nullptr the blocks go to fixed slots of lit_all / tok_all (the format of the one-lane-per-block kernel: cross-check path).
 extern "C" __global__ void __launch_bounds__(64)
 bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                       uint8_t *__restrict__ lit_all, uint32_t *__restrict__ tok_all, InflateMeta *__restrict__ meta,
-                      uint8_t *__restrict__ stage_lit, uint32_t *__restrict__ stage_tok, uint32_t *__restrict__ counter) {
+                      uint8_t *__restrict__ stage_lit, uint32_t *__restrict__ stage_tok, uint32_t *__restrict__ counter,
+                      uint8_t *__restrict__ pool, unsigned long long pool_cap, unsigned long long *__restrict__ pool_used, unsigned long long *__restrict__ blk_off,
+                      uint8_t *__restrict__ wg_lit, uint32_t *__restrict__ wg_tok) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[HW_LDS_BYTES];
     uint8_t *slit = stage_lit + (size_t)blockIdx.x * HW_STAGE_LIT_BYTES;
     uint32_t *stok = stage_tok + (size_t)blockIdx.x * HW_STAGE_TOK_WORDS;
@@ -940,13 +946,49 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
 #else
     unsigned long long *hwd = nullptr;
 #endif
+    const int lane = threadIdx.x;
     uint32_t b = blockIdx.x;
     while (b < (uint32_t)nblk) {
         InflateMeta m;
-        hw_block(smem, blk0 + (int64_t)b, comp, tab, lit_all + (size_t)b * DHTS_LIT_STRIDE, tok_all + (size_t)b * DHTS_TOK_STRIDE, m, slit, stok, hwd);
-        if (threadIdx.x == 0) meta[b] = m;
+        if (pool == nullptr) {
+            hw_block(smem, blk0 + (int64_t)b, comp, tab, lit_all + (size_t)b * DHTS_LIT_STRIDE, tok_all + (size_t)b * DHTS_TOK_STRIDE, m, slit, stok, hwd);
+        } else {
+            uint8_t *wl = wg_lit + (size_t)blockIdx.x * (DHTS_LIT_STRIDE + 64u);
+            uint32_t *wt = wg_tok + (size_t)blockIdx.x * DHTS_TOK_STRIDE;
+            hw_block(smem, blk0 + (int64_t)b, comp, tab, wl, wt, m, slit, stok, hwd);
+            HWD_T(t_p0);
+            if (m.status == 0) {
+                const uint32_t lbytes = (m.nlit + 15u) & ~15u, need = lbytes + 4u * m.ntok;
+                unsigned long long off = 0;
+                if (lane == 0) off = atomicAdd(pool_used, (unsigned long long)((need + 63u) & ~63u));
+                off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+                if (off + need > pool_cap) m.status = DHTS_BLK_ERR_SCRATCH;
+                else {
+                    uint8_t *dl = pool + off; uint8_t *dt = dl + lbytes;
+                    // (eight 16-byte pieces per lane in flight: the area was written a moment ago and comes from the caches, but every piece
+                    //  is still a round trip)
+                    const uint32_t tbytes = 4u * m.ntok;
+                    for (int part = 0; part < 2; part++) {
+                        const uint8_t *sp = part ? (const uint8_t *)wt : wl; uint8_t *dp = part ? dt : dl;
+                        const uint32_t nbytes = part ? (tbytes & ~15u) : lbytes;
+                        uint32_t k = 16u * (uint32_t)lane;
+                        for (; k + 7u * 1024u < nbytes; k += 8u * 1024u) {
+                            uint4 v[8];
+                            for (int u = 0; u < 8; u++) __builtin_memcpy(&v[u], sp + k + 1024u * (uint32_t)u, 16);
+                            for (int u = 0; u < 8; u++) __builtin_memcpy(dp + k + 1024u * (uint32_t)u, &v[u], 16);
+                        }
+                        for (; k < nbytes; k += 1024u) { uint4 v; __builtin_memcpy(&v, sp + k, 16); __builtin_memcpy(dp + k, &v, 16); }
+                    }
+                    if (lane < (int)(m.ntok & 3u)) ((uint32_t *)dt)[(m.ntok & ~3u) + (uint32_t)lane] = wt[(m.ntok & ~3u) + (uint32_t)lane];
+                    if (lane == 0) blk_off[b] = off;
+                }
+            }
+            __syncthreads();                                   // the copies have read the workgroup's area before the next block overwrites it
+            HWD_T(t_p1); HWD_ADD(15, t_p0, t_p1);
+        }
+        if (lane == 0) meta[b] = m;
         uint32_t nb_ = 0;
-        if (threadIdx.x == 0) nb_ = atomicAdd(counter, 1u);
+        if (lane == 0) nb_ = atomicAdd(counter, 1u);
         b = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb_);
     }
 #if defined(HW_DIAG)
@@ -954,7 +996,8 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
 #endif
 }
 
-// bgzf_inflate_fused: the product path.  The wave that decoded a block's Huffman symbols resolves its LZ77 copies right away
+// bgzf_inflate_fused (DHTS_INFLATE=fused; measured slower than the two launches: 202 ms against 178 ms per 92 M-record step, because phase B
+// then runs at phase A's ten waves per CU instead of sixteen).  The wave that decoded a block's Huffman symbols resolves its LZ77 copies right away
 // (lz_block, bgzf_inflate.hip): literals and tokens never leave the workgroup's own 152 KiB area (`wg_lit` / `wg_tok`, reused for every
 // block the workgroup takes, i.e. cache-resident), so the inflate stage reads the compressed block and writes the inflated one -- there
 // is no per-block scratch.  The two phases use the same LDS (phase A's tables are dead when phase B builds its window).

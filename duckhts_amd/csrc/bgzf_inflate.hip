@@ -921,10 +921,15 @@ extern "C" __global__ void __launch_bounds__(64)
 bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                 const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
                 const InflateMeta *__restrict__ meta, int64_t scratch_b0, uint8_t *__restrict__ out, uint64_t out_base,
-                int32_t *__restrict__ blk_status) {
+                int32_t *__restrict__ blk_status, const unsigned long long *__restrict__ blk_off) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int64_t)blockIdx.x >= nblk) return;
     const int64_t bi = blk0 + blockIdx.x;
     const int64_t s = bi - scratch_b0;            // slot in the phase-A scratch (phase A may run ahead over a larger block range)
-    lz_block(smem, comp, tab, bi, meta[s], lit_all + (size_t)s * DHTS_LIT_STRIDE, tok_all + (size_t)s * DHTS_TOK_STRIDE, out, out_base, blk_status);
+    const InflateMeta m = meta[s];
+    if (blk_off != nullptr) {
+        // packed scratch (bgzf_huff_decode_wave): literals at the block's offset of the pool `lit_all`, tokens behind them
+        const uint8_t *lp = lit_all + (m.status == 0 ? blk_off[s] : 0ull);
+        lz_block(smem, comp, tab, bi, m, lp, (const uint32_t *)(lp + ((m.nlit + 15u) & ~15u)), out, out_base, blk_status);
+    } else lz_block(smem, comp, tab, bi, m, lit_all + (size_t)s * DHTS_LIT_STRIDE, tok_all + (size_t)s * DHTS_TOK_STRIDE, out, out_base, blk_status);
 }

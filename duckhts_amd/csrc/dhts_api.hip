@@ -181,7 +181,9 @@ struct dhts_ctx {
     // inflate scratch
     DevBuf lit, tok, meta;
     DevBuf stg_lit, stg_tok, wave_ctr;             // wave kernel: staging slices of the resident workgroups, block counter
-    DevBuf wg_lit[2], wg_tok[2], stg2_lit, stg2_tok;  // fused inflate: the workgroups' own literal / token areas ([1], stg2_*: launches on stream_b)
+    DevBuf wg_lit[2], wg_tok[2], stg2_lit, stg2_tok;  // the workgroups' own literal / token areas ([1], stg2_*: fused launches on stream_b)
+    DevBuf blk_off; bool huff_packed = false;      // packed phase-A scratch: per-block offsets into `lit` (used as the pool)
+    int64_t pool_per_block = 65536 + 4096;         // room per block in the packed scratch (a retry after DHTS_BLK_ERR_SCRATCH uses the full 152 KiB)
     DevBuf sg_cnt, sg_base, sg_cand, sg_hits;      // block discovery scratch
     // index writer
     std::vector<uint8_t> built_index; DevBuf ix_end; BamStream last_stream;   // last_stream: the inflated buffer of the latest batch
@@ -842,9 +844,7 @@ static int wave_slots(dhts_ctx *c) {
     return 0;
 }
 // phase A over [b0, b0+nb): tokens + literals into the scratch
-static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {      // force: -1 default choice, 0 / 1 lane kernel (all symbols in LDS / far table), 2 wave kernel
-    ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 8192);
-    ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
+static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {      // force: -1 default choice, 0 / 1 lane kernel (all symbols in LDS / far table), 2 / 3 wave kernel into fixed slots / the packed pool
     ENSURE(c, c->meta, (size_t)nb * sizeof(InflateMeta));
     BgzfTable t = dev_table(c);
     // Two kernels fill the scratch (same format, cross-checked by the tests):
@@ -853,20 +853,44 @@ static int huff_blocks(dhts_ctx *c, int64_t b0, int64_t nb, int force = -1) {   
     //   lane: one LANE per block, canonical arithmetic (bgzf_inflate.hip): 13.0 ms per 65,536 blocks in long launches and never less than one
     //         lane's serial decode of a whole block (13-15 ms) in short ones; kept as the cross-check of the wave kernel (DHTS_PHASE_A=lane).
     static const char *env_a = getenv("DHTS_PHASE_A");
-    const bool env_lane = force >= 0 ? force != 2 : (env_a && !strcmp(env_a, "lane"));
+    const bool env_lane = force >= 0 ? (force != 2 && force != 3) : (env_a && !strcmp(env_a, "lane"));
     if (!env_lane) {
-        // persistent launch: as many workgroups (one wave each) as the device holds at once, each with its own staging slices; the
-        // workgroups take blocks from a counter that starts behind the blocks they begin with
+        // persistent launch: as many workgroups (one wave each) as the device holds at once, each with its own staging slices and block
+        // assembly area; the workgroups take blocks from a counter that starts behind the blocks they begin with.  `packed`: the blocks'
+        // tokens and literals go to a pool, each block exactly the room it needs (force == 2, the tests' cross-check: fixed slots)
+        const bool packed = force < 0 || force == 3;
         if (wave_slots(c)) return -1;
+        {   // DHTS_POOL_PER_BLOCK: room per block in the packed scratch (tuning knob; the tests use a tiny value to exercise the retry)
+            const int64_t env_ppb = getenv("DHTS_POOL_PER_BLOCK") ? atoll(getenv("DHTS_POOL_PER_BLOCK")) : 0;        // (read per launch: a test sets it)
+            if (env_ppb > 0 && c->pool_per_block == 65536 + 4096) c->pool_per_block = env_ppb;
+        }
         const int64_t grid = nb < c->wave_slots ? nb : c->wave_slots;
         ENSURE(c, c->stg_lit, (size_t)grid * HW_STAGE_LIT_BYTES + 64);
         ENSURE(c, c->stg_tok, (size_t)grid * HW_STAGE_TOK_WORDS * 4 + 64);
         ENSURE(c, c->wave_ctr, 64);
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->wave_ctr.p, (int)grid, 1, c->stream));
+        uint64_t pool_cap = 0;
+        if (packed) {
+            pool_cap = (uint64_t)nb * (uint64_t)c->pool_per_block;
+            ENSURE(c, c->lit, pool_cap + 8192);
+            ENSURE(c, c->blk_off, (size_t)nb * 8 + 64);
+            ENSURE(c, c->wg_lit[0], (size_t)grid * (DHTS_LIT_STRIDE + 64) + 8192);
+            ENSURE(c, c->wg_tok[0], (size_t)grid * DHTS_TOK_STRIDE * 4 + 64);
+            HIPCHK(c, hipMemsetAsync((uint8_t *)c->wave_ctr.p + 16, 0, 8, c->stream));
+        } else {
+            ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 8192);
+            ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
+        }
+        c->huff_packed = packed;
         KTimer tm(c, DHTS_K_HUFF);
         hipLaunchKernelGGL(bgzf_huff_decode_wave, dim3((unsigned)grid), dim3(64), 0, c->stream, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
-                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p, (uint8_t *)c->stg_lit.p, (uint32_t *)c->stg_tok.p, (uint32_t *)c->wave_ctr.p);
+                           (uint8_t *)c->lit.p, (uint32_t *)c->tok.p, (InflateMeta *)c->meta.p, (uint8_t *)c->stg_lit.p, (uint32_t *)c->stg_tok.p, (uint32_t *)c->wave_ctr.p,
+                           packed ? (uint8_t *)c->lit.p : (uint8_t *)nullptr, (unsigned long long)pool_cap, (unsigned long long *)((uint8_t *)c->wave_ctr.p + 16),
+                           (unsigned long long *)c->blk_off.p, (uint8_t *)c->wg_lit[0].p, (uint32_t *)c->wg_tok[0].p);
     } else {
+        ENSURE(c, c->lit, (size_t)nb * DHTS_LIT_STRIDE + 8192);
+        ENSURE(c, c->tok, (size_t)nb * DHTS_TOK_STRIDE * 4 + 64);
+        c->huff_packed = false;
         KTimer tm(c, DHTS_K_HUFF);
         // a launch that six waves per CU can hold at once keeps every symbol in LDS; a longer one runs eight waves per CU
         static const int64_t env_nlo = getenv("DHTS_PHASE_A_NLO") ? atoll(getenv("DHTS_PHASE_A_NLO")) : 0;     // tuning knob: 196 or 288
@@ -885,7 +909,8 @@ static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t
     {
         KTimer tm(c, DHTS_K_LZ, s);
         hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)nb), dim3(64), B_LDS_BYTES, s, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
-                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, c->huff_b0, out, out_base, (int32_t *)c->blk_status.p);
+                           (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, c->huff_b0, out, out_base, (int32_t *)c->blk_status.p,
+                           c->huff_packed ? (const unsigned long long *)c->blk_off.p : (const unsigned long long *)nullptr);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -912,8 +937,8 @@ static int launch_fused(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint6
     HIPCHK(c, hipGetLastError());
     return 0;
 }
-static bool inflate_split() {       // DHTS_INFLATE=split: phase A into per-block scratch slots, phase B as its own launch (the round-2 structure)
-    static const bool v = getenv("DHTS_INFLATE") && !strcmp(getenv("DHTS_INFLATE"), "split");
+static bool inflate_split() {       // default: phase A over the shard into the packed scratch, phase B per batch; DHTS_INFLATE=fused: one launch per batch does both
+    static const bool v = !(getenv("DHTS_INFLATE") && !strcmp(getenv("DHTS_INFLATE"), "fused"));
     return v;
 }
 static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t out_base, int64_t ahead_limit) {
@@ -933,7 +958,7 @@ static int inflate_blocks(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uin
             // the token/literal scratch of a super-batch may take at most 45 % of the HBM that is free (or already ours)
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-                const double per_block = ((double)DHTS_LIT_STRIDE + (double)DHTS_TOK_STRIDE * 4 + sizeof(InflateMeta)) * 1.125;
+                const double per_block = ((double)c->pool_per_block + 8.0 + sizeof(InflateMeta)) * 1.125;
                 size_t pooled = 0; { std::lock_guard<std::mutex> lk(g_pool_mu); pooled = g_pool_bytes; }       // (idle buffers of earlier contexts can be taken back)
                 const int64_t fit = (int64_t)(0.45 * ((double)fr + (double)pooled + (double)c->lit.cap + (double)c->tok.cap) / per_block);
                 if (sb > fit) sb = fit;
@@ -964,9 +989,19 @@ int64_t dhts_bgzf_inflate_to_host(dhts_ctx *c, int64_t blk0, int64_t nblk, uint8
     if (total > cap) return fail(c, "output capacity too small (%llu needed)", (unsigned long long)total);
     ENSURE(c, c->ubuf[0], total + PAD_BYTES);
     HIPCHK(c, hipMemsetAsync(c->ubuf[0].p, 0, total + PAD_BYTES, c->stream));
-    if (inflate_blocks(c, blk0, nblk, (uint8_t *)c->ubuf[0].p, base, blk0 + nblk)) return -1;
+    std::vector<int32_t> bs((size_t)nblk);
+    for (int attempt = 0; ; attempt++) {
+        if (inflate_blocks(c, blk0, nblk, (uint8_t *)c->ubuf[0].p, base, blk0 + nblk)) return -1;
+        HIPCHK(c, hipMemcpyAsync(bs.data(), (int32_t *)c->blk_status.p + blk0, nblk * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bool scratch = false;
+        for (int64_t k = 0; k < nblk; k++) if (bs[(size_t)k] == DHTS_BLK_ERR_SCRATCH) { scratch = true; break; }
+        if (!scratch) break;
+        if (attempt > 0) return fail(c, "internal: phase-A scratch exhausted twice");
+        c->pool_per_block = (int64_t)DHTS_LIT_STRIDE + (int64_t)DHTS_TOK_STRIDE * 4; c->huff_b0 = c->huff_nb = 0;      // (see batch_begin)
+    }
     HIPCHK(c, hipMemcpyAsync(out, c->ubuf[0].p, total, hipMemcpyDeviceToHost, c->stream));
-    if (blk_status) HIPCHK(c, hipMemcpyAsync(blk_status, (int32_t *)c->blk_status.p + blk0, nblk * 4, hipMemcpyDeviceToHost, c->stream));
+    if (blk_status) memcpy(blk_status, bs.data(), (size_t)nblk * 4);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timing_collect(c);
     return (int64_t)total;
@@ -2419,8 +2454,21 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     int blk_err = 0;
     if (nb > 0) {
         std::vector<int32_t> bs(nb);
-        HIPCHK(c, hipMemcpyAsync(bs.data(), (int32_t *)c->blk_status.p + b0, nb * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int attempt = 0; ; attempt++) {
+            HIPCHK(c, hipMemcpyAsync(bs.data(), (int32_t *)c->blk_status.p + b0, nb * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            bool scratch = false;
+            for (int64_t k = 0; k < nb; k++) if (bs[k] == DHTS_BLK_ERR_SCRATCH) { scratch = true; break; }
+            if (!scratch) break;
+            // the packed phase-A scratch was too small for some block (data that expands into far more tokens than a BAM or BCF does):
+            // decode this range again with the full 152 KiB per block
+            if (attempt > 0) return fail(c, "internal: phase-A scratch exhausted twice");
+            discard_prefetch(c);
+            c->pool_per_block = (int64_t)DHTS_LIT_STRIDE + (int64_t)DHTS_TOK_STRIDE * 4; c->huff_b0 = c->huff_nb = 0;
+            const int64_t ahead = c->shard_b1 + 8 < c->n_blocks ? c->shard_b1 + 8 : c->n_blocks;
+            if (inflate_blocks(c, b0, nb, u, out_base, ahead)) return -1;
+            HIPCHK(c, hipMemsetAsync(u + ulen, 0, PAD_BYTES, c->stream));
+        }
         for (int64_t k = 0; k < nb; k++) if (bs[k] != 0) { blk_err = bs[k]; ulen = carry + (c->h_uoff[b0 + k] - c->h_uoff[b0]); break; }
     }
     // (where only index windows are resident, the last resident block is not the end of the FILE: the record that runs out of it is cut by
@@ -3486,7 +3534,7 @@ extern "C" double dhts_debug_time_huff(dhts_ctx *c, int64_t b0, int64_t nb, int 
 // cross-check aid for the tests (not part of the public header): run ONE phase-A kernel over blocks [b0, b0+nb) (kernel: 0 / 1 = lane
 // per block with all symbols in LDS / with the far table, 2 = wave per block), then read a scratch slot back
 extern "C" int dhts_debug_huff_run(dhts_ctx *c, int64_t b0, int64_t nb, int kernel) {
-    if (!c || b0 < 0 || nb <= 0 || b0 + nb > c->n_blocks || kernel < 0 || kernel > 2) return -1;
+    if (!c || b0 < 0 || nb <= 0 || b0 + nb > c->n_blocks || kernel < 0 || kernel > 3) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     discard_prefetch(c);
     if (huff_blocks(c, b0, nb, kernel)) return -1;
@@ -3498,6 +3546,14 @@ extern "C" int dhts_debug_scratch_get(dhts_ctx *c, int64_t s, uint32_t *meta4, u
     HIPCHK(c, hipMemcpy(meta4, (InflateMeta *)c->meta.p + s, 16, hipMemcpyDeviceToHost));
     if (meta4[3] != 0u) return 0;                                     // failed block: the scratch content is unspecified
     if (meta4[1] > DHTS_LIT_STRIDE || meta4[0] > DHTS_TOK_STRIDE) return fail(c, "scratch counts out of range");
+    if (c->huff_packed) {
+        unsigned long long off = 0;
+        HIPCHK(c, hipMemcpy(&off, (unsigned long long *)c->blk_off.p + s, 8, hipMemcpyDeviceToHost));
+        const uint8_t *lp = (const uint8_t *)c->lit.p + off;
+        if (lit && meta4[1]) HIPCHK(c, hipMemcpy(lit, lp, meta4[1], hipMemcpyDeviceToHost));
+        if (tok && meta4[0]) HIPCHK(c, hipMemcpy(tok, lp + ((meta4[1] + 15u) & ~15u), (size_t)meta4[0] * 4, hipMemcpyDeviceToHost));
+        return 0;
+    }
     if (lit && meta4[1]) HIPCHK(c, hipMemcpy(lit, (uint8_t *)c->lit.p + (size_t)s * DHTS_LIT_STRIDE, meta4[1], hipMemcpyDeviceToHost));
     if (tok && meta4[0]) HIPCHK(c, hipMemcpy(tok, (uint32_t *)c->tok.p + (size_t)s * DHTS_TOK_STRIDE, (size_t)meta4[0] * 4, hipMemcpyDeviceToHost));
     return 0;

@@ -39,5 +39,6 @@ struct InflateMeta {           // per stream, written by phase A
 #define DHTS_BLK_ERR_INFLATE (-3)
 #define DHTS_BLK_ERR_CRC (-4)
 #define DHTS_BLK_ERR_ISIZE (-5)
+#define DHTS_BLK_ERR_SCRATCH (-6)      /* internal: the packed phase-A scratch was too small for this block (the host repeats the range with full-size room) */
 
 static inline const char *dhts_hip_err(hipError_t e) { return hipGetErrorString(e); }
