@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--max-blocks", type=int, default=24576, help="BGZF blocks per batch (24,576 is the largest that keeps in-batch offsets below 2^32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-operator", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the read_bcf (config 3) and region / overlap-join (config 5) legs behind the timed loop")
     ap.add_argument("--no-parity-sample", action="store_true")
     ap.add_argument("--strong", action="store_true", help="N>1: ONE file, every rank stages and scans its own byte window")
     args = ap.parse_args()
@@ -329,11 +330,26 @@ def main():
                 traffic_src = os.path.relpath(cand[-1], ROOT)
         except Exception:
             traffic = None
-        roof = {"bound": "hbm", "kernel": "bgzf_huff_decode+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        # per-kernel entries of SURVEY 8(d): inflate (C+U)/t1, boundary (U+8)/t2 (tile scan + repair + row bases: reads the inflated stream,
+        # writes an 8-byte offset per record), unpack (U+O)/t3 (fixed-width unpack, scans, string writer: reads it again, writes the columns)
+        def _pk(bytes_step, ms_step):
+            a_ = bytes_step / (ms_step * 1e-3) / 1e9 if ms_step > 0 else 0.0
+            return {"bytes_per_step": int(bytes_step), "ms_per_step": round(ms_step, 3), "achieved": round(a_, 2), "unit": "GB/s", "frac": round(a_ / HBM_PEAK_GBPS, 5)}
+        rows_f = float(rows) * frac_of_file if strong else float(rows)
+        t2_ms = ktimes["tiles"][0] / args.steps
+        t3_ms = (ktimes["core_unpack"][0] + ktimes["scan"][0] + ktimes["string_write"][0]) / args.steps
+        per_kernel = {
+            "inflate": dict(_pk(bytes_per_step, inflate_ms_step), kernels="bgzf_huff_decode_wave + bgzf_lz_resolve", bytes="C + U"),
+            "huff_decode": dict(_pk(file_bytes * frac_of_file, ktimes["huff_decode"][0] / args.steps), kernels="bgzf_huff_decode_wave", bytes="C (read); tokens and literals are scratch"),
+            "lz_resolve": dict(_pk(raw_bytes * frac_of_file, ktimes["lz_resolve"][0] / args.steps), kernels="bgzf_lz_resolve", bytes="U (written)"),
+            "boundary": dict(_pk(raw_bytes * frac_of_file + 8.0 * rows_f, t2_ms), kernels="bam_tile_scan + bam_tile_fix + bam_tile_finalize", bytes="U + 8 per record"),
+            "unpack": dict(_pk(raw_bytes * frac_of_file + float(out_bytes), t3_ms), kernels="bam_tile_unpack + scans + bam_tile_strings", bytes="U + O"),
+        }
+        roof = {"bound": "hbm", "kernel": "bgzf_huff_decode_wave+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src,
                 "ms_per_step": round(inflate_ms_step, 3), "bytes_per_step": int(bytes_per_step),
                 "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
-                "path_frac": round(value * (C_ + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5)}
+                "path_frac": round(value * (C_ + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5), "per_kernel": per_kernel}
 
         # ---- parity sample + CPU baseline on one whole segment (>= 1 % of the file), inside this run ----
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -403,6 +419,27 @@ def main():
         else:
             operator = {"error": err}
 
+    # ---- configs 3 and 5 (BASELINE.json): read_bcf on a synthetic 1 GB 16-sample BCF; region queries and the overlap join on a BAM ----
+    # Run by the tools that profiles/ quotes, as child processes after the timed loop (their own contexts and files); one JSON line per query.
+    def tool_lines(script, extra, timeout):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + extra, capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                return {"error": (r.stdout + r.stderr)[-300:]}
+            out = {}
+            for l in r.stdout.splitlines():
+                if l.startswith("{"):
+                    d = json.loads(l)
+                    out[d.get("query", str(len(out)))] = {k: d[k] for k in ("value", "unit", "rows_per_s", "ms_per_step", "bgzf_GBps", "projected_columns", "index_windows", "blocks_scanned", "index_build_s", "rows_out", "pairs_out", "pairs_per_s", "cpu_baseline", "config") if k in d and d[k] is not None}
+            return out
+        except Exception as e:                                   # (a bench line without these legs is still a bench line)
+            return {"error": repr(e)[:300]}
+    bcf_leg = region_leg = None
+    if not args.no_extra_configs and world == 1:
+        bcf_leg = tool_lines("bench_bcf.py", ["--steps", "3", "--warmup", "1", "--cpu-sample-records", "20000"], 400)
+        region_leg = tool_lines("bench_overlap.py", ["--steps", "3", "--warmup", "1", "--target-gb", "1.0", "--indexed-records", "4000000",
+                                                     "--queries", "region,overlap,indexed1,indexed10k"], 500)
+
     try:
         os.unlink(path)
     except OSError:
@@ -421,6 +458,7 @@ def main():
                    "parallelism": f"bgzf-block-range shards x{world}" + (" of one file, byte-window staging" if strong else "")},
         "bgzf_GBps": round(total_file_bytes / sec_per_step / 1e9, 3),
         "roofline": roof, "operator": operator, "parity_sample": parity, "cpu_baseline": cpu, "kernels": kt, "gen_seconds": round(gen_s, 1),
+        "bcf": bcf_leg, "region": region_leg,
     }
     if strong:
         line["staged_bytes_total"] = staged_total
