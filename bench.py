@@ -317,17 +317,22 @@ def main():
         lz_n = max(ktimes["lz_resolve"][1], 1)
         # HBM traffic of the inflate stage from the committed PMC passes (rocprofv3 cannot wrap itself): bytes per BGZF block
         # measured on full-size launches of this same workload (profiles/<round>/pmc_traffic_*.json), times the blocks of one step
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_detail = None, None, None
         try:
             import re as _re
             cand = sorted((f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
                            [os.path.join(ROOT, "profiles", r_, x) for x in os.listdir(os.path.join(ROOT, "profiles", r_)) if x.startswith("pmc_traffic_")]),
                           key=lambda f: (os.path.basename(os.path.dirname(f)), [int(t) for t in _re.findall(r"\d+", os.path.basename(f))]))   # latest round, highest version
             if cand:
-                pj = json.load(open(cand[-1]))["per_block"]
+                pjd = json.load(open(cand[-1]))
+                pj = pjd["per_block"]
                 per_blk = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in pj.values())
+                per_blk_raw = sum(v["fetch_bytes_raw"] + v["write_bytes"] for v in pj.values())
                 traffic = int(per_blk * nb)
                 traffic_src = os.path.relpath(cand[-1], ROOT)
+                traffic_detail = {"per_block_raw": round(per_blk_raw, 1), "per_block_fetch_x2": round(per_blk, 1), "algorithmic_per_block": round(bytes_per_step / nb, 1),
+                                  "measured_on_blocks": int(max(v.get("blocks_sampled", 0) for v in pj.values())), "command": pjd.get("run", {}).get("cmd"),
+                                  "note": "FETCH_SIZE + WRITE_SIZE of the two inflate kernels (separate rocprofv3 --pmc passes, tools/profile_round.sh); x2 = the gfx950 correction for wide reads, an upper estimate for these narrow ones; the counters also count Infinity-Cache hits"}
         except Exception:
             traffic = None
         # per-kernel entries of SURVEY 8(d): inflate (C+U)/t1, boundary (U+8)/t2 (tile scan + repair + row bases: reads the inflated stream,
@@ -346,7 +351,7 @@ def main():
             "unpack": dict(_pk(raw_bytes * frac_of_file + float(out_bytes), t3_ms), kernels="bam_tile_unpack + scans + bam_tile_strings", bytes="U + O"),
         }
         roof = {"bound": "hbm", "kernel": "bgzf_huff_decode_wave+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                 "ms_per_step": round(inflate_ms_step, 3), "bytes_per_step": int(bytes_per_step),
                 "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
                 "path_frac": round(value * (C_ + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5), "per_kernel": per_kernel}

@@ -41,17 +41,25 @@ def main():
         n = max(fl[1], wl[1], 1)
         res["kernels"][k] = {"launches": n, "fetch_bytes_per_launch": fl[0] * 1024 * 2 / n, "write_bytes_per_launch": wl[0] * 1024 / n,
                              "fetch_counter_sum": fl[0], "write_counter_sum": wl[0]}
-    # per BGZF block figures of the two inflate kernels (bench.py multiplies them by the blocks of a step): phase A runs one
-    # LANE per block (blocks = grid threads, rounded up to 64), phase B one 64-lane workgroup per block
+    # per BGZF block figures of the two inflate kernels (bench.py multiplies them by the blocks of a step).  Phase B runs one 64-lane
+    # workgroup per block, so its grids count the blocks; phase A is persistent since round 3 (bgzf_huff_decode_wave: a workgroup
+    # decodes many blocks) and covers the same blocks as phase B in the profiled command, so it is divided by phase B's block count
+    # (round 1-2 layouts: bgzf_huff_decode ran one LANE per block)
     res["per_block"] = {}
-    for k, lanes_per_block in (("bgzf_huff_decode", 1), ("bgzf_lz_resolve", 64)):
+    lz_f, lz_w = f.get("bgzf_lz_resolve"), w.get("bgzf_lz_resolve")
+    for k, lanes_per_block in (("bgzf_huff_decode", 1), ("bgzf_huff_decode_wave", 0), ("bgzf_lz_resolve", 64)):
         fl, wl = f.get(k), w.get(k)
         if not fl or not wl or not fl[2]:
             continue
-        blocks_f, blocks_w = fl[2] / lanes_per_block, wl[2] / lanes_per_block
+        if lanes_per_block == 0:
+            if not lz_f or not lz_w or not lz_f[2]:
+                continue
+            blocks_f, blocks_w = lz_f[2] / 64, lz_w[2] / 64
+        else:
+            blocks_f, blocks_w = fl[2] / lanes_per_block, wl[2] / lanes_per_block
         res["per_block"][k] = {"launch_blocks": blocks_f / max(fl[1], 1), "fetch_bytes_raw": fl[0] * 1024 / blocks_f,
                                "fetch_bytes_corrected": fl[0] * 1024 * 2 / blocks_f, "write_bytes": wl[0] * 1024 / blocks_w,
-                               "launches_sampled": fl[1]}
+                               "launches_sampled": fl[1], "blocks_sampled": blocks_f}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(f"{k:32s} n={v['launches']:5d} fetch/launch={v['fetch_bytes_per_launch'] / 1e6:10.2f} MB write/launch={v['write_bytes_per_launch'] / 1e6:10.2f} MB")
