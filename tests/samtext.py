@@ -25,7 +25,10 @@ def _tag(t):
 
 def sam_fixture_as_bam(name, **kw):
     """-> BAM file bytes made from the lines of tests/golden/<name> (a gzip / BGZF compressed SAM text file)"""
-    text = gzip.open(os.path.join(GOLD, name), "rb").read().decode()
+    return sam_text_as_bam(gzip.open(os.path.join(GOLD, name), "rb").read().decode(), **kw)
+
+
+def sam_text_as_bam(text, **kw):
     hdr = "".join(l + "\n" for l in text.split("\n") if l.startswith("@"))
     refs = []
     for l in hdr.split("\n"):
