@@ -446,6 +446,32 @@ def test_read_bam_pipeline_modes(tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_read_bam_on_two_different_gpus(tmp_path):
+    """DHTS_DEVICES=0,1 with two DIFFERENT device ids (skipped on a one-GPU box): each producer thread must select its own device before
+    any allocation, stage its own byte window there and hand off on BGZF virtual offsets -- the rows come out in file order, chunk for chunk,
+    exactly as from one device; also through the C ABI with two Context objects on devices 0 and 1 (block-range shards, 8-byte hand-off)."""
+    import duckhts_amd
+    if duckhts_amd.lib().dhts_device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from duckhts_amd import synth
+    data = synth.bam_file(250000, seed=29)
+    fn = os.path.join(str(tmp_path), "p2.bam")
+    open(fn, "wb").write(data)
+    exp = orc.bam_read(data)
+    rc, out, dump = run_host(fn, threads=1, env={"DHTS_DEVICES": "0,1", "DHTS_BATCH_BLOCKS": "150"})
+    assert rc == 0, out
+    schema, chunks = parse_chunks(dump)
+    names = [s[0] for s in SCHEMA]
+    want = list(zip(*[[None if v is None else (bytes(v) if isinstance(v, (bytes, bytearray)) else int(v)) for v in exp[nm]] for nm in names]))
+    assert [c[0] for c in chunks] == [min(2048, exp["n_rows"] - i) for i in range(0, exp["n_rows"], 2048)]
+    assert _rows(chunks, 13) == want
+    parts = [duckhts_amd.read_bam(data, device=r, shard=(r, 2), max_blocks=60) for r in range(2)]
+    assert sum(p["n_rows"] for p in parts) == exp["n_rows"]
+    for k in duckhts_amd.BAM_COLUMNS:
+        assert [x for p in parts for x in list(p[k])] == list(exp[k]), k
+
+
+@pytest.mark.gpu
 def test_read_bam_two_ranks_error_in_first_rank_ends_the_scan(tmp_path):
     """a damaged block inside rank 0's window: with one worker the scan ends there, rows before it only (bam_reader.c:754-766)"""
     from duckhts_amd import synth
