@@ -655,19 +655,6 @@ bam_overlap_cells(BamStream st, OverlapDev ov, const uint32_t *rec_off, BamCols 
     if (!WRITE) cnt[row] = n;
 }
 
-// ---- index build: per row the inputs of hts_idx_push (htslib sam.c:1007-1011): bam_endpos ----
-extern "C" __global__ void __launch_bounds__(256)
-bam_index_rows(BamStream st, const uint32_t *rec_off, BamCols c, int64_t nrows, int64_t *endpos) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= nrows) return;
-    const uint8_t *cig = st.u + rec_off[row] + c.cig_rel[row];
-    const uint32_t ne = c.ncig_eff[row];
-    int64_t rlen = 0;
-    if (!(c.flag[row] & 4)) for (uint32_t j = 0; j < ne; j++) { const uint32_t op = ldu32(cig + 4ull * j); if ((0x3C1A7u >> ((op & 0xf) << 1)) & 2u) rlen += op >> 4; }
-    if (rlen == 0) rlen = 1;
-    endpos[row] = (c.pos[row] - 1) + rlen;
-}
-
 // full bam_read1 validation of every row of a batch (what bam_tile_unpack checks while it writes): used to tell a false start of a
 // speculated shard from a good one before any column is written
 extern "C" __global__ void __launch_bounds__(256)

@@ -10,6 +10,7 @@
 #include "vcf_text.hip"
 #include "bam_tags.hip"
 #include "bgzf_deflate.hip"
+#include "hts_index.hip"
 #include "bcf_header.h"
 
 #include <errno.h>
@@ -30,6 +31,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <chrono>
 
 #define TILE_BYTES TL_TILE               /* record-stage tile = what bam_tiles_lds.hip stages per wave */
 #define PAD_BYTES 256u
@@ -1803,139 +1805,6 @@ static int bam_aux_map(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts_bam
 // idx_save_core (hts.c:2754-2818).  The scan supplies (tid, pos, bam_endpos, mapped) per record; virtual offsets follow
 // bgzf_tell's rule (bgzf.c bgzf_read: a read that ends exactly at a block end reports the NEXT block's address with offset 0).
 // Bins are written in ascending order (the reference writes them in khash order; readers do not depend on it).
-namespace {
-struct BaiBuild {                     // hts_idx_t as hts_idx_push / hts_idx_finish / idx_save_core build it: BAI (min_shift 14, 5 levels) or CSI
-    int n_ref = 0; int min_shift = 14, n_lvls = 5; uint32_t n_bins = ((1u << (3 * 5 + 3)) - 1) / 7; bool csi = false;
-    bool tbi = false; std::vector<uint8_t> aux;                             // tabix: "TBI\1" instead of "BAI\1" / the CSI aux block = tbx_set_meta's header (tbx.c:375-407); the index grows with the names met
-    std::vector<std::map<uint32_t, uint64_t>> loff;                        // CSI: per bin, the linear-index offset of its first window (update_loff, hts.c:2426-2455)
-    void set_csi(int ms, int lv) { csi = true; min_shift = ms; n_lvls = lv; n_bins = (uint32_t)((((uint64_t)1 << (3 * lv + 3)) - 1) / 7); }
-    struct Ch { uint64_t u, v; };
-    std::vector<std::map<uint32_t, std::vector<Ch>>> bidx; std::vector<char> has_b; std::vector<std::vector<uint64_t>> lidx;
-    int32_t save_tid = -1, last_tid = -1; uint32_t save_bin = 0xffffffffu, last_bin = 0xffffffffu;
-    uint64_t save_off = 0, last_off = 0, off_beg = 0, off_end = 0, n_mapped = 0, n_unmapped = 0, n_no_coor = 0; int64_t last_coor = 0xffffffffll;
-    std::string err;
-    void init(int n, uint64_t offset0) { n_ref = n; bidx.assign(n, {}); has_b.assign(n, 0); lidx.assign(n, {}); loff.assign(n, {}); save_off = last_off = off_beg = off_end = offset0; }
-    uint32_t reg2bin(int64_t beg, int64_t end) const {                     // hts_reg2bin (htslib/hts.h)
-        int s = min_shift; uint32_t t = (uint32_t)((((uint64_t)1 << ((n_lvls << 1) + n_lvls)) - 1) / 7);
-        --end;
-        for (int l = n_lvls; l > 0; --l, s += 3, t -= 1u << ((l << 1) + l)) if ((beg >> s) == (end >> s)) return t + (uint32_t)(beg >> s);
-        return 0;
-    }
-    bool push(int32_t tid, int64_t beg, int64_t end, uint64_t offset, bool mapped) {
-        if (tid < 0) { beg = -1; end = 0; }
-        const int64_t maxpos = 1ll << (min_shift + 3 * n_lvls);
-        if (tid >= 0 && !(beg <= maxpos && end <= maxpos)) { err = csi ? "Region cannot be stored in a csi index with these parameters. Please use a larger min_shift or depth" : "Region cannot be stored in a bai index. Try using a csi index"; return false; }
-        if (tid >= n_ref) { if (!csi && !tbi) { err = "record refers to a reference beyond the header"; return false; } n_ref = tid + 1; bidx.resize(n_ref); has_b.resize(n_ref, 0); lidx.resize(n_ref); loff.resize(n_ref); }   // (hts_idx_push enlarges the index)
-        if (last_tid != tid || (last_tid >= 0 && tid < 0)) {
-            if (tid >= 0 && n_no_coor) { err = "NO_COOR reads not in a single block at the end"; return false; }
-            if (tid >= 0 && has_b[tid]) { err = "Chromosome blocks not continuous"; return false; }
-            last_tid = tid; last_bin = 0xffffffffu;
-        } else if (tid >= 0 && last_coor > beg) { err = "Unsorted positions"; return false; }
-        if (end < beg) { err = "Invalid record: end < begin"; return false; }
-        if (tid >= 0) {
-            has_b[tid] = 1;
-            if (beg < 0) beg = 0;
-            if (end <= 0) end = 1;
-            std::vector<uint64_t> &l = lidx[tid];
-            const int64_t b = beg >> min_shift, e = (end - 1) >> min_shift;
-            if ((int64_t)l.size() < e + 1) l.resize((size_t)e + 1, ~0ull);
-            for (int64_t i = b; i <= e; i++) if (l[(size_t)i] == ~0ull) l[(size_t)i] = last_off;
-        } else n_no_coor++;
-        const uint32_t bin = reg2bin(beg, end);
-        if (last_bin != bin) {
-            if (save_bin != 0xffffffffu) bidx[save_tid][save_bin].push_back({save_off, last_off});
-            if (last_bin == 0xffffffffu && save_bin != 0xffffffffu) {
-                off_end = last_off;
-                bidx[save_tid][n_bins + 1].push_back({off_beg, off_end});
-                bidx[save_tid][n_bins + 1].push_back({n_mapped, n_unmapped});
-                n_mapped = n_unmapped = 0; off_beg = off_end;
-            }
-            save_off = last_off; save_bin = last_bin = bin; save_tid = tid;
-        }
-        if (mapped) ++n_mapped; else ++n_unmapped;
-        last_off = offset; last_coor = beg;
-        return true;
-    }
-    void finish(uint64_t final_offset) {
-        if (save_tid >= 0) {
-            bidx[save_tid][save_bin].push_back({save_off, final_offset});
-            bidx[save_tid][n_bins + 1].push_back({off_beg, final_offset});
-            bidx[save_tid][n_bins + 1].push_back({n_mapped, n_unmapped});
-        }
-        for (int i = 0; i < n_ref; i++) {
-            std::vector<uint64_t> &l = lidx[i];
-            for (int64_t k = (int64_t)l.size() - 2; k >= 0; k--) if (l[(size_t)k] == ~0ull) l[(size_t)k] = l[(size_t)k + 1];   // update_loff
-            if (!has_b[i]) continue;
-            auto &B = bidx[i];
-            if (csi) for (auto &kv : B) {                                            // the bins' loff, before compress_binning moves chunks into parents
-                uint64_t lo = 0;
-                if (kv.first < n_bins) {
-                    int lvl = 0; for (uint32_t b2 = kv.first; b2; b2 = (b2 - 1) >> 3) lvl++;                    // hts_bin_level
-                    const uint32_t first = (uint32_t)((((uint64_t)1 << ((lvl << 1) + lvl)) - 1) / 7);          // hts_bin_first
-                    const uint64_t bot = (uint64_t)(kv.first - first) << ((n_lvls - lvl) * 3);                // hts_bin_bot
-                    lo = bot < l.size() ? l[(size_t)bot] : 0;
-                }
-                loff[i][kv.first] = lo;
-            }
-            auto by_u = [](const Ch &a, const Ch &b) { return a.u < b.u; };
-            for (int lv = n_lvls; lv > 0; --lv) {                                    // compress_binning
-                const uint32_t start = ((1u << ((lv << 1) + lv)) - 1) / 7;
-                std::vector<uint32_t> keys;
-                for (auto &kv : B) if (kv.first < n_bins && kv.first >= start) keys.push_back(kv.first);
-                for (uint32_t key : keys) {
-                    auto it = B.find(key); if (it == B.end()) continue;
-                    std::vector<Ch> &p = it->second;
-                    if (lv < n_lvls && p.size() > 1) std::sort(p.begin(), p.end(), by_u);
-                    if ((p.back().v >> 16) - (p.front().u >> 16) < 0x10000ull) {
-                        auto q = B.find((key - 1) >> 3);
-                        if (q == B.end()) continue;
-                        q->second.insert(q->second.end(), p.begin(), p.end());
-                        B.erase(it);
-                    }
-                }
-            }
-            auto z = B.find(0); if (z != B.end()) std::sort(z->second.begin(), z->second.end(), by_u);
-            for (auto &kv : B) {                                                     // merge adjacent chunks that start from the same BGZF block
-                if (kv.first >= n_bins) continue;
-                std::vector<Ch> &p = kv.second; size_t m = 0;
-                for (size_t l2 = 1; l2 < p.size(); ++l2) {
-                    if ((p[m].v >> 16) >= (p[l2].u >> 16)) { if (p[m].v < p[l2].v) p[m].v = p[l2].v; }
-                    else p[++m] = p[l2];
-                }
-                p.resize(m + 1);
-            }
-        }
-    }
-    void save(std::vector<uint8_t> &o) const {
-        auto w32 = [&](uint32_t x) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(x >> (8 * k))); };
-        auto w64 = [&](uint64_t x) { for (int k = 0; k < 8; k++) o.push_back((uint8_t)(x >> (8 * k))); };
-        o.clear();
-        if (csi) {                                                                   // hts_idx_save_as CSI (hts.c:2820-2900): magic, min_shift, depth, l_aux = 0
-            o.push_back('C'); o.push_back('S'); o.push_back('I'); o.push_back(1);
-            w32((uint32_t)min_shift); w32((uint32_t)n_lvls); w32((uint32_t)aux.size());
-            o.insert(o.end(), aux.begin(), aux.end());
-            w32((uint32_t)n_ref);
-            for (int i = 0; i < n_ref; i++) {
-                w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
-                if (has_b[i]) for (auto &kv : bidx[i]) { w32(kv.first); auto lf = loff[i].find(kv.first); w64(lf == loff[i].end() ? 0 : lf->second); w32((uint32_t)kv.second.size()); for (auto &ch : kv.second) { w64(ch.u); w64(ch.v); } }
-            }
-            w64(n_no_coor);
-            return;
-        }
-        o.push_back(tbi ? 'T' : 'B'); o.push_back(tbi ? 'B' : 'A'); o.push_back('I'); o.push_back(1);
-        w32((uint32_t)n_ref);
-        if (tbi) o.insert(o.end(), aux.begin(), aux.end());
-        for (int i = 0; i < n_ref; i++) {
-            w32(has_b[i] ? (uint32_t)bidx[i].size() : 0u);
-            if (has_b[i]) for (auto &kv : bidx[i]) { w32(kv.first); w32((uint32_t)kv.second.size()); for (auto &ch : kv.second) { w64(ch.u); w64(ch.v); } }
-            w32((uint32_t)lidx[i].size());
-            for (uint64_t x : lidx[i]) w64(x);
-        }
-        w64(n_no_coor);
-    }
-};
-}  // namespace
-
 // Builds a BAI for the open BAM with one full scan (the scan state is rewound before and after).  Returns the index size.
 static int64_t bam_build_index_impl(dhts_ctx *c, int min_shift);
 int64_t dhts_bam_build_index(dhts_ctx *c) { return bam_build_index_impl(c, 0); }
@@ -1956,7 +1825,7 @@ static int64_t bam_build_index_impl(dhts_ctx *c, int min_shift) {
         if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
         return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
     };
-    BaiBuild ib;
+    IndexAcc ib;
     if (min_shift > 0) {
         int64_t max_len = 0; for (uint32_t l : c->ref_len) if ((int64_t)l > max_len) max_len = l;
         int n_lvls = 0;                                                              // hts_adjust_csi_settings (hts.c:2367-2400) from n_lvls = 0
@@ -1965,43 +1834,84 @@ static int64_t bam_build_index_impl(dhts_ctx *c, int min_shift) {
         else { n_lvls = 9; int64_t maxpos = 1ll << (min_shift + 27); while (need > maxpos) { ++min_shift; maxpos *= 2; } }
         ib.set_csi(min_shift, n_lvls);
     }
-    ib.init((int)c->ref_name.size(), tell(c->first_rec_uoff));
-    std::vector<int32_t> tid; std::vector<int64_t> pos, endp; std::vector<uint16_t> flag; std::vector<uint32_t> ro;
-    dhts_bam_batch b;
-    bool ok = true;
+    const int n_ref = (int)c->ref_name.size();
+    ib.begin(n_ref, tell(c->first_rec_uoff));
+    // device state of the passes (hts_index.hip): the windows of every sequence (its length plus 1 Mb of room for reads that hang over its end),
+    // counts, violation flags, the last row of the previous batch
+    std::vector<uint64_t> lin_base((size_t)n_ref + 1, 0);
+    for (int t = 0; t < n_ref; t++) lin_base[(size_t)t + 1] = lin_base[(size_t)t] + ((((uint64_t)c->ref_len[(size_t)t] + (1u << 20)) >> ib.g.min_shift) + 2);
+    const uint64_t n_win = lin_base[(size_t)n_ref];
+    DevBuf d_lin, d_base, d_cnt, d_misc;
+    ENSURE(c, d_lin, n_win * 8 + 64); ENSURE(c, d_base, ((size_t)n_ref + 1) * 8 + 64); ENSURE(c, d_cnt, (size_t)n_ref * 24 + 64); ENSURE(c, d_misc, 256);
+    HIPCHK(c, hipMemsetAsync(d_lin.p, 0xff, n_win * 8 + 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, (size_t)n_ref * 24 + 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_misc.p, 0, 256, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_base.p, lin_base.data(), ((size_t)n_ref + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    {   // the carry of "batch -1": no row yet, the reader stands in front of the first record
+        IdxCarry k{}; k.v = ib.v0;
+        HIPCHK(c, hipMemcpyAsync((uint8_t *)d_misc.p + 64, &k, sizeof(k), hipMemcpyHostToDevice, c->stream));
+    }
+    IdxDev dv; dv.g = ib.g; dv.n_ref = n_ref; dv.lin_base = (const uint64_t *)d_base.p; dv.lin = (unsigned long long *)d_lin.p;
+    dv.nmap = (unsigned long long *)d_cnt.p; dv.nunmap = dv.nmap + n_ref; dv.tid_runs = (uint32_t *)(dv.nunmap + n_ref); dv.max_win = dv.tid_runs + n_ref;
+    dv.n_nocoor = (unsigned long long *)d_misc.p; dv.err = (uint32_t *)((uint8_t *)d_misc.p + 8);
+    IdxCarry *carry2 = (IdxCarry *)((uint8_t *)d_misc.p + 64);
+    dhts_bam_batch b; int slot = 0; int rc = 0;
+    std::vector<IdxRun> hruns;
+    const bool timing = getenv("DHTS_IDX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_scan = 0, t_pass = 0; const double t_begin = now();
     for (;;) {
         const uint32_t mask = (1u << DHTS_BAM_FLAG) | (1u << DHTS_BAM_RNAME) | (1u << DHTS_BAM_POS);
+        const double t0 = now();
         if (dhts_bam_next_batch(c, 0, mask, &b)) return -1;
+        const double t1 = now(); t_scan += t1 - t0;
         const int64_t n = b.n_rows;
         if (n > 0) {
-            ENSURE(c, c->ix_end, (size_t)n * 8 + 64);
-            tid.resize(n); pos.resize(n); endp.resize(n); flag.resize(n); ro.resize(n);
+            ENSURE(c, c->ix_end, (size_t)n * sizeof(IdxRun) * 2 + 64); ENSURE(c, c->c_keep, (size_t)n * 4 + 16); ENSURE(c, c->c_rowmap, ((size_t)n + 1) * 4 + 16);
             BamCols bc; memset(&bc, 0, sizeof(bc));
             bc.flag = (uint16_t *)c->c_flag.p; bc.pos = (int64_t *)c->c_pos.p; bc.cig_rel = (uint32_t *)c->cig_rel.p; bc.ncig_eff = (uint32_t *)c->ncig_eff.p;
-            hipLaunchKernelGGL(bam_index_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->last_stream, (const uint32_t *)c->rec_off.p, bc, n, (int64_t *)c->ix_end.p);
+            uint32_t r0 = 0; HIPCHK(c, hipMemcpyAsync(&r0, c->rec_off.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+            const uint64_t out_base = b.first_rec_uoff - r0;
+            dv.carry_in = carry2 + slot; dv.carry_out = carry2 + (slot ^ 1); slot ^= 1;
+            IdxRun *row_run = (IdxRun *)c->ix_end.p, *runs_dev = row_run + n;
+            hipLaunchKernelGGL(bam_index_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->last_stream, (const uint32_t *)c->rec_off.p, bc, (const int32_t *)b.tid, n,
+                               out_base, b.end_uoff, (const uint64_t *)c->uoff.p, (const uint64_t *)c->coff.p, nb, c->comp_len, dv, (uint32_t *)c->c_keep.p, row_run);
+            const uint32_t *kin[1] = {(const uint32_t *)c->c_keep.p}; uint32_t *kout[1] = {(uint32_t *)c->c_rowmap.p}; uint64_t nruns = 0;
+            if (run_scan(c, 1, kin, kout, nullptr, n, &nruns)) return -1;
+            hipLaunchKernelGGL(idx_runs_write, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)c->c_keep.p, (const uint32_t *)c->c_rowmap.p, (const IdxRun *)row_run, n, runs_dev);
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(endp.data(), c->ix_end.p, n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(tid.data(), b.tid, n * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(pos.data(), b.pos, n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(flag.data(), b.flag, n * 2, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(ro.data(), c->rec_off.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+            const size_t at = hruns.size(); hruns.resize(at + (size_t)nruns);
+            if (nruns) HIPCHK(c, hipMemcpyAsync(hruns.data() + at, runs_dev, (size_t)nruns * sizeof(IdxRun), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            const uint64_t base = b.first_rec_uoff - ro[0];
-            for (int64_t i = 0; i < n && ok; i++) {
-                const uint64_t u_end = (i + 1 < n) ? base + ro[i + 1] : b.end_uoff;      // records are contiguous: end = next start
-                ok = ib.push(tid[i], pos[i] - 1, endp[i], tell(u_end), !(flag[i] & 4));
-            }
-            if (!ok) break;
         }
+        t_pass += now() - t1;
         if (b.status != 0) { if (b.status < 0) { dhts_bam_rewind(c); return fail(c, "index build: the scan ended on an error (status %d)", b.status); } break; }
     }
+    const double t_loop = now();
     dhts_bam_rewind(c);
-    if (!ok) return fail(c, "index build: %s", ib.err.c_str());
-    // hts_idx_finish(idx, bgzf_tell(fp)) after the failing read at EOF: the address of the last trailing empty block, else the file size
+    {   // the passes' results: violation flags, counts, the linear index up to the last window touched
+        uint32_t err = 0; std::vector<uint64_t> cnt((size_t)n_ref * 3 + 8, 0);
+        HIPCHK(c, hipMemcpy(&err, dv.err, 4, hipMemcpyDeviceToHost));
+        if (err) return fail(c, "index build: %s", ib.err_text(err));
+        HIPCHK(c, hipMemcpy(&ib.n_nocoor, dv.n_nocoor, 8, hipMemcpyDeviceToHost));
+        if (n_ref) HIPCHK(c, hipMemcpy(cnt.data(), d_cnt.p, (size_t)n_ref * 24, hipMemcpyDeviceToHost));
+        const uint32_t *tr = (const uint32_t *)(cnt.data() + 2 * (size_t)n_ref), *mw = tr + n_ref;
+        for (int t = 0; t < n_ref; t++) {
+            ib.nmap[(size_t)t] = cnt[(size_t)t]; ib.nunmap[(size_t)t] = cnt[(size_t)n_ref + (size_t)t]; ib.tid_runs[(size_t)t] = tr[t];
+            ib.lin[(size_t)t].resize(mw[t]);
+            if (mw[t]) HIPCHK(c, hipMemcpy(ib.lin[(size_t)t].data(), (const uint64_t *)d_lin.p + lin_base[(size_t)t], (size_t)mw[t] * 8, hipMemcpyDeviceToHost));
+        }
+        ib.runs.swap(hruns);
+    }
+    (void)rc;
+    // where the reader stands after the failing read at EOF: the address of the last trailing empty block, else the file size
     uint64_t fin = c->comp_len;
     if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
-    ib.finish(fin << 16);
+    const double t_dl = now();
+    if (!ib.finish(fin << 16)) return fail(c, "index build: %s", ib.err.c_str());
     ib.save(c->built_index);
+    if (timing) fprintf(stderr, "index build: setup %.2f ms, scan %.2f ms, passes %.2f ms, rewind+download %.2f ms, finish+save %.2f ms (%zu runs)\n", 0.0, t_scan, t_pass, t_dl - t_loop, now() - t_dl, ib.runs.size());
+    (void)t_begin;
     return (int64_t)c->built_index.size();
 }
 int dhts_bam_index_bytes(dhts_ctx *c, uint8_t *out, uint64_t cap) {
@@ -2049,12 +1959,14 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
         if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
         return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
     };
-    BaiBuild ib;
+    IndexAcc ib;
     if (tbi) ib.tbi = true; else ib.set_csi(min_shift, n_lvls);
-    ib.init(text ? 0 : nids, tell(c->first_rec_uoff));
+    ib.grow = true;                                                                  // (sequences are numbered as they are met / as the header numbers them: the table grows)
+    ib.begin(text ? 0 : nids, tell(c->first_rec_uoff));
     std::vector<int32_t> tid_of; std::vector<std::string> tnames;                    // text: sequence ids in the order of first appearance (get_tid, tbx.c:82-107)
     bool ok = true; int rc = 0;
     std::vector<uint32_t> ro; std::vector<uint8_t> core;
+    std::vector<int32_t> a_tid; std::vector<int64_t> a_beg, a_end; std::vector<uint64_t> a_v; std::vector<uint8_t> a_map;
     for (;;) {
         dhts_bcf_batch b;
         if (dhts_bcf_next_batch(c, 0, &b)) { rc = -1; break; }
@@ -2069,18 +1981,21 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
             HIPCHK(c, hipMemcpyAsync(core.data(), c->ix_end.p, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             const uint64_t base = b.first_rec_uoff - ro[0];
+            // the batch as arrays: sequence, interval, the virtual offset behind every record (IndexAcc::add_rows makes the passes)
+            a_tid.resize(n); a_beg.resize(n); a_end.resize(n); a_v.resize(n); a_map.assign(n, 1);
             for (int64_t i = 0; i < n && ok; i++) {
                 int32_t rid, pos, rlen; memcpy(&rid, &core[(size_t)i * 12], 4); memcpy(&pos, &core[(size_t)i * 12 + 4], 4); memcpy(&rlen, &core[(size_t)i * 12 + 8], 4);
                 const uint64_t u_end = (i + 1 < n) ? base + ro[i + 1] : b.end_uoff;
                 const int64_t p64 = (uint32_t)pos == 0xffffffffu ? -1 : (int64_t)pos;
+                a_v[(size_t)i] = tell(u_end);
                 if (text) {
                     if (rid < 0 || rid >= (int32_t)c->bh.ctg.size()) { ok = false; ib.err = "record without a sequence name"; break; }
                     if ((int32_t)tid_of.size() < (int32_t)c->bh.ctg.size()) tid_of.resize(c->bh.ctg.size(), -1);
                     if (tid_of[rid] < 0) { tid_of[rid] = (int32_t)tnames.size(); tnames.push_back(c->bh.ctg[rid]); }
-                    ok = ib.push(tid_of[rid], p64 < 0 ? 0 : p64, p64 + rlen, tell(u_end), true);       // the interval of tbx_parse1: rlen of a text record is its tabix END - pos
-                } else
-                ok = ib.push(rid, p64, p64 + rlen, tell(u_end), true);
+                    a_tid[(size_t)i] = tid_of[rid]; a_beg[(size_t)i] = p64 < 0 ? 0 : p64; a_end[(size_t)i] = p64 + rlen;      // the interval of tbx_parse1: rlen of a text record is its tabix END - pos
+                } else { a_tid[(size_t)i] = rid; a_beg[(size_t)i] = p64; a_end[(size_t)i] = p64 + rlen; }
             }
+            if (ok) ok = ib.add_rows(a_tid.data(), a_beg.data(), a_end.data(), a_v.data(), a_map.data(), n);
             if (!ok) break;
         }
         if (b.status != 0) { if (b.status < 0) { rc = fail(c, "index build: the scan ended on an error (status %d)", b.status); } break; }
@@ -2091,7 +2006,7 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
     if (!ok) return fail(c, "index build: %s", ib.err.c_str());
     uint64_t fin = c->comp_len;
     if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
-    ib.finish(fin << 16);
+    if (!ib.finish(fin << 16)) return fail(c, "index build: %s", ib.err.c_str());
     if (text) {                                                                      // tbx_set_meta: the VCF preset {TBX_VCF, 1, 2, 0, '#', 0}, l_nm, names
         const uint32_t conf[6] = {2, 1, 2, 0, '#', 0}; uint32_t l_nm = 0;
         for (auto &nm : tnames) l_nm += (uint32_t)nm.size() + 1;
@@ -2525,7 +2440,8 @@ extern "C" int64_t dhts_tabix_build_index(dhts_ctx *c, int preset, int sc, int b
         if (lo <= nb && uo[lo] == u) return (lo < nb ? c->h_coff[lo] : c->comp_len) << 16;
         return (c->h_coff[lo - 1] << 16) | (u - uo[lo - 1]);
     };
-    BaiBuild ib; bool inited = false; uint64_t last_off = tell(0); int64_t lineno = 0, max_ref_len = 0;
+    IndexAcc ib; ib.grow = true; bool inited = false; uint64_t last_off = tell(0); int64_t lineno = 0, max_ref_len = 0;
+    std::vector<int32_t> a_tid; std::vector<int64_t> a_beg, a_end; std::vector<uint64_t> a_v; std::vector<uint8_t> a_map;     // the data lines of a batch as arrays
     auto init_index = [&]() {
         if (tbi) ib.tbi = true;
         else {
@@ -2537,7 +2453,7 @@ extern "C" int64_t dhts_tabix_build_index(dhts_ctx *c, int preset, int sc, int b
             } else n_lvls = min_shift < 10 ? 9 : min_shift < 25 ? 9 - (min_shift - 10) / 3 : 4;
             ib.set_csi(min_shift, n_lvls);
         }
-        ib.init(0, last_off); inited = true;
+        ib.begin(0, last_off); inited = true;
     };
     std::vector<std::string> names; std::map<std::string, int32_t> tid_of; int32_t last_tid = -1;
     std::vector<TbxLine> rows; std::vector<uint32_t> lo; std::string nm;
@@ -2569,6 +2485,7 @@ extern "C" int64_t dhts_tabix_build_index(dhts_ctx *c, int preset, int sc, int b
             rows.resize((size_t)nlines);
             HIPCHK(c, hipMemcpyAsync(rows.data(), c->v_undef.p, (size_t)nlines * sizeof(TbxLine), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            a_tid.clear(); a_beg.clear(); a_end.clear(); a_v.clear();
             for (int64_t i = 0; i < nlines && rc == 0; i++) {
                 const TbxLine &r = rows[(size_t)i];
                 ++lineno;
@@ -2592,7 +2509,11 @@ extern "C" int64_t dhts_tabix_build_index(dhts_ctx *c, int preset, int sc, int b
                     if (it == tid_of.end()) { tid = (int32_t)names.size(); tid_of[nm] = tid; names.push_back(nm); } else tid = it->second;
                     last_tid = tid;
                 }
-                if (!ib.push(tid, r.beg, r.end, after, true)) { rc = -1; err = ib.err; }
+                a_tid.push_back(tid); a_beg.push_back(r.beg); a_end.push_back(r.end); a_v.push_back(after);
+            }
+            if (rc == 0 && !a_tid.empty()) {
+                a_map.assign(a_tid.size(), 1);
+                if (!ib.add_rows(a_tid.data(), a_beg.data(), a_end.data(), a_v.data(), a_map.data(), (int64_t)a_tid.size())) { rc = -1; err = ib.err; }
             }
         }
         if (rc) break;
@@ -2607,7 +2528,7 @@ extern "C" int64_t dhts_tabix_build_index(dhts_ctx *c, int preset, int sc, int b
     if (!inited) init_index();
     uint64_t fin = c->comp_len;
     if (nb > 0 && c->h_isize[nb - 1] == 0) fin = c->h_coff[nb - 1];
-    ib.finish(fin << 16);
+    if (!ib.finish(fin << 16)) return fail(c, "tabix_index: %s", ib.err.c_str());
     {
         const uint32_t conf[6] = {(uint32_t)preset, (uint32_t)sc, (uint32_t)bc, (uint32_t)ec, (uint32_t)meta_char, (uint32_t)line_skip}; uint32_t l_nm = 0;
         for (auto &x : names) l_nm += (uint32_t)x.size() + 1;
