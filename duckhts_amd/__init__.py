@@ -74,7 +74,7 @@ ENC_PLAIN, ENC_CONTIG, ENC_DICT, ENC_SAMPLE, ENC_FLOAT_TEXT = 0, 1, 2, 3, 4
 EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy", "dhts_error", "dhts_open_path",
            "dhts_open_host", "dhts_open_tiled", "dhts_resident_bytes", "dhts_bgzf_index", "dhts_bgzf_table",
            "dhts_bgzf_inflate_to_host", "dhts_bam_open", "dhts_bam_header_get", "dhts_bam_set_shard", "dhts_bam_set_block_range", "dhts_shard_cut",
-           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_scan_window_stats", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_set_overlap_intervals", "dhts_bam_build_index", "dhts_bam_index_bytes", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
+           "dhts_bam_set_regions", "dhts_bam_load_index", "dhts_scan_window_stats", "dhts_bam_std_tag_count", "dhts_bam_std_tag_info", "dhts_bam_set_tag_columns", "dhts_bam_set_aux_map", "dhts_bam_set_overlap_intervals", "dhts_bam_set_overlap_bed", "dhts_bam_set_overlap_bed_path", "dhts_bam_build_index", "dhts_bam_index_bytes", "dhts_bam_rewind", "dhts_bam_next_batch", "dhts_memcpy_d2h", "dhts_sync", "dhts_kernel_time_ms",
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
@@ -281,6 +281,19 @@ class Context:
         tid = np.ascontiguousarray(tid, np.int32); beg = np.ascontiguousarray(beg, np.int64); end = np.ascontiguousarray(end, np.int64)
         assert len(tid) == len(beg) == len(end)
         self._chk(self.L.dhts_bam_set_overlap_intervals(self.h, tid.ctypes.data, beg.ctypes.data, end.ctypes.data, len(tid)))
+
+    def set_overlap_bed(self, bed):
+        """The join's intervals from a BED: bytes = the text itself, str / PathLike = a plain or bgzipped file.  Returns the number of
+        read_bed rows; interval ids are those row numbers."""
+        if isinstance(bed, (bytes, bytearray, memoryview)):
+            buf = np.frombuffer(bytes(bed), dtype=np.uint8)
+            self.L.dhts_bam_set_overlap_bed.restype = C.c_int64; self.L.dhts_bam_set_overlap_bed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+            n = self.L.dhts_bam_set_overlap_bed(self.h, buf.ctypes.data if buf.nbytes else None, buf.nbytes)
+        else:
+            self.L.dhts_bam_set_overlap_bed_path.restype = C.c_int64; self.L.dhts_bam_set_overlap_bed_path.argtypes = [C.c_void_p, C.c_char_p]
+            n = self.L.dhts_bam_set_overlap_bed_path(self.h, os.fsencode(bed))
+        self._chk(-1 if n < 0 else 0)
+        return int(n)
 
     def overlap_lists(self, b):
         """(offsets u32[n_rows+1], ids u32[n_ov]) of one batch; ids are positions in the arrays given to set_overlap_intervals"""
@@ -701,7 +714,7 @@ def std_tags():
     return _STD_TAGS
 
 
-def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None, overlap=None, sparse=None):
+def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, std_tags_cols=None, aux_map=None, overlap=None, sparse=None, overlap_bed=None):
     """Full sequential scan (reference mode (i)): all rows in file order.
     region: the reference's region := string (rows filtered on the device); index: BAI bytes narrowing the scan window.
     sparse=(header_bytes, beg[], end[]) with a path: only the header blocks and those file ranges are staged (Context.region_segments)."""
@@ -726,6 +739,9 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
             ctx.set_aux_map(True, bool(aux_map == "exclude_standard"))
         if overlap is not None:
             ctx.set_overlap_intervals(*overlap)          # (tid, beg, end) arrays: out["OVERLAPS"] = per-row arrays of interval ids
+        n_bed = None
+        if overlap_bed is not None:                      # BED text (bytes) or file (path): ids = read_bed row numbers
+            n_bed = ctx.set_overlap_bed(overlap_bed); overlap = True
         parts, tparts, aparts, oparts = [], [], [], []
         status = 0
         while True:
@@ -746,6 +762,8 @@ def read_bam(src, device=0, max_blocks=0, shard=None, region=None, index=None, s
             out["tags"] = {"n_rows": out["n_rows"], "cols": _concat_tables(tparts, None) or []}
         if aux_map is not None:
             out["aux"] = {"n_rows": out["n_rows"], "cols": _concat_tables(aparts, None) or []}
+        if n_bed is not None:
+            out["n_bed_rows"] = n_bed
         if overlap is not None:
             out["OVERLAPS"] = [ids[off[i]:off[i + 1]] for off, ids in oparts for i in range(len(off) - 1)]
         for k in BAM_COLUMNS + ["tid", "mtid"]:

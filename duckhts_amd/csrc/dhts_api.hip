@@ -2211,6 +2211,87 @@ int dhts_bam_set_overlap_intervals(dhts_ctx *c, const int32_t *tid, const int64_
     return 0;
 }
 
+// read_bed rows as the join's intervals (src/interval_udf.c:330-426): the device splits the text into lines and parses chrom / start / end of
+// every row (bed_intervals); the host only maps the chrom names, where they change, to the header's reference ids.  Interval id = row number of
+// read_bed (meta lines do not count).  A row whose start or end is NULL, or whose chrom the BAM header does not have, never matches.  text = the
+// (uncompressed) BED bytes.  Returns the number of rows, < 0 on error (a line with fewer than 3 fields: read_bed's error).
+extern "C" int64_t dhts_bam_set_overlap_bed(dhts_ctx *c, const uint8_t *text, uint64_t n) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ov_active = false; c->ov_n = 0;
+    if (!c->bam_open) return fail(c, "dhts_bam_open not called");
+    if (n && !text) return fail(c, "overlap bed: null text");
+    if (n >= 0xfffffff0ull) return fail(c, "overlap bed: text of 4 GiB or more");
+    if (n == 0) return 0;
+    DevBuf d_text, d_cnt, d_base, d_off, d_rows;
+    ENSURE(c, d_text, n + 64);
+    HIPCHK(c, hipMemcpyAsync(d_text.p, text, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync((uint8_t *)d_text.p + n, 0, 64, c->stream));
+    const uint8_t *u = (const uint8_t *)d_text.p;
+    const int64_t nchunks = (int64_t)((n + VCF_CHUNK - 1) / VCF_CHUNK);
+    ENSURE(c, d_cnt, (size_t)nchunks * 4 + 64); ENSURE(c, d_base, (size_t)(nchunks + 1) * 4 + 64);
+    hipLaunchKernelGGL(vcf_line_count, dim3((unsigned)nchunks), dim3(256), 0, c->stream, u, (uint64_t)0, n, (uint32_t *)d_cnt.p, nchunks);
+    const uint32_t *kin[1] = {(const uint32_t *)d_cnt.p}; uint32_t *kout[1] = {(uint32_t *)d_base.p}; uint64_t nl = 0;
+    if (run_scan(c, 1, kin, kout, nullptr, nchunks, &nl)) return -1;
+    ENSURE(c, d_off, (size_t)(nl + 2) * 4 + 64);
+    hipLaunchKernelGGL(vcf_line_fill, dim3((unsigned)nchunks), dim3(256), 0, c->stream, u, (uint64_t)0, n, (const uint32_t *)d_base.p, (uint32_t *)d_off.p, nchunks);
+    int64_t nlines = (int64_t)nl; int last_open = 0;
+    if (text[n - 1] != '\n') { nlines++; last_open = 1; }
+    ENSURE(c, d_rows, (size_t)nlines * sizeof(TbxLine) + 64);
+    hipLaunchKernelGGL(bed_intervals, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, c->stream, u, (const uint32_t *)d_off.p, nlines, n, last_open, (TbxLine *)d_rows.p);
+    HIPCHK(c, hipGetLastError());
+    std::vector<TbxLine> rows((size_t)nlines);
+    HIPCHK(c, hipMemcpyAsync(rows.data(), d_rows.p, (size_t)nlines * sizeof(TbxLine), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::map<std::string, int32_t> tid_of;
+    for (size_t t = 0; t < c->ref_name.size(); t++) tid_of.emplace(c->ref_name[t], (int32_t)t);   // (a name listed twice: the first @SQ, as sam_hdr_name2tid's hash keeps)
+    std::vector<int32_t> tid; std::vector<int64_t> beg, end; tid.reserve((size_t)nlines); beg.reserve((size_t)nlines); end.reserve((size_t)nlines);
+    int32_t cur = -1; int64_t lineno = 0;
+    for (const TbxLine &r : rows) {
+        ++lineno;
+        if (r.flag == 1) continue;
+        if (r.flag == 2) return fail(c, "read_bed: BED line has fewer than 3 tab-delimited fields (line %lld)", (long long)lineno);
+        if (!r.same || tid.empty()) { auto it = tid_of.find(std::string((const char *)text + r.name_off, r.name_len)); cur = it == tid_of.end() ? -1 : it->second; }
+        tid.push_back((r.flag & 12u) ? -1 : cur); beg.push_back(r.beg); end.push_back(r.end);
+    }
+    const int64_t m = (int64_t)tid.size();
+    if (m && dhts_bam_set_overlap_intervals(c, tid.data(), beg.data(), end.data(), m)) return -1;
+    return m;
+}
+// the same from a file: plain text, or BGZF / gzip members (inflated by a context of its own on the same device)
+extern "C" int64_t dhts_bam_set_overlap_bed_path(dhts_ctx *c, const char *path) {
+    if (!c) return -1;
+    if (!path) return fail(c, "overlap bed: null path");
+    std::vector<uint8_t> raw;
+    {
+        FILE *f = fopen(path, "rb");
+        if (!f) return fail(c, "overlap bed: cannot open %s", path);
+        uint8_t buf[1 << 16]; size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), f)) > 0) raw.insert(raw.end(), buf, buf + got);
+        fclose(f);
+    }
+    if (raw.size() >= 18 && raw[0] == 0x1f && raw[1] == 0x8b) {
+        dhts_ctx *t = dhts_create(c->device);
+        if (!t) return fail(c, "overlap bed: no context for %s", path);
+        std::vector<uint8_t> text; std::string err; bool ok = false;
+        do {
+            if (dhts_open_host(t, raw.data(), raw.size())) { err = dhts_error(t); break; }
+            const int64_t nb = dhts_bgzf_index(t);
+            if (nb < 0) { err = dhts_error(t); break; }
+            text.resize((size_t)t->h_uoff[(size_t)nb] + 64);
+            std::vector<int32_t> st((size_t)nb + 1, 0);
+            const int64_t got = nb ? dhts_bgzf_inflate_to_host(t, 0, nb, text.data(), text.size(), st.data()) : 0;
+            if (got < 0) { err = dhts_error(t); break; }
+            text.resize((size_t)got); ok = true;
+        } while (0);
+        dhts_destroy(t);
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!ok) return fail(c, "overlap bed: %s: %s", path, err.c_str());
+        return dhts_bam_set_overlap_bed(c, text.data(), text.size());
+    }
+    return dhts_bam_set_overlap_bed(c, raw.data(), raw.size());
+}
+
 static int bam_overlap_join(dhts_ctx *c, const BamStream &st, const BamCols &bc, int64_t nrows, dhts_bam_batch *out) {
     out->ov_off = nullptr; out->ov_ids = nullptr; out->n_ov = 0;
     if (!c->ov_active) return 0;

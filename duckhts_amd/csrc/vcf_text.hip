@@ -331,6 +331,42 @@ tabix_intervals(const uint8_t *__restrict__ u, const uint32_t *__restrict__ line
     out[li] = r;
 }
 
+// ---- read_bed rows for the overlap join (src/interval_udf.c:141-157 is_meta_bed_line / count_tab_fields, 159-181 get_field_span, 127-139
+// parse_int64_span_local, 330-342 next_bed_line) ---------------------------------------------------------------------------------------------
+// One lane per line.  flag 1 = not a row (empty, '#', "track", "browser"), 2 = fewer than 3 tab-delimited fields (read_bed raises), else bit 2 /
+// bit 3 = start / end is NULL (the field is empty or strtoll does not consume all of it); chrom = u[name_off, +name_len); same as in TbxLine.
+extern "C" __global__ void __launch_bounds__(256)
+bed_intervals(const uint8_t *__restrict__ u, const uint32_t *__restrict__ line_off, int64_t nlines, uint64_t text_end, int32_t last_open, TbxLine *__restrict__ out) {
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nlines) return;
+    const uint32_t l0 = line_off[li];
+    uint32_t l1 = (li + 1 < nlines || !last_open) ? line_off[li + 1] - 1u : (uint32_t)text_end;
+    if (l1 > l0 && u[l1 - 1] == '\r') l1--;
+    TbxLine r; r.name_off = l0; r.name_len = 0; r.beg = 0; r.end = 0; r.flag = 0; r.same = 0;
+    auto starts = [&](uint32_t a, uint32_t b, const char *w, uint32_t n) { if (b - a < n) return false; for (uint32_t k = 0; k < n; k++) if (u[a + k] != (uint8_t)w[k]) return false; return true; };
+    if (l1 == l0 || u[l0] == 0 || u[l0] == '#' || starts(l0, l1, "track", 5) || starts(l0, l1, "browser", 7)) { r.flag = 1; out[li] = r; return; }
+    int id = 0; uint32_t b = l0;
+    for (uint32_t i = l0; i <= l1; i++) {
+        const bool stop = i == l1 || u[i] == 0;                                     // (the reference walks a C string)
+        if (!stop && u[i] != '\t') continue;
+        if (id == 0) { r.name_off = b; r.name_len = i - b; }
+        else if (id <= 2) {
+            uint32_t adv = 0; const long long v = vcf_strtoll(u, b, i, 10, &adv);
+            const bool ok = i > b && adv == i - b;
+            if (id == 1) { r.beg = v; if (!ok) r.flag |= 4u; } else { r.end = v; if (!ok) r.flag |= 8u; }
+        }
+        ++id; b = i + 1;
+        if (stop) break;
+    }
+    if (id < 3) r.flag = 2;
+    else if (li > 0) {
+        const uint32_t p0 = line_off[li - 1]; uint32_t p1 = line_off[li] - 1u;
+        uint32_t k = 0; while (k < r.name_len && p0 + k < p1 && u[p0 + k] == u[l0 + k]) k++;
+        r.same = (k == r.name_len && p0 + k < p1 && u[p0 + k] == '\t') ? 1u : 0u;
+    }
+    out[li] = r;
+}
+
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
 #define VCF_MAXF 32

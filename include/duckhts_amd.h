@@ -229,6 +229,14 @@ int dhts_bam_index_bytes(dhts_ctx *, uint8_t *out, uint64_t cap);
  * beg_i < read_end && read_beg < end_i on the read's contig (read interval = [pos, bam_endpos)), i.e. cr_overlap's answer as
  * a set.  n = 0 switches the join off.  Host pointers; copied.                                                              */
 int dhts_bam_set_overlap_intervals(dhts_ctx *, const int32_t *tid, const int64_t *beg, const int64_t *end, int64_t n);
+/* The intervals from BED text, i.e. the rows read_bed would return for it (src/interval_udf.c:330-426: next_bed_line skips empty lines and
+ * those that begin with '#', "track" or "browser", 141-147; a line with fewer than 3 tab-delimited fields is read_bed's error, 358-365;
+ * start / end through strtoll over the whole field, else NULL, 127-139).  The device splits the text into lines and parses chrom / start /
+ * end of each (bed_intervals, vcf_text.hip); chrom names are mapped to the BAM header's reference ids.  Interval id = row number of
+ * read_bed; rows with a NULL start or end, or a chrom the header does not have, never match.  Returns the number of rows, < 0 on error.
+ * _path: a plain or BGZF / gzip-compressed BED file (what hts_open + hts_getline accept, 330-337).                                   */
+int64_t dhts_bam_set_overlap_bed(dhts_ctx *, const uint8_t *text, uint64_t n);
+int64_t dhts_bam_set_overlap_bed_path(dhts_ctx *, const char *path);
 /* Next batch of rows (<= max_blocks BGZF blocks of input; 0 = default 16,384, at most 24,576).  colmask = projection pushdown, bit i
  * = read_bam core column i (DHTS_BAM_*): the fixed-width columns are always produced; the string heaps (QNAME, CIGAR, SEQ, QUAL,
  * READ_GROUP_ID) of columns that are not projected are not written, and with none of them projected the string pass is skipped

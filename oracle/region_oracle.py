@@ -250,6 +250,56 @@ def overlap_join(table, tid, beg, end):
     return out
 
 
+def _strtoll_whole(f):
+    """parse_int64_span_local (src/interval_udf.c:127-139): strtoll(field, &end, 10) with *end == 0, else None (NULL).  C's strtoll:
+    white space, one optional sign, decimal digits, saturating at the ends of int64."""
+    if not f:
+        return None
+    i = 0
+    while i < len(f) and f[i:i + 1] in (b" ", b"\t", b"\n", b"\v", b"\f", b"\r"):
+        i += 1
+    neg = False
+    if i < len(f) and f[i:i + 1] in (b"+", b"-"):
+        neg = f[i:i + 1] == b"-"
+        i += 1
+    d = f[i:]
+    if not d or not d.isdigit() or any(c > 0x39 for c in d):
+        return None
+    v = -int(d) if neg else int(d)
+    return max(-(1 << 63), min((1 << 63) - 1, v))
+
+
+def bed_rows(text):
+    """The rows read_bed returns for BED text (src/interval_udf.c:330-342 next_bed_line over hts_getline: lines lose their '\n' and a
+    '\r' in front of it; empty lines and those starting with '#', 'track', 'browser' are skipped, 141-147; fewer than 3 tab-delimited
+    fields raises, 358-365; a C string ends at a NUL).  -> list of (chrom bytes, start or None, end or None)."""
+    rows = []
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    for ln in lines:
+        if ln.endswith(b"\r"):
+            ln = ln[:-1]
+        ln = ln.split(b"\0", 1)[0]
+        if not ln or ln[:1] == b"#" or ln[:5] == b"track" or ln[:7] == b"browser":
+            continue
+        f = ln.split(b"\t")
+        if len(f) < 3:
+            raise ValueError("read_bed: BED line has fewer than 3 tab-delimited fields")
+        rows.append((f[0], _strtoll_whole(f[1]), _strtoll_whole(f[2])))
+    return rows
+
+
+def bed_join_intervals(rows, ref_names):
+    """(tid, beg, end) of the join for read_bed rows: chrom -> index in the BAM header (first of equal names), -1 (never matches) when
+    the header lacks it or start / end is NULL"""
+    first = {}
+    for i, nm in enumerate(ref_names):
+        first.setdefault(bytes(nm), i)
+    tid = [(-1 if (b is None or e is None) else first.get(bytes(c), -1)) for c, b, e in rows]
+    return (np.array(tid, np.int32), np.array([b or 0 for _, b, _ in rows], np.int64), np.array([e or 0 for _, _, e in rows], np.int64))
+
+
 def cgranges_overlap(lib_path, names, tid, beg, end, queries):
     """The REFERENCE's own cgranges (oracle/_ref/libcgranges.so, compiled from /root/reference by oracle/Makefile) through
     ctypes: cr_add every interval with label = its id, cr_index, then cr_overlap per query (name, st, en) -> sorted labels."""

@@ -663,6 +663,85 @@ def test_overlap_join_synthetic_batches_and_regions():
     _overlap_check(data, tid2, beg2, end2)
 
 
+def _bed_join_check(data, bed, max_blocks=0, as_path=None):
+    """read_bam x BED: the device's read_bed rows and join against the oracle's (bed_rows -> overlap_join)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle as ro
+    t = orc.bam_read(data)
+    rows = ro.bed_rows(bed)
+    exp = ro.overlap_join(t, *ro.bed_join_intervals(rows, [bytes(x) for x in t["ref_names"]]))
+    got = duckhts_amd.read_bam(data, overlap_bed=as_path if as_path is not None else bed, max_blocks=max_blocks)
+    assert got["n_bed_rows"] == len(rows)
+    assert got["n_rows"] == len(exp) == len(got["OVERLAPS"])
+    for i, (a, b) in enumerate(zip(got["OVERLAPS"], exp)):
+        assert np.sort(a).tolist() == b.tolist(), (i, a, b)
+    return rows, exp, t
+
+
+@pytest.mark.gpu
+def test_overlap_join_with_the_reference_bed(tmp_path):
+    """the reference's test/data/targets.bed x range.bam: read_bed's rows (duckhts.test:241-251) as the join's intervals, checked against the
+    oracle and, where it is built, against the reference's own cgranges"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle as ro
+    data, bed = read_golden("range.bam"), read_golden("targets.bed")
+    rows, exp, t = _bed_join_check(data, bed)
+    assert len(rows) == 4                                  # (the targets lie in the first 20 bases; the reads of range.bam begin near 900: no pairs)
+    # the same targets moved onto the reads: 1 kb further along, each 100 times as long
+    moved = b"".join(b"\t".join([f[0], b"%d" % (int(f[1]) * 100 + 1000), b"%d" % (int(f[2]) * 100 + 1000)] + f[3:]) + b"\n" for f in (ln.split(b"\t") for ln in bed.splitlines() if ln))
+    rows, exp, t = _bed_join_check(data, moved)
+    assert len(rows) == 4 and sum(len(x) for x in exp) > 20
+    lib = os.path.join(ROOT, "oracle", "_ref", "libcgranges.so")
+    if os.path.exists(lib):
+        names = [bytes(x).decode() for x in t["ref_names"]]
+        tid, beg, end = ro.bed_join_intervals(rows, t["ref_names"])
+        q = []
+        for i in range(t["n_rows"]):
+            st = int(t["POS"][i]) - 1
+            q.append((names[int(t["tid"][i])], st, ro.endpos(st, int(t["FLAG"][i]), t["CIGAR"][i])))
+        ref = ro.cgranges_overlap(lib, names, tid, beg, end, q)
+        assert all(a.tolist() == b.tolist() for a, b in zip(exp, ref))
+    # the same BED as a file: plain, and bgzipped by the device (duckhts.test:260-284 read the .bed.gz)
+    p = tmp_path / "targets.bed"; p.write_bytes(bed)
+    _bed_join_check(data, bed, as_path=str(p))
+    pz = tmp_path / "targets.bed.gz"; 
+    cx = duckhts_amd.Context(0)
+    try:
+        pz.write_bytes(cx.bgzf_compress(bed))
+    finally:
+        cx.close()
+    _bed_join_check(data, bed, as_path=str(pz))
+
+
+@pytest.mark.gpu
+def test_overlap_join_bed_line_rules_and_size():
+    data = synth.bam_file(30000, seed=4)
+    hdr = duckhts_amd.read_bam(data)["header"]
+    names = [bytes(x) for x in hdr["ref_names"]]
+    rng = np.random.default_rng(8)
+    lines = [b"#header", b"track name=t", b"browser position chr1:1-2", b""]
+    for k in range(50000):                              # sorted runs of the same chrom, a few unknown names, NULL fields, CRLF, extra columns
+        nm = names[int(rng.integers(0, len(names)))] if k % 97 else b"chrUn_%d" % k
+        b = int(rng.integers(0, 50_000_000)); e = b + int(rng.choice([0, 1, 150, 4000, 2_000_000]))
+        f1 = b"%d" % b if k % 211 else b"12x"
+        f2 = b"%d" % e if k % 307 else b""
+        ln = nm + b"\t" + f1 + b"\t" + f2 + (b"\tname%d\t0\t+" % k if k % 3 == 0 else b"") + (b"\r" if k % 5 == 0 else b"")
+        lines.append(ln)
+        if k % 1000 == 0:
+            lines.append(b"")
+    bed = b"\n".join(lines)                            # no newline at the end of the last line
+    rows, exp, _ = _bed_join_check(data, bed, max_blocks=4)
+    assert len(rows) == 50000 and sum(len(x) for x in exp) > 1000
+    _bed_join_check(data, bed + b"\n")
+    # a line with fewer than 3 fields is read_bed's error; empty text = no intervals
+    with pytest.raises(duckhts_amd.DhtsError, match="fewer than 3"):
+        duckhts_amd.read_bam(data, overlap_bed=b"chr1\t5\t9\nchr1\t7\n")
+    got = duckhts_amd.read_bam(data, overlap_bed=b"#only a comment\n")
+    assert got["n_bed_rows"] == 0 and sum(len(x) for x in got["OVERLAPS"]) == 0
+
+
 # ---- standard_tags (row A5) ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["sam_equiv", "matrix", "fuzz", "fuzz_small_batches", "golden_range"])

@@ -353,6 +353,21 @@ def test_overlap_join_matches_reference_build_on_random_intervals():
         assert all(a.tolist() == b.tolist() for a, b in zip(got, ref))
 
 
+def test_read_bed_rows_pins_from_the_sql_tests():
+    """test/sql/duckhts.test:241-251: read_bed(targets.bed) has 4 rows, the first is CHROMOSOME_I 0 10; plus the line rules of next_bed_line"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import region_oracle as ro
+    rows = ro.bed_rows(read_golden("targets.bed"))
+    assert len(rows) == 4 and rows[0] == (b"CHROMOSOME_I", 0, 10) and rows[3] == (b"CHROMOSOME_III", 0, 6)
+    txt = b"#c\ntrack name=x\nbrowser position\n\nchr1\t5\t9\r\nchr1\t 7\t+12\textra\nchr2\t1x\t3\nchr2\t\t4\nchr3\t-2\t99999999999999999999"
+    assert ro.bed_rows(txt) == [(b"chr1", 5, 9), (b"chr1", 7, 12), (b"chr2", None, 3), (b"chr2", None, 4), (b"chr3", -2, (1 << 63) - 1)]
+    with pytest.raises(ValueError):
+        ro.bed_rows(b"chr1\t5\n")
+    tid, beg, end = ro.bed_join_intervals(ro.bed_rows(txt), [b"chr2", b"chr1", b"chr1"])
+    assert tid.tolist() == [1, 1, -1, -1, -1] and beg.tolist()[:2] == [5, 7] and end.tolist()[:2] == [9, 12]
+
+
 def test_first_row_flag_and_cigar_pins_from_the_udf_tests():
     """duckhts.test:705-790 apply the (out-of-scope) SAM-flag / CIGAR UDFs to the first row of read_bam('range.bam'): those
     expectations pin FLAG and CIGAR of that row: paired, mapped, mate mapped, reverse, last segment; not proper pair, not duplicate;
