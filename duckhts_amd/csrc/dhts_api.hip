@@ -172,7 +172,9 @@ struct dhts_ctx {
     const uint8_t *last_bcf_u = nullptr;   // where the records of the last read_bcf batch live (inflated stream or, for text, v_out)
     bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
     bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
-    DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ, vd_id_ftyp;
+    DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ, vd_id_ftyp, vd_ctg_hash, vd_id_hash, v_tok_off, v_tok_bytes, v_tok_bits;
+    uint32_t v_undef_cap = 65536, v_patch_cap = 1u << 20;      // entries the device may record per batch; grown (and the pass repeated) when a batch needs more
+    uint32_t vd_ctg_hmask = 0, vd_id_hmask = 0;
     bool cache_hit = false; std::string pending_tag;       // the file's bytes came out of the pool (no read, no copy); tag to put on `comp` once staging has succeeded
     // dhts_open_path_async: the file is still arriving; the block table covers the staged prefix and grows (dhts_bgzf_index_staged)
     std::thread stager; StageProg *prog = nullptr; bool growing = false; uint64_t stage_total = 0;
@@ -2888,7 +2890,7 @@ static int bcf_upload_dicts(dhts_ctx *c) {
     HIPCHK(c, hipMemcpy(c->d_info_slot.p, islot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_fmt_slot.p, fslot.data(), (ni + 1) * 2, hipMemcpyHostToDevice));
     if (!c->vcf_text) return 0;
-    auto upload = [&](std::vector<std::pair<std::string, int32_t>> &names, const std::vector<uint8_t> *typ_of_id, DevBuf &d_off, DevBuf &d_bytes, DevBuf &d_id, DevBuf *d_typ, const std::vector<uint8_t> *ftyp_of_id = nullptr, DevBuf *d_ftyp = nullptr) -> int {
+    auto upload = [&](std::vector<std::pair<std::string, int32_t>> &names, const std::vector<uint8_t> *typ_of_id, DevBuf &d_off, DevBuf &d_bytes, DevBuf &d_id, DevBuf *d_typ, DevBuf &d_hash, uint32_t &hmask, const std::vector<uint8_t> *ftyp_of_id = nullptr, DevBuf *d_ftyp = nullptr) -> int {
         std::sort(names.begin(), names.end(), [](const std::pair<std::string, int32_t> &a, const std::pair<std::string, int32_t> &b) {
             const size_t n = a.first.size() < b.first.size() ? a.first.size() : b.first.size();
             const int cmp = memcmp(a.first.data(), b.first.data(), n);
@@ -2901,6 +2903,17 @@ static int bcf_upload_dicts(dhts_ctx *c) {
         if (!bytes.empty()) HIPCHK(c, hipMemcpy(d_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(d_id.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
         if (d_typ) HIPCHK(c, hipMemcpy(d_typ->p, typ.data(), typ.size(), hipMemcpyHostToDevice));
+        {   // the lookup table of vcf_dict_find: at most half full, linear probing
+            uint32_t cap = 16; while (cap < names.size() * 2 + 2) cap <<= 1;
+            std::vector<uint32_t> tab(cap, 0); hmask = cap - 1;
+            for (size_t i = 0; i < names.size(); i++) {
+                uint32_t h = vcf_name_hash((const uint8_t *)names[i].first.data(), (uint32_t)names[i].first.size()) & hmask;
+                while (tab[h]) h = (h + 1) & hmask;
+                tab[h] = (uint32_t)i + 1;
+            }
+            if (d_hash.ensure((size_t)cap * 4 + 64)) return fail(c, "hipMalloc failed");
+            HIPCHK(c, hipMemcpy(d_hash.p, tab.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+        }
         if (d_ftyp) {
             std::vector<uint8_t> ft(names.size() + 1, 15);
             for (size_t i = 0; i < names.size(); i++) ft[i] = (*ftyp_of_id)[names[i].second];
@@ -2916,7 +2929,7 @@ static int bcf_upload_dicts(dhts_ctx *c) {
         if (c->bh.ids[i].has[dhts::BCF_HL_INFO]) ityp[i] = (uint8_t)c->bh.ids[i].type[dhts::BCF_HL_INFO];
         if (c->bh.ids[i].has[dhts::BCF_HL_FMT]) ftyp[i] = (uint8_t)c->bh.ids[i].type[dhts::BCF_HL_FMT];
     }
-    if (upload(cn, nullptr, c->vd_ctg_off, c->vd_ctg_bytes, c->vd_ctg_id, nullptr) || upload(in, &ityp, c->vd_id_off, c->vd_id_bytes, c->vd_id_id, &c->vd_id_typ, &ftyp, &c->vd_id_ftyp)) return -1;
+    if (upload(cn, nullptr, c->vd_ctg_off, c->vd_ctg_bytes, c->vd_ctg_id, nullptr, c->vd_ctg_hash, c->vd_ctg_hmask) || upload(in, &ityp, c->vd_id_off, c->vd_id_bytes, c->vd_id_id, &c->vd_id_typ, c->vd_id_hash, c->vd_id_hmask, &ftyp, &c->vd_id_ftyp)) return -1;
     return 0;
 }
 
@@ -3133,22 +3146,41 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     }
     if (nlines == 0) return 0;
     ENSURE(c, c->v_rec_len, (size_t)(nlines + 1) * 4 + 64); ENSURE(c, c->b_rec_off, (size_t)(nlines + 1) * 4 + 64); ENSURE(c, c->v_ctr, 64);
-    const uint32_t UCAP = 65536, PCAP = 1u << 20;
-    ENSURE(c, c->v_undef, (size_t)UCAP * sizeof(VcfUndef)); ENSURE(c, c->v_patch, (size_t)PCAP * sizeof(VcfPatch));
+    if (const char *e = getenv("DHTS_VCF_CAPS")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && c->v_undef_cap == 65536 && c->v_patch_cap == (1u << 20)) c->v_undef_cap = c->v_patch_cap = v; }   // (tests: small caps make the growth path cheap to reach)
+    ENSURE(c, c->v_undef, (size_t)c->v_undef_cap * sizeof(VcfUndef)); ENSURE(c, c->v_patch, (size_t)c->v_patch_cap * sizeof(VcfPatch));
+    // the tokens of `n` recorded entries (VcfUndef / VcfPatch: pos and len in words pos_w / len_w), fetched with one gather and one copy
+    std::vector<uint32_t> tk_off; std::vector<char> tk_bytes;
+    auto fetch_tokens = [&](const void *ent_dev, const uint32_t *ent_host, int pos_w, int len_w, uint32_t n) -> int {
+        tk_off.assign((size_t)n + 1, 0);
+        for (uint32_t i = 0; i < n; i++) tk_off[(size_t)i + 1] = tk_off[i] + ent_host[4u * i + (uint32_t)len_w];
+        tk_bytes.assign((size_t)tk_off[n] + 1, 0);
+        if (tk_off[n] == 0) return 0;
+        ENSURE(c, c->v_tok_off, (size_t)n * 4 + 64); ENSURE(c, c->v_tok_bytes, (size_t)tk_off[n] + 64);
+        HIPCHK(c, hipMemcpyAsync(c->v_tok_off.p, tk_off.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(vcf_gather_tokens, dim3((n + 255) / 256), dim3(256), 0, c->stream, u, (const uint32_t *)ent_dev, pos_w, len_w, (const uint32_t *)c->v_tok_off.p, n, (uint8_t *)c->v_tok_bytes.p);
+        HIPCHK(c, hipMemcpyAsync(tk_bytes.data(), c->v_tok_bytes.p, tk_off[n], hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    };
     VcfArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.line_off = (const uint32_t *)c->v_line_off.p; a.nlines = nlines; a.text_end = ulen; a.last_open = last_open;
     a.n_smp = (int32_t)c->bh.samples.size(); a.v44 = c->bh.version >= 4004000 ? 1 : 0;
     { static const bool no_stage = getenv("DHTS_VCF_STAGE") && atoi(getenv("DHTS_VCF_STAGE")) == 0; a.lds_budget = no_stage ? 0u : VCF_LDS_BYTES; if (getenv("DHTS_VCF_STAGE") && atoi(getenv("DHTS_VCF_STAGE")) == 2) a.lds_budget = VCF_LDS_BYTES - 15u; }
     a.rec_len = (uint32_t *)c->v_rec_len.p; a.rec_off = (const uint32_t *)c->b_rec_off.p; a.first_bad = (unsigned long long *)((uint64_t *)c->v_ctr.p + 2);
-    a.counters = (uint32_t *)c->v_ctr.p; a.undef = (VcfUndef *)c->v_undef.p; a.undef_cap = UCAP; a.patch = (VcfPatch *)c->v_patch.p; a.patch_cap = PCAP;
+    a.counters = (uint32_t *)c->v_ctr.p; a.undef = (VcfUndef *)c->v_undef.p; a.undef_cap = c->v_undef_cap; a.patch = (VcfPatch *)c->v_patch.p; a.patch_cap = c->v_patch_cap;
+    // Lines so long that 64 of them overflow a workgroup's LDS staging get a wave each (vcf_encode_wave): INFO fields parsed one per lane.
+    // DHTS_VCF_WAVE=0 / 1 forces the choice (tests run both ways).
+    bool wave_lines = nlines > 0 && ((ulen - t0) / (uint64_t)nlines) * VCF_ENC_THREADS > VCF_LDS_BYTES;
+    if (const char *e = getenv("DHTS_VCF_WAVE")) wave_lines = atoi(e) != 0;
     unsigned long long first_bad = ~0ull;
     for (int round = 0;; round++) {
         if (round > 1000) return fail(c, "read_bcf: too many names without a header definition");
-        a.ctg = {(const uint32_t *)c->vd_ctg_off.p, (const uint8_t *)c->vd_ctg_bytes.p, (const int32_t *)c->vd_ctg_id.p, nullptr, nullptr, 0};
-        a.ids = {(const uint32_t *)c->vd_id_off.p, (const uint8_t *)c->vd_id_bytes.p, (const int32_t *)c->vd_id_id.p, (const uint8_t *)c->vd_id_typ.p, (const uint8_t *)c->vd_id_ftyp.p, 0};
+        a.ctg = {(const uint32_t *)c->vd_ctg_off.p, (const uint8_t *)c->vd_ctg_bytes.p, (const int32_t *)c->vd_ctg_id.p, nullptr, nullptr, 0, (const uint32_t *)c->vd_ctg_hash.p, c->vd_ctg_hmask};
+        a.ids = {(const uint32_t *)c->vd_id_off.p, (const uint8_t *)c->vd_id_bytes.p, (const int32_t *)c->vd_id_id.p, (const uint8_t *)c->vd_id_typ.p, (const uint8_t *)c->vd_id_ftyp.p, 0, (const uint32_t *)c->vd_id_hash.p, c->vd_id_hmask};
         { int32_t n1 = 0, n2 = 0; for (size_t i = 0; i < c->bh.ctg.size(); i++) n1 += c->bh.ctg_present[i] ? 1 : 0; for (auto &e : c->bh.ids) n2 += e.present ? 1 : 0; a.ctg.n = n1; a.ids.n = n2; }
         HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream)); HIPCHK(c, hipMemsetAsync((uint64_t *)c->v_ctr.p + 2, 0xff, 8, c->stream));
-        hipLaunchKernelGGL(vcf_encode<false>, dim3((unsigned)((nlines + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
+        if (wave_lines) hipLaunchKernelGGL(vcf_encode_wave<false>, dim3((unsigned)nlines), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(vcf_encode<false>, dim3((unsigned)((nlines + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
         uint64_t ctr[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(ctr, c->v_ctr.p, 24, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3157,15 +3189,23 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
         if (n_undef == 0) break;
         // names used without a definition: htslib adds dummy definitions as it meets them, so ids follow the order of first appearance;
         // FORMAT Floats in strtod's forms are checked here (the number has to end where the token ends)
-        const uint32_t got = n_undef < UCAP ? n_undef : UCAP;
+        if (n_undef > c->v_undef_cap) {                                          // more than there was room to record: make room, measure again
+            c->v_undef_cap = n_undef + n_undef / 4 + 1024;
+            ENSURE(c, c->v_undef, (size_t)c->v_undef_cap * sizeof(VcfUndef));
+            a.undef = (VcfUndef *)c->v_undef.p; a.undef_cap = c->v_undef_cap;
+            continue;
+        }
+        const uint32_t got = n_undef;
         std::vector<VcfUndef> ud(got);
         HIPCHK(c, hipMemcpy(ud.data(), c->v_undef.p, (size_t)got * sizeof(VcfUndef), hipMemcpyDeviceToHost));
-        std::sort(ud.begin(), ud.end(), [](const VcfUndef &x, const VcfUndef &y) { return x.line != y.line ? x.line < y.line : x.pos < y.pos; });
+        if (fetch_tokens(c->v_undef.p, (const uint32_t *)ud.data(), 1, 2, got)) return -1;
+        std::vector<uint32_t> order(got); for (uint32_t i = 0; i < got; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return ud[x].line != ud[y].line ? ud[x].line < ud[y].line : ud[x].pos < ud[y].pos; });
         bool added = false; unsigned long long cut = first_bad;
-        for (auto &x : ud) {
+        for (const uint32_t oi : order) {
+            const VcfUndef &x = ud[oi];
             if ((unsigned long long)x.line >= cut) break;                        // lines behind the first bad one are never parsed
-            std::string name(x.len, '\0');
-            if (x.len) HIPCHK(c, hipMemcpy(&name[0], u + x.pos, x.len, hipMemcpyDeviceToHost));
+            std::string name(tk_bytes.data() + tk_off[oi], x.len);
             if (x.cls == 4) {
                 char *end = nullptr; (void)strtod(name.c_str(), &end);
                 if (strlen(name.c_str()) != name.size() || end != name.c_str() + name.size()) { cut = x.line; break; }      // "Invalid character": the record is an error
@@ -3188,10 +3228,7 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
             first_bad = cut; a.nlines = nlines = (int64_t)cut; rec_err = true; a.last_open = 0;
             if (nlines == 0) { nrec = 0; return 0; }
         }
-        if (!added && !shortened) {
-            if (n_undef > UCAP) return fail(c, "read_bcf: too many names without a header definition in one batch; use a smaller max_blocks");
-            break;                                                               // only float checks are left, and they passed
-        }
+        if (!added && !shortened) break;                                         // only float checks are left, and they passed
         st.n_ctg = (int32_t)c->bh.ctg.size(); st.n_ids = (int32_t)c->bh.ids.size();
         st.ctg_ok = (const uint8_t *)c->d_ctg_ok.p; st.id_ok = (const uint8_t *)c->d_id_ok.p; st.info_slot = (const int16_t *)c->d_info_slot.p; st.fmt_slot = (const int16_t *)c->d_fmt_slot.p;
     }
@@ -3205,24 +3242,34 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
     a.nlines = nrec; a.out = (uint8_t *)c->v_out.p;
     if (nrec < nlines) { a.last_open = 0; }
     HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream));
-    hipLaunchKernelGGL(vcf_encode<true>, dim3((unsigned)((nrec + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
+    if (wave_lines) hipLaunchKernelGGL(vcf_encode_wave<true>, dim3((unsigned)nrec), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(vcf_encode<true>, dim3((unsigned)((nrec + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
     HIPCHK(c, hipMemsetAsync((uint8_t *)c->v_out.p + total, 0, PAD_BYTES, c->stream));
     uint32_t ctr2[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(ctr2, c->v_ctr.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ctr2[1] > PCAP) {
-        VcfPatch p0; char tokb[48] = {0};
-        if (hipMemcpy(&p0, c->v_patch.p, sizeof(p0), hipMemcpyDeviceToHost) == hipSuccess && p0.len < sizeof(tokb)) (void)hipMemcpy(tokb, u + p0.pos, p0.len, hipMemcpyDeviceToHost);
-        return fail(c, "read_bcf: %u numbers outside the device's conversion path in one batch (e.g. '%s'); use a smaller max_blocks", ctr2[1], tokb);
+    if (ctr2[1] > c->v_patch_cap) {                          // more numbers for the host than there was room to record: make room, write again
+        c->v_patch_cap = ctr2[1] + ctr2[1] / 4 + 1024;
+        ENSURE(c, c->v_patch, (size_t)c->v_patch_cap * sizeof(VcfPatch));
+        a.patch = (VcfPatch *)c->v_patch.p; a.patch_cap = c->v_patch_cap;
+        HIPCHK(c, hipMemsetAsync(c->v_ctr.p, 0, 16, c->stream));
+        if (wave_lines) hipLaunchKernelGGL(vcf_encode_wave<true>, dim3((unsigned)nrec), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(vcf_encode<true>, dim3((unsigned)((nrec + VCF_ENC_THREADS - 1) / VCF_ENC_THREADS)), dim3(VCF_ENC_THREADS), VCF_LDS_BYTES, c->stream, a);
+        HIPCHK(c, hipMemcpyAsync(ctr2, c->v_ctr.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ctr2[1] > c->v_patch_cap) return fail(c, "read_bcf: the write pass recorded %u numbers for the host, room for %u", ctr2[1], c->v_patch_cap);
     }
     if (ctr2[1]) {
-        // numbers hts_str2dbl hands to strtod (exponents, > 14 digits, inf / nan / hex) and QUAL values outside that form: converted here
-        std::vector<VcfPatch> pt(ctr2[1]);
-        HIPCHK(c, hipMemcpy(pt.data(), c->v_patch.p, (size_t)ctr2[1] * sizeof(VcfPatch), hipMemcpyDeviceToHost));
+        // numbers hts_str2dbl hands to strtod (exponents, > 14 digits, inf / nan / hex) and QUAL values outside that form: converted here.
+        // One gather + one copy brings the tokens, one copy + one scatter takes the words back.
+        const uint32_t np = ctr2[1];
+        std::vector<VcfPatch> pt(np); std::vector<uint32_t> words(np);
+        HIPCHK(c, hipMemcpy(pt.data(), c->v_patch.p, (size_t)np * sizeof(VcfPatch), hipMemcpyDeviceToHost));
+        if (fetch_tokens(c->v_patch.p, (const uint32_t *)pt.data(), 0, 1, np)) return -1;
         std::string tok;
-        for (auto &x : pt) {
-            tok.assign(x.len, '\0');
-            if (x.len) HIPCHK(c, hipMemcpy(&tok[0], u + x.pos, x.len, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < np; i++) {
+            const VcfPatch &x = pt[i];
+            tok.assign(tk_bytes.data() + tk_off[i], x.len);
             uint32_t bits;
             if (x.kind == 0) { const float f = (float)atof(tok.c_str()); memcpy(&bits, &f, 4); }
             else {
@@ -3230,9 +3277,12 @@ static int vcf_text_records(dhts_ctx *c, const Batch &B, BcfStream &st, int64_t 
                 if (end == tok.c_str() && x.kind == 1) bits = 0x7F800001u;                     // INFO: a failed conversion is a missing value
                 else { const float f = (end == tok.c_str()) ? 0.0f : (float)d; memcpy(&bits, &f, 4); }   // (FORMAT stores what strtod returned: 0.0)
             }
-            HIPCHK(c, hipMemcpy((uint8_t *)c->v_out.p + x.dst, &bits, 4, hipMemcpyHostToDevice));
+            words[i] = bits;
         }
-        HIPCHK(c, hipDeviceSynchronize());                   // (small pageable uploads: make sure they have landed before the record stage reads the records)
+        ENSURE(c, c->v_tok_bits, (size_t)np * 4 + 64);
+        HIPCHK(c, hipMemcpyAsync(c->v_tok_bits.p, words.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(vcf_scatter_words, dim3((np + 255) / 256), dim3(256), 0, c->stream, (uint8_t *)c->v_out.p, (const VcfPatch *)c->v_patch.p, (const uint32_t *)c->v_tok_bits.p, np);
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // (`words` is pageable host memory: the copy must have left it before it goes out of scope)
     }
     HIPCHK(c, hipMemcpyAsync(&rec0_text, c->v_line_off.p, 4, hipMemcpyDeviceToHost, c->stream));
     st.u = (const uint8_t *)c->v_out.p; st.ulen = total;

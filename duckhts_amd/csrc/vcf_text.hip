@@ -15,7 +15,7 @@
 // again.  One lane per line; two passes (measure, then write behind an exclusive scan of the record lengths).
 #pragma once
 
-struct VcfDictDev { const uint32_t *off; const uint8_t *bytes; const int32_t *id; const uint8_t *ityp; const uint8_t *ftyp; int32_t n; };   // sorted by name (byte order); ityp / ftyp: INFO / FORMAT type of the id, 15 = none
+struct VcfDictDev { const uint32_t *off; const uint8_t *bytes; const int32_t *id; const uint8_t *ityp; const uint8_t *ftyp; int32_t n; const uint32_t *hash; uint32_t hmask; };   // sorted by name (byte order); ityp / ftyp: INFO / FORMAT type of the id, 15 = none
 struct VcfUndef { uint32_t line, pos, len, cls; };        // cls: 0 contig, 1 FILTER, 2 INFO key, 3 FORMAT key; 4: a FORMAT Float the host has to convert AND check (strtod must stop at the
                                                           // end of the token, else "Invalid character"); pos = offset of the name / token in the batch text
 struct VcfPatch { uint32_t pos, len, dst, kind; };        // kind 0: (float)atof(token) -> f32 at dst; 1: hts_str2dbl(token) -> f32 (or missing) at dst; 2: the same, 0.0 when it fails (FORMAT)
@@ -81,19 +81,30 @@ vcf_line_fill(const uint8_t *__restrict__ u, uint64_t start, uint64_t ulen, cons
     while (m) { const uint32_t b = __ffs(m) - 1; m &= m - 1; line_off[++rank] = (uint32_t)(p + b + 1); }
 }
 
-__device__ __forceinline__ int vcf_dict_find(const VcfDictDev &d, const uint8_t *s, uint32_t l) {
-    int lo = 0, hi = d.n - 1;
-    while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        const uint8_t *m = d.bytes + d.off[mid]; const uint32_t ml = d.off[mid + 1] - d.off[mid];
-        const uint32_t n = ml < l ? ml : l;
-        int c = 0;
-        for (uint32_t i = 0; i < n; i++) if (m[i] != s[i]) { c = m[i] < s[i] ? -1 : 1; break; }
-        if (c == 0) c = ml < l ? -1 : ml > l ? 1 : 0;
-        if (c == 0) return mid;
-        if (c < 0) lo = mid + 1; else hi = mid - 1;
+// Name -> its position in the sorted table.  A parser's lookups are chains of dependent loads, so the chain is kept short: an open-addressing
+// table over FNV-1a of the name (built by the host next to the sorted arrays; slot = position + 1, 0 = free) finds the one candidate, and the
+// bytes are compared eight at a time (eight loads in flight, one wait).
+__host__ __device__ __forceinline__ uint32_t vcf_name_hash(const uint8_t *s, uint32_t l) { uint32_t h = 2166136261u; for (uint32_t i = 0; i < l; i++) h = (h ^ s[i]) * 16777619u; return h; }
+__device__ __forceinline__ bool vcf_bytes_equal(const uint8_t *m, const uint8_t *s, uint32_t l) {
+    uint32_t i = 0;
+    for (; i + 8 <= l; i += 8) {
+        uint64_t x = 0, y = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x |= (uint64_t)m[i + k] << (8 * k); y |= (uint64_t)s[i + k] << (8 * k); }
+        if (x != y) return false;
     }
-    return -1;
+    uint32_t x = 0, y = 0;
+    for (; i < l; i++) { x = (x << 8) | m[i]; y = (y << 8) | s[i]; }
+    return x == y;
+}
+__device__ __forceinline__ int vcf_dict_find(const VcfDictDev &d, const uint8_t *s, uint32_t l) {
+    if (d.n <= 0) return -1;
+    for (uint32_t h = vcf_name_hash(s, l) & d.hmask;; h = (h + 1) & d.hmask) {
+        const uint32_t e = d.hash[h];
+        if (!e) return -1;
+        const uint32_t o0 = d.off[e - 1], o1 = d.off[e];
+        if (o1 - o0 == l && vcf_bytes_equal(d.bytes + o0, s, l)) return (int)(e - 1);
+    }
 }
 
 // byte sink of one record: counts in the measure pass, stores in the write pass
@@ -204,7 +215,10 @@ __device__ __forceinline__ bool vcf_svlen_alt(const uint8_t *u, uint32_t a, uint
     return u[a + l - 1] == '>';
 }
 // end of the line's interval; beg = POS - 1 clamped at 0; [r0,r1) REF, [a0,a1) ALT, [i0,i1) INFO, [x0,x1) FORMAT + samples (x0 == x1: none)
-__device__ __forceinline__ long long vcf_tabix_end(const uint8_t *u, long long beg, uint32_t r0, uint32_t r1, uint32_t a0, uint32_t a1, uint32_t i0, uint32_t i1, uint32_t x0, uint32_t x1) {
+// found = true: pe_in / ps_in are where the values of the first INFO field that starts with "END=" / "SVLEN=" begin (0xffffffff: none), found by
+// the caller (the wave kernel sees every field anyway); false: the INFO string is walked here
+__device__ __forceinline__ long long vcf_tabix_end(const uint8_t *u, long long beg, uint32_t r0, uint32_t r1, uint32_t a0, uint32_t a1, uint32_t i0, uint32_t i1, uint32_t x0, uint32_t x1,
+                                                   const bool found = false, const uint32_t pe_in = 0xffffffffu, const uint32_t ps_in = 0xffffffffu) {
     if (beg < 0) beg = 0;
     const long long reflen = (long long)(r1 - r0);
     long long end = 1, svlen = 0, fmtlen = 0;
@@ -222,9 +236,9 @@ __device__ __forceinline__ long long vcf_tabix_end(const uint8_t *u, long long b
     // strstr(info, "END=") at the start of INFO, else strstr(info, ";END=") (tbx.c:213-233) = the first ';'-separated field that starts
     // with "END="; the same for "SVLEN=".  One walk over the fields, the ';' found eight bytes at a time.  SVLEN can only matter when an
     // allele is symbolic or REF is empty (its contribution is otherwise 1 <= reflen).
-    uint32_t pe = 0xffffffffu, ps = 0xffffffffu;
     const bool want_sv = svmask != 0 || reflen < 1;
-    for (uint32_t f = i0; f < i1;) {
+    uint32_t pe = found ? pe_in : 0xffffffffu, ps = (found && want_sv) ? ps_in : 0xffffffffu;
+    for (uint32_t f = i0; !found && f < i1;) {
         if (pe == 0xffffffffu && f + 4 <= i1 && u[f] == 'E' && u[f + 1] == 'N' && u[f + 2] == 'D' && u[f + 3] == '=') pe = f + 4;
         else if (want_sv && ps == 0xffffffffu && f + 6 <= i1 && u[f] == 'S' && u[f + 1] == 'V' && u[f + 2] == 'L' && u[f + 3] == 'E' && u[f + 4] == 'N' && u[f + 5] == '=') ps = f + 6;
         if (pe != 0xffffffffu && (ps != 0xffffffffu || !want_sv)) break;
@@ -367,10 +381,119 @@ bed_intervals(const uint8_t *__restrict__ u, const uint32_t *__restrict__ line_o
     out[li] = r;
 }
 
+// One INFO field u[key, fend) -- the text between two ';' --: key[=value] (vcf_parse_info, vcf.c:3744-3985).  Returns 0 for an empty key (the
+// field is skipped and does not count), else 1.  QUIET: a measure pass that leaves no record of undefined names (the write pass of the wave
+// kernel measures again to place its fields).
+// DEFER: a string value longer than VCF_DEFER_MIN is given its place but not copied; (*d_src, *d_dst, *d_len) tell the caller what is left to do
+// (the wave kernel copies such a value with all its lanes).
+#define VCF_DEFER_MIN 96u
+template <bool WRITE, bool QUIET, bool DEFER = false>
+__device__ __forceinline__ int vcf_info_field(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, const uint32_t key, const uint32_t fend, VcfSink<WRITE> &o,
+                                              uint32_t *d_src = nullptr, uint32_t *d_dst = nullptr, uint32_t *d_len = nullptr) {
+    uint32_t kend = key; while (kend < fend && u[kend] != '=') kend++;
+    if (kend == key) return 0;
+    const uint32_t val = kend < fend ? kend + 1 : 0xffffffffu, end = fend;
+    const int k = vcf_dict_find(a.ids, u + key, kend - key);
+    int ht = 3; int32_t id = 0;
+    if (k < 0 || a.ids.ityp[k] == 15) { if (!WRITE && !QUIET) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, key + bias, kend - key, 2u}; } }
+    else { ht = a.ids.ityp[k]; id = a.ids.id[k]; }
+    o.key(id);
+    if (val == 0xffffffffu) o.b(0x00);
+    else if (ht == 0 || ht == 3) {
+        if (DEFER && WRITE && end - val > VCF_DEFER_MIN) { o.size(end - val, 7); *d_src = val; *d_dst = o.n; *d_len = end - val; o.n += end - val; }
+        else o.vchar(u + val, end - val);
+    } else {
+        uint32_t n_val = 1; for (uint32_t t = val; t < end; t++) n_val += u[t] == ',';
+        if (ht == 1 && n_val == 1) o.b(0x13); else o.size(n_val, ht == 1 ? 3 : 5);
+        uint32_t t = val;
+        for (uint32_t i = 0; i < n_val; i++, t++) {
+            uint32_t te = t, w;
+            if (ht == 1) {                                                               // hts_str2int, 64 bits
+                bool neg = false, over = false; uint64_t n = 0, limit = (1ull << 63) - 1;
+                if (te < end && u[te] == '-') { limit++; neg = true; te++; } else if (te < end && u[te] == '+') te++;
+                for (; te < end && u[te] >= '0' && u[te] <= '9'; te++) { const uint32_t d = u[te] - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
+                const int64_t v = neg ? (int64_t)(0 - n) : (int64_t)n;
+                w = (te == t || over || v < -2147483640ll || v > 2147483647ll) ? 0x80000000u : (uint32_t)(int32_t)v;
+            } else {
+                uint32_t tok_end = t; while (tok_end < end && u[tok_end] != ',') tok_end++;
+                double d; uint32_t e;
+                if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { w = __float_as_uint(__double2float_rn(d)); te = t + e; }
+                else { w = 0x7F800001u; te = tok_end; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + o.n, 1u}; } }
+            }
+            o.w32(w);
+            for (t = te; t < end && u[t] != ','; t++) {}
+        }
+    }
+    return 1;
+}
+
+// ---- tokens the host has to look at (undefined names, numbers in strtod's wider forms): gathered into one buffer for one copy each way ----------
+// ent = VcfUndef / VcfPatch records (four words each); pos_w / len_w = which words hold the token's position and length; tok_off = where each
+// token goes in `out` (an exclusive scan of the lengths, made by the host from the same records)
+extern "C" __global__ void __launch_bounds__(256)
+vcf_gather_tokens(const uint8_t *__restrict__ u, const uint32_t *__restrict__ ent, int pos_w, int len_w, const uint32_t *__restrict__ tok_off, uint32_t n, uint8_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = ent[4u * i + (uint32_t)pos_w], l = ent[4u * i + (uint32_t)len_w], o = tok_off[i];
+    for (uint32_t k = 0; k < l; k++) out[o + k] = u[p + k];
+}
+// the converted numbers go back: word i to out[patch[i].dst .. +4) (records are byte-packed: no alignment)
+extern "C" __global__ void __launch_bounds__(256)
+vcf_scatter_words(uint8_t *__restrict__ out, const VcfPatch *__restrict__ patch, const uint32_t *__restrict__ bits, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = patch[i].dst, w = bits[i];
+    out[d] = (uint8_t)w; out[d + 1] = (uint8_t)(w >> 8); out[d + 2] = (uint8_t)(w >> 16); out[d + 3] = (uint8_t)(w >> 24);
+}
+
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
 #define VCF_MAXF 32
-template <bool WRITE> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias);
+#define VCF_WSEP 2048u                                        // ';' positions a wave collects before it parses the fields between them (LDS, 8 KB)
+template <bool WRITE, bool WAVE> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep);
+
+// ---- a wave per line (lines too long for 64 of them to share the LDS staging: gnomAD-style INFO of hundreds of keys) ----------------------------
+// first position in [from, to) that holds ch, else `to`: 16 bytes per lane, a ballot per KiB (the stream is padded, so whole 16-byte words are read)
+__device__ __forceinline__ uint32_t vcf_eq_mask16(const uint8_t *u, uint32_t p, uint32_t from, uint32_t to, uint32_t pat) {       // bit k: u[p + k] == ch, p + k in [from, to)
+    const uint4 v = *(const uint4 *)(u + p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t x = w[q] ^ pat;
+        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);               // 0x80 exactly where the byte is zero
+        m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * q);
+    }
+    if (p < from) m &= 0xffffu << (from - p);
+    if (p + 16 > to) m &= to > p ? (0xffffu >> (p + 16 - to)) : 0u;
+    return m;
+}
+__device__ __forceinline__ uint32_t vcf_wave_find(const uint8_t *u, uint32_t from, uint32_t to, uint8_t ch) {
+    const uint32_t lane = threadIdx.x & 63u, pat = 0x01010101u * ch;
+    for (uint32_t base = from & ~15u; base < to; base += 1024u) {
+        const uint32_t p = base + lane * 16u;
+        const uint32_t m = p < to ? vcf_eq_mask16(u, p, from, to, pat) : 0u;
+        const unsigned long long hit = __ballot(m != 0);
+        if (hit) { const int l = __builtin_ctzll(hit); const uint32_t ml = (uint32_t)__shfl((int)m, l); return base + (uint32_t)l * 16u + (uint32_t)__builtin_ctz(ml); }
+    }
+    return to;
+}
+__device__ __forceinline__ uint32_t vcf_wave_excl_scan(uint32_t v, uint32_t *total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if (lane >= d) x += y; }
+    *total = (uint32_t)__shfl((int)x, 63);
+    return x - v;
+}
+// The line stays where it lies (HBM / L2): staging it in LDS was measured and bought nothing -- the parse is a chain of dependent byte reads
+// either way, and what hides their latency is the number of waves per CU, which 8 KB of LDS per wave leaves at twenty.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) vcf_encode_wave(VcfArgs a) {
+    __shared__ uint32_t sep[VCF_WSEP];
+    const int64_t li = blockIdx.x;
+    if (li < a.nlines) vcf_encode_line<WRITE, true>(a, li, a.u, 0u, sep);
+}
 
 // The lines of a workgroup are consecutive in the text: their span is staged in LDS with coalesced 16-byte loads and parsed from there (a
 // lane walks its line byte by byte); a span that does not fit is parsed from HBM.  Two separate calls, so that the LDS copy is reached
@@ -386,17 +509,23 @@ __global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
     if (staged) {
         for (uint32_t q = threadIdx.x * 16u; s0 + q < s1; q += blockDim.x * 16u) *(uint4 *)(vcf_lds + q) = *(const uint4 *)(a.u + s0 + q);   // (the stream is padded: reading up to 15 bytes past s1 is safe)
         __syncthreads();
-        if (li < a.nlines) vcf_encode_line<WRITE>(a, li, vcf_lds, s0);
-    } else if (li < a.nlines) vcf_encode_line<WRITE>(a, li, a.u, 0u);
+        if (li < a.nlines) vcf_encode_line<WRITE, false>(a, li, vcf_lds, s0, nullptr);
+    } else if (li < a.nlines) vcf_encode_line<WRITE, false>(a, li, a.u, 0u, nullptr);
 }
 
 // every position below is relative to `bias` (the start of the staged span, or 0): u[] is either the LDS copy or the stream itself
-template <bool WRITE>
-__device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias) {
+// WAVE: the 64 lanes of a wave share one line.  What is short (the first seven columns, the FORMAT keys) every lane computes alike -- stores
+// then hit one address, and `lead` keeps the records of undefined names and patches single --; what is long is shared out: the searches for
+// the line's NUL and INFO's end (vcf_wave_find), and INFO, whose ';' are collected 16 bytes per lane and whose fields are then parsed one per
+// lane, measured, placed by a scan of the sizes and written.
+template <bool WRITE, bool WAVE>
+__device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep) {
+    const bool lead = !WAVE || (threadIdx.x & 63u) == 0;
     const uint32_t l0 = a.line_off[li] - bias;
     uint32_t l1 = ((li + 1 == a.nlines && a.last_open) ? (uint32_t)a.text_end : a.line_off[li + 1] - 1) - bias;
     if (l1 > l0 && u[l1 - 1] == '\r') l1--;                                                          // KS_SEP_LINE drops the carriage return
-    { uint32_t e = l0; while (e < l1 && u[e]) e++; l1 = e; }                                         // the parser works on a C string
+    if (WAVE) l1 = vcf_wave_find(u, l0, l1, 0);
+    else { uint32_t e = l0; while (e < l1 && u[e]) e++; l1 = e; }                                    // the parser works on a C string
     VcfSink<WRITE> o; o.p = WRITE ? a.out + a.rec_off[li] : nullptr; o.n = 0;
     bool bad = false;
     // the eight mandatory columns (kstrtok on '\t': empty tokens count); a ninth one is not looked at (no samples: vcf_parse_format returns at once)
@@ -404,17 +533,20 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
     {
         uint32_t p = l0;
         for (;;) {
-            fs[nf] = p; while (p < l1 && u[p] != '\t') p++; fe[nf] = p; nf++;
+            fs[nf] = p;
+            if (WAVE && nf == 7) p = vcf_wave_find(u, p, l1, '\t'); else while (p < l1 && u[p] != '\t') p++;
+            fe[nf] = p; nf++;
             if (p >= l1 || nf == 8) break;
             p++;
         }
     }
+    uint32_t w_pe = 0xffffffffu, w_ps = 0xffffffffu;                                                  // WAVE: where the values of END= / SVLEN= begin
     if (nf < 8) bad = true;
     int32_t rid = 0; int64_t pos = 0; uint32_t n_allele = 1, n_info = 0, qbits = 0x7F800001u; int32_t rlen = 0;
     if (!bad) {
         // CHROM
         const int k = vcf_dict_find(a.ctg, u + fs[0], fe[0] - fs[0]);
-        if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, fs[0] + bias, fe[0] - fs[0], 0u}; } }
+        if (k < 0) { if (!WRITE && lead) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, fs[0] + bias, fe[0] - fs[0], 0u}; } }
         else rid = a.ctg.id[k];
         // POS: hts_str2uint(.., 62 bits), the whole token
         {
@@ -433,7 +565,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         // REF, ALT
         o.vchar(u + fs[3], fe[3] - fs[3]);
         // rlen: pos + rlen = the END the tabix iterator tests regions with (text carries no rlen; see vcf_tabix_end)
-        if (WRITE) rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1) - pos);
+        if (WRITE && !WAVE) rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1) - pos);
         if (!(fe[4] - fs[4] == 1 && u[fs[4]] == '.')) {
             uint32_t t = fs[4];
             for (uint32_t r = fs[4];; r++) {
@@ -447,7 +579,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         if (!(fe[5] - fs[5] == 1 && u[fs[5]] == '.')) {
             double d; uint32_t e;
             if (vcf_str2dbl_fast(u + fs[5], fe[5] - fs[5], &d, &e) == 0) { const float f = __double2float_rn(d); qbits = __float_as_uint(f); }
-            else { qbits = 0; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {fs[5] + bias, fe[5] - fs[5], a.rec_off[li] + 20u, 0u}; } }
+            else { qbits = 0; if (WRITE && lead) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {fs[5] + bias, fe[5] - fs[5], a.rec_off[li] + 20u, 0u}; } }
         }
         // FILTER
         if (fe[6] - fs[6] == 1 && u[fs[6]] == '.') o.b(0x00);
@@ -458,7 +590,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
             uint32_t t = fs[6];
             for (uint32_t r = fs[6];; r++) if (r == e6 || u[r] == ';') {
                 const int k = vcf_dict_find(a.ids, u + t, r - t);
-                if (k < 0) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, r - t, 1u}; } o.w32(0); }
+                if (k < 0) { if (!WRITE && lead) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, r - t, 1u}; } o.w32(0); }
                 else o.w32((uint32_t)a.ids.id[k]);
                 t = r + 1;
                 if (r == e6) break;
@@ -467,48 +599,65 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         // INFO
         if (!(fe[7] - fs[7] == 1 && u[fs[7]] == '.')) {
             uint32_t e7 = fe[7]; if (e7 > fs[7] && u[e7 - 1] == ';') e7--;
-            uint32_t r = fs[7], key = fs[7];
-            for (;; r++) {
-                while (r < e7 && u[r] != ';' && u[r] != '=') r++;
-                if (n_info == 65535) { bad = true; break; }
-                uint32_t val = 0xffffffffu, end; uint8_t c = r < e7 ? u[r] : 0; const uint32_t kend = r;
-                if (c == '=') { val = r + 1; for (end = val; end < e7 && u[end] != ';'; end++) {} c = end < e7 ? u[end] : 0; } else end = r;
-                if (kend == key) { if (c == 0) break; r = end; key = r + 1; continue; }             // empty key (";;"): skipped
-                const int k = vcf_dict_find(a.ids, u + key, kend - key);
-                int ht = 3; int32_t id = 0;
-                if (k < 0 || a.ids.ityp[k] == 15) { if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, key + bias, kend - key, 2u}; } }
-                else { ht = a.ids.ityp[k]; id = a.ids.id[k]; }
-                n_info++;
-                o.key(id);
-                if (val == 0xffffffffu) o.b(0x00);
-                else if (ht == 0 || ht == 3) o.vchar(u + val, end - val);
-                else {
-                    uint32_t n_val = 1; for (uint32_t t = val; t < end; t++) n_val += u[t] == ',';
-                    if (ht == 1 && n_val == 1) o.b(0x13); else o.size(n_val, ht == 1 ? 3 : 5);
-                    uint32_t t = val;
-                    for (uint32_t i = 0; i < n_val; i++, t++) {
-                        uint32_t te = t, w;
-                        if (ht == 1) {                                                               // hts_str2int, 64 bits
-                            bool neg = false, over = false; uint64_t n = 0, limit = (1ull << 63) - 1;
-                            if (te < end && u[te] == '-') { limit++; neg = true; te++; } else if (te < end && u[te] == '+') te++;
-                            for (; te < end && u[te] >= '0' && u[te] <= '9'; te++) { const uint32_t d = u[te] - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
-                            const int64_t v = neg ? (int64_t)(0 - n) : (int64_t)n;
-                            w = (te == t || over || v < -2147483640ll || v > 2147483647ll) ? 0x80000000u : (uint32_t)(int32_t)v;
-                        } else {
-                            uint32_t tok_end = t; while (tok_end < end && u[tok_end] != ',') tok_end++;
-                            double d; uint32_t e;
-                            if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { w = __float_as_uint(__double2float_rn(d)); te = t + e; }
-                            else { w = 0x7F800001u; te = tok_end; if (WRITE) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + o.n, 1u}; } }
-                        }
-                        o.w32(w);
-                        for (t = te; t < end && u[t] != ','; t++) {}
+            if (WAVE) {
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t seg = fs[7], nsep = 0;                                                       // seg: where the first field of the collected stretch begins
+                for (uint32_t base = fs[7] & ~15u;; base += 1024u) {
+                    const bool last = base + 1024u >= e7;
+                    if (base < e7) {                                                                  // the ';' of this KiB, in order, behind those already collected
+                        const uint32_t p = base + lane * 16u;
+                        uint32_t m = p < e7 ? vcf_eq_mask16(u, p, fs[7], e7, 0x3b3b3b3bu) : 0u, tot;
+                        uint32_t at = nsep + vcf_wave_excl_scan((uint32_t)__builtin_popcount(m), &tot);
+                        for (; m; m &= m - 1) sep[at++] = p + (uint32_t)__builtin_ctz(m);
+                        nsep += tot;
                     }
+                    if (last) { if (lane == 0) sep[nsep] = e7; nsep++; }                              // the last field ends where INFO does
+                    if (!last && nsep + 1025u <= VCF_WSEP) continue;
+                    __syncthreads();
+                    for (uint32_t k0 = 0; k0 < nsep; k0 += 64u) {                                     // a field per lane
+                        const uint32_t k = k0 + lane; const bool have = k < nsep;
+                        const uint32_t key = have ? (k ? sep[k - 1] + 1u : seg) : 0u, fend = have ? sep[k] : 0u;
+                        VcfSink<false> ms; ms.p = nullptr; ms.n = 0;
+                        int cnt = 0;
+                        if (have) cnt = WRITE ? vcf_info_field<false, true>(a, li, u, bias, key, fend, ms) : vcf_info_field<false, false>(a, li, u, bias, key, fend, ms);
+                        uint32_t tot_n, tot_c;
+                        const uint32_t off = vcf_wave_excl_scan(ms.n, &tot_n), before = vcf_wave_excl_scan((uint32_t)cnt, &tot_c);
+                        if (__ballot(have && n_info + before == 65535u)) bad = true;
+                        if (WRITE) {
+                            uint32_t d_src = 0, d_dst = 0, d_len = 0;
+                            if (have && !bad) { VcfSink<WRITE> ws; ws.p = o.p; ws.n = o.n + off; vcf_info_field<WRITE, false, true>(a, li, u, bias, key, fend, ws, &d_src, &d_dst, &d_len); }
+                            for (unsigned long long big = __ballot(d_len != 0); big; big &= big - 1) {      // long strings: all lanes copy, a byte each per step
+                                const int l = __builtin_ctzll(big);
+                                const uint32_t src = (uint32_t)__shfl((int)d_src, l), dst = (uint32_t)__shfl((int)d_dst, l), len = (uint32_t)__shfl((int)d_len, l);
+                                for (uint32_t i = lane; i < len; i += 64u) o.p[dst + i] = u[src + i];
+                            }
+                        }
+                        if (WRITE) {                                                                  // the first fields that begin with END= / SVLEN= (vcf_tabix_end)
+                            const bool is_e = have && fend - key >= 4 && u[key] == 'E' && u[key + 1] == 'N' && u[key + 2] == 'D' && u[key + 3] == '=';
+                            const bool is_s = have && fend - key >= 6 && u[key] == 'S' && u[key + 1] == 'V' && u[key + 2] == 'L' && u[key + 3] == 'E' && u[key + 4] == 'N' && u[key + 5] == '=';
+                            const unsigned long long be = __ballot(is_e), bs = __ballot(is_s);
+                            if (be && w_pe == 0xffffffffu) w_pe = (uint32_t)__shfl((int)key, __builtin_ctzll(be)) + 4u;
+                            if (bs && w_ps == 0xffffffffu) w_ps = (uint32_t)__shfl((int)key, __builtin_ctzll(bs)) + 6u;
+                        }
+                        o.n += tot_n; n_info += tot_c;
+                        if (bad) break;
+                    }
+                    seg = sep[nsep - 1] + 1u;
+                    __syncthreads();
+                    nsep = 0;
+                    if (last || bad) break;
                 }
-                if (c == 0) break;
-                r = end; key = r + 1;
+            } else
+            for (uint32_t key = fs[7];;) {                                                           // fields between ';' (kstrtok)
+                uint32_t fend = key; while (fend < e7 && u[fend] != ';') fend++;
+                if (n_info == 65535) { bad = true; break; }
+                n_info += (uint32_t)vcf_info_field<WRITE, false>(a, li, u, bias, key, fend, o);
+                if (fend >= e7) break;
+                key = fend + 1;
             }
         }
     }
+    if (WAVE && WRITE && !bad) rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1, true, w_pe, w_ps) - pos);
     // FORMAT + sample columns (vcf_parse_format vcf.c:3686-3742; steps 3137-3684): per-sample text A:B:C becomes per-field arrays
     uint32_t n_fmt_kept = 0, n_sample = 0; const uint32_t indiv0 = o.n;
     if (!bad && a.n_smp > 0 && fe[7] < l1) {
@@ -526,7 +675,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                 key[n_fmt] = 0; ht[n_fmt] = 3;
                 if (k < 0 || a.ids.ftyp[k] == 15) {
                     if (c - t == 1 && u[t] == '.') { bad = true; break; }                            // "Invalid FORMAT tag name '.'"
-                    if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, c - t, 3u}; }
+                    if (!WRITE && lead) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, c - t, 3u}; }
                 } else { key[n_fmt] = a.ids.id[k]; ht[n_fmt] = a.ids.ftyp[k]; }
                 flg[n_fmt] = (c - t == 2 && u[t] == 'G' && u[t + 1] == 'T') ? 1 : 0;
                 mx_l[n_fmt] = mx_m[n_fmt] = mx_g[n_fmt] = 0;
@@ -649,8 +798,8 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                                     else if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { put32(l++, __float_as_uint(__double2float_rn(d))); t += e; }
                                     else {
                                         // strtod's forms: the host converts (write pass) and checks that the number ends where the token ends (measure pass)
-                                        if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, tok_end - t, 4u}; }
-                                        else { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + at + 4 * l, 2u}; }
+                                        if (!WRITE) { if (lead) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, tok_end - t, 4u}; } }
+                                        else if (lead) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + at + 4 * l, 2u}; }
                                         put32(l++, 0u);
                                         t = tok_end;
                                     }

@@ -156,6 +156,118 @@ def test_gpu_cases(name, data):
         _check(data, max_blocks=1)
 
 
+def _long_info_lines(n, seed=3):
+    """gnomAD-shaped sites-only lines: hundreds of numeric INFO keys, flags, a long vep string, END= / SVLEN= on some, a few odd fields"""
+    import random
+    rnd = random.Random(seed)
+    keys = [("K%03d" % i, rnd.choice(["Integer", "Float", "String", "Flag"]), rnd.choice(["1", "A", "."])) for i in range(260)]
+    hdr = ["##fileformat=VCFv4.2", '##FILTER=<ID=RF,Description="x">', "##contig=<ID=22,length=50818468>", '##ALT=<ID=DEL,Description="d">',
+           '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=SVLEN,Number=.,Type=Integer,Description="s">',
+           '##INFO=<ID=vep,Number=.,Type=String,Description="Consequence annotations from Ensembl VEP. Format: Allele|Consequence|SYMBOL">']
+    hdr += ['##INFO=<ID=%s,Number=%s,Type=%s,Description="x">' % (k, "0" if t == "Flag" else num, t) for k, t, num in keys]
+    hdr.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO")
+    out = ["\n".join(hdr)]
+    pos = 1000
+    for r in range(n):
+        pos += rnd.randrange(1, 500)
+        info = []
+        for k, t, num in keys:
+            if rnd.random() < 0.15:
+                continue
+            if t == "Flag":
+                info.append(k)
+            elif t == "Integer":
+                info.append("%s=%s" % (k, ",".join(rnd.choice([str(rnd.randrange(-9, 250000)), ".", "+7", "99999999999", "1x"]) for _ in range(rnd.choice([1, 1, 1, 3])))))
+            elif t == "Float":
+                info.append("%s=%s" % (k, ",".join(rnd.choice(["%.5e" % rnd.random(), "%.3f" % (rnd.random() * 100), ".", "1e-30", "0.12345678901234567", "nan", "-inf"]) for _ in range(rnd.choice([1, 1, 2])))))
+            else:
+                info.append("%s=%s" % (k, "s" * rnd.choice([0, 1, 5, 95, 96, 97, 300])))
+        info.append("vep=" + ",".join("|".join(["A", "missense_variant", "GENE%d" % rnd.randrange(900)] + ["x" * rnd.randrange(20)]) for _ in range(rnd.randrange(1, 120))))
+        if r % 7 == 0:
+            info.insert(rnd.randrange(len(info)), "END=%d" % (pos + 400))
+        if r % 11 == 0:
+            info.insert(rnd.randrange(len(info)), "SVLEN=-300")
+        if r % 13 == 0:
+            info.insert(rnd.randrange(len(info)), "UNDEFINED_%d=4" % (r % 3))
+        if r % 17 == 0:
+            info.insert(rnd.randrange(len(info)), "")                    # ";;"
+        if r % 19 == 0:
+            info.insert(rnd.randrange(len(info)), "=5")
+        alt = "<DEL>" if r % 11 == 0 else rnd.choice("ACGT")
+        out.append("22\t%d\t.\tA\t%s\t%s\t%s\t%s%s" % (pos, alt, rnd.choice([".", "50", "1e-30"]), rnd.choice([".", "PASS", "RF"]), ";".join(info), ";" if r % 23 == 0 else ""))
+    return ("\n".join(out) + "\n").encode()
+
+
+@pytest.mark.gpu
+def test_gpu_wave_per_line_encoder(monkeypatch):
+    """vcf_encode_wave (a wave per line, INFO fields one per lane) against the oracle: forced onto every case of the lane-per-line tests, and on
+    long INFO lines"""
+    monkeypatch.setenv("DHTS_VCF_WAVE", "1")
+    for name, data in CASES:
+        _check(data)
+    txt = _long_info_lines(300)
+    exp, got = _check(txt)
+    assert got["n_rows"] == 300
+    _check(txt, max_blocks=1)
+    import bamwriter
+    _check(bamwriter.bgzf_file(txt, payload=30000), max_blocks=2)
+    _check(vep_cases.fixture_text().encode())
+
+
+def _many_host_numbers(n_info, n_fmt):
+    """more numbers outside the device's conversion path than one batch used to have room for: 17-digit INFO floats (Python's repr), tiny
+    FORMAT p-values (1e-30), a few inf / nan"""
+    import random
+    rnd = random.Random(11)
+    hdr = ["##fileformat=VCFv4.2", "##contig=<ID=1,length=248956422>", '##INFO=<ID=P,Number=.,Type=Float,Description="p">',
+           '##FORMAT=<ID=PV,Number=1,Type=Float,Description="pv">', "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\tS3\tS4"]
+    lines = ["\n".join(hdr)]
+    per = 64
+    for r in range(max(n_info // per, n_fmt // 4) + 1):
+        vals = ",".join(repr(rnd.random() * 10 ** rnd.randrange(-3, 4)) if k % 31 else rnd.choice(["inf", "nan", "1e-300", "0x1p-3"]) for k in range(per))
+        smp = "\t".join(rnd.choice(["1e-30", "3.5e-45", "1e-30", "0.5"]) for _ in range(4))
+        lines.append("1\t%d\t.\tA\tC\t%s\t.\tP=%s\tPV\t%s" % (100 + r, rnd.choice([".", "1e-40", "30"]), vals, smp))
+    return ("\n".join(lines) + "\n").encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_gpu_more_host_converted_numbers_than_the_initial_room(wave, monkeypatch):
+    """the per-batch records of tokens for the host (undefined names / strtod checks, numbers to convert) grow and the pass is repeated; the
+    tokens travel in one gather + one copy.  Small initial room, so that a few thousand numbers already overflow it"""
+    monkeypatch.setenv("DHTS_VCF_CAPS", "257")
+    monkeypatch.setenv("DHTS_VCF_WAVE", wave)
+    data = _many_host_numbers(20000, 3000)
+    exp, got = _check(data)
+    assert got["n_rows"] == exp["n_rows"] > 300
+    _check(data, max_blocks=1)
+
+
+@pytest.mark.gpu
+def test_gpu_a_million_host_converted_numbers_in_one_batch():
+    """the sizes the advisor named: > 1M 17-digit INFO floats and > 65536 FORMAT floats such as 1e-30 in one batch, default room"""
+    data = _many_host_numbers(1_100_000, 70_000)
+    import duckhts_amd
+    got = duckhts_amd.read_bcf(data)
+    n = data.count(b"\n") - 5
+    assert got["n_rows"] == n and got["status"] == 1
+    p = orc.bcf_col_py(got["by_name"]["INFO_P"])
+    assert len(p) == n and all(len(x) == 64 for x in p[:50])
+    # spot check against Python's own float(): f32 of the 17-digit text
+    import numpy as np
+    first = data.split(b"\n")[5].split(b"\t")[7][2:].split(b",")
+    want = np.array([float.fromhex(t.decode()) if t.startswith(b"0x") else float(t) for t in first], np.float64).astype(np.float32)
+    have = np.array(p[0], np.float32)
+    assert np.array_equal(np.isnan(want), np.isnan(have)) and np.array_equal(want[~np.isnan(want)], have[~np.isnan(have)])
+
+
+@pytest.mark.gpu
+def test_gpu_long_lines_choose_the_wave_encoder_by_themselves():
+    txt = _long_info_lines(200, seed=5)
+    exp, got = _check(txt)
+    assert got["n_rows"] == 200
+
+
 @pytest.mark.gpu
 def test_gpu_reference_fixtures():
     txt = vep_cases.fixture_text().encode()
