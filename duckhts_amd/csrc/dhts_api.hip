@@ -1969,6 +1969,10 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
     bool ok = true; int rc = 0;
     std::vector<uint32_t> ro; std::vector<uint8_t> core;
     std::vector<int32_t> a_tid; std::vector<int64_t> a_beg, a_end; std::vector<uint64_t> a_v; std::vector<uint8_t> a_map;
+    struct Restore {                                                                 // every way out puts the caller's projection back and rewinds the scan
+        dhts_ctx *c; const std::vector<int32_t> &proj;
+        ~Restore() { const std::string keep = c->err; (void)dhts_bcf_set_projection(c, proj.data(), (int32_t)proj.size()); (void)dhts_bcf_rewind(c); if (!keep.empty()) c->err = keep; }
+    } restore{c, saved_proj};
     for (;;) {
         dhts_bcf_batch b;
         if (dhts_bcf_next_batch(c, 0, &b)) { rc = -1; break; }
@@ -2002,8 +2006,6 @@ int64_t dhts_bcf_build_index(dhts_ctx *c, int min_shift) {
         }
         if (b.status != 0) { if (b.status < 0) { rc = fail(c, "index build: the scan ended on an error (status %d)", b.status); } break; }
     }
-    (void)dhts_bcf_set_projection(c, saved_proj.data(), (int32_t)saved_proj.size());
-    (void)dhts_bcf_rewind(c);
     if (rc) return -1;
     if (!ok) return fail(c, "index build: %s", ib.err.c_str());
     uint64_t fin = c->comp_len;
@@ -2098,6 +2100,7 @@ extern "C" int dhts_bgzip_file(dhts_ctx *c, const char *in_path, const char *out
     if (pin) dhts_host_free(pin);
     close(fd);
     if (fclose(fo) != 0 && rc == 0) { rc = -5; fail(c, "bgzip: close error"); }
+    if (rc) unlink(out_path);
     if (bytes_in) *bytes_in = nin;
     if (bytes_out) *bytes_out = nout;
     return rc;
@@ -2113,7 +2116,7 @@ extern "C" int dhts_bgunzip_file(dhts_ctx *c, const char *in_path, const char *o
         const int fd = open(in_path, O_RDONLY);
         if (fd < 0) { fail(c, "bgunzip: cannot open input %s", in_path); return -2; }
         uint8_t magic[2] = {0, 0}; const ssize_t got = pread(fd, magic, 2, 0);
-        if (got == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+        if (got >= 0 && !(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {   // (a file shorter than the magic is not gzip either)
             FILE *fo = fopen(out_path, "wb");
             if (!fo) { close(fd); fail(c, "bgunzip: cannot open output %s: %s", out_path, strerror(errno)); return -3; }
             std::vector<uint8_t> buf(1u << 20); int rc = 0; int64_t n = 0;
@@ -2121,6 +2124,7 @@ extern "C" int dhts_bgunzip_file(dhts_ctx *c, const char *in_path, const char *o
                        if (fwrite(buf.data(), 1, (size_t)r, fo) != (size_t)r) { rc = -5; fail(c, "bgunzip: write error"); break; } n += r; }
             close(fd);
             if (fclose(fo) != 0 && rc == 0) { rc = -5; fail(c, "bgunzip: write error"); }
+            if (rc) unlink(out_path);                        // no partial output behind an error
             if (bytes_in) *bytes_in = n;
             if (bytes_out) *bytes_out = n;
             return rc;
@@ -2150,6 +2154,7 @@ extern "C" int dhts_bgunzip_file(dhts_ctx *c, const char *in_path, const char *o
     }
     if (pin) dhts_host_free(pin);
     if (fclose(fo) != 0 && rc == 0) { rc = -5; fail(c, "bgunzip: write error"); }
+    if (rc) unlink(out_path);
     if (bytes_in) *bytes_in = (int64_t)c->file_size;
     if (bytes_out) *bytes_out = nout;
     return rc;

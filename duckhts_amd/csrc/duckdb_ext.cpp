@@ -702,7 +702,7 @@ extern "C" __attribute__((visibility("default"))) void register_read_bam_functio
 // =====================================================================================================================
 // read_bcf -- mirrors register_read_bcf_function src/bcf_reader.c:2055-2080, bcf_read_bind 452-880 (schema 540-760),
 // global/local init 886-1150 (projection ids, region error), bcf_read_function 1155-2049 (<= vector_size rows per call).
-// Sequential mode; tidy_format and region supported; VCF text input is rejected with the reference's header error.
+// Sequential mode; tidy_format and region supported; BCF, and VCF text (plain or bgzipped) through the device text encoder.
 // =====================================================================================================================
 struct BcfBind {
     std::string path, region;
@@ -739,8 +739,8 @@ struct BcfScan {
         { std::lock_guard<std::mutex> lk(mu); cancel = true; }
         cv_free.notify_all(); cv_ready.notify_all();
         if (th.joinable()) th.join();
+        if (ctx) dhts_destroy(ctx);                 // first: it waits for the copy stream, whose D2H may still be writing into an arena (error paths leave one in flight)
         for (auto hb : all) { dhts_host_free(hb->arena); delete hb; }
-        if (ctx) dhts_destroy(ctx);
     }
 };
 struct BcfLocal {

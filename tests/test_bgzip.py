@@ -119,6 +119,9 @@ def test_gpu_bgzip_and_bgunzip_files(tmp_path):
         open(dst, "wb").write(bytes(bad))
         with pytest.raises(duckhts_amd.DhtsError, match="read error"):
             ctx.bgunzip_file(dst, back)
+        assert not os.path.exists(back)                                               # no partial output behind an error
+        one = os.path.join(str(tmp_path), "one.byte"); open(one, "wb").write(b"\x1f")
+        assert ctx.bgunzip_file(one, back) == (1, 1) and open(back, "rb").read() == b"\x1f"      # shorter than the gzip magic: not gzip, handed through
         assert ctx.bgunzip_file(src, back) == (len(raw), len(raw)) and open(back, "rb").read() == raw      # not gzip: handed through (bgzf_open reads it transparently)
         open(dst, "wb").write(gzip.compress(raw[:5000]))
         with pytest.raises(duckhts_amd.DhtsError, match="not BGZF"):

@@ -197,7 +197,14 @@ def test_no_hbm_leak_over_200_queries():
     assert max(held) - min(held) < (64 << 20), f"the pool keeps growing: {held}"        # steady state, not a leak with a pool in front
     L.dhts_release_pools()
     free1 = free_hbm()
-    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 10} KiB of HBM lost over 200 create -> scan -> destroy cycles"
+    # What the HIP runtime keeps for itself (scratch and kernel-argument room of the queues behind the pooled streams) is sized on first use and
+    # depends on which queues the tests before this one have touched; a leak grows with every cycle.  So: a second run of cycles may not cost more.
+    assert free0 - free1 < (64 << 20), f"{(free0 - free1) >> 10} KiB of HBM lost over 200 create -> scan -> destroy cycles"
+    for i in range(200):
+        cycle(i)
+    L.dhts_release_pools()
+    free2 = free_hbm()
+    assert free1 - free2 < (4 << 20), f"{(free1 - free2) >> 10} KiB of HBM lost over 200 more cycles"
 
 
 def test_format_flag_column_stays_inside_its_payload():

@@ -37,7 +37,27 @@ def run(fn, path, proj=None, named=(), threads=1, repeat=4, env=None):
     return rows, dt, runs
 
 
+def main_threads():
+    """fill-thread scaling: rows/s of the operator against DHTS_THREADS = host threads that copy batches back and fill
+    DataChunks, on a file that stays resident in HBM (DHTS_FILE_CACHE=1, warm queries) with count(*) and a fixed-width projection, so that
+    neither the file read nor PCIe H2D is the limit"""
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16_000_000
+    d = tempfile.mkdtemp(dir="/tmp")
+    bam = os.path.join(d, "s.bam")
+    synth.bam_segment(n, seed=42)[0].tofile(bam)
+    size = os.path.getsize(bam)
+    ncpu = os.cpu_count() or 1
+    for name, proj in (("count(*) (QNAME)", [0]), ("fixed-width (FLAG,POS,MAPQ)", [1, 3, 4]), ("all 13 columns", None)):
+        for thr in (1, 2, 4, 8, 16, 32):
+            rows, dt, runs = run("read_bam", bam, proj=proj, threads=thr, repeat=5, env={"DHTS_THREADS": str(thr), "DHTS_FILE_CACHE": "1"})
+            warm = sorted(runs[1:])[len(runs[1:]) // 2]
+            print(json.dumps({"operator": "read_bam through the DuckDB table function (mini host), file resident in HBM", "projection": name, "rows": rows, "DHTS_THREADS": thr,
+                              "host_cpus": ncpu, "file_GB": round(size / 1e9, 3), "warm_query_s": round(warm, 4), "records_per_s": round(rows / warm, 1)}), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "threads":
+        return main_threads()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
     threads = int(os.environ.get("BENCH_THREADS", "8"))
     d = tempfile.mkdtemp(dir="/tmp")
