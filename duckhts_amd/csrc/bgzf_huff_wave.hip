@@ -141,7 +141,8 @@ W_DEV uint32_t hw_d_entry(uint32_t sym) {
 }
 
 #if defined(HOSTSIM_W) && defined(HW_STATS)
-static unsigned long long g_hw_stat_p1[8], g_hw_stat_dirty, g_hw_stat_seg, g_hw_stat_fallback;
+static unsigned long long g_hw_stat_p1[8], g_hw_stat_dirty, g_hw_stat_seg, g_hw_stat_fallback, g_hw_stat_p0bad, g_hw_stat_p0n, g_hw_stat_wrong, g_hw_stat_wrong_nominal;
+static unsigned long long g_hw_stat_big[8];
 #endif
 // -DHW_DIAG (device builds for tools/dbg/hw_diag.py): cycles per phase, summed over blocks by lane 0
 #if defined(HW_DIAG) && !defined(HOSTSIM_W)
@@ -759,6 +760,9 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
                     HwLane tmp;
                     hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, subbits, lane, tmp, nullptr, nullptr, 0, 0, 0);
                     if (tmp.flags == 0u) PL(prop) = tmp.end;
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+                    g_hw_stat_p0n++; if (tmp.flags != 0u) g_hw_stat_p0bad++;
+#endif
                 }
             }
             W_SYNC();
@@ -774,6 +778,7 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
                 HWD_CNT(9, 1);
 #if defined(HOSTSIM_W) && defined(HW_STATS)
                 g_hw_stat_p1[guard < 7 ? guard : 7]++; g_hw_stat_dirty += (unsigned long long)w_popc64(dirty);
+                if (S >= 1024u) g_hw_stat_big[guard < 7 ? guard : 7]++;
 #endif
                 W_LANES {
                     if ((dirty >> lane) & 1ull) {
@@ -798,6 +803,9 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
                 // restart every lane behind a broken link from its predecessor's end (the first of them becomes confirmed next round)
                 uint64_t nd_;
                 W_BALLOT(nd_, (uint32_t)lane >= k_conf && (uint32_t)lane < nlanes && (xch[HX_FLAG * 64 + lane - 1] & (HWF_EOB | HWF_BAD)) == 0u && xch[HX_END * 64 + lane - 1] != PL(ln).start);
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+                if (guard == 0) for (int lane = 1; lane < 64; lane++) if ((nd_ >> lane) & 1ull) { g_hw_stat_wrong++; if (PL(ln).start == p0 + (uint32_t)lane * S) g_hw_stat_wrong_nominal++; }
+#endif
                 W_LANES { if ((nd_ >> lane) & 1ull) PL(ln).start = xch[HX_END * 64 + lane - 1]; }
                 dirty = nd_;
                 if (dirty == 0ull) { status = DHTS_BLK_ERR_INFLATE; break; }            // (cannot happen: lane k_conf's link is broken, so it is dirty)
@@ -1021,7 +1029,9 @@ bgzf_inflate_fused(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0
         InflateMeta m;
         hw_block(smem, blk0 + (int64_t)b, comp, tab, lit, tok, m, slit, stok, hwd);
         __syncthreads();                                       // the block's tokens and literals are stored; phase A's LDS is free
-        lz_block(smem, comp, tab, blk0 + (int64_t)b, m, lit, tok, out, out_base, blk_status);
+        lz_load_crc_tables((uint32_t *)(smem + B_CRCT));
+        __syncthreads();
+        lz_block(smem + B_WIN, (uint32_t *)(smem + B_CRCT), smem + B_RING, comp, tab, blk0 + (int64_t)b, m, lit, tok, out, out_base, blk_status);
         __syncthreads();
         uint32_t nb_ = 0;
         if (threadIdx.x == 0) nb_ = atomicAdd(counter, 1u);

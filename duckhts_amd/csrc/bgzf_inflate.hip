@@ -596,6 +596,9 @@ static_assert(BR_R >= BR_FLUSH + BR_SPAN + 265u, "far sources must always be flu
 #define B_RING (B_CRCT + 4096)           /* u8 [2048] literal staging ring */
 #define B_LDS_BYTES (B_RING + 2048)
 #define B_NULLTOK 0xffffffffu
+#ifndef B_SEQ_T
+#define B_SEQ_T 6u                        /* pending matches at or below which the rounds of a batch give way to the in-order replay */
+#endif
 #ifdef DHTS_DIAG
 __device__ unsigned long long g_diag[8];   // batches, rounds, easy, hard, lit_iters, long_lit
 #define DIAG_ADD(i, v) do { dcnt[i] += (unsigned long long)(v); } while (0)
@@ -634,17 +637,23 @@ __device__ __forceinline__ uint32_t crc_xpow8(uint32_t nbytes) {
 }
 
 // Block-independent CRC constants, computed once per context by crc_const_init:
-//   [0,64)  K_lane = x^(8*BR_PIECE*(63-lane)),  [64] x^(8*BR_FLUSH),  [65,82) x^(8*2^k) for k < 17,  [96,1120) slice-by-4 tables
+//   [0,64)  K_lane = x^(8*BR_PIECE*(63-lane)),  [64] x^(8*BR_FLUSH),  [65,82) x^(8*2^k) for k < 17,  [96,1120) slice-by-4 tables,
+//   [1120,1248) products of every nibble position with x^(8*(BR_FLUSH-BR_PIECE))
 #define CRCC_K 0
 #define CRCC_XF 64
 #define CRCC_XP2 65
 #define CRCC_TAB 96
-__device__ uint32_t g_crcc[96 + 1024];
+#define CRCC_MK (96 + 1024)              /* u32 [8][16]: (nibble << 4j) * x^(8*(BR_FLUSH-BR_PIECE)): a lane's CRC state carried over the other lanes' pieces */
+__device__ uint32_t g_crcc[96 + 1024 + 128];
 extern "C" __global__ void __launch_bounds__(64) crc_const_init() {
     const uint32_t lane = threadIdx.x;
     g_crcc[CRCC_K + lane] = crc_xpow8(BR_PIECE * (63u - lane));
     if (lane == 0) g_crcc[CRCC_XF] = crc_xpow8(BR_FLUSH);
     if (lane < 17) g_crcc[CRCC_XP2 + lane] = crc_xpow8(1u << lane);
+    {
+        const uint32_t kadv = crc_xpow8(BR_FLUSH - BR_PIECE);
+        for (uint32_t e = lane; e < 128u; e += 64u) g_crcc[CRCC_MK + e] = crc_mulmod((e & 15u) << (4u * (e >> 4)), kadv);
+    }
     for (uint32_t k = lane; k < 256; k += 64) {
         uint32_t t[4], c = k;
         for (int j = 0; j < 8; j++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
@@ -667,22 +676,24 @@ __device__ __forceinline__ uint32_t crc_xpow8_tab(uint32_t nbytes) {
 // One BGZF block: the tokens / literals `tok` / `lit` described by `m` become the block's bytes at out + (uoff[bi] - out_base); the CRC-32 and
 // ISIZE of the trailer are checked (blk_status[bi]).  Called by bgzf_lz_resolve (one workgroup per block, scratch slots written by a
 // phase-A launch) and by bgzf_inflate_fused (bgzf_huff_wave.hip: the wave that decoded the block resolves it right away).
-__device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restrict__ comp, BgzfTable tab, int64_t bi, const InflateMeta m,
+// The waves of a workgroup never exchange data (each resolves a block of its own in its own window; the CRC tables are read-only), and the
+// LDS operations of ONE wave execute in program order: what a phase boundary needs is that the compiler keeps that order.
+#define LZ_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// slice-by-4 tables: 4 KiB copied from the per-device constants (by every wave of the workgroup: the same words)
+__device__ __forceinline__ void lz_load_crc_tables(uint32_t *crct) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; q++) *(uint4 *)(crct + q * 256 + lane * 4) = *(const uint4 *)(g_crcc + CRCC_TAB + q * 256 + lane * 4);
+}
+__device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *ring, const uint8_t *__restrict__ comp, BgzfTable tab, int64_t bi, const InflateMeta m,
                                          const uint8_t *__restrict__ lit, const uint32_t *__restrict__ tok,
                                          uint8_t *__restrict__ out, uint64_t out_base, int32_t *__restrict__ blk_status) {
-    uint8_t *win = smem + B_WIN;
-    uint32_t *crct = (uint32_t *)(smem + B_CRCT);
-    uint8_t *ring = smem + B_RING;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t isize = tab.isize[bi];
     const uint32_t clen = tab.clen[bi];
     DIAG_DECL;
     DIAG_T(t_begin);
 
-    // slice-by-4 tables: 4 KiB copied from the per-device constants
-#pragma unroll
-    for (int q = 0; q < 4; q++) *(uint4 *)(crct + q * 256 + lane * 4) = *(const uint4 *)(g_crcc + CRCC_TAB + q * 256 + lane * 4);
-    __syncthreads();
     DIAG_T(t_tab);
     DIAG_TADD(0, t_begin, t_tab);
 
@@ -691,22 +702,32 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
     if (st != 0) { if (lane == 0) blk_status[bi] = st; return; }
 
     uint8_t *dstp = out + (tab.uoff[bi] - out_base);
-    uint32_t outpos = 0, litpos = 0, flushed = 0, crc_run = 0;
-    // constants of the flush-chunk CRC: lane's BR_PIECE-byte piece is followed by BR_PIECE*(63-lane) bytes of the chunk
-    const uint32_t K_lane = g_crcc[CRCC_K + lane];
+    uint32_t outpos = 0, litpos = 0, flushed = 0, crc_acc = 0;
+    // constants of the flush-chunk CRC: the lane's rows of the advance table (entries lane and 64 + lane)
+    const uint32_t mk_lo = g_crcc[CRCC_MK + lane], mk_hi = g_crcc[CRCC_MK + 64 + lane];
 
-    // Flush the chunk [flushed, flushed + BR_FLUSH): fold its CRC into crc_run, store it with 1 KiB coalesced wave stores.
+    // Flush the chunk [flushed, flushed + BR_FLUSH): store it with 1 KiB coalesced wave stores and run its bytes through the CRC.
+    // Every lane carries ONE CRC state across all flushes of the block (crc_acc): its BR_PIECE-byte piece of this chunk continues the
+    // state it left behind its piece of the previous chunk, advanced over the BR_FLUSH - BR_PIECE bytes of the other lanes in between
+    // (a multiplication by the constant x^(8*(BR_FLUSH-BR_PIECE)): linear, so eight nibble look-ups in the 128-entry table that the
+    // wave holds in two registers, fetched with ds_bpermute).  The 64 states are combined once, behind the block's last full chunk.
     // BR_R is a multiple of BR_PIECE, so neither a lane's CRC piece nor a 16-byte store unit wraps in the ring.
+#define CRC_ADVANCE(r_) ({                                                                                                  \
+        const uint32_t a_ = (r_); uint32_t m_ = 0;                                                                          \
+        _Pragma("unroll") for (uint32_t j_ = 0; j_ < 4; j_++) {                                                            \
+            m_ ^= (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((a_ >> (4u * j_)) & 15u) + 16u * j_) << 2), (int)mk_lo);      \
+            m_ ^= (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((a_ >> (16u + 4u * j_)) & 15u) + 16u * j_) << 2), (int)mk_hi); \
+        }                                                                                                                   \
+        m_; })
 #define FLUSH_CHUNK() do {                                                                                              \
         const uint32_t pi_ = ridx(flushed + (uint32_t)lane * BR_PIECE);                                                 \
-        uint32_t c_ = lane == 0 ? (flushed == 0 ? 0xffffffffu : crc_run) : 0u;   /* lane 0 continues the running CRC */      \
+        uint32_t c_ = CRC_ADVANCE(crc_acc);                                                                             \
+        if (flushed == 0 && lane == 0) c_ = 0xffffffffu;                         /* the stream's first byte */            \
         for (uint32_t q_ = 0; q_ < BR_PIECE; q_ += 4) {                                                                      \
             uint32_t v_ = *(const uint32_t *)(win + pi_ + q_) ^ c_;                                                     \
             c_ = crct[768 + (v_ & 0xff)] ^ crct[512 + ((v_ >> 8) & 0xff)] ^ crct[256 + ((v_ >> 16) & 0xff)] ^ crct[v_ >> 24]; \
         }                                                                                                               \
-        c_ = crc_mulmod(c_, K_lane);                                                                                    \
-        _Pragma("unroll") for (int d_ = 32; d_ >= 1; d_ >>= 1) c_ ^= __shfl_xor(c_, d_, 64);                           \
-        crc_run = c_;                                                                                                   \
+        crc_acc = c_;                                                                                                   \
         for (uint32_t k_ = 0; k_ < BR_FLUSH; k_ += 1024) {                                                              \
             const uint32_t p_ = flushed + k_ + (uint32_t)lane * 16u;                                                    \
             uint4 v4_ = *(const uint4 *)(win + ridx(p_));                                                               \
@@ -751,14 +772,12 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
             uint64_t fv0 = 0, fv1 = 0, fv2 = 0, fv3 = 0;
             if (farm) {
                 const uint8_t *g = dstp + ms;
-                __builtin_memcpy(&fv0, g, 8);
-                if (mlen > 8u) __builtin_memcpy(&fv1, g + 8, 8);
-                if (mlen > 16u) __builtin_memcpy(&fv2, g + 16, 8);
-                if (mlen > 24u) __builtin_memcpy(&fv3, g + 24, 8);
+                uint64_t a[2]; __builtin_memcpy(a, g, 16); fv0 = a[0]; fv1 = a[1];
+                if (mlen > 16u) { uint64_t b[2]; __builtin_memcpy(b, g + 16, 16); fv2 = b[0]; fv3 = b[1]; }
             }
             // ---- literals ----
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
-            __syncthreads();
+            LZ_SYNC();
             // 8 bytes per lane per step: one (usually unaligned) 64-bit ring read, then an exact-length store
             for (uint32_t q0 = 0; __ballot(q0 < lrun) != 0ull; q0 += 8) {
                 DIAG_ADD(4, 1);
@@ -770,7 +789,7 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
                     win_st_n(win, dst + q0, v, lrun - q0);
                 }
             }
-            __syncthreads();
+            LZ_SYNC();
             DIAG_T(t_b);
             DIAG_TADD(1, t_a, t_b);
             // ---- matches ----
@@ -781,12 +800,24 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
             uint32_t sh = 4; while ((tot_adv >> sh) > 63u) sh++;
             uint64_t dmask = 0, smask = 0;
             if (farm) {
-                const uint8_t *g = dstp + ms;
-                win_st_n(win, md, fv0, mlen);
-                if (mlen > 8u) win_st_n(win, md + 8, fv1, mlen - 8u);
-                if (mlen > 16u) win_st_n(win, md + 16, fv2, mlen - 16u);
-                if (mlen > 24u) win_st_n(win, md + 24, fv3, mlen - 24u);
-                for (uint32_t c = 32; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, g + c, 8); win_st_n(win, md + c, v, mlen - c); }
+                const uint32_t rdm = ridx(md);
+                if (mlen <= 32u && rdm + 40u <= BR_R) {
+                    // the usual case: whole 8-byte pieces out of the registers, then the exact tail
+                    uint8_t *dp = win + rdm;
+                    const uint32_t full = mlen >> 3, tail = mlen & 7u;
+                    if (full > 0u) __builtin_memcpy(dp, &fv0, 8);
+                    if (full > 1u) __builtin_memcpy(dp + 8, &fv1, 8);
+                    if (full > 2u) __builtin_memcpy(dp + 16, &fv2, 8);
+                    if (full > 3u) __builtin_memcpy(dp + 24, &fv3, 8);
+                    if (tail) { const uint64_t vt = full == 0u ? fv0 : full == 1u ? fv1 : full == 2u ? fv2 : fv3; lds_st_n(dp + 8u * full, vt, tail); }
+                } else {
+                    const uint8_t *g = dstp + ms;
+                    win_st_n(win, md, fv0, mlen);
+                    if (mlen > 8u) win_st_n(win, md + 8, fv1, mlen - 8u);
+                    if (mlen > 16u) win_st_n(win, md + 16, fv2, mlen - 16u);
+                    if (mlen > 24u) win_st_n(win, md + 24, fv3, mlen - 24u);
+                    for (uint32_t c = 32; c < mlen; c += 8) { uint64_t v; __builtin_memcpy(&v, g + c, 8); win_st_n(win, md + c, v, mlen - c); }
+                }
             }
             if (mlen > 0) {
                 const uint32_t lo = (md - outpos) >> sh, hi = (md - outpos + mlen - 1) >> sh;
@@ -799,18 +830,23 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
             uint64_t P = __ballot(mlen > 0 && !farm);
             DIAG_T(t_b2);
             DIAG_TADD(7, t_b, t_b2);
-            __syncthreads();                                   // far copies are in the ring before anybody reads them
+            LZ_SYNC();                                   // far copies are in the ring before anybody reads them
             DIAG_ADD(6, __popcll(P)); DIAG_ADD(5, __popcll(__ballot(farm)));
-            while (P) {
+            // Parallel rounds while they pay: on BAM data 84 % of a batch's matches are ready in the first round, 11 % in the second,
+            // and the dependency chains of the rest would cost a full round for one or two copies each.  As soon as B_SEQ_T or fewer
+            // matches are pending (or a round found nothing it could copy) the rest is replayed one match at a time in stream order
+            // -- always ready by construction, no readiness test -- by the whole wave (one byte per lane).
+            bool more = P != 0ull;
+            while (more) {
                 DIAG_ADD(1, 1);
                 const bool pending = (P >> lane) & 1ull;
                 const uint64_t e = pending ? dmask : 0ull;
                 const uint32_t el = wave_shr1(wave_incl_scan_or((uint32_t)e)), eh = wave_shr1(wave_incl_scan_or((uint32_t)(e >> 32)));
                 const uint64_t owed = ((uint64_t)eh << 32) | el;                   // exclusive prefix-OR over earlier lanes
                 const bool ready = pending && ((smask & owed) == 0ull);
-                // (a) lane-parallel, 8 bytes per step with unaligned 64-bit LDS accesses: byte runs (dist 1), non-overlapping
-                //     copies, and overlapping copies with dist >= 8 (a chunk never reads what it writes; chunks go in order).
-                //     Matches whose source or destination would wrap in the ring go to (b).
+                // lane-parallel, 8 bytes per step with unaligned 64-bit LDS accesses: byte runs (dist 1), non-overlapping copies, and
+                // overlapping copies with dist >= 8 (a chunk never reads what it writes; chunks go in order).  Matches whose source or
+                // destination would wrap in the ring, and long ones, stay pending for the sequential replay.
                 const uint32_t rs = ridx(ms), rd = ridx(md);
                 const bool easy = ready && (mlen <= 32u) && (mdist >= 8u || mdist >= mlen || mdist == 1u) && (rs + 40u <= BR_R) && (rd + 40u <= BR_R);
                 if (easy) {
@@ -827,20 +863,22 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
                         if (tail) lds_st_n(dp + 8 * full, lds_ld64(sp + 8 * full), tail);
                     }
                 }
-                // (b) the rest of the ready set, one at a time, replayed by the whole wave
-                uint64_t H = __ballot(ready && !easy);
-                DIAG_ADD(2, __popcll(__ballot(easy))); DIAG_ADD(3, __popcll(H));
-                while (H) {
-                    const int i = __ffsll((unsigned long long)H) - 1; H &= H - 1;
-                    const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
-                    const uint32_t src0 = d0 - di;
-                    if (l0 <= di) { for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = win[ridx(src0 + k)]; }
-                    else if (di == 1u) { const uint8_t v = win[ridx(src0)]; for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = v; }
-                    else { for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = win[ridx(src0 + (k % di))]; }
-                }
-                __syncthreads();
-                P &= ~__ballot(ready);
+                const uint64_t E = __ballot(easy);
+                DIAG_ADD(2, __popcll(E));
+                LZ_SYNC();
+                P &= ~E;
+                more = E != 0ull && (uint32_t)__popcll(P) > B_SEQ_T;
             }
+            DIAG_ADD(3, __popcll(P));
+            while (P) {
+                const int i = __ffsll((unsigned long long)P) - 1; P &= P - 1;
+                const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
+                const uint32_t src0 = d0 - di;
+                if (l0 <= di) { for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = win[ridx(src0 + k)]; }
+                else if (di == 1u) { const uint8_t v = win[ridx(src0)]; for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = v; }
+                else { for (uint32_t k = lane; k < l0; k += 64) win[ridx(d0 + k)] = win[ridx(src0 + (k % di))]; }
+            }
+            LZ_SYNC();
             DIAG_T(t_c);
             DIAG_TADD(2, t_b, t_c);
             outpos += tot_adv; litpos += tot_lit;
@@ -852,14 +890,14 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
                 const uint32_t lr = RDLANE(lrun, i), ml = RDLANE(mlen, i), di = RDLANE(mdist, i);
                 for (uint32_t k = lane; k < lr; k += 64) win[ridx(outpos + k)] = lit[litpos + k];
                 outpos += lr; litpos += lr;
-                __syncthreads();
+                LZ_SYNC();
                 if (ml) {
                     const uint32_t src0 = outpos - di;
                     const uint32_t thr = outpos + ml > BR_R ? outpos + ml - BR_R : 0u;      // older bytes are read back from HBM
                     if (ml <= di) { for (uint32_t k = lane; k < ml; k += 64) { const uint32_t sx = src0 + k; win[ridx(outpos + k)] = sx < thr ? dstp[sx] : win[ridx(sx)]; } }
                     else { for (uint32_t k = lane; k < ml; k += 64) win[ridx(outpos + k)] = win[ridx(src0 + (k % di))]; }          // overlapping: dist < 258, never far
                     outpos += ml;
-                    __syncthreads();
+                    LZ_SYNC();
                 }
                 while (outpos - flushed >= BR_FLUSH) FLUSH_CHUNK();
             }
@@ -876,11 +914,11 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
             const uint32_t n = rem < BR_FLUSH / 2u ? rem : BR_FLUSH / 2u;
             for (uint32_t k = lane; k < n; k += 64) win[ridx(outpos + k)] = lit[litpos + k];
             outpos += n; litpos += n; rem -= n;
-            __syncthreads();
+            LZ_SYNC();
             while (outpos - flushed >= BR_FLUSH) FLUSH_CHUNK();
         }
     }
-    __syncthreads();
+    LZ_SYNC();
     if (outpos != m.outlen) { if (lane == 0) blk_status[bi] = DHTS_BLK_ERR_INFLATE; return; }
 
     DIAG_T(t_crc0);
@@ -889,6 +927,13 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
     const uint32_t chunk = ((n + 63) / 64 + 3) & ~3u;          // multiple of 4; flushed is a multiple of 4, so dwords never wrap
     uint32_t beg = lane * chunk; if (beg > n) beg = n;
     uint32_t end = beg + chunk; if (end > n) end = n;
+    // the flushed chunks: a lane's state is followed by the BR_PIECE*(63-lane) bytes of the lanes behind it in the last chunk
+    uint32_t crc_run = 0;
+    if (flushed != 0) {
+        crc_run = crc_mulmod(crc_acc, g_crcc[CRCC_K + lane]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) crc_run ^= __shfl_xor(crc_run, d, 64);
+    }
     uint32_t c = lane == 0 ? (flushed == 0 ? 0xffffffffu : crc_run) : 0u;      // lane 0 continues the running CRC
     uint32_t q = beg;
     for (; q + 4 <= end; q += 4) {
@@ -917,19 +962,54 @@ __device__ __forceinline__ void lz_block(uint8_t *smem, const uint8_t *__restric
     DIAG_FLUSH;
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+// B_NW waves per workgroup, one BGZF block each: the waves share the 4 KiB of CRC tables, so a wave costs 6 KiB of LDS instead of 10
+// (4 KiB ring window + 2 KiB literal staging) and a CU holds 20 waves instead of 16.  Measured per 92 M-record step: one wave per workgroup
+// 175.4 ms, four 174.2 ms, eight (24 waves per CU) 182.3 ms -- the kernel is bound by the SIMDs' instruction issue (VALU and SALU together,
+// about 3 cycles per wave-instruction), not by latency, so more resident waves only take issue slots from the record stage beside it.
+#ifndef B_NW
+#define B_NW 4
+#endif
+#define B_WAVE_LDS (BR_R + 2048u)
+#define B_LDS_BYTES_NW (4096u + B_NW * B_WAVE_LDS)
+extern "C" __global__ void __launch_bounds__(64 * B_NW)
 bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, int32_t nblk,
                 const uint8_t *__restrict__ lit_all, const uint32_t *__restrict__ tok_all,
                 const InflateMeta *__restrict__ meta, int64_t scratch_b0, uint8_t *__restrict__ out, uint64_t out_base,
                 int32_t *__restrict__ blk_status, const unsigned long long *__restrict__ blk_off) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if ((int64_t)blockIdx.x >= nblk) return;
-    const int64_t bi = blk0 + blockIdx.x;
+    uint32_t *crct = (uint32_t *)smem;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint8_t *win = smem + 4096u + wave * B_WAVE_LDS, *ring = win + BR_R;
+    if (wave == 0) lz_load_crc_tables(crct);
+    __syncthreads();                                       // the only workgroup-wide barrier: every wave reaches it
+    const int64_t k = (int64_t)blockIdx.x * B_NW + wave;
+    if (k >= nblk) return;
+    const int64_t bi = blk0 + k;
     const int64_t s = bi - scratch_b0;            // slot in the phase-A scratch (phase A may run ahead over a larger block range)
     const InflateMeta m = meta[s];
     if (blk_off != nullptr) {
         // packed scratch (bgzf_huff_decode_wave): literals at the block's offset of the pool `lit_all`, tokens behind them
         const uint8_t *lp = lit_all + (m.status == 0 ? blk_off[s] : 0ull);
-        lz_block(smem, comp, tab, bi, m, lp, (const uint32_t *)(lp + ((m.nlit + 15u) & ~15u)), out, out_base, blk_status);
-    } else lz_block(smem, comp, tab, bi, m, lit_all + (size_t)s * DHTS_LIT_STRIDE, tok_all + (size_t)s * DHTS_TOK_STRIDE, out, out_base, blk_status);
+        lz_block(win, crct, ring, comp, tab, bi, m, lp, (const uint32_t *)(lp + ((m.nlit + 15u) & ~15u)), out, out_base, blk_status);
+    } else lz_block(win, crct, ring, comp, tab, bi, m, lit_all + (size_t)s * DHTS_LIT_STRIDE, tok_all + (size_t)s * DHTS_TOK_STRIDE, out, out_base, blk_status);
+}
+
+// First damaged block of a batch, found on the device so that the host need not read the whole status array (and need not wait for it
+// before it queues the record stage): res[0] = index (relative to blk0) of the first block whose status is not 0, res[1] = that status,
+// res[2] = index of the first block marked DHTS_BLK_ERR_SCRATCH; 0xffffffff = none.  One workgroup.
+extern "C" __global__ void __launch_bounds__(1024)
+bgzf_first_bad_block(const int32_t *__restrict__ blk_status, int64_t blk0, int32_t nblk, uint32_t *__restrict__ res) {
+    __shared__ uint32_t s_bad, s_scr;
+    if (threadIdx.x == 0) { s_bad = 0xffffffffu; s_scr = 0xffffffffu; }
+    __syncthreads();
+    uint32_t bad = 0xffffffffu, scr = 0xffffffffu;
+    for (int32_t k = (int32_t)threadIdx.x; k < nblk; k += 1024) {
+        const int32_t v = blk_status[blk0 + k];
+        if (v != 0 && (uint32_t)k < bad) bad = (uint32_t)k;
+        if (v == DHTS_BLK_ERR_SCRATCH && (uint32_t)k < scr) scr = (uint32_t)k;
+    }
+    if (bad != 0xffffffffu) atomicMin(&s_bad, bad);
+    if (scr != 0xffffffffu) atomicMin(&s_scr, scr);
+    __syncthreads();
+    if (threadIdx.x == 0) { res[0] = s_bad; res[1] = s_bad != 0xffffffffu ? (uint32_t)blk_status[blk0 + s_bad] : 0u; res[2] = s_scr; res[3] = 0u; }
 }

@@ -201,7 +201,7 @@ struct dhts_ctx {
     // inflated stream double buffer (carry moves between them)
     DevBuf ubuf[2]; int ucur = 0; uint64_t carry_len = 0;
     // tiles
-    DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed, t_recs, t_recs_first;
+    DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed, d_bstat, t_recs, t_recs_first;
     DevBuf t2_first, t2_end, t2_count, t2_err;      // second tile table: repair rounds are out of place
     // rows
     DevBuf c_rgflag;
@@ -325,11 +325,13 @@ dhts_ctx *dhts_create(int device_id) {
     // the prefetch stream has the LOWEST priority: the record-stage kernels of the current batch (short, latency-bound) should get wave
     // slots as soon as they ask, the next batch's phase B fills what is left
     int pr_lo = 0, pr_hi = 0; (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-    if (hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, pr_lo) != hipSuccess || hipEventCreateWithFlags(&c->pf_done, hipEventDisableTiming) != hipSuccess) {
+    static const char *env_pp = getenv("DHTS_PF_PRIO");      // tuning knob: "hi" / "normal" instead of the lowest priority
+    const int pr_b = (env_pp && !strcmp(env_pp, "hi")) ? pr_hi : (env_pp && !strcmp(env_pp, "normal")) ? 0 : pr_lo;
+    if (hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, pr_b) != hipSuccess || hipEventCreateWithFlags(&c->pf_done, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return nullptr;
     }
     // the LDS-window kernel needs more than the default dynamic LDS limit
-    if (hipFuncSetAttribute((const void *)bgzf_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES) != hipSuccess ||
+    if (hipFuncSetAttribute((const void *)bgzf_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES_NW) != hipSuccess ||
         hipFuncSetAttribute((const void *)bgzf_huff_decode, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return nullptr;     // no gfx950 code object for this device
     }
@@ -912,7 +914,7 @@ static int launch_lz(dhts_ctx *c, int64_t b0, int64_t nb, uint8_t *out, uint64_t
     BgzfTable t = dev_table(c);
     {
         KTimer tm(c, DHTS_K_LZ, s);
-        hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)nb), dim3(64), B_LDS_BYTES, s, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
+        hipLaunchKernelGGL(bgzf_lz_resolve, dim3((unsigned)((nb + B_NW - 1) / B_NW)), dim3(64 * B_NW), B_LDS_BYTES_NW, s, (const uint8_t *)c->comp.p, t, b0, (int32_t)nb,
                            (const uint8_t *)c->lit.p, (const uint32_t *)c->tok.p, (const InflateMeta *)c->meta.p, c->huff_b0, out, out_base, (int32_t *)c->blk_status.p,
                            c->huff_packed ? (const unsigned long long *)c->blk_off.p : (const unsigned long long *)nullptr);
     }
@@ -2409,8 +2411,13 @@ static int bam_tag_columns(dhts_ctx *c, const BamStream &st, int64_t nrows, dhts
 struct Batch {
     int64_t b0 = 0, nb = 0; bool in_halo = false, last_of_stream = false, sharded_tail = false, final_batch = false;
     uint64_t carry = 0, ulen = 0, out_base = 0; uint8_t *u = nullptr; int blk_err = 0;
+    bool status_pending = false;      // the blocks' status words have not been looked at yet (batch_status_resolve)
 };
-static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
+static const uint32_t NONE32 = 0xffffffffu;
+// `defer`: do not wait for the inflate here.  The first damaged block is found on the device (bgzf_first_bad_block -> c->d_bstat) and the
+// caller reads those four words together with its own first results, then calls batch_status_resolve: the record stage is queued behind
+// the inflate without a host round trip, and is queued again on the shortened stream in the rare case that a block was bad.
+static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B, bool defer = false) {
     if (max_blocks <= 0) max_blocks = 16384;
     if (max_blocks > 24576) max_blocks = 24576;               // keep every in-batch offset below 2^32
     B.sharded_tail = (c->shard_b1 < c->n_blocks);              // later shards exist: our last record may need halo blocks
@@ -2455,7 +2462,11 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     }
     // first bad block (if any) ends the byte stream there (bgzf.c:1241-1291: the read fails)
     int blk_err = 0;
-    if (nb > 0) {
+    if (nb > 0 && defer) {
+        ENSURE(c, c->d_bstat, 64);
+        hipLaunchKernelGGL(bgzf_first_bad_block, dim3(1), dim3(1024), 0, c->stream, (const int32_t *)c->blk_status.p, b0, (int32_t)nb, (uint32_t *)c->d_bstat.p);
+        B.status_pending = true;
+    } else if (nb > 0) {
         std::vector<int32_t> bs(nb);
         for (int attempt = 0; ; attempt++) {
             HIPCHK(c, hipMemcpyAsync(bs.data(), (int32_t *)c->blk_status.p + b0, nb * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2478,6 +2489,31 @@ static int batch_begin(dhts_ctx *c, int64_t max_blocks, Batch &B) {
     // the staging, not truncated)
     B.final_batch = (B.last_of_stream && !(c->partial_tail && !c->segs.empty())) || blk_err != 0;
     B.carry = carry; B.ulen = ulen; B.out_base = out_base; B.u = u; B.blk_err = blk_err;
+    return 0;
+}
+// The four words of bgzf_first_bad_block have reached the host (`bst`).  Returns 0 when every block of the batch is good, 1 when the batch
+// changed and the caller has to queue its record stage again (a damaged block cut the stream: B.ulen / B.final_batch / B.blk_err are
+// updated; or the packed phase-A scratch was too small: the range has been inflated again with full-size room and the status is pending
+// again), -1 on failure.
+static int batch_status_resolve(dhts_ctx *c, Batch &B, const uint32_t bst[4], int attempt) {
+    B.status_pending = false;
+    if (bst[2] != NONE32) {
+        if (attempt > 0) return fail(c, "internal: phase-A scratch exhausted twice");
+        discard_prefetch(c);
+        c->pool_per_block = (int64_t)DHTS_LIT_STRIDE + (int64_t)DHTS_TOK_STRIDE * 4; c->huff_b0 = c->huff_nb = 0;
+        const int64_t ahead = c->shard_b1 + 8 < c->n_blocks ? c->shard_b1 + 8 : c->n_blocks;
+        if (inflate_blocks(c, B.b0, B.nb, B.u, B.out_base, ahead)) return -1;
+        HIPCHK(c, hipMemsetAsync(B.u + B.ulen, 0, PAD_BYTES, c->stream));
+        hipLaunchKernelGGL(bgzf_first_bad_block, dim3(1), dim3(1024), 0, c->stream, (const int32_t *)c->blk_status.p, B.b0, (int32_t)B.nb, (uint32_t *)c->d_bstat.p);
+        B.status_pending = true;
+        return 1;
+    }
+    if (bst[0] != NONE32) {
+        B.blk_err = (int)(int32_t)bst[1];
+        B.ulen = B.carry + (c->h_uoff[B.b0 + bst[0]] - c->h_uoff[B.b0]);
+        B.final_batch = true;
+        return 1;
+    }
     return 0;
 }
 // advance the scan position; *status as documented for dhts_bam_batch.status
@@ -2651,9 +2687,14 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
     if (!c->bam_open) return fail(c, "dhts_bam_open not called");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->stream_done) { out->status = 1; return 0; }
+    // Host round trips of one batch (the plain case: no region filter, no shard cut inside the batch): (1) behind the tile pass -- rows,
+    // carry position, the repair rounds' verdict and the inflate's block status in ONE copy; (2) behind the string scan -- heap sizes,
+    // first invalid row, first record offset; (3) the end of the batch.  The inflate, the tile scan, two repair rounds and the finalize
+    // pass are queued back to back; so are unpack, validity packing and the scans.
     Batch B;
-    if (batch_begin(c, max_blocks, B)) return -1;
-    const bool sharded_tail = B.sharded_tail, final_batch = B.final_batch;
+    if (batch_begin(c, max_blocks, B, true)) return -1;
+    const bool sharded_tail = B.sharded_tail;
+    bool final_batch = B.final_batch;
     uint8_t *u = B.u; uint64_t ulen = B.ulen; const uint64_t out_base = B.out_base;
     BamStream st; st.u = u; st.ulen = ulen; st.n_ref = (int32_t)c->ref_name.size(); st.final_batch = final_batch ? 1 : 0; st.seq_packed = c->seq_packed ? 1 : 0;
     st.want_rg = (colmask & ((1u << DHTS_BAM_READ_GROUP_ID) | (1u << DHTS_BAM_SAMPLE_ID))) ? 1 : 0;
@@ -2678,17 +2719,48 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
     // survives; when every retry fails as well the damage is real and the first attempt's result stands.
     const bool speculative = (start0 == NONE64);
     uint64_t spec_from = 0; int spec_tries = 0; bool restoring = false;
+    int status_attempt = 0;
     for (;;) {
         to.first = (uint64_t *)c->t_first.p; to.end_next = (uint64_t *)c->t_end.p; to.count = (uint32_t *)c->t_count.p; to.err = (int32_t *)c->t_err.p;
         to2.first = (uint64_t *)c->t2_first.p; to2.end_next = (uint64_t *)c->t2_end.p; to2.count = (uint32_t *)c->t2_count.p; to2.err = (int32_t *)c->t2_err.p;
+        uint32_t nfh[2] = {0, 0}, bst[4] = {NONE32, 0, NONE32, 0};
         {
             KTimer tm(c, DHTS_K_TILES);
             hipLaunchKernelGGL(bam_tile_scan, dim3((unsigned)ntiles), dim3(64), 0, c->stream, st, start0, ntiles, to, (uint16_t *)c->t_recs.p, (uint64_t *)c->t_recs_first.p, spec_from);
-            int rounds = 0;
+            // two repair rounds are queued unconditionally (a 30x BAM converges in two; a round that finds nothing to repair copies the table)
+            uint32_t *nf = (uint32_t *)c->d_nfixed.p;
+            (void)hipMemsetAsync(nf, 0, 8, c->stream);
+            for (int r = 0; r < 2; r++) {
+                hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, nf + r);
+                TileOut tmp = to; to = to2; to2 = tmp;             // the round's output is the current table
+            }
+            hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
+        }
+        HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&first0, to.first, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(nfh, c->d_nfixed.p, 8, hipMemcpyDeviceToHost, c->stream));
+        if (B.status_pending) HIPCHK(c, hipMemcpyAsync(bst, c->d_bstat.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (B.status_pending) {
+            const int rs = batch_status_resolve(c, B, bst, status_attempt++);
+            if (rs < 0) return -1;
+            if (rs > 0) {           // the stream is shorter than assumed (or was inflated again): the tile pass starts over
+                ulen = B.ulen; final_batch = B.final_batch;
+                st.ulen = ulen; st.final_batch = final_batch ? 1 : 0; c->last_stream = st;
+                ntiles = (int64_t)((ulen + TILE_BYTES - 1) / TILE_BYTES); if (ntiles < 1) ntiles = 1;
+                spec_from = 0; spec_tries = 0; restoring = false;
+                continue;
+            }
+        }
+        if (g_debug) fprintf(stderr, "[dhts] tiles=%lld nfixed=%u,%u\n", (long long)ntiles, nfh[0], nfh[1]);
+        if (nfh[1] != 0) {
+            // the second round still repaired tiles: go on round by round, then finalize again
+            KTimer tm(c, DHTS_K_TILES);
+            int rounds = 2;
             for (;;) {
                 (void)hipMemsetAsync(c->d_nfixed.p, 0, 4, c->stream);
                 hipLaunchKernelGGL(bam_tile_fix, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream, st, TILE_BYTES, ntiles, to, to2, (uint32_t *)c->d_nfixed.p);
-                { TileOut tmp = to; to = to2; to2 = tmp; }         // the round's output is the current table
+                { TileOut tmp = to; to = to2; to2 = tmp; }
                 uint32_t nfixed = 0;
                 HIPCHK(c, hipMemcpyAsync(&nfixed, c->d_nfixed.p, 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2697,10 +2769,10 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
                 if (++rounds > 256) { hipLaunchKernelGGL(bam_tile_fix_seq, dim3(1), dim3(1), 0, c->stream, st, TILE_BYTES, ntiles, to); break; }
             }
             hipLaunchKernelGGL(bam_tile_finalize, dim3(1), dim3(1024), 0, c->stream, ntiles, to, (uint32_t *)c->t_rowbase.p, (uint64_t *)c->d_res.p);
+            HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&first0, to.first, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        HIPCHK(c, hipMemcpyAsync(res, c->d_res.p, 32, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&first0, to.first, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         if (!speculative || restoring) break;
         bool false_start = res[2] != 0 && first0 != NONE64;
         const bool exhausted = spec_tries > 0 && first0 == NONE64;
@@ -2758,6 +2830,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
     BamCols bc; memset(&bc, 0, sizeof(bc));
     const int64_t nrows_scan = nrows;                          // rows the tile pass counted (before the region filter / a bad row / the shard cut)
     const uint32_t *row_map_s = nullptr;
+    uint32_t first_rec_rel = 0; bool have_first_rec = false;   // offset of the batch's first row (read with the heap sizes when there are any)
     if (nrows > 0) {
         size_t n = (size_t)nrows;
         ENSURE(c, c->rec_off, n * 4 + 16); ENSURE(c, c->c_rgflag, n + 64);
@@ -2797,15 +2870,24 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
                                (const uint64_t *)c->d_res.p, nrows, (uint32_t *)c->rec_off.p, (uint8_t *)c->c_rgflag.p, bc, (unsigned long long *)((uint64_t *)c->d_res.p + 4), row_map,
                                (const uint16_t *)c->t_recs.p, (const uint64_t *)c->t_recs_first.p);
         }
-        {   // the first row that fails bam_read1's validation ends the scan there (rows before it are kept)
-            unsigned long long bad = ~0ull;
-            HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+        // the first row that fails bam_read1's validation ends the scan there (rows before it are kept).  In the plain case the verdict is
+        // read together with the heap sizes below; a region filter or a shard cut inside the batch need it now.
+        bool bad_pending = true;
+        unsigned long long bad = ~0ull;
+        const bool shard_cut = !filtered && sharded_tail && out_base + ulen > shard_end_u;
+        auto apply_bad = [&]() -> int {
             if (bad < (unsigned long long)nrows) {
                 rec_err = true;
                 if (filtered) { uint32_t kb = 0; HIPCHK(c, hipMemcpy(&kb, (const uint32_t *)c->c_rowmap.p + bad, 4, hipMemcpyDeviceToHost)); kept_total = kb; }
                 nrows = (int64_t)bad;
             }
+            return 0;
+        };
+        if (filtered || shard_cut) {
+            HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            bad_pending = false;
+            if (apply_bad()) return -1;
         }
         if (filtered) {
             if (sharded_tail && out_base + ulen > shard_end_u && carry_start >= shard_end_u - out_base) shard_finished = true;   // rows past the index window never match
@@ -2813,7 +2895,7 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
             // last one ends in the last resident block, and the records behind the cut are not a truncated tail)
             if (c->scan_end_uoff != ~0ull && out_base + ulen >= c->scan_end_uoff && !rec_err) shard_finished = true;
             nrows = (int64_t)kept_total;
-        } else if (nrows > 0 && sharded_tail && out_base + ulen > shard_end_u) {
+        } else if (nrows > 0 && shard_cut) {
             // drop rows whose record starts at/after the shard end (they belong to the next shard): binary search on rec_off
             std::vector<uint32_t> ro(nrows);
             HIPCHK(c, hipMemcpyAsync(ro.data(), c->rec_off.p, nrows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2824,42 +2906,67 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
             if (lo < nrows) { carry_start = ro[lo]; nrows = lo; shard_finished = true; }
             else if (carry_start >= lim) shard_finished = true;
         }
-    }
-    if (nrows > 0) {
-        {
-            KTimer tm(c, DHTS_K_CORE);
-            hipLaunchKernelGGL(bam_pack_validity, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->c_rgflag.p, nrows, (uint64_t *)c->c_rgvalid.p);
-        }
-        uint32_t *o32[5] = {(uint32_t *)c->o_qname.p, (uint32_t *)c->o_cigar.p, (uint32_t *)c->o_seq.p, (uint32_t *)c->o_qual.p, (uint32_t *)c->o_rg.p};
-        uint64_t tot[5] = {0, 0, 0, 0, 0};
-        BamStrOut so; memset(&so, 0, sizeof(so));
-        so.off_qname = o32[0]; so.off_cigar = o32[1]; so.off_seq = o32[2]; so.off_qual = o32[3]; so.off_rg = o32[4]; so.alen_qual = (uint32_t *)c->alen_qual.p;
-        if (c->seq_packed && (colmask & (1u << DHTS_BAM_SEQ))) { ENSURE(c, c->seq_chars, (size_t)nrows * 4 + 64); so.seq_chars = (uint32_t *)c->seq_chars.p; }
-        const uint32_t str_cols = (1u << DHTS_BAM_QNAME) | (1u << DHTS_BAM_CIGAR) | (1u << DHTS_BAM_SEQ) | (1u << DHTS_BAM_QUAL) | (1u << DHTS_BAM_READ_GROUP_ID);
-        if (colmask & str_cols) {      // projection pushdown: with no string column projected the whole string pass is skipped
-            const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
+        if (nrows > 0) {
             {
+                KTimer tm(c, DHTS_K_CORE);
+                hipLaunchKernelGGL(bam_pack_validity, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->c_rgflag.p, nrows, (uint64_t *)c->c_rgvalid.p);
+            }
+            uint32_t *o32[5] = {(uint32_t *)c->o_qname.p, (uint32_t *)c->o_cigar.p, (uint32_t *)c->o_seq.p, (uint32_t *)c->o_qual.p, (uint32_t *)c->o_rg.p};
+            uint64_t tot[5] = {0, 0, 0, 0, 0};
+            BamStrOut so; memset(&so, 0, sizeof(so));
+            so.off_qname = o32[0]; so.off_cigar = o32[1]; so.off_seq = o32[2]; so.off_qual = o32[3]; so.off_rg = o32[4]; so.alen_qual = (uint32_t *)c->alen_qual.p;
+            if (c->seq_packed && (colmask & (1u << DHTS_BAM_SEQ))) { ENSURE(c, c->seq_chars, (size_t)nrows * 4 + 64); so.seq_chars = (uint32_t *)c->seq_chars.p; }
+            const uint32_t str_cols = (1u << DHTS_BAM_QNAME) | (1u << DHTS_BAM_CIGAR) | (1u << DHTS_BAM_SEQ) | (1u << DHTS_BAM_QUAL) | (1u << DHTS_BAM_READ_GROUP_ID);
+            const bool strings = (colmask & str_cols) != 0;     // projection pushdown: with no string column projected the whole string pass is skipped
+            if (strings) {
+                const uint32_t *in[5] = {bc.len_qname, bc.len_cigar, bc.len_seq, bc.len_qual, bc.len_rg};
                 KTimer tm(c, DHTS_K_SCAN);
                 if (run_scan(c, 5, in, o32, nullptr, nrows, nullptr)) return -1;
+                HIPCHK(c, hipMemcpyAsync(tot, c->scan_total.p, 40, hipMemcpyDeviceToHost, c->stream));
             }
-            HIPCHK(c, hipMemcpyAsync(tot, c->scan_total.p, 40, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            ENSURE(c, c->a_qname, tot[0] + PAD_BYTES); ENSURE(c, c->a_cigar, tot[1] + PAD_BYTES); ENSURE(c, c->a_seq, tot[2] + PAD_BYTES);
-            ENSURE(c, c->a_qual, tot[3] + PAD_BYTES); ENSURE(c, c->a_rg, tot[4] + PAD_BYTES);
-            so.qname = (uint8_t *)c->a_qname.p; so.cigar = (uint8_t *)c->a_cigar.p; so.seq = (uint8_t *)c->a_seq.p; so.qual = (uint8_t *)c->a_qual.p; so.rg = (uint8_t *)c->a_rg.p;
-            KTimer tm(c, DHTS_K_STRINGS);
-            hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(TS_THREADS), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
-                               nrows_scan, nrows, (const uint32_t *)c->rec_off.p, row_map_s, bc, so, colmask);
+            if (strings || bad_pending) {
+                // ONE round trip: heap sizes, the first invalid row and the first record's offset
+                if (bad_pending) HIPCHK(c, hipMemcpyAsync(&bad, (uint64_t *)c->d_res.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(&first_rec_rel, c->rec_off.p, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                have_first_rec = true;
+                if (bad_pending) {
+                    bad_pending = false;
+                    const int64_t before = nrows;
+                    if (apply_bad()) return -1;
+                    if (nrows != before && nrows > 0) {
+                        // rare: a row failed validation.  The offsets of the rows in front of it stand (exclusive sums); the heap sizes and the
+                        // validity words are made again for the shorter table
+                        hipLaunchKernelGGL(bam_pack_validity, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)c->c_rgflag.p, nrows, (uint64_t *)c->c_rgvalid.p);
+                        if (strings) {
+                            uint32_t t32[5] = {0, 0, 0, 0, 0};
+                            for (int k = 0; k < 5; k++) HIPCHK(c, hipMemcpyAsync(&t32[k], o32[k] + nrows, 4, hipMemcpyDeviceToHost, c->stream));
+                            HIPCHK(c, hipStreamSynchronize(c->stream));
+                            for (int k = 0; k < 5; k++) tot[k] = t32[k];
+                        }
+                    }
+                }
+            }
+            if (strings && nrows > 0) {
+                ENSURE(c, c->a_qname, tot[0] + PAD_BYTES); ENSURE(c, c->a_cigar, tot[1] + PAD_BYTES); ENSURE(c, c->a_seq, tot[2] + PAD_BYTES);
+                ENSURE(c, c->a_qual, tot[3] + PAD_BYTES); ENSURE(c, c->a_rg, tot[4] + PAD_BYTES);
+                so.qname = (uint8_t *)c->a_qname.p; so.cigar = (uint8_t *)c->a_cigar.p; so.seq = (uint8_t *)c->a_seq.p; so.qual = (uint8_t *)c->a_qual.p; so.rg = (uint8_t *)c->a_rg.p;
+                KTimer tm(c, DHTS_K_STRINGS);
+                hipLaunchKernelGGL(bam_tile_strings, dim3((unsigned)ntiles), dim3(TS_THREADS), 0, c->stream, st, ntiles, to, (const uint32_t *)c->t_rowbase.p, (const uint64_t *)c->d_res.p,
+                                   nrows_scan, nrows, (const uint32_t *)c->rec_off.p, row_map_s, bc, so, colmask);
+            }
+            HIPCHK(c, hipGetLastError());
+            if (nrows > 0) {
+                out->flag = bc.flag; out->pos = bc.pos; out->mapq = bc.mapq; out->pnext = bc.pnext; out->tlen = bc.tlen; out->tid = bc.tid; out->mtid = bc.mtid;
+                out->rg_idx = bc.rg_idx; out->rg_valid = bc.rg_valid;
+                out->qname = {o32[0], bc.len_qname, so.qname, tot[0]};
+                out->cigar = {o32[1], bc.len_cigar, so.cigar, tot[1]};
+                out->seq = {o32[2], so.seq_chars ? so.seq_chars : bc.len_seq, so.seq, tot[2]};
+                out->seq_packed = so.seq_chars ? 1 : 0;
+                out->qual = {o32[3], so.alen_qual, so.qual, tot[3]};
+                out->rg = {o32[4], bc.len_rg, so.rg, tot[4]};
+            }
         }
-        HIPCHK(c, hipGetLastError());
-        out->flag = bc.flag; out->pos = bc.pos; out->mapq = bc.mapq; out->pnext = bc.pnext; out->tlen = bc.tlen; out->tid = bc.tid; out->mtid = bc.mtid;
-        out->rg_idx = bc.rg_idx; out->rg_valid = bc.rg_valid;
-        out->qname = {o32[0], bc.len_qname, so.qname, tot[0]};
-        out->cigar = {o32[1], bc.len_cigar, so.cigar, tot[1]};
-        out->seq = {o32[2], so.seq_chars ? so.seq_chars : bc.len_seq, so.seq, tot[2]};
-        out->seq_packed = so.seq_chars ? 1 : 0;
-        out->qual = {o32[3], so.alen_qual, so.qual, tot[3]};
-        out->rg = {o32[4], bc.len_rg, so.rg, tot[4]};
     }
     if (bam_tag_columns(c, st, nrows, out)) return -1;
     if (bam_aux_map(c, st, nrows, out)) return -1;
@@ -2868,7 +2975,8 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
     out->end_uoff = out_base + carry_start;
     {
         uint64_t f = NONE64;
-        if (nrows > 0) { uint32_t r0 = 0; HIPCHK(c, hipMemcpyAsync(&r0, c->rec_off.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); f = out_base + r0; }
+        if (nrows > 0 && !have_first_rec) { HIPCHK(c, hipMemcpyAsync(&first_rec_rel, c->rec_off.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+        if (nrows > 0) f = out_base + first_rec_rel;
         out->first_rec_uoff = f;
     }
     // ---- advance ----

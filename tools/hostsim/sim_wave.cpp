@@ -120,6 +120,8 @@ int main(int argc, char **argv) {
     printf("segments %llu; pass-1 rounds executed (by round index):", g_hw_stat_seg);
     for (int i = 0; i < 8; i++) printf(" %llu", g_hw_stat_p1[i]);
     printf("; lane-decodes in pass 1: %llu; sequential fallbacks %llu\n", g_hw_stat_dirty, g_hw_stat_fallback);
+    printf("rounds of segments with ranges >= 1024 bits:"); for (int i = 0; i < 8; i++) printf(" %llu", g_hw_stat_big[i]); printf("\n");
+    printf("pass 0: %llu boundary proposals, %llu ended on an invalid code (nominal boundary proposed); round 1 found %llu wrong starts, %llu of them nominal\n", g_hw_stat_p0n, g_hw_stat_p0bad, g_hw_stat_wrong, g_hw_stat_wrong_nominal);
 #endif
     return rc;
 }
