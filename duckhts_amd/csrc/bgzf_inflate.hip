@@ -752,9 +752,10 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
         const bool pure = (lrun == DHTS_TOK_PURE) || (t == B_NULLTOK);
         const uint32_t mlen = pure ? 0 : ((t >> 15) & 255u) + 3;
         const uint32_t mdist = (t & 0x7fffu) + 1;
-        const uint32_t adv_i = wave_incl_scan(lrun + mlen, lane);
-        const uint32_t lit_i = wave_incl_scan(lrun, lane);
-        const uint32_t tot_adv = RDLANE(adv_i, 63), tot_lit = RDLANE(lit_i, 63);
+        // one scan for both sums: a token advances the output by at most 511 + 258 bytes, 64 of them by less than 2^16
+        const uint32_t both_i = wave_incl_scan(((lrun + mlen) << 16) | lrun, lane);
+        const uint32_t adv_i = both_i >> 16, lit_i = both_i & 0xffffu;
+        const uint32_t both_t = RDLANE(both_i, 63), tot_adv = both_t >> 16, tot_lit = both_t & 0xffffu;
         const uint32_t dst = outpos + adv_i - (lrun + mlen);       // where this token's literals start
         const uint32_t lsrc = litpos + lit_i - lrun;               // absolute index of its first literal byte
         // a distance may not reach in front of the block's first byte (RFC 1951 3.2.3): the wave kernel of phase A cannot make this
@@ -778,16 +779,22 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
             // ---- literals ----
             while (litpos + tot_lit > stage_hi && stage_hi < m.nlit) { STAGE_ISSUE(); STAGE_COMMIT(); }
             LZ_SYNC();
-            // 8 bytes per lane per step: one (usually unaligned) 64-bit ring read, then an exact-length store
-            for (uint32_t q0 = 0; __ballot(q0 < lrun) != 0ull; q0 += 8) {
-                DIAG_ADD(4, 1);
-                if (q0 < lrun) {
-                    const uint32_t ri = (lsrc + q0) & 2047u;
-                    uint64_t v;
-                    if (ri <= 2040u) v = lds_ld64(ring + ri);
-                    else { v = 0; for (uint32_t k = 0; k < 8; k++) v |= (uint64_t)ring[(ri + k) & 2047u] << (8 * k); }
-                    win_st_n(win, dst + q0, v, lrun - q0);
-                }
+            // the first 8 bytes of every run lane-parallel: one (usually unaligned) 64-bit ring read, then an exact-length store; the few
+            // runs that are longer (3 % on BAM data) are finished one at a time by the whole wave, a byte per lane -- a second and third
+            // lane-parallel step would cost the whole wave a full iteration each for one or two lanes' bytes
+            DIAG_ADD(4, 1);
+            if (lrun) {
+                const uint32_t ri = lsrc & 2047u;
+                uint64_t v;
+                if (ri <= 2040u) v = lds_ld64(ring + ri);
+                else { v = 0; for (uint32_t k = 0; k < 8; k++) v |= (uint64_t)ring[(ri + k) & 2047u] << (8 * k); }
+                win_st_n(win, dst, v, lrun);
+            }
+            uint64_t LL = __ballot(lrun > 8u);
+            while (LL) {
+                const int i = __ffsll((unsigned long long)LL) - 1; LL &= LL - 1;
+                const uint32_t d0 = RDLANE(dst, i) + 8u, s0 = RDLANE(lsrc, i) + 8u, n0 = RDLANE(lrun, i) - 8u;
+                for (uint32_t k = lane; k < n0; k += 64) win[ridx(d0 + k)] = ring[(s0 + k) & 2047u];
             }
             LZ_SYNC();
             DIAG_T(t_b);

@@ -2798,12 +2798,16 @@ static int bam_next_batch_one(dhts_ctx *c, int64_t max_blocks, uint32_t colmask,
 
     // sharding: rows belong to this shard iff their record STARTS before the shard's end in the inflated stream
     uint64_t shard_end_u = sharded_tail ? c->h_uoff[c->shard_b1] : ~0ull;
-    // ---- phase B of the NEXT batch, concurrent with the rest of this one ----
+    // ---- phase B of the NEXT batch, concurrent with the rest of this one (DHTS_PREFETCH=1; off by default since round 3) ----
     // The carry (where this batch's last complete record ends) is known now, so the next batch's destination is too.  Only the
     // plain case is prefetched: the stream goes on inside this shard, phase A already covers the blocks, nothing can cut this
     // batch short from here on except a bad row (then batch_end discards the prefetch).
+    // Measured on the 92 M-record bench file: with the prefetch 173.0-174.5 ms per step, without 176.2 ms -- phase B and the record stage
+    // are both bound by instruction issue, so running them side by side only stretches both (bgzf_lz_resolve 4.8 ms per launch beside
+    // the record stage, 2.8 ms alone; bam_tile_unpack 1.35 / 0.88 ms), and the 1 % it gains is not worth a second stream, a second set of
+    // buffers in flight and per-kernel times that no longer say what a kernel costs.
     {
-        static const bool no_pf = getenv("DHTS_NO_PREFETCH") != nullptr;
+        const bool no_pf = !(getenv("DHTS_PREFETCH") && atoi(getenv("DHTS_PREFETCH")) != 0) || getenv("DHTS_NO_PREFETCH") != nullptr;
         int64_t mb = max_blocks <= 0 ? 16384 : (max_blocks > 24576 ? 24576 : max_blocks);
         const int64_t nb0 = B.b0 + B.nb;
         int64_t nbn = c->shard_b1 - nb0; if (nbn > mb) nbn = mb;

@@ -212,6 +212,16 @@ def test_read_bam_synthetic_wgs_shape():
     assert_same(got, exp, "synth300k/mb100")
 
 
+def test_read_bam_with_the_next_batch_prefetch(monkeypatch):
+    """DHTS_PREFETCH=1: phase B of batch k+1 on a second stream beside the record stage of batch k (the default until round 3)"""
+    from duckhts_amd import synth
+    monkeypatch.setenv("DHTS_PREFETCH", "1")
+    d = synth.bam_file(200000, seed=5)
+    exp = orc.bam_read(d)
+    for mb in (64, 100, 1000):
+        assert_same(duckhts_amd.read_bam(d, max_blocks=mb), exp, f"prefetch/mb{mb}")
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_read_bam_sharded_concat(world):
     """BGZF block ranges shard across ranks; concatenating the shards gives the sequential scan, and the
@@ -530,7 +540,8 @@ def test_packed_seq_and_overlapped_fetch_at_the_c_abi():
 
 # ---- next-batch prefetch: a caller that changes the batch size invalidates the prefetched phase B ---------------------------
 @pytest.mark.gpu
-def test_varying_batch_sizes_discard_the_prefetch():
+def test_varying_batch_sizes_discard_the_prefetch(monkeypatch):
+    monkeypatch.setenv("DHTS_PREFETCH", "1")        # the next batch's phase B beside the record stage is opt-in since round 3
     data = synth.bam_file(120000, seed=17)
     exp = orc.bam_read(data)
     ctx = duckhts_amd.Context(0)
