@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of environment settings (GPU box): one short bench per "NAME=VALUE[,NAME=VALUE]" argument ("-" = defaults)
-out="gpurun_out/s2/env"; mkdir -p "$out"
+out="gpurun_out/ab/env"; mkdir -p "$out"
 for spec in "$@"; do
   tag=$(echo "$spec" | tr ',=' '__')
   ( if [ "$spec" != "-" ]; then for kv in ${spec//,/ }; do export "$kv"; done; fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library variants (GPU box): short bench per variant library given as arguments (paths under build/)
-out="gpurun_out/s2/var"; mkdir -p "$out"
+out="gpurun_out/ab/var"; mkdir -p "$out"
 for lib in "$@"; do
   tag=$(basename "$lib" .so)
   DHTS_LIB="$lib" python bench.py --steps 3 --warmup 1 --no-extra-configs --no-operator --no-cpu-baseline --no-parity-sample > "$out/$tag.json" 2> "$out/$tag.err" || { tail -3 "$out/$tag.err"; continue; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # phase-B iteration helper (GPU box): BAM parity tests, cycle split (-DDHTS_DIAG build), short bench; PMC=1 adds the SQ counter passes
-tag="${1:-x}"; out="gpurun_out/s2/$tag"; mkdir -p "$out"
+tag="${1:-x}"; out="gpurun_out/ab/$tag"; mkdir -p "$out"
 timeout -k 10 600 python -m pytest tests/test_gpu_bam.py -x -q -m gpu > "$out/tests.txt" 2>&1; tail -2 "$out/tests.txt"
 grep -q passed "$out/tests.txt" || exit 1
 grep -q failed "$out/tests.txt" && exit 1
