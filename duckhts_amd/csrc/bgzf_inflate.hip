@@ -596,6 +596,18 @@ static_assert(BR_R >= BR_FLUSH + BR_SPAN + 265u, "far sources must always be flu
 #define B_RING (B_CRCT + 4096)           /* u8 [2048] literal staging ring */
 #define B_LDS_BYTES (B_RING + 2048)
 #define B_NULLTOK 0xffffffffu
+// knock-out experiments (tools/dbg/time_lz.py; the output is wrong on purpose): -DB_EXP_NOCRC, -DB_EXP_NOLIT, -DB_EXP_NOFAR, -DB_EXP_NOROUNDS,
+// -DB_EXP_NOREPLAY, -DB_EXP_NOSTORE leave out one part of the kernel each, so that its cost can be read off the launch time
+#ifdef B_EXP_NOSTORE
+#define B_EXP_STORE(p_, v_) do { asm volatile("" :: "v"((v_).x), "v"((v_).y), "v"((v_).z), "v"((v_).w)); } while (0)
+#else
+#define B_EXP_STORE(p_, v_) __builtin_memcpy((p_), &(v_), 16)
+#endif
+#ifdef B_EXP_NOCRC
+#define B_EXP_CRC_BYTES 0u
+#else
+#define B_EXP_CRC_BYTES BR_PIECE
+#endif
 #ifndef B_SEQ_T
 #define B_SEQ_T 6u                        /* pending matches at or below which the rounds of a batch give way to the in-order replay */
 #endif
@@ -723,7 +735,7 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
         const uint32_t pi_ = ridx(flushed + (uint32_t)lane * BR_PIECE);                                                 \
         uint32_t c_ = CRC_ADVANCE(crc_acc);                                                                             \
         if (flushed == 0 && lane == 0) c_ = 0xffffffffu;                         /* the stream's first byte */            \
-        for (uint32_t q_ = 0; q_ < BR_PIECE; q_ += 4) {                                                                      \
+        for (uint32_t q_ = 0; q_ < B_EXP_CRC_BYTES; q_ += 4) {                                                               \
             uint32_t v_ = *(const uint32_t *)(win + pi_ + q_) ^ c_;                                                     \
             c_ = crct[768 + (v_ & 0xff)] ^ crct[512 + ((v_ >> 8) & 0xff)] ^ crct[256 + ((v_ >> 16) & 0xff)] ^ crct[v_ >> 24]; \
         }                                                                                                               \
@@ -731,7 +743,7 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
         for (uint32_t k_ = 0; k_ < BR_FLUSH; k_ += 1024) {                                                              \
             const uint32_t p_ = flushed + k_ + (uint32_t)lane * 16u;                                                    \
             uint4 v4_ = *(const uint4 *)(win + ridx(p_));                                                               \
-            __builtin_memcpy(dstp + p_, &v4_, 16);                                                                      \
+            B_EXP_STORE(dstp + p_, v4_);                                                                                \
         }                                                                                                               \
         __builtin_amdgcn_s_waitcnt(0x0f70);                   /* vmcnt(0): the chunk is in L2 before any far-match read-back */ \
         flushed += BR_FLUSH;                                                                                            \
@@ -769,7 +781,11 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
             // the block's own output is always readable 40 bytes past a far source: ms + 40 < bend)
             const uint32_t md = dst + lrun, ms = md - mdist, mspan = mlen < mdist ? mlen : mdist;
             const uint32_t bend = outpos + tot_adv, rlo = bend > BR_R ? bend - BR_R : 0u;
+#ifdef B_EXP_NOFAR
+            const bool farm = false;
+#else
             const bool farm = mlen > 0 && ms < rlo;
+#endif
             uint64_t fv0 = 0, fv1 = 0, fv2 = 0, fv3 = 0;
             if (farm) {
                 const uint8_t *g = dstp + ms;
@@ -783,14 +799,22 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
             // runs that are longer (3 % on BAM data) are finished one at a time by the whole wave, a byte per lane -- a second and third
             // lane-parallel step would cost the whole wave a full iteration each for one or two lanes' bytes
             DIAG_ADD(4, 1);
+#ifdef B_EXP_NOLIT
+            if (false) {
+#else
             if (lrun) {
+#endif
                 const uint32_t ri = lsrc & 2047u;
                 uint64_t v;
                 if (ri <= 2040u) v = lds_ld64(ring + ri);
                 else { v = 0; for (uint32_t k = 0; k < 8; k++) v |= (uint64_t)ring[(ri + k) & 2047u] << (8 * k); }
                 win_st_n(win, dst, v, lrun);
             }
+#ifdef B_EXP_NOLIT
+            uint64_t LL = 0;
+#else
             uint64_t LL = __ballot(lrun > 8u);
+#endif
             while (LL) {
                 const int i = __ffsll((unsigned long long)LL) - 1; LL &= LL - 1;
                 const uint32_t d0 = RDLANE(dst, i) + 8u, s0 = RDLANE(lsrc, i) + 8u, n0 = RDLANE(lrun, i) - 8u;
@@ -834,7 +858,11 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
                     smask = ((~0ull) >> (63u - shi)) & ((~0ull) << slo);
                 }
             }
+#ifdef B_EXP_NOROUNDS
+            uint64_t P = 0;
+#else
             uint64_t P = __ballot(mlen > 0 && !farm);
+#endif
             DIAG_T(t_b2);
             DIAG_TADD(7, t_b, t_b2);
             LZ_SYNC();                                   // far copies are in the ring before anybody reads them
@@ -877,6 +905,9 @@ __device__ __forceinline__ void lz_block(uint8_t *win, uint32_t *crct, uint8_t *
                 more = E != 0ull && (uint32_t)__popcll(P) > B_SEQ_T;
             }
             DIAG_ADD(3, __popcll(P));
+#ifdef B_EXP_NOREPLAY
+            P = 0;
+#endif
             while (P) {
                 const int i = __ffsll((unsigned long long)P) - 1; P &= P - 1;
                 const uint32_t d0 = RDLANE(md, i), l0 = RDLANE(mlen, i), di = RDLANE(mdist, i);
