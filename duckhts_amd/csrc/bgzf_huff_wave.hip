@@ -252,12 +252,17 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
     } while (0)
 #define HW_TAKE(n_) do { const uint32_t u_ = (n_); lo = hw_shr64lo(hi, lo, u_); hi >>= u_; cnt -= u_; pos += u_; } while (0)
 #define HW_PUSH_TOK(v_) do { *HW_TRING_AT(smem, lane, ntok) = (v_); ntok++; } while (0)
+#ifdef HW_EXP_NOEMIT            /* knock-out experiment: what the 16-byte stores into the lane's slice cost; the output is invalid */
+#define HW_EXP_CAP(c_) 0u
+#else
+#define HW_EXP_CAP(c_) (c_)
+#endif
 #define HW_FLUSH_TOK() do {                                                                                                                             \
-        if (tfl + 4u <= tok_cap) { const uint4 v_ = hw_tring_chunk(smem, lane, tfl); __builtin_memcpy(tok_out + tfl, &v_, 16); } else flags |= HWF_OVF;  \
+        if (tfl + 4u <= HW_EXP_CAP(tok_cap)) { const uint4 v_ = hw_tring_chunk(smem, lane, tfl); __builtin_memcpy(tok_out + tfl, &v_, 16); } else flags |= HWF_OVF;  \
         tfl += 4u;                                                                                                                                        \
     } while (0)
 #define HW_FLUSH_LIT() do {                                                                                                                             \
-        if (lfl + 16u <= lit_cap) { const uint4 v_ = hw_lring_chunk(smem, lane, lfl); __builtin_memcpy(lit_out + lfl, &v_, 16); } else flags |= HWF_OVF; \
+        if (lfl + 16u <= HW_EXP_CAP(lit_cap)) { const uint4 v_ = hw_lring_chunk(smem, lane, lfl); __builtin_memcpy(lit_out + lfl, &v_, 16); } else flags |= HWF_OVF; \
         lfl += 16u;                                                                                                                                       \
     } while (0)
     uint32_t pos = start, flags = 0;
@@ -885,7 +890,11 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
             HWD_T(t_s3); HWD_ADD(4, t_s2, t_s3);
             // ---- every lane moves its slice to its place in the block's slot ----
             W_LANES {
+#ifdef HW_EXP_NOSLICE           /* knock-out experiment: what the slice -> block area copies cost; the output is invalid */
+                if (false) {
+#else
                 if ((uint32_t)lane < n_ok) {
+#endif
                     const uint32_t *st = stok + (uint32_t)lane * HW_LANE_TOK;
                     uint32_t *dt = tok + ntok_tot + PL(o_tok);
                     for (uint32_t k = 0; k < PL(extra); k++) dt[k] = DHTS_TOK_PURE << 23;
@@ -976,7 +985,11 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
                     // (eight 16-byte pieces per lane in flight: the area was written a moment ago and comes from the caches, but every piece
                     //  is still a round trip)
                     const uint32_t tbytes = 4u * m.ntok;
+#ifdef HW_EXP_NOPOOL            /* knock-out experiment (tools/dbg/time_huff.py): what the move to the pool costs; the output is invalid */
+                    for (int part = 2; part < 2; part++) {
+#else
                     for (int part = 0; part < 2; part++) {
+#endif
                         const uint8_t *sp = part ? (const uint8_t *)wt : wl; uint8_t *dp = part ? dt : dl;
                         const uint32_t nbytes = part ? (tbytes & ~15u) : lbytes;
                         uint32_t k = 16u * (uint32_t)lane;
