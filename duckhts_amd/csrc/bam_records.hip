@@ -383,14 +383,14 @@ bgzf_sig_count(const uint8_t *d, uint64_t n, uint32_t *cnt, uint16_t *hits, uint
     if (lane == 0) { cnt[span] = w; if (w > SIG_SLOTS) atomicOr(overflow, 1u); }
 }
 extern "C" __global__ void __launch_bounds__(256)
-bgzf_sig_gather(const uint32_t *cnt, const uint32_t *base, const uint16_t *hits, int64_t nspans, uint64_t *cand) {
+bgzf_sig_gather(const uint32_t *cnt, const uint32_t *base, const uint16_t *hits, int64_t nspans, uint64_t *cand, uint64_t add) {
     const int64_t span = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (span >= nspans) return;
     const uint32_t c = cnt[span] < SIG_SLOTS ? cnt[span] : SIG_SLOTS, w = base[span];
-    for (uint32_t k = 0; k < c; k++) cand[w + k] = (uint64_t)span * 65536 + hits[span * SIG_SLOTS + k];
+    for (uint32_t k = 0; k < c; k++) cand[w + k] = add + (uint64_t)span * 65536 + hits[span * SIG_SLOTS + k];
 }
 extern "C" __global__ void __launch_bounds__(256)
-bgzf_sig_write(const uint8_t *d, uint64_t n, const uint32_t *base, uint64_t *cand) {
+bgzf_sig_write(const uint8_t *d, uint64_t n, const uint32_t *base, uint64_t *cand, uint64_t add) {
     const int lane = threadIdx.x & 63;
     int64_t span = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t b = (uint64_t)span * 65536;
@@ -402,7 +402,7 @@ bgzf_sig_write(const uint8_t *d, uint64_t n, const uint32_t *base, uint64_t *can
 #pragma unroll
         for (int k = 1; k < 64; k <<= 1) { uint32_t t = __shfl_up(inc, k, 64); if (lane >= k) inc += t; }
         uint32_t at = w + inc - c;
-        while (m) { int j = __ffs(m) - 1; m &= m - 1; cand[at++] = p + lane * 16 + j; }
+        while (m) { int j = __ffs(m) - 1; m &= m - 1; cand[at++] = add + p + lane * 16 + j; }
         w += __shfl(inc, 63, 64);
     }
 }
@@ -434,13 +434,13 @@ extern "C" __global__ void bgzf_chain_walk_seq(const uint8_t *d, uint64_t n, uin
 // partial_tail: the resident bytes are a window that stops short of the end of the file, so the last block may be cut off.  Candidates
 // whose block runs past the end of the buffer are then counted in bad[1] instead ("cut"), and must be the last ones.
 extern "C" __global__ void __launch_bounds__(256)
-bgzf_chain_check(const uint8_t *d, uint64_t n, const uint64_t *cand, int64_t ncand, uint32_t *clen, uint32_t *isize, uint32_t *bad, int partial_tail) {
+bgzf_chain_check(const uint8_t *d, uint64_t n, const uint64_t *cand, int64_t ncand, uint32_t *clen, uint32_t *isize, uint32_t *bad, int partial_tail, uint64_t first_off) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncand) return;
     uint64_t o = cand[i];
     uint32_t bl = ((uint32_t)d[o + 16] | ((uint32_t)d[o + 17] << 8)) + 1;
     bool ok = true, cut = false;
-    if (i == 0 && o != 0) ok = false;
+    if (i == 0 && o != first_off) ok = false;            // the chain starts at the top of the buffer (or, for an extension, behind the last known block)
     if (bl < 26) ok = false;
     if (o + bl > n) { if (partial_tail) cut = true; else ok = false; }
     if (ok && !cut) { if (i + 1 < ncand) ok = (cand[i + 1] == o + bl); else ok = partial_tail ? true : (o + bl == n); }

@@ -178,6 +178,7 @@ struct dhts_ctx {
     bool cache_hit = false; std::string pending_tag;       // the file's bytes came out of the pool (no read, no copy); tag to put on `comp` once staging has succeeded
     // dhts_open_path_async: the file is still arriving; the block table covers the staged prefix and grows (dhts_bgzf_index_staged)
     std::thread stager; StageProg *prog = nullptr; bool growing = false; uint64_t stage_total = 0;
+    uint64_t debug_full_len = 0; bool debug_prefix = false;     // dhts_debug_index_prefix (tests)
     // block table
     int64_t n_blocks = 0; int bgzf_status = 0;
     DevBuf coff, clen, isize, uoff, blk_status;

@@ -93,7 +93,7 @@ __device__ __forceinline__ bool vcf_bytes_equal(const uint8_t *m, const uint8_t 
         for (int k = 0; k < 8; k++) { x |= (uint64_t)m[i + k] << (8 * k); y |= (uint64_t)s[i + k] << (8 * k); }
         if (x != y) return false;
     }
-    uint32_t x = 0, y = 0;
+    uint64_t x = 0, y = 0;                                   // up to seven bytes are left (a 32-bit accumulator dropped the first of them: soak seeds 3037 / 3086)
     for (; i < l; i++) { x = (x << 8) | m[i]; y = (y << 8) | s[i]; }
     return x == y;
 }

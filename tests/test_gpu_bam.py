@@ -1005,6 +1005,56 @@ def test_whole_file_stays_resident_for_the_next_query(tmp_path):
     L.dhts_release_pools()
 
 
+def test_block_table_extended_piece_by_piece_equals_the_one_shot_table():
+    """a file that is still being staged: the block table is extended behind its last complete block (index_extend_tail) instead of being
+    rebuilt over the whole prefix -- the table at the end, and the scan that runs on it while it grows, equal those of the whole file"""
+    import ctypes as C
+    L = duckhts_amd.lib()
+    L.dhts_debug_index_prefix.argtypes = [C.c_void_p, C.c_uint64]
+    L.dhts_debug_index_prefix.restype = C.c_int64
+    L.dhts_blocks_ahead.argtypes = [C.c_void_p]
+    L.dhts_blocks_ahead.restype = C.c_int64
+    for payload, step in ((20000, 1 << 20), (65280, 3 << 20), (777, 100000)):
+        data = synth.bam_file(150000, seed=11, payload=payload)
+        exp = orc.bam_read(data)
+        ref = duckhts_amd.Context(0)
+        try:
+            ref.open(data); nb_ref = ref.bgzf_index(); table_ref = ref.bgzf_table(nb_ref)
+        finally:
+            ref.close()
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(data)
+            hdr = None; names = []; pos = []; extensions = 0; finished = False; upto = step; last_nb = 0
+            while not finished:
+                nb = L.dhts_debug_index_prefix(ctx.h, upto); extensions += 1
+                assert nb >= last_nb, duckhts_amd.last_error(ctx) if hasattr(duckhts_amd, "last_error") else nb
+                last_nb = nb
+                whole = upto >= len(data)
+                if nb > 0 and hdr is None:
+                    hdr = ctx.bam_open()
+                while hdr is not None:
+                    if not whole and L.dhts_blocks_ahead(ctx.h) < 8:
+                        break                                   # leave the last blocks: a record may run into bytes that "are not there yet"
+                    b = ctx.next_batch(5)
+                    if b.n_rows:
+                        h = ctx.batch_to_host(b, hdr)
+                        names += h["QNAME"]; pos += list(h["POS"])
+                    if b.status != 0:
+                        assert b.status == 1
+                        finished = True
+                        break
+                upto += step
+            assert extensions >= 4
+            assert names == exp["QNAME"] and pos == list(exp["POS"]), (payload, len(names), len(exp["QNAME"]))
+            table = ctx.bgzf_table(nb_ref)
+            assert table[3] == table_ref[3]
+            for a_, b_ in zip(table[:3], table_ref[:3]):
+                assert (a_ == b_).all(), payload
+        finally:
+            ctx.close()
+
+
 @pytest.mark.gpu
 def test_concurrent_contexts_in_one_process():
     """an engine runs several table functions at once (a join of two read_bam calls, a UNION of files): contexts are independent, the device /

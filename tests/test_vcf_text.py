@@ -88,6 +88,10 @@ def test_undefined_names_get_dummy_definitions():
     assert _col(t, "CHROM") == [b"chrUn_1", b"chr2", b"chrUn_2", b"chrUn_1"]          # fix_chromosome (vcf.c:3744-3761)
     assert _col(t, "FILTER") == [[b"lowq"], [b"lowq", b"other"], [b"PASS"], [b"other"]]
     assert _col(t, "INFO_DP") == [1, None, None, None] and _col(t, "INFO_AF")[3] == [0.5]
+    t3 = orc.bcf_read(dict(CASES)["undefined_names_same_tails"])
+    assert t3["n_rows"] == 11 and t3["status"] == 0
+    assert _col(t3, "CHROM") == [b"chrUn1", b"c8rUn1", b"2hrUn1", b"chrUn1", b"xbrUn", b"abrUn", b"chr_unplaced_1", b"chr_unplXced_1", b"Xhr_unplaced_1", b"c8rUn1", b"chr_unplaced_1"]
+    assert _col(t3, "FILTER")[:3] == [[b"lowq7"], [b"Xowq7"], [b"lXwq7"]]
     t2 = orc.bcf_read(dict(CASES)["undefined_names_bgzf_small_blocks"])
     assert t2["n_rows"] == 160 and _col(t2, "CHROM")[:4] == _col(t, "CHROM")
 

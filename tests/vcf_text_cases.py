@@ -116,7 +116,13 @@ def all_cases():
     """-> list of (name, file bytes)"""
     out = [("numbers_plain", text(NUMBERS)), ("numbers_bgzf", W.bgzf_file(text(NUMBERS))),
            ("fields", text(FIELDS)), ("fields_crlf_no_final_eol", text(FIELDS, eol="\r\n", last_eol=False)),
-           ("undefined_names", text(UNDEFINED)), ("undefined_names_bgzf_small_blocks", W.bgzf_file(text(UNDEFINED * 40), payload=700))]
+           ("undefined_names", text(UNDEFINED)), ("undefined_names_bgzf_small_blocks", W.bgzf_file(text(UNDEFINED * 40), payload=700)),
+           # names of 5, 6, 7, 13, 14 and 15 bytes that differ only in their FIRST bytes (the device compares names 8 bytes at a time and
+           # then the rest: soak seeds 3037 / 3086 found the rest compared through a 32-bit accumulator, i.e. by its last four bytes)
+           ("undefined_names_same_tails", text([L(chrom=c, pos=i + 1, flt=f, info=k + "=1") for i, (c, f, k) in enumerate(
+               [("chrUn1", "lowq7", "NEWKEY1"), ("c8rUn1", "Xowq7", "NxWKEY1"), ("2hrUn1", "lXwq7", "XEWKEY1"), ("chrUn1", "lowq7", "NEWKEY1"), ("xbrUn", "loXq7x", "NEWKEY1"),
+                ("abrUn", "lowq7x", "NEXKEY1"), ("chr_unplaced_1", "filter_name_15", "INFO_KEY_13_"), ("chr_unplXced_1", "fXlter_name_15", "INFO_XEY_13_"),
+                ("Xhr_unplaced_1", "filter_nXme_15", "XNFO_KEY_13_"), ("c8rUn1", "Xowq7", "NxWKEY1"), ("chr_unplaced_1", "filter_name_15", "INFO_KEY_13_")])]))]
     for name, bad in (("bad_pos", L(pos="1x")), ("bad_pos_overflow", L(pos="9223372036854775807")), ("pos_too_large_for_bcf", L(pos=2147483648)), ("too_few_columns", "chr1\t5\t.\tA\tT\t.\tPASS"),
                       ("empty_line", ""), ("undefined_contig_with_bad_name", L(chrom="a,b>")), ("empty_filter_name", L(flt="q10;;s50"))):
         out.append((name, text(FIELDS[:3] + [bad] + FIELDS[3:6])))

@@ -234,6 +234,15 @@ def main():
                 d = orc.bcf_cols_diff(exp, got)
                 if d is not None:
                     msgs.append("vcf text: " + d)
+                    if os.environ.get("SOAK_DUMP"):            # keep the input of a failing seed for tools/dbg (and say where the tables part)
+                        os.makedirs(os.environ["SOAK_DUMP"], exist_ok=True)
+                        open(os.path.join(os.environ["SOAK_DUMP"], f"vcf_seed_{seed}{'_tidy' if tidy else ''}.bin"), "wb").write(data)
+                        try:
+                            ce = orc.bcf_col_py(exp["by_name"]["CHROM"]); cg = orc.bcf_col_py(got["by_name"]["CHROM"])
+                            k = next((i for i, (a, b) in enumerate(zip(ce, cg)) if a != b), None)
+                            msgs.append(f"first CHROM difference at row {k}: oracle {ce[k] if k is not None else None} gpu {cg[k] if k is not None else None}; oracle rows {exp['n_rows']} gpu rows {got['n_rows']}")
+                        except Exception as e2:
+                            msgs.append(f"(dump: {e2})")
                 elif (got["status"] == 1) != (exp["status"] == 0):
                     msgs.append(f"vcf text status {got['status']} vs {exp['status']}")
                 if not msgs and exp["status"] == 0 and exp["n_rows"] > 0:
