@@ -281,13 +281,45 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16
     uint64_t en = NONE64; uint32_t cnt = 0; int err = 0;
     if (first != NONE64 && first < te) {
         uint64_t o = first;
-        while (o < te) {
-            uint32_t bl = 0;
-            const int rc = ((o - tb) + 64 <= (uint64_t)s.len) ? rec_hop_uniform(st, ls, o, lane, bl) : rec_hop(st, gs, o, bl);
-            if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }
-            if (rc == REC_INVALID) { err = 1; break; }
-            if (lane == 0 && cnt < TL_RECS) rl[cnt] = (uint16_t)(o - tb);
-            cnt++; o += 4ull + bl;
+        // Inside the staged window the walk runs on 32-bit offsets relative to the tile (a batch is < 2^32 bytes: ulen - tb fits; a hop
+        // is 4 + block_len < 2^31 + 4): the scalar unit has no 64-bit compare, so the 64-bit form of rec_hop_uniform spent a third of its
+        // ~75 instructions per hop moving scalars into vector registers for v_cmp_u64 (1,794 SALU + 1,019 VALU per tile, profiles/r03).
+        // Same predicates, same order of outcomes as rec_hop; a record whose core is not inside the window takes the general path.
+        {
+            uint32_t rel = (uint32_t)(first - tb);
+            const uint32_t lim = (uint32_t)(te - tb), win = s.len;
+            const uint64_t left64 = st.ulen - tb;
+            const uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;      // bytes of the stream from the tile's first byte on
+            bool general = false;
+            while (rel < lim) {
+                if (rel + 64u > win) { general = true; break; }
+                uint32_t v; __builtin_memcpy(&v, buf + rel + 4u * (uint32_t)(lane & 15), 4);      // the core as dwords across lanes 0..8
+                const int32_t b = (int32_t)__builtin_amdgcn_readlane((int)v, 0);
+                if (b < 32) { err = 1; break; }
+                // (rel + 64 <= win <= left: the core is inside the stream, so neither of rec_hop's first two "incomplete" tests can hold)
+                const int32_t l_seq = __builtin_amdgcn_readlane((int)v, 5);
+                const uint32_t l_qname = (uint32_t)__builtin_amdgcn_readlane((int)v, 3) & 0xffu, n_cigar = (uint32_t)__builtin_amdgcn_readlane((int)v, 4) & 0xffffu;
+                if (l_seq < 0 || l_qname < 1u) { err = 1; break; }
+                // n_cigar * 4 + l_qname + ceil(l_seq / 2) + l_seq < 2^18 + 2^8 + 2^30 + 2^31: no 32-bit overflow
+                const uint32_t core = (n_cigar << 2) + l_qname + (((uint32_t)l_seq + 1u) >> 1) + (uint32_t)l_seq, body = (uint32_t)b - 32u;
+                if (core > body) { err = 1; break; }
+                if (left - rel - 36u < body) { if (st.final_batch) err = 1; break; }          // incomplete (o < ulen holds: the core is inside the stream)
+                const int32_t tid = __builtin_amdgcn_readlane((int)v, 1), mtid = __builtin_amdgcn_readlane((int)v, 6);
+                if (tid >= st.n_ref || tid < -1 || mtid >= st.n_ref || mtid < -1) { err = 1; break; }
+                if (lane == 0 && cnt < TL_RECS) rl[cnt] = (uint16_t)rel;
+                cnt++; rel += 4u + (uint32_t)b;
+            }
+            o = tb + rel;
+            if (general && err == 0) {
+                while (o < te) {
+                    uint32_t bl = 0;
+                    const int rc = ((o - tb) + 64 <= (uint64_t)s.len) ? rec_hop_uniform(st, ls, o, lane, bl) : rec_hop(st, gs, o, bl);
+                    if (rc == REC_INCOMPLETE) { if (st.final_batch && o < st.ulen) err = 1; break; }
+                    if (rc == REC_INVALID) { err = 1; break; }
+                    if (lane == 0 && cnt < TL_RECS) rl[cnt] = (uint16_t)(o - tb);
+                    cnt++; o += 4ull + bl;
+                }
+            }
         }
         en = o;
     } else if (first != NONE64) en = first;
