@@ -215,6 +215,7 @@ struct BamDict {
     int32_t n_rg;
     const uint32_t *rg_off;     // n_rg+1 offsets into rg_bytes (@RG ID strings, header order, first ID wins)
     const uint8_t *rg_bytes;
+    int32_t n_bytes;            // rg_off[n_rg]
 };
 
 struct BamCols {

@@ -333,7 +333,15 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16
     for (uint32_t k = lane; k < cnt && k < TL_RECS; k += 64) tile_recs[(size_t)t * TL_RECS + k] = rl[k];
 }
 
-template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &st, const S &s, const BamDict &dict, uint64_t o, int64_t row,
+// The @RG dictionary as unpack_one reads it: in HBM (DictG), or -- when it is small, as it nearly always is -- in a copy the workgroup made
+// in LDS (DictL).  Two types with the same members so that each instantiation keeps its address space (a pointer that may be either
+// becomes a flat access, and flat accesses to LDS fault on this system).  The comparison loop is a chain of dependent byte loads per
+// record: out of HBM that was three ~600-cycle round trips per record of a file with one three-letter read group.
+struct DictG { const uint32_t *off; const uint8_t *bytes; int32_t n; };
+struct DictL { const uint32_t *off; const uint8_t *bytes; int32_t n; };
+#define RGL_N 32
+#define RGL_BYTES 256
+template <class S, class D> __device__ __forceinline__ bool unpack_one(const BamStream &st, const S &s, const D &dict, uint64_t o, int64_t row,
                                                          uint32_t *rec_off, uint8_t *rg_flag, const BamCols &c) {
     RecInfo r; const int rcv = rec_check_t(st, s, o, r, true);
     if (row < 0) return rcv == REC_OK;                      // filtered out by the region predicate: still validated (the iterator reads it)
@@ -367,11 +375,11 @@ template <class S> __device__ __forceinline__ bool unpack_one(const BamStream &s
     if (rg != NONE64 && (s.u8(rg) == 'Z' || s.u8(rg) == 'H')) {
         rgv = 1;
         rl = (uint32_t)(find_nul_t(s, rg + 1, end) - (rg + 1));      // aux_find_t proved the value is NUL-terminated inside the record
-        for (int32_t q = 0; q < dict.n_rg; q++) {
-            const uint32_t a = dict.rg_off[q], b = dict.rg_off[q + 1];
+        for (int32_t q = 0; q < dict.n; q++) {
+            const uint32_t a = dict.off[q], b = dict.off[q + 1];
             if (b - a != rl) continue;
             bool eq = true;
-            for (uint32_t j = 0; j < rl; j++) if (dict.rg_bytes[a + j] != s.u8(rg + 1 + j)) { eq = false; break; }
+            for (uint32_t j = 0; j < rl; j++) if (dict.bytes[a + j] != s.u8(rg + 1 + j)) { eq = false; break; }
             if (eq) { rgi = q; break; }
         }
         c.rg_rel[row] = (uint32_t)(rg + 1 - o);
@@ -388,6 +396,8 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
                 const uint16_t *tile_recs, const uint64_t *tile_recs_first) {
     __shared__ __attribute__((aligned(16))) uint8_t buf[TL_TILE + TL_HALO + 16];     // +16: 8-byte reads may run past the last record
     __shared__ uint32_t recs[TL_RECS];
+    __shared__ uint32_t rg_lo[RGL_N + 1];
+    __shared__ uint8_t rg_lb[RGL_BYTES];
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
     if (t >= ntiles || (uint64_t)t > res[3]) return;
@@ -397,6 +407,13 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
     const uint32_t row0 = rowbase[t];
     if ((int64_t)row0 >= nrows) return;
     const uint64_t tb = (uint64_t)t * TL_TILE;
+    const bool dict_lds = st.want_rg && dict.n_rg > 0 && dict.n_rg <= RGL_N && dict.n_bytes <= RGL_BYTES;
+    if (dict_lds) {                                             // (visible behind tile_stage's barrier)
+        for (int k = lane; k <= dict.n_rg; k += 64) rg_lo[k] = dict.rg_off[k];
+        for (int k = lane; k < dict.n_bytes; k += 64) rg_lb[k] = dict.rg_bytes[k];
+    }
+    DictG dg; dg.off = dict.rg_off; dg.bytes = dict.rg_bytes; dg.n = dict.n_rg;
+    DictL dl; dl.off = rg_lo; dl.bytes = rg_lb; dl.n = dict.n_rg;
     LSrc s; tile_stage(st, tb, buf, s, lane);
     PSrc ls; ls.l = buf; ls.base = tb;
     GSrc gs; gs.g = st.u;
@@ -420,7 +437,8 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
         // with a region filter: row_map[row] = compacted row if kept (map[row+1] > map[row]), rows are validated either way
         int64_t dst = row;
         if (row_map) dst = (row_map[row + 1] > row_map[row]) ? (int64_t)row_map[row] : -1;
-        const bool good = fast ? unpack_one(st, ls, dict, o, dst, rec_off, rg_flag, c) : unpack_one(st, gs, dict, o, dst, rec_off, rg_flag, c);
+        const bool good = fast ? (dict_lds ? unpack_one(st, ls, dl, o, dst, rec_off, rg_flag, c) : unpack_one(st, ls, dg, o, dst, rec_off, rg_flag, c))
+                               : unpack_one(st, gs, dg, o, dst, rec_off, rg_flag, c);
         if (!good) atomicMin(bad_row, (unsigned long long)row);
     }
 }
