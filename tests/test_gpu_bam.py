@@ -1005,6 +1005,30 @@ def test_whole_file_stays_resident_for_the_next_query(tmp_path):
     L.dhts_release_pools()
 
 
+def test_fused_inflate_option_in_a_child_process(tmp_path):
+    """DHTS_INFLATE=fused (one wave decodes AND resolves a block: bgzf_inflate_fused) is read once per process: a child scans a
+    multi-batch file and the golden files with it, column digests against the oracle"""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import duckhts_amd, orc
+from duckhts_amd import synth
+for d in (synth.bam_file(120000, seed=23), open(os.path.join(%r, "tests", "golden", "range.bam"), "rb").read(), synth.bam_file(3000, seed=4, payload=700)):
+    exp = orc.bam_read(d)
+    for mb in (0, 7):
+        got = duckhts_amd.read_bam(d, max_blocks=mb)
+        assert got["n_rows"] == exp["n_rows"], (got["n_rows"], exp["n_rows"])
+        for k in duckhts_amd.BAM_COLUMNS:
+            assert list(got[k]) == list(exp[k]), k
+print("fused ok")
+""" % (ROOT, ROOT, ROOT)
+    env = dict(os.environ, DHTS_INFLATE="fused")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "fused ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_block_table_extended_piece_by_piece_equals_the_one_shot_table():
     """a file that is still being staged: the block table is extended behind its last complete block (index_extend_tail) instead of being
     rebuilt over the whole prefix -- the table at the end, and the scan that runs on it while it grows, equal those of the whole file"""
