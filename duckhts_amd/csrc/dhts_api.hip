@@ -6,6 +6,7 @@
 #include "bgzf_huff_wave.hip"
 #include "bam_records.hip"
 #include "bam_tiles_lds.hip"
+#include "bam_tile_rows.hip"
 #include "bcf_records.hip"
 #include "vcf_text.hip"
 #include "bam_tags.hip"
@@ -204,6 +205,7 @@ struct dhts_ctx {
     // tiles
     DevBuf t_first, t_end, t_count, t_err, t_rowbase, d_res, d_nfixed, d_bstat, t_recs, t_recs_first;
     DevBuf t2_first, t2_end, t2_count, t2_err;      // second tile table: repair rounds are out of place
+    DevBuf t_look; int64_t rows_slots = 0, rows_hint = 0; uint64_t heap_hint[5] = {0, 0, 0, 0, 0};   // bam_tile_rows: look-back records; sizes the last batches needed (+ 1/8)
     // rows
     DevBuf c_rgflag;
     DevBuf rec_off, c_flag, c_pos, c_mapq, c_pnext, c_tlen, c_tid, c_mtid, c_rgidx, c_rgvalid;

@@ -1029,6 +1029,34 @@ print("fused ok")
     assert r.returncode == 0 and "fused ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_fused_row_pass_option_in_a_child_process(tmp_path):
+    """DHTS_ROWS=fused (bam_tile_rows: unpack + heap offsets by decoupled look-back + strings on one staging of every tile, one host
+    round trip per batch) is read once per process: a child scans multi-batch files, the golden file, long records, a projection without
+    strings and a damaged record with it -- every column against the oracle"""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import duckhts_amd, orc
+from duckhts_amd import synth
+import cases
+files = [synth.bam_file(120000, seed=23), open(os.path.join(%r, "tests", "golden", "range.bam"), "rb").read(), synth.bam_file(3000, seed=4, payload=700)]
+files += [cases.ALL_CASES[k]() for k in sorted(cases.ALL_CASES)]
+for d in files:
+    exp = orc.bam_read(d)
+    for mb in (0, 7, 2):
+        got = duckhts_amd.read_bam(d, max_blocks=mb)
+        assert got["n_rows"] == exp["n_rows"], (got["n_rows"], exp["n_rows"])
+        for k in duckhts_amd.BAM_COLUMNS:
+            assert list(got[k]) == list(exp[k]), k
+print("fused rows ok")
+""" % (ROOT, ROOT, ROOT)
+    env = dict(os.environ, DHTS_ROWS="fused")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "fused rows ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_block_table_extended_piece_by_piece_equals_the_one_shot_table():
     """a file that is still being staged: the block table is extended behind its last complete block (index_extend_tail) instead of being
     rebuilt over the whole prefix -- the table at the end, and the scan that runs on it while it grows, equal those of the whole file"""
