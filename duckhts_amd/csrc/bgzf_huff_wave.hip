@@ -143,6 +143,8 @@ W_DEV uint32_t hw_d_entry(uint32_t sym) {
 #if defined(HOSTSIM_W) && defined(HW_STATS)
 static unsigned long long g_hw_stat_p1[8], g_hw_stat_dirty, g_hw_stat_seg, g_hw_stat_fallback, g_hw_stat_p0bad, g_hw_stat_p0n, g_hw_stat_wrong, g_hw_stat_wrong_nominal;
 static unsigned long long g_hw_stat_big[8];
+// balance of the lanes of a pass: loop iterations (4 units each) of every lane; the wave pays the maximum
+static unsigned long long g_hw_it[64], g_hw_stat_itmax[2], g_hw_stat_itsum[2], g_hw_stat_units[2];
 #endif
 // -DHW_DIAG (device builds for tools/dbg/hw_diag.py): cycles per phase, summed over blocks by lane 0
 #if defined(HW_DIAG) && !defined(HOSTSIM_W)
@@ -322,7 +324,13 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
         }                                                                                                                                                 \
     } while (0)
     hw_u32x4 inq; inq.x = 0; inq.y = 0; inq.z = 0; inq.w = 0;
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+    g_hw_it[lane] = 0;
+#endif
     while (pos < stopv) {
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+        g_hw_it[lane]++;
+#endif
         // stage point: four units take at most 24 bytes (6 words) and the refill reads one word ahead: with fewer than 8 words in the ring
         // beyond widx the lane fetches its next 16 bytes and waits for them (a rare burst of long matches); otherwise it requests
         // them when the ring has a free slot (the chunks [widx / 4, gnext) are in it or on their way) and collects them four units later
@@ -373,11 +381,11 @@ W_DEV uint32_t hw_hdr_take(HwHdr &h, uint32_t n) { hw_hdr_fill(h); const uint32_
 // tokens) and described by `mres`.  `slit` / `stok` are the workgroup's staging slices.
 #ifdef HOSTSIM_W
 static void hw_block(uint8_t *smem, int64_t bi, const uint8_t *comp, BgzfTable tab,
-                     uint8_t *lit, uint32_t *tok, InflateMeta &mres, uint8_t *slit, uint32_t *stok)
+                     uint8_t *lit, uint32_t *tok, InflateMeta &mres, uint8_t *slit, uint32_t *stok, uint32_t *dens)
 #else
 __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_t *__restrict__ comp, BgzfTable tab,
                                          uint8_t *__restrict__ lit, uint32_t *__restrict__ tok, InflateMeta &mres,
-                                         uint8_t *__restrict__ slit, uint32_t *__restrict__ stok, unsigned long long *hwd)
+                                         uint8_t *__restrict__ slit, uint32_t *__restrict__ stok, unsigned long long *hwd, uint32_t &dens)
 #endif
 {
     W_LANE_DECL
@@ -741,6 +749,8 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
         // ---- symbols: segments of up to 64 bit ranges until the end-of-block symbol ----
         uint32_t p0 = hpos;
         bool eob_seen = false;
+        bool first_seg = outpos == 0u && nlit_tot == 0u && ntok_tot == 0u;      // the block's first DEFLATE block: its window starts empty
+        bool force_even = false;
         while (!eob_seen && status == 0) {
             if (p0 > limit_bits) { status = DHTS_BLK_ERR_INFLATE; break; }
             const uint32_t span = limit_bits - p0;
@@ -749,19 +759,54 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
 #if defined(HOSTSIM_W) && defined(HW_STATS)
             g_hw_stat_seg++;
 #endif
+            // ---- where the ranges are cut ----
+            // Equal BIT ranges are not equal work: a BGZF block is compressed on its own, so its first DEFLATE block starts with an empty
+            // window -- mostly literals, i.e. many short units per bit -- and the first lanes of an equal cut decode a third more units than
+            // the rest while the wave waits for them (host simulation on the bench data: 90 / 85 / 81 / 76 loop iterations in lanes 0..3
+            // against 64 in the rest).  Every lane therefore remembers how many units per bit ITS range of the previous blocks held
+            // (`dens`, units per 4,096 bits, a running mean over the blocks this wave has decoded) and the first segment of a block is cut
+            // so that the expected units are equal: lane i gets bits in proportion to 1 / dens_i.  Only the cut moves; what is decoded
+            // does not depend on it.  Later segments (the small trailing DEFLATE blocks: full window) are cut evenly.
+            PLD(uint32_t, cut0); PLD(uint32_t, cut1);                 // the lane's range [cut0, cut1) (nominal; cut1 of the last lane is never used as a stop)
+            PLD(uint32_t, syncw);                                     // bits decoded in front of cut1 for the proposal: HW_SYNC_W at the mean density, fewer where units are short
+            const bool profiled = first_seg && !force_even && S >= 1024u && nlanes == 64u;
+            bool used_profile = false;
+            {
+                PLD(uint32_t, wgt); PLD(uint32_t, cw); uint32_t wtot;
+                // (lanes that have not seen a range of their own yet -- the ones behind the first block's end-of-block symbol -- take the mean)
+                uint64_t have; W_BALLOT(have, PL(dens) != 0u);
+                const bool use = profiled && w_popc64(have) >= 32u;
+                W_LANES { PL(wgt) = (use && PL(dens) != 0u) ? (1u << 22) / (PL(dens) < 64u ? 64u : PL(dens)) : 0u; }
+                W_EXCL_SCAN(cw, wgt, wtot);
+                const uint32_t wmean = use ? wtot / w_popc64(have) : 1024u;
+                // (no range more than 1.5 times the even one: the lanes' staging slices hold four times the average, as before)
+                W_LANES { if (!use || PL(dens) == 0u) PL(wgt) = wmean; else PL(wgt) = PL(wgt) > wmean + wmean / 2u ? wmean + wmean / 2u : PL(wgt) < wmean / 2u ? wmean / 2u : PL(wgt); }
+                W_EXCL_SCAN(cw, wgt, wtot);
+                used_profile = use;
+                W_LANES {
+                    PL(cut0) = use ? p0 + (uint32_t)(((uint64_t)span * PL(cw)) / wtot) : p0 + (uint32_t)lane * S;
+                    uint32_t sw = use ? (uint32_t)(((uint64_t)HW_SYNC_W * PL(wgt)) / wmean) : HW_SYNC_W;
+                    PL(syncw) = sw < HW_SYNC_W / 2u ? HW_SYNC_W / 2u : sw > HW_SYNC_W + HW_SYNC_W / 4u ? HW_SYNC_W + HW_SYNC_W / 4u : sw;
+                }
+                W_SYNC();
+                W_LANES { xch[HX_A * 64 + lane] = PL(cut0); }
+                W_SYNC();
+                W_LANES { PL(cut1) = lane < 63 ? xch[HX_A * 64 + lane + 1] : p0 + 64u * S; if (!use) PL(cut1) = p0 + ((uint32_t)lane + 1u) * S; }
+                W_SYNC();
+            }
             // pass 0: propose the start of lane i + 1 from the last HW_SYNC_W bits of range i
             HWD_T(t_s0); HWD_CNT(8, 1);
             PLD(HwLane, ln); PLD(uint32_t, prop);
             W_LANES {
-                PL(ln).start = p0 + (uint32_t)lane * S; PL(ln).end = 0; PL(ln).flags = 0;
+                PL(ln).start = PL(cut0); PL(ln).end = 0; PL(ln).flags = 0;
                 PL(ln).nlit = 0; PL(ln).ntok = 0; PL(ln).run = 0; PL(ln).outb = 0;
-                PL(prop) = p0 + ((uint32_t)lane + 1u) * S;          // what lane i proposes for lane i + 1: the nominal boundary unless its decoder finds better
+                PL(prop) = PL(cut1);                                // what lane i proposes for lane i + 1: the nominal boundary unless its decoder finds better
             }
             W_SYNC();
             W_LANES {
                 if ((uint32_t)lane + 1u < nlanes) {
-                    const uint32_t bnd = p0 + ((uint32_t)lane + 1u) * S;
-                    const uint32_t from = bnd - p0 > HW_SYNC_W + (uint32_t)lane * S ? bnd - HW_SYNC_W : p0 + (uint32_t)lane * S;
+                    const uint32_t bnd = PL(cut1);
+                    const uint32_t from = bnd - PL(cut0) > PL(syncw) ? bnd - PL(syncw) : PL(cut0);
                     HwLane tmp;
                     hw_span<0>(smem, in32, from, bnd, limit_bits, mask_ll, mask_d, rll, rd, subbits, lane, tmp, nullptr, nullptr, 0, 0, 0);
                     if (tmp.flags == 0u) PL(prop) = tmp.end;
@@ -770,6 +815,9 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
 #endif
                 }
             }
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+            { unsigned long long mx = 0; for (int q = 0; q + 1 < (int)nlanes; q++) { g_hw_stat_itsum[0] += g_hw_it[q]; if (g_hw_it[q] > mx) mx = g_hw_it[q]; } g_hw_stat_itmax[0] += mx; for (int q = 0; q < 64; q++) g_hw_it[q] = 0; }
+#endif
             W_SYNC();
             W_LANES { xch[HX_START * 64 + lane] = PL(prop); }
             W_SYNC();
@@ -787,13 +835,18 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
 #endif
                 W_LANES {
                     if ((dirty >> lane) & 1ull) {
-                        const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? p0 + ((uint32_t)lane + 1u) * S : 0xffffffffu;   // the last lane runs to the end-of-block symbol
+                        const uint32_t bnd = (uint32_t)lane + 1u < nlanes ? PL(cut1) : 0xffffffffu;   // the last lane runs to the end-of-block symbol
                         // (lane 0 continues the literal run that is open at the start of the segment)
                         hw_span<1>(smem, in32, PL(ln).start, bnd, limit_bits, mask_ll, mask_d, rll, rd, subbits, lane, PL(ln),
                                    slit + (uint32_t)lane * HW_LANE_LIT, stok + (uint32_t)lane * HW_LANE_TOK, HW_LANE_LIT, HW_LANE_TOK, lane == 0 ? run : 0u);
                         // a range whose first unit starts at or beyond its boundary holds nothing: it ends where it starts
                     }
                 }
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+                { unsigned long long mx = 0; for (int q = 0; q < 64; q++) if ((dirty >> q) & 1ull) { g_hw_stat_itsum[1] += g_hw_it[q]; if (g_hw_it[q] > mx) mx = g_hw_it[q]; } g_hw_stat_itmax[1] += mx;
+                  if (getenv("HW_DUMP_IT") && guard == 0 && S >= 1024u && g_hw_stat_seg < 12) { printf("seg S=%u:", S); for (int q = 0; q < 64; q++) printf(" %llu", g_hw_it[q]); printf("\n"); }
+                  for (int q = 0; q < 64; q++) g_hw_it[q] = 0; }
+#endif
                 W_SYNC();
                 W_LANES { xch[HX_END * 64 + lane] = PL(ln).end; xch[HX_FLAG * 64 + lane] = PL(ln).flags; }
                 W_SYNC();
@@ -809,7 +862,7 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
                 uint64_t nd_;
                 W_BALLOT(nd_, (uint32_t)lane >= k_conf && (uint32_t)lane < nlanes && (xch[HX_FLAG * 64 + lane - 1] & (HWF_EOB | HWF_BAD)) == 0u && xch[HX_END * 64 + lane - 1] != PL(ln).start);
 #if defined(HOSTSIM_W) && defined(HW_STATS)
-                if (guard == 0) for (int lane = 1; lane < 64; lane++) if ((nd_ >> lane) & 1ull) { g_hw_stat_wrong++; if (PL(ln).start == p0 + (uint32_t)lane * S) g_hw_stat_wrong_nominal++; }
+                if (guard == 0) for (int lane = 1; lane < 64; lane++) if ((nd_ >> lane) & 1ull) { g_hw_stat_wrong++; if (PL(ln).start == PL(cut0)) g_hw_stat_wrong_nominal++; }
 #endif
                 W_LANES { if ((nd_ >> lane) & 1ull) PL(ln).start = xch[HX_END * 64 + lane - 1]; }
                 dirty = nd_;
@@ -827,6 +880,7 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
             if (!eob_seen && seg_end >= limit_bits) { status = DHTS_BLK_ERR_INFLATE; break; }     // the payload ended without an end-of-block symbol
             uint64_t ovf;
             W_BALLOT(ovf, (uint32_t)lane < n_ok && (PL(ln).flags & HWF_OVF) != 0u);
+            if (ovf && used_profile) { force_even = true; continue; }       // (an uneven cut overfilled a slice: the segment again with the even cut, nothing has been placed yet)
             if (ovf) {
                 // ---- a staging slice was too small: lane 0 decodes the whole segment and appends to the block's slot itself ----
                 HWD_CNT(10, 1);
@@ -844,11 +898,22 @@ __device__ __forceinline__ void hw_block(uint8_t *smem, int64_t bi, const uint8_
                 if (f0 != HWF_EOB || xch[HX_END * 64] != seg_end) { status = DHTS_BLK_ERR_INFLATE; break; }      // (an overflow here means more output than a block may hold)
                 if (outpos + xch[HX_START * 64] > 65536u) { status = DHTS_BLK_ERR_INFLATE; break; }
                 nlit_tot += xch[HX_A * 64]; ntok_tot += xch[HX_B * 64]; run = xch[HX_C * 64]; outpos += xch[HX_START * 64];
-                p0 = seg_end;
+                p0 = seg_end; first_seg = false;
                 W_SYNC();
                 HWD_T(t_sf); HWD_ADD(5, t_s2, t_sf);
                 continue;
             }
+            if (profiled) {
+                // what the lanes' ranges held: units per 4,096 bits, folded into the running mean (lanes beyond the end-of-block symbol keep theirs)
+                W_LANES {
+                    if ((uint32_t)lane < n_ok && PL(ln).end > PL(ln).start) {
+                        const uint32_t bits = PL(ln).end - PL(ln).start, units = PL(ln).nlit + PL(ln).ntok;
+                        const uint32_t d = (uint32_t)(((uint64_t)units << 12) / bits) + 1u;
+                        PL(dens) = PL(dens) ? (3u * PL(dens) + d + 2u) >> 2 : d;
+                    }
+                }
+            }
+            first_seg = false;
             // ---- places: exclusive sums over the lanes of the segment ----
             PLD(uint32_t, v_nlit); PLD(uint32_t, v_out); PLD(uint32_t, v_run); PLD(uint32_t, v_ntok); PLD(uint32_t, o_lit); PLD(uint32_t, o_out); PLD(uint32_t, o_run); PLD(uint32_t, o_tok);
             PLD(uint32_t, plead); PLD(uint32_t, extra); PLD(uint32_t, newrun);
@@ -965,14 +1030,15 @@ bgzf_huff_decode_wave(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t b
 #endif
     const int lane = threadIdx.x;
     uint32_t b = blockIdx.x;
+    uint32_t dens = 0;                                       // the lane's units per 4,096 bits in the blocks decoded so far (hw_block: where the ranges are cut)
     while (b < (uint32_t)nblk) {
         InflateMeta m;
         if (pool == nullptr) {
-            hw_block(smem, blk0 + (int64_t)b, comp, tab, lit_all + (size_t)b * DHTS_LIT_STRIDE, tok_all + (size_t)b * DHTS_TOK_STRIDE, m, slit, stok, hwd);
+            hw_block(smem, blk0 + (int64_t)b, comp, tab, lit_all + (size_t)b * DHTS_LIT_STRIDE, tok_all + (size_t)b * DHTS_TOK_STRIDE, m, slit, stok, hwd, dens);
         } else {
             uint8_t *wl = wg_lit + (size_t)blockIdx.x * (DHTS_LIT_STRIDE + 64u);
             uint32_t *wt = wg_tok + (size_t)blockIdx.x * DHTS_TOK_STRIDE;
-            hw_block(smem, blk0 + (int64_t)b, comp, tab, wl, wt, m, slit, stok, hwd);
+            hw_block(smem, blk0 + (int64_t)b, comp, tab, wl, wt, m, slit, stok, hwd, dens);
             HWD_T(t_p0);
             if (m.status == 0) {
                 const uint32_t lbytes = (m.nlit + 15u) & ~15u, need = lbytes + 4u * m.ntok;
@@ -1038,9 +1104,10 @@ bgzf_inflate_fused(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0
     unsigned long long *hwd = nullptr;
 #endif
     uint32_t b = blockIdx.x;
+    uint32_t dens = 0;
     while (b < (uint32_t)nblk) {
         InflateMeta m;
-        hw_block(smem, blk0 + (int64_t)b, comp, tab, lit, tok, m, slit, stok, hwd);
+        hw_block(smem, blk0 + (int64_t)b, comp, tab, lit, tok, m, slit, stok, hwd, dens);
         __syncthreads();                                       // the block's tokens and literals are stored; phase A's LDS is free
         lz_load_crc_tables((uint32_t *)(smem + B_CRCT));
         __syncthreads();

@@ -35,5 +35,5 @@ for nblk in (2048, 65536):
         L.dhts_debug_hw_diag(C.c_void_p(h), d, 1)
         v = [int(x) for x in d]
         blocks = max(v[7], 1)
-        line += " | per block (cycles): " + ", ".join(f"{n} {v[i] / blocks:.0f}" for i, n in enumerate(names[:7])) + f" | hdr: stage {v[11] / blocks:.0f} cltab {v[12] / blocks:.0f} walk {v[14] / blocks:.0f} | segments/block {v[8] / blocks:.2f} p1 rounds/block {v[9] / blocks:.2f} (sampled blocks {v[7]})"
+        line += " | per block (cycles): " + ", ".join(f"{n} {v[i] / blocks:.0f}" for i, n in enumerate(names[:7])) + f" | hdr: stage {v[11] / blocks:.0f} cltab {v[12] / blocks:.0f} walk {v[14] / blocks:.0f} | segments/block {v[8] / blocks:.2f} p1 rounds/block {v[9] / blocks:.2f} fallbacks {v[10]} (sampled blocks {v[7]})"
     print(line, flush=True)

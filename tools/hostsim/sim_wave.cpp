@@ -83,12 +83,16 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> smem(A_LDS_BYTES_FOR(A_NLO_ALL), 0); g_smem = smem.data();
             for (int lane = 0; lane < A_SL; lane++) { blockIdx.x = (unsigned)wg; threadIdx.x = (unsigned)lane; bgzf_huff_decode(d.data(), t, 0, (int32_t)nb, lit.data(), tok.data(), meta.data(), A_NLO_ALL); }
         }
-        // wave-per-block kernel
+        // wave-per-block kernel (one persistent wave takes every block: its per-lane density memory carries from block to block)
+        // SIM_WAVES=k: k persistent waves take the blocks round-robin, as the device's atomic counter would deal them
+        const int nwaves = getenv("SIM_WAVES") ? atoi(getenv("SIM_WAVES")) : 1;
+        std::vector<uint32_t> dens_all((size_t)64 * nwaves, 0u);
         for (int64_t b = 0; b < nb; b++) {
+            uint32_t *dens_w = dens_all.data() + 64 * (size_t)(b % nwaves);
             // (exact-size LDS image and staging slices: ASAN sees every overrun; the fill pattern shows reads of unwritten bytes)
             std::vector<uint8_t> smem(HW_LDS_BYTES, (uint8_t)(getenv("FILL") ? atoi(getenv("FILL")) : 0xAB));
             std::vector<uint8_t> slit(HW_STAGE_LIT_BYTES, 0xCD); std::vector<uint32_t> stok(HW_STAGE_TOK_WORDS, 0xCDCDCDCDu);
-            hw_block(smem.data(), b, d.data(), t, lit2.data() + (size_t)b * DHTS_LIT_STRIDE, tok2.data() + (size_t)b * DHTS_TOK_STRIDE, meta2[b], slit.data(), stok.data());
+            hw_block(smem.data(), b, d.data(), t, lit2.data() + (size_t)b * DHTS_LIT_STRIDE, tok2.data() + (size_t)b * DHTS_TOK_STRIDE, meta2[b], slit.data(), stok.data(), dens_w);
         }
         int bad = 0, mism = 0, differ = 0;
         for (int64_t b = 0; b < nb; b++) {
@@ -120,6 +124,7 @@ int main(int argc, char **argv) {
     printf("segments %llu; pass-1 rounds executed (by round index):", g_hw_stat_seg);
     for (int i = 0; i < 8; i++) printf(" %llu", g_hw_stat_p1[i]);
     printf("; lane-decodes in pass 1: %llu; sequential fallbacks %llu\n", g_hw_stat_dirty, g_hw_stat_fallback);
+    for (int q = 0; q < 2; q++) printf("pass %d: loop iterations (4 units each) paid by the wave (max over lanes, summed over rounds) %llu; mean over 64 lanes %.1f -> lane utilisation %.3f\n", q, g_hw_stat_itmax[q], (double)g_hw_stat_itsum[q] / 64.0, g_hw_stat_itmax[q] ? (double)g_hw_stat_itsum[q] / 64.0 / (double)g_hw_stat_itmax[q] : 0.0);
     printf("rounds of segments with ranges >= 1024 bits:"); for (int i = 0; i < 8; i++) printf(" %llu", g_hw_stat_big[i]); printf("\n");
     printf("pass 0: %llu boundary proposals, %llu ended on an invalid code (nominal boundary proposed); round 1 found %llu wrong starts, %llu of them nominal\n", g_hw_stat_p0n, g_hw_stat_p0bad, g_hw_stat_wrong, g_hw_stat_wrong_nominal);
 #endif
