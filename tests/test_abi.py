@@ -22,6 +22,23 @@ def test_library_exports_every_declared_symbol():
     assert sorted(duckhts_amd.EXPORTS) == names
 
 
+def test_library_exports_nothing_the_headers_do_not_declare():
+    """the reference hides everything but its entry point (CMakeLists.txt:92-95: C_VISIBILITY_PRESET hidden); here the dynamic symbol table
+    is exactly what include/*.h declares -- no kernel stubs, pools or helpers (linker version script made from the headers by build())"""
+    import subprocess
+    import __graft_entry__ as ge
+    declared = set(ge.declared_exports())
+    out = subprocess.run(["nm", "-D", "--defined-only", duckhts_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported, "no dynamic symbols?"
+    assert not (exported - declared), f"exported but not declared in include/: {sorted(exported - declared)}"
+    diag_only = {"dhts_debug_diag", "dhts_debug_hw_diag", "dhts_debug_tr_diag"}      # defined by -DDHTS_DIAG / -DHW_DIAG / -DTR_DIAG builds only
+    missing = {n for n in declared - exported - diag_only if n.startswith(("dhts_", "duckhts_", "register_read_", "duckdb_ext_api"))}
+    assert not missing, f"declared but not exported: {sorted(missing)}"
+    for n in ("duckhts_init_c_api", "register_read_bam_function", "register_read_bcf_function", "duckdb_ext_api"):
+        assert n in exported
+
+
 def test_abi_version_and_no_device_fails_loudly():
     L = duckhts_amd.lib()
     assert L.dhts_abi_version() == 1
