@@ -77,59 +77,70 @@ def crc_str(off, ln, data):
     return zlib.crc32(ln.tobytes()), zlib.crc32(np.ascontiguousarray(body).tobytes())
 
 
-def gpu_digest(ctx, hdr, b0, b1, speculative, max_blocks):
+class DigestAcc:
+    """running CRC-32 digests of the 13 columns in the oracle's digest layout (oracle/dhts_oracle.c orc_bam_digest); batches may come from
+    several scans (block-range shards in file order): a CRC continued over the pieces is the CRC of their concatenation"""
+
+    def __init__(self, hdr):
+        self.n = 0
+        self.crc = [0] * 32
+        sm = [x if x is not None else None for x in hdr["rg_sm"]]
+        self.smlen = np.array([len(x) if x is not None else 0 for x in sm] + [0], np.uint32)
+        self.has = np.array([1 if x is not None else 0 for x in sm] + [0], np.uint8)
+        self.flat = np.frombuffer(b"".join(x or b"" for x in sm), np.uint8)
+        self.starts = np.concatenate([[0], np.cumsum(self.smlen[:-1])]).astype(np.int64)
+        self.nsm = len(sm)
+
+    def _up(self, i, arr):
+        self.crc[i] = zlib.crc32(np.ascontiguousarray(arr).tobytes() if not isinstance(arr, (bytes, bytearray)) else arr, self.crc[i])
+
+    def add(self, ctx, b):
+        r = int(b.n_rows)
+        if not r:
+            return
+        self._up(2, ctx.d2h(b.flag, r, np.uint16)); self._up(3, ctx.d2h(b.tid, r, np.int32)); self._up(4, ctx.d2h(b.pos, r, np.int64))
+        self._up(5, ctx.d2h(b.mapq, r, np.int32)); self._up(6, ctx.d2h(b.mtid, r, np.int32)); self._up(7, ctx.d2h(b.pnext, r, np.int64)); self._up(8, ctx.d2h(b.tlen, r, np.int64))
+        rgi = ctx.d2h(b.rg_idx, r, np.int32)
+        w = ctx.d2h(b.rg_valid, (r + 63) // 64, np.uint64)
+        valid = np.unpackbits(w.view(np.uint8), bitorder="little")[:r].astype(np.uint8)
+        strs = {}
+        for k, c in (("qname", b.qname), ("cigar", b.cigar), ("seq", b.seq), ("qual", b.qual), ("rg", b.rg)):
+            off = ctx.d2h(c.off, r + 1, np.uint32); ln = ctx.d2h(c.len, r, np.uint32); data = ctx.d2h(c.bytes, int(c.nbytes), np.uint8)
+            total = int(ln.sum(dtype=np.uint64))
+            if total != int(off[-1]):        # reserved != actual somewhere (a QUAL cut at a NUL): gather the actual bytes
+                start = off[:-1].astype(np.int64); cum = np.concatenate([[0], np.cumsum(ln.astype(np.int64))])[:-1]
+                data = data[np.repeat(start - cum, ln) + np.arange(total, dtype=np.int64)]
+            strs[k] = (ln, data[:total])
+        for i, k in enumerate(("qname", "cigar", "seq", "qual")):
+            self._up(9 + 2 * i, strs[k][0]); self._up(10 + 2 * i, strs[k][1])
+        self._up(17, valid); self._up(18, (strs["rg"][0] * valid).astype(np.uint32)); self._up(19, strs["rg"][1])      # (an absent RG writes no bytes on either side)
+        # SAMPLE_ID: @RG index -> SM by the header dictionary (dictionary-coded column), NULL without RG / without SM
+        idx = np.where(rgi >= 0, rgi, self.nsm)
+        sval = valid & self.has[idx]
+        sl = self.smlen[idx] * sval
+        tot = int(sl.sum(dtype=np.uint64))
+        cum = np.concatenate([[0], np.cumsum(sl.astype(np.int64))])[:-1]
+        body = self.flat[np.repeat(self.starts[idx] - cum, sl) + np.arange(tot, dtype=np.int64)] if tot else np.zeros(0, np.uint8)
+        self._up(20, sval); self._up(21, sl.astype(np.uint32)); self._up(22, body)
+        self.n += r
+
+    def result(self, status):
+        out = list(self.crc)
+        out[0], out[1] = self.n, status & 0xffffffff
+        return out
+
+
+def gpu_digest(ctx, hdr, b0, b1, speculative, max_blocks, acc=None):
     """the oracle's digest layout (oracle/dhts_oracle.c orc_bam_digest) over the rows of blocks [b0, b1) of the resident file"""
     ctx.set_block_range(b0, b1, speculative)
-    cols = {k: [] for k in ("flag", "tid", "pos", "mapq", "mtid", "pnext", "tlen", "rgi", "valid")}
-    strs = {k: ([], []) for k in ("qname", "cigar", "seq", "qual", "rg")}
-    n = 0
+    acc = acc or DigestAcc(hdr)
     while True:
         b = ctx.next_batch(max_blocks)
-        r = int(b.n_rows)
-        if r:
-            cols["flag"].append(ctx.d2h(b.flag, r, np.uint16)); cols["tid"].append(ctx.d2h(b.tid, r, np.int32)); cols["pos"].append(ctx.d2h(b.pos, r, np.int64))
-            cols["mapq"].append(ctx.d2h(b.mapq, r, np.int32)); cols["mtid"].append(ctx.d2h(b.mtid, r, np.int32)); cols["pnext"].append(ctx.d2h(b.pnext, r, np.int64))
-            cols["tlen"].append(ctx.d2h(b.tlen, r, np.int64)); cols["rgi"].append(ctx.d2h(b.rg_idx, r, np.int32))
-            w = ctx.d2h(b.rg_valid, (r + 63) // 64, np.uint64)
-            cols["valid"].append(np.unpackbits(w.view(np.uint8), bitorder="little")[:r])
-            for k, c in (("qname", b.qname), ("cigar", b.cigar), ("seq", b.seq), ("qual", b.qual), ("rg", b.rg)):
-                off = ctx.d2h(c.off, r + 1, np.uint32); ln = ctx.d2h(c.len, r, np.uint32); data = ctx.d2h(c.bytes, int(c.nbytes), np.uint8)
-                total = int(ln.sum(dtype=np.uint64))
-                if total != int(off[-1]):
-                    start = off[:-1].astype(np.int64); cum = np.concatenate([[0], np.cumsum(ln.astype(np.int64))])[:-1]
-                    data = data[np.repeat(start - cum, ln) + np.arange(total, dtype=np.int64)]
-                strs[k][0].append(ln); strs[k][1].append(data[:total])
-            n += r
+        acc.add(ctx, b)
         if b.status != 0:
             st = 0 if b.status == 1 else int(b.status)
             break
-    cat = {k: (np.concatenate(v) if v else np.zeros(0, np.uint8)) for k, v in cols.items()}
-    out = [0] * 32
-    out[0], out[1] = n, st & 0xffffffff
-    out[2] = zlib.crc32(cat["flag"].tobytes()); out[3] = zlib.crc32(cat["tid"].tobytes()); out[4] = zlib.crc32(cat["pos"].tobytes()); out[5] = zlib.crc32(cat["mapq"].tobytes())
-    out[6] = zlib.crc32(cat["mtid"].tobytes()); out[7] = zlib.crc32(cat["pnext"].tobytes()); out[8] = zlib.crc32(cat["tlen"].tobytes())
-    for i, k in enumerate(("qname", "cigar", "seq", "qual")):
-        ln = np.concatenate(strs[k][0]) if strs[k][0] else np.zeros(0, np.uint32)
-        out[9 + 2 * i] = zlib.crc32(ln.tobytes()); out[10 + 2 * i] = zlib.crc32(b"".join(x.tobytes() for x in strs[k][1]))
-    valid = cat["valid"].astype(np.uint8)
-    ln = (np.concatenate(strs["rg"][0]) if strs["rg"][0] else np.zeros(0, np.uint32)) * valid
-    out[17] = zlib.crc32(valid.tobytes()); out[18] = zlib.crc32(ln.astype(np.uint32).tobytes())
-    # (an absent RG writes no bytes on either side)
-    out[19] = zlib.crc32(b"".join(x.tobytes() for x in strs["rg"][1]))
-    # SAMPLE_ID: @RG index -> SM by the header dictionary (dictionary-coded column), NULL without RG / without SM
-    sm = [x if x is not None else None for x in hdr["rg_sm"]]
-    smlen = np.array([len(x) if x is not None else 0 for x in sm] + [0], np.uint32)
-    has = np.array([1 if x is not None else 0 for x in sm] + [0], np.uint8)
-    idx = np.where(cat["rgi"] >= 0, cat["rgi"], len(sm))
-    sval = valid & has[idx]
-    sl = smlen[idx] * sval
-    flat = np.frombuffer(b"".join(x or b"" for x in sm), np.uint8)
-    starts = np.concatenate([[0], np.cumsum(smlen[:-1])]).astype(np.int64)
-    tot = int(sl.sum(dtype=np.uint64))
-    cum = np.concatenate([[0], np.cumsum(sl.astype(np.int64))])[:-1]
-    body = flat[np.repeat(starts[idx] - cum, sl) + np.arange(tot, dtype=np.int64)] if tot else np.zeros(0, np.uint8)
-    out[20] = zlib.crc32(sval.tobytes()); out[21] = zlib.crc32(sl.astype(np.uint32).tobytes()); out[22] = zlib.crc32(body.tobytes())
-    return out
+    return acc.result(st)
 
 
 def cpu_info():
@@ -356,7 +367,11 @@ def main():
                 "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
                 "path_frac": round(value * (C_ + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5), "per_kernel": per_kernel}
 
-        # ---- parity sample + CPU baseline on one whole segment (>= 1 % of the file), inside this run ----
+        # ---- parity over the WHOLE file + CPU baseline on one segment, inside this run ----
+        # Every one of the file's `reps` segments is a BAM of its own once the header is put in front of it (records never straddle segments),
+        # so the oracle digests them independently -- in child processes, a few at a time -- while this process takes the same rows out of the
+        # resident file segment by segment (block range of the segment, speculative start, halo) and keeps their running CRCs: all 13 columns of
+        # all records of the launch are compared with the oracle, not a sample.
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         parity, cpu = None, None
         k_s = reps // 2
@@ -368,18 +383,43 @@ def main():
                 f.seek(seg_off)
                 sample = head_b + f.read(sizes[k_s]) + EOF_BLOCK
             if not args.no_parity_sample:
-                coff, _, _, _ = ctx.bgzf_table(int(nb))
-                b0 = int(np.searchsorted(coff, seg_off)); b1 = int(np.searchsorted(coff, seg_off + sizes[k_s]))
                 t1 = time.perf_counter()
-                got = gpu_digest(ctx, hdr, b0, b1, True, 4096)
-                want = orc.bam_digest(sample)
+                worker = ("import sys, json; sys.path.insert(0, %r); import orc\n"
+                          "p, h, o, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])\n"
+                          "f = open(p, 'rb'); d = f.read(h); f.seek(o); d += f.read(n) + bytes.fromhex(%r)\n"
+                          "print(json.dumps(orc.bam_digest(d)))\n") % (os.path.join(ROOT, "tests"), EOF_BLOCK.hex())
+                segs = list(range(reps)) if not os.environ.get("DHTS_BENCH_PARITY_SEGMENTS") else list(range(reps))[:int(os.environ["DHTS_BENCH_PARITY_SEGMENTS"])]
+                nwork = max(1, min(8, ncpu // 8, len(segs)))
+                pending, running, want = list(segs), {}, {}
+                def pump(block):
+                    for k in [k for k, pr in running.items() if block or pr.poll() is not None]:
+                        pr = running.pop(k); out_, err_ = pr.communicate()
+                        assert pr.returncode == 0, f"oracle digest of segment {k} failed: {err_[-300:]}"
+                        want[k] = json.loads(out_.strip().splitlines()[-1])
+                        if block:
+                            break
+                    while pending and len(running) < nwork:
+                        k = pending.pop(0)
+                        running[k] = subprocess.Popen([sys.executable, "-c", worker, path, str(hdr_bytes), str(hdr_bytes + sum(sizes[:k])), str(sizes[k])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                pump(False)
+                coff, _, _, _ = ctx.bgzf_table(int(nb))
                 names = ["n_rows", "status", "FLAG", "RNAME(id)", "POS", "MAPQ", "RNEXT(id)", "PNEXT", "TLEN", "QNAME.len", "QNAME", "CIGAR.len", "CIGAR", "SEQ.len", "SEQ", "QUAL.len", "QUAL",
                          "RG.valid", "RG.len", "READ_GROUP_ID", "SM.valid", "SM.len", "SAMPLE_ID"]
-                bad = [names[i] for i in range(23) if got[i] != want[i]]
-                assert not bad, f"parity sample: digests differ in {bad}: gpu {got[:23]} oracle {want[:23]}"
-                parity = {"rows": got[0], "fraction_of_file": round(got[0] / n_records, 4), "columns": 13, "digest": "CRC-32 of each column's values (lengths + bytes for strings, validity for nullable ones)",
-                          "segment": k_s, "equal": True, "seconds": round(time.perf_counter() - t1, 1),
-                          "how": "rows of the segment's block range from the resident 10 GB scan (speculative start, halo) vs the oracle on header + that segment"}
+                got, rows_checked = {}, 0
+                for k in segs:
+                    o_k = hdr_bytes + sum(sizes[:k])
+                    b0 = int(np.searchsorted(coff, o_k)); b1 = int(np.searchsorted(coff, o_k + sizes[k]))
+                    got[k] = gpu_digest(ctx, hdr, b0, b1, k > 0, 4096)
+                    pump(False)
+                while pending or running:
+                    pump(True)
+                for k in segs:
+                    bad = [names[i] for i in range(23) if got[k][i] != want[k][i]]
+                    assert not bad, f"parity: segment {k}: digests differ in {bad}: gpu {got[k][:23]} oracle {want[k][:23]}"
+                    rows_checked += got[k][0]
+                parity = {"rows": rows_checked, "fraction_of_file": round(rows_checked / n_records, 4), "columns": 13, "digest": "CRC-32 of each column's values (lengths + bytes for strings, validity for nullable ones)",
+                          "segments": len(segs), "of_segments": reps, "equal": True, "seconds": round(time.perf_counter() - t1, 1), "oracle_processes": nwork,
+                          "how": "every segment's rows from the resident 10 GB scan (the segment's block range, speculative start, halo) vs the oracle on header + that segment; oracle digests in child processes"}
             if not args.no_cpu_baseline:
                 zl = orc.use_system_zlib(True)
                 modes = {}

@@ -308,6 +308,9 @@ static void producer_main(BamScan *g, Producer *p) {
         if (g->error.empty()) g->error = msg;
         p->done = true; g->cv_ready.notify_all();
     };
+    // the producer, the staging readers it starts and the pinned arenas it allocates live on the NUMA node of its GPU
+    const int numa_rc = dhts_bind_thread_near_device(p->device);
+    if (trace) fprintf(stderr, "[dhts] producer %d: device %d on NUMA node %d (%s)\n", p->rank, p->device, dhts_device_numa_node(p->device), numa_rc == 0 ? "bound" : numa_rc == 1 ? "not bound" : "bind failed");
     dhts_ctx *c = dhts_create(p->device);
     if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);                    // a scratch the device pool keeps from query to query (29 GB instead of 67 GB for a 10 GB file)
@@ -859,6 +862,7 @@ static void bcf_producer_main(BcfScan *g) {
     };
     static const bool trace = getenv("DHTS_TRACE") != nullptr;       // stage timings on stderr
     const double t_start = now_s();
+    (void)dhts_bind_thread_near_device(bind->device);          // (as read_bam's producers: thread, staging readers and pinned arenas on the GPU's NUMA node)
     dhts_ctx *c = g->ctx = dhts_create(bind->device);
     if (!c) { finish("read_bcf: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);

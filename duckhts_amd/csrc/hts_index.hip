@@ -87,7 +87,10 @@ bam_index_rows(BamStream st, const uint32_t *rec_off, BamCols c, const int32_t *
     {
         // neighbour exchange inside the wave
         p_tid = __shfl_up(tid, 1, 64); p_bin = (uint32_t)__shfl_up((int)bin, 1, 64);
-        const uint32_t pb_lo = (uint32_t)__shfl_up((int)(uint32_t)beg, 1, 64), pb_hi = (uint32_t)__shfl_up((int)(uint32_t)((uint64_t)beg >> 32), 1, 64);
+        // (hts_idx_push remembers the CLAMPED begin of a placed row -- last_coor = beg after `if (beg < 0) beg = 0`, hts.c:2591, 2620-2633 -- and
+        //  compares it with the next row's unclamped one: two placed rows with POS = 0 in a row are "unsorted" there, and here)
+        const int64_t kbeg = tid >= 0 ? cb : beg;
+        const uint32_t pb_lo = (uint32_t)__shfl_up((int)(uint32_t)kbeg, 1, 64), pb_hi = (uint32_t)__shfl_up((int)(uint32_t)((uint64_t)kbeg >> 32), 1, 64);
         p_beg = (int64_t)(((uint64_t)pb_hi << 32) | pb_lo);
         const uint32_t pe_lo = (uint32_t)__shfl_up((int)(uint32_t)e_win, 1, 64), pe_hi = (uint32_t)__shfl_up((int)(uint32_t)((uint64_t)e_win >> 32), 1, 64);
         p_e = (int64_t)(((uint64_t)pe_hi << 32) | pe_lo);
@@ -108,6 +111,7 @@ bam_index_rows(BamStream st, const uint32_t *rec_off, BamCols c, const int32_t *
                 const int64_t qb = p_beg < 0 ? 0 : p_beg, qe = pe <= 0 ? 1 : pe;
                 p_bin = idx_reg2bin(p_tid < 0 ? p_beg : qb, p_tid < 0 ? pe : qe, d.g);
                 p_e = p_tid >= 0 ? (qe - 1) >> d.g.min_shift : -1;
+                if (p_tid >= 0) p_beg = qb;
                 v_before = idx_tell(uoff, coff, nb, comp_len, out_base + rec_off[row]);
             }
         }
@@ -131,7 +135,8 @@ bam_index_rows(BamStream st, const uint32_t *rec_off, BamCols c, const int32_t *
         const int64_t b_win = cb >> d.g.min_shift;
         int64_t w0 = b_win; if (!new_tid && p_e >= w0) w0 = p_e + 1;
         const uint64_t base = d.lin_base[tid], cap = d.lin_base[tid + 1] - base;
-        if ((uint64_t)(e_win + 1) > cap) err |= IDX_ERR_LINCAP;
+        // (a row that reaches beyond the room still says how many windows its sequence needs: the host repeats the build with that room)
+        if ((uint64_t)(e_win + 1) > cap) { err |= IDX_ERR_LINCAP; atomicMax(d.max_win + tid, (uint32_t)(e_win + 1 > 0x7fffffffll ? 0x7fffffffll : e_win + 1)); }
         else {
             for (int64_t w = w0; w <= e_win; w++) atomicMin(d.lin + base + (uint64_t)w, (unsigned long long)v_before);
             if (w0 <= e_win || new_tid) atomicMax(d.max_win + tid, (uint32_t)(e_win + 1));
@@ -153,7 +158,7 @@ bam_index_rows(BamStream st, const uint32_t *rec_off, BamCols c, const int32_t *
         }
     }
     if (err) atomicOr(d.err, err);
-    if (row == nrows - 1) { IdxCarry k; k.tid = tid; k.bin = bin; k.beg = beg; k.e = e_win; k.v = v_after; k.any = 1; k.pad = 0; *d.carry_out = k; }
+    if (row == nrows - 1) { IdxCarry k; k.tid = tid; k.bin = bin; k.beg = tid >= 0 ? cb : beg; k.e = e_win; k.v = v_after; k.any = 1; k.pad = 0; *d.carry_out = k; }
 }
 // the runs of a batch, compacted: pos[] = exclusive scan of start[]
 extern "C" __global__ void __launch_bounds__(256)
@@ -179,6 +184,7 @@ struct IndexAcc {
     uint32_t n_bins() const { return (uint32_t)((((uint64_t)1 << (3 * g.n_lvls + 3)) - 1) / 7); }
     void set_csi(int ms, int lv) { csi = true; g.min_shift = ms; g.n_lvls = lv; }
     void begin(int n, uint64_t first_offset) { n_ref = n; v0 = first_offset; lin.assign(n, {}); nmap.assign(n, 0); nunmap.assign(n, 0); tid_runs.assign(n, 0); last = IdxCarry{}; last.v = first_offset; }
+    void reset_rows() { runs.clear(); n_nocoor = 0; }              // a build that starts over (begin() follows)
     void ensure_ref(int32_t tid) { if (tid >= n_ref) { n_ref = tid + 1; lin.resize(n_ref); nmap.resize(n_ref, 0); nunmap.resize(n_ref, 0); tid_runs.resize(n_ref, 0); } }
     const char *err_text(uint32_t e) const {
         if (e & IDX_ERR_MAXPOS) return csi ? "Region cannot be stored in a csi index with these parameters. Please use a larger min_shift or depth" : "Region cannot be stored in a bai index. Try using a csi index";
@@ -211,7 +217,8 @@ struct IndexAcc {
         for (int64_t i = 0; i < n; i++) {                        // neighbours: runs, order, the linear index, counts
             const bool hp = i > 0 || last.any;
             const int32_t pt = i > 0 ? tid[i - 1] : last.tid; const uint32_t pb = i > 0 ? bin[(size_t)i - 1] : last.bin;
-            const int64_t pbeg = i > 0 ? b0[(size_t)i - 1] : last.beg, pe = i > 0 ? ew[(size_t)i - 1] : last.e;
+            int64_t pbeg = i > 0 ? b0[(size_t)i - 1] : last.beg; const int64_t pe = i > 0 ? ew[(size_t)i - 1] : last.e;
+            if (pt >= 0 && pbeg < 0) pbeg = 0;                   // hts_idx_push's last_coor is the clamped begin (hts.c:2620-2633)
             const uint64_t vb = i > 0 ? vafter[i - 1] : last.v;
             const bool new_tid = !hp || pt != tid[i];
             if (hp && !new_tid && tid[i] >= 0 && pbeg > b0[(size_t)i]) e |= IDX_ERR_UNSORTED;

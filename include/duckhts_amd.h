@@ -311,6 +311,14 @@ int dhts_bcf_next_batch(dhts_ctx *, int64_t max_blocks, dhts_bcf_batch *out);
  * queued, one wait -- and fills `out` = `b` with HOST pointers for those columns (NULL for unprojected ones); tag columns, the
  * auxiliary map and the overlap lists keep their device pointers.  dhts_bam_batch_host_bytes = the room `dst` needs.
  * This is the seam a DuckDB scan callback fills DataChunks from (src/bam_reader.c:783-918 reads the same values out of bam1_t). */
+/* NUMA placement of the host side of a device (multi-GPU hosts have several sockets): the node a device hangs off (hipDeviceGetPCIBusId ->
+ * /sys/bus/pci/devices/<id>/numa_node; -1 unknown), and binding of the CALLING thread -- and of the threads it starts afterwards: a
+ * producer's staging readers -- to that node's CPUs.  Pinned buffers (dhts_host_alloc) remember the node of the thread that allocated them
+ * and are handed to threads of the same node first.  0 bound, 1 nothing to do (no NUMA information, DHTS_NUMA=0), -1 failed.
+ * The reference's reader threads (hts_set_threads, src/bam_reader.c:584, 625) are placed by the OS. */
+int dhts_device_numa_node(int device);
+int dhts_bind_thread_to_node(int node);
+int dhts_bind_thread_near_device(int device);
 void *dhts_host_alloc(uint64_t nbytes);
 void dhts_host_free(void *p);
 /* Device buffers of destroyed contexts and freed pinned buffers are kept in process-wide pools (a context per query would otherwise pay

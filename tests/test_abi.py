@@ -52,3 +52,34 @@ def test_abi_version_and_no_device_fails_loudly():
         else:
             raise AssertionError("Context() must raise without a device")
         assert b"no context" in L.dhts_error(None)
+
+
+def test_numa_binding_of_the_calling_thread():
+    """dhts_bind_thread_to_node binds the CALLING thread to the CPUs of a NUMA node (never to an empty set: the intersection with the CPUs
+    the process may use), threads started afterwards inherit it; node -1 (unknown) and DHTS_NUMA=0 leave the thread alone"""
+    import subprocess
+    import sys
+    import threading
+    L = duckhts_amd.lib()
+    assert L.dhts_bind_thread_to_node(-1) == 1
+    res = {}
+
+    def body():
+        before = os.sched_getaffinity(0)
+        rc = L.dhts_bind_thread_to_node(0)
+        after = os.sched_getaffinity(0)
+        child = {}
+        t2 = threading.Thread(target=lambda: child.setdefault("aff", os.sched_getaffinity(0))); t2.start(); t2.join()
+        res.update(rc=rc, before=before, after=after, child=child["aff"])
+    t = threading.Thread(target=body); t.start(); t.join()
+    assert res["rc"] in (0, 1)
+    assert res["after"] and res["after"] <= res["before"] and res["child"] == res["after"]
+    if res["rc"] == 0 and os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        node0 = set()
+        for part in open("/sys/devices/system/node/node0/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-"); node0 |= set(range(int(a), int(b or a) + 1))
+        assert res["after"] == (res["before"] & node0)
+    assert os.sched_getaffinity(0) == res["before"] or threading.current_thread() is not threading.main_thread()      # the caller of the test is untouched
+    code = "import sys; sys.path.insert(0, %r); import duckhts_amd; print(duckhts_amd.lib().dhts_bind_thread_to_node(0))" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, DHTS_NUMA="0"), timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "1", (r.stdout, r.stderr[-300:])

@@ -72,6 +72,45 @@ def test_packed_scratch_retry(monkeypatch):
         assert list(got[k]) == list(exp[k]), k
 
 
+@pytest.mark.parametrize("pool_per_block", [None, "2048"])
+def test_damaged_block_in_the_first_batch_of_a_speculative_shard(monkeypatch, pool_per_block):
+    """the batch driver queues the tile pass behind the inflate before the host has seen the blocks' status: a damaged block inside the
+    FIRST batch of a shard that starts mid-stream (its first record found by speculation, possibly walking bytes of the failed block) must
+    end that shard's rows in front of the damage, exactly where the sequential scan of the damaged file ends -- also when the packed
+    phase-A scratch overflows at the same time (DHTS_POOL_PER_BLOCK)"""
+    if pool_per_block:
+        monkeypatch.setenv("DHTS_POOL_PER_BLOCK", pool_per_block)
+    data = bytearray(cases.case_basic(payload=777, n=3000, seed=12))
+    p, blocks = 0, []
+    while p + 18 <= len(data):
+        bl = (data[p + 16] | (data[p + 17] << 8)) + 1
+        blocks.append((p, bl)); p += bl
+    nb = len(blocks)
+    for k in (nb * 5 // 8, nb // 2 + 1):
+        d = bytearray(data)
+        o, bl = blocks[k]
+        d[o + 18 + (bl - 26) // 2] ^= 0x55                           # a payload byte in the middle of the block
+        d = bytes(d)
+        exp = orc.bam_read(d)
+        assert 0 < exp["n_rows"] < 3000
+        names = []
+        for rank in range(2):
+            ctx = duckhts_amd.Context(0)
+            try:
+                ctx.open(d); ctx.bgzf_index(); ctx.bam_open()
+                ctx.set_block_range(0 if rank == 0 else nb // 2, nb // 2 if rank == 0 else nb, rank > 0)
+                status = 0
+                while status == 0:
+                    b = ctx.next_batch(0)                           # the whole shard in one (first) batch
+                    if b.n_rows:
+                        names += ctx.strings(b.qname, int(b.n_rows))
+                    status = int(b.status)
+                assert (status == 1) if rank == 0 else (status < 0), (rank, status)
+            finally:
+                ctx.close()
+        assert names == list(exp["QNAME"]), (k, len(names), exp["n_rows"])
+
+
 @pytest.mark.parametrize("case", ["basic", "basic_small_blocks", "basic_tiny_blocks", "basic_stored", "basic_level1",
                                   "basic_level9", "fixed_huffman", "long_record", "empty_blocks"])
 def test_bgzf_inflate_cases(case):
@@ -428,6 +467,43 @@ def test_index_writer_and_join_edge_cases():
             ctx.build_index()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_index_writer_follows_hts_idx_push_on_pos_zero_and_on_understated_lengths():
+    """(a) hts_idx_push remembers the CLAMPED begin of a placed record (POS 0 = begin -1 is stored as 0) and compares it with the next
+    record's unclamped begin: two placed records with POS 0 in a row are "Unsorted positions" (hts.c:2591, 2620-2633); one followed by POS 1
+    is fine.  (b) htslib grows a sequence's linear index on demand: a header whose LN understates the sequence does not stop the build,
+    and the index equals the one built with the right length."""
+    import bamwriter as bw
+    hdr = "@HD\tVN:1.6\n@SQ\tSN:a\tLN:1000\n"
+    two_zero = bw.bam_bytes([("a", 1000)], [bw.record(qname="x", tid=0, pos=-1, cigar="4M", seq="ACGT"), bw.record(qname="y", tid=0, pos=-1, cigar="4M", seq="ACGT")], text=hdr)
+    zero_one = bw.bam_bytes([("a", 1000)], [bw.record(qname="x", tid=0, pos=-1, cigar="4M", seq="ACGT"), bw.record(qname="y", tid=0, pos=0, cigar="4M", seq="ACGT")], text=hdr)
+    for data, ok in ((two_zero, False), (zero_one, True)):
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(data); ctx.bgzf_index(); ctx.bam_open()
+            if ok:
+                refs, nnc = _parse_bai(ctx.build_index())
+                assert nnc == 0 and len(refs) == 1
+            else:
+                with pytest.raises(duckhts_amd.DhtsError, match="Unsorted"):
+                    ctx.build_index()
+        finally:
+            ctx.close()
+    recs = [bw.record(qname=f"r{i}", tid=0, pos=p, cigar="50M", seq="A" * 50) for i, p in enumerate((10, 900, 5_000_000, 5_000_020, 40_000_000))]
+    built = []
+    for ln in (1000, 50_000_000):
+        data = bw.bam_bytes([("a", ln)], recs, text=f"@HD\tVN:1.6\n@SQ\tSN:a\tLN:{ln}\n")
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(data); ctx.bgzf_index(); ctx.bam_open()
+            built.append(_parse_bai(ctx.build_index()))
+            # the scan is usable afterwards (rewound on every exit)
+            assert ctx.next_batch(0).n_rows == 5
+        finally:
+            ctx.close()
+    assert built[0] == built[1] and len(built[0][0][0][1]) >= 40_000_000 >> 14
 
 
 # ---- a wrong ISIZE ends the stream at that block (documented deviation: htslib never looks at ISIZE) --------------------------

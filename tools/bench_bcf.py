@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--target-gb", type=float, default=1.0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--max-blocks", type=int, default=4096)
+    ap.add_argument("--max-blocks", type=int, default=24576, help="BGZF blocks per batch (profiles/r04/bcf/bcf_batch_size_*.jsonl: count(*) 17.4 / 16.8 / 16.0 ms with 4,096 / 8,192 / 24,576)")
     ap.add_argument("--queries", default="count,core,info6,format96,all,tidy")
     ap.add_argument("--cpu-sample-records", type=int, default=100_000)
     args = ap.parse_args()
@@ -56,13 +56,20 @@ def main():
                 "format96": [n for n in names if n.startswith("FORMAT_")], "all": names, "tidy": names}[q]
         sc.set_projection(proj)
 
+        import ctypes as C
+        ctx.L.dhts_bcf_batch_host_bytes.restype = C.c_uint64
+        ctx.L.dhts_bcf_batch_host_bytes.argtypes = [C.c_void_p]
+        outb = [0]
+
         def step():
             ctx.bgzf_index()
             sc.rewind()
-            rows = 0
+            rows = 0; outb[0] = 0
             while True:
                 b = sc.next_batch(args.max_blocks)
                 rows += b.n_rows
+                if b.n_rows:
+                    outb[0] += int(ctx.L.dhts_bcf_batch_host_bytes(ctx.h))        # bytes of the batch's projected columns (validity, payloads, offsets, children)
                 if b.status != 0:
                     if b.status < 0:
                         raise RuntimeError(f"scan ended with status {b.status}")
@@ -80,12 +87,27 @@ def main():
         want = n_records * (16 if q == "tidy" else 1)
         assert rows == want, (rows, want)
         kt = {k: {"ms_per_step": round(v[0] / args.steps, 3), "launches_per_step": v[1] // args.steps} for k, v in ctx.kernel_times().items() if v[1]}
+        # roofline of the query: B_alg = C + 2 U + O_cols -- compressed bytes read, inflated bytes written by the inflate and read by
+        # the record stage, projected columns written; per-kernel entries from the HIP-event times of the same run (every kernel alone on the stream)
+        PEAK = 8000.0
+        kms = {k: v["ms_per_step"] for k, v in kt.items()}
+        def pk(nbytes, ms):
+            return {"bytes_per_step": int(nbytes), "ms_per_step": round(ms, 3), "achieved": round(nbytes / ms / 1e6, 2) if ms > 0 else None, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / PEAK, 5) if ms > 0 else None}
+        infl = kms.get("huff_decode", 0.0) + kms.get("lz_resolve", 0.0)
+        rec = kms.get("tiles", 0.0) + kms.get("bcf_check", 0.0)
+        cells = kms.get("bcf_measure", 0.0) + kms.get("scan", 0.0) + kms.get("bcf_write", 0.0)
+        b_alg = file_bytes + 2 * raw_bytes + outb[0]
+        roofline = {"bound": "hbm", "peak": PEAK, "unit": "GB/s", "bytes_per_step": int(b_alg), "bytes": "C + 2 U + O_cols", "achieved": round(b_alg / dt / 1e9, 2), "frac": round(b_alg / dt / 1e9 / PEAK, 5),
+                    "device_ms_per_step": round(sum(kms.values()), 3), "wall_ms_per_step": round(dt * 1e3, 3),
+                    "per_kernel": {"inflate": dict(pk(file_bytes + raw_bytes, infl), kernels="bgzf_huff_decode_wave + bgzf_lz_resolve", bytes="C + U"),
+                                   "boundary+check": dict(pk(raw_bytes + 4.0 * n_records, rec), kernels="bcf_tile_scan + bcf_tile_fix + bam_tile_finalize + bcf_tile_offsets + bcf_rec_check", bytes="U + directory"),
+                                   "cells": dict(pk(raw_bytes + outb[0], cells), kernels="bcf_cells<measure> + mscan_* + bcf_cells<write>", bytes="U + O_cols")}}
         print(json.dumps({"metric": "read_bcf_records_per_sec", "query": q, "value": round(n_records / dt, 1), "unit": "records/s", "rows_per_s": round(rows / dt, 1),
                           "ms_per_step": round(dt * 1e3, 2), "bgzf_GBps": round(file_bytes / dt / 1e9, 3), "projected_columns": len(proj),
                           "config": {"workload": f"read_bcf, synthetic {file_bytes / 1e9:.2f} GB BCF ({reps} x {n_u} records, 16 samples, zlib-6), inputs resident in HBM",
                                      "records": n_records, "bgzf_blocks": int(nb), "compressed_bytes_per_record": round(file_bytes / n_records, 1),
                                      "inflated_bytes_per_record": round(raw_bytes / n_records, 1), "batch_blocks": args.max_blocks},
-                          "kernels": kt, "cpu_baseline": cpu if q == "all" else None}), flush=True)
+                          "kernels": kt, "roofline": roofline, "output_bytes_per_record": round(outb[0] / n_records, 1), "cpu_baseline": cpu if q == "all" else None}), flush=True)
         ctx.close()
 
 
