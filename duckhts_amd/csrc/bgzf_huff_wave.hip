@@ -323,10 +323,91 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
             }                                                                                                                                             \
         }                                                                                                                                                 \
     } while (0)
-    hw_u32x4 inq; inq.x = 0; inq.y = 0; inq.z = 0; inq.w = 0;
 #if defined(HOSTSIM_W) && defined(HW_STATS)
     g_hw_it[lane] = 0;
 #endif
+#ifdef HW_PER_SYMBOL           /* (not the default: measured slower, see below) */
+    // ONE SYMBOL per step, the same instructions for both alphabets (round 4).  A lane is either in front of a literal / length code or -- `ind`
+    // -- in front of the distance code of the length it has just read; the two cases differ in the table they index, in two field widths
+    // and in what the value means, all of which are selects, not branches.  A unit-per-step loop made every lane walk through the distance
+    // half in every step because SOME lane of 64 always holds a length (a third of the units are matches), although two thirds of the
+    // lanes had nothing to do there.  A range still ends between units: a lane that has read a length goes on to its distance whatever
+    // `stopv` says.  MEASURED AND NOT USED (profiles/r04/pmc_sq_per_unit_vs_per_symbol.txt, huff_per_unit_vs_per_symbol.txt): the
+    // symbol step costs ~93 wave-instructions as compiled, a unit step ~110, and a unit is 1.33 symbols: 80.0 k instead of 70.8 k
+    // wave-instructions per BGZF block, 10.1 instead of 9.0 ms per 65,536 blocks.  It would need < 83 per step to pay.  Kept because it is
+    // exact (host simulation, word for word the lane kernel's output) and is the shape a hand-scheduled version would start from.
+    // (`ind` is kept as 0 / 1 in a vector register and the bookkeeping is arithmetic on it: a bool makes the compiler juggle lane masks on the
+    //  scalar unit, and scalar instructions take the same issue slots)
+    uint32_t ind = 0, want3p = 0;                             // want3p = (length - 3) + 3 of the pending match
+#define HW_SYM() do {                                                                                                                                 \
+        if (pos < stopv || ind != 0u) {                                                                                                                   \
+            HW_REFILL();                                                                                                                                  \
+            const uint32_t a_ll = (lo & mask_ll) << 1, a_d = HW_OFF_D + ((lo & mask_d) << 2);                                                              \
+            uint32_t e; __builtin_memcpy(&e, smem + (ind ? a_d : a_ll), 4);   /* (a literal/length entry is the low half: the fields below never look higher) */ \
+            if (HW_ANY((e & 15u) == 0u)) {                                                                                                                \
+                if ((e & 15u) == 0u) {                                                                                                                    \
+                    if (ind) e = !(e & HW_LONG) ? 0u : hw_long_code(smem, lo, 1u, rd);                                                                    \
+                    else if (e & 0x20u) e = ((const uint16_t *)(smem + HW_OFF_SUB))[(((e & 0xffffu) >> 6) << subbits) + hw_bfe(lo, rll, subbits)];          \
+                    else e = (e & HW_LONG) ? hw_long_code(smem, lo, 0u, rll) : 0u;                                                                        \
+                    if ((e & 15u) == 0u) { flags |= HWF_BAD; stopv = 0; e = 0x0001u; ind = 0u; }                                                          \
+                }                                                                                                                                         \
+            }                                                                                                                                             \
+            const uint32_t L = e & 15u, x = hw_bfe(e, 4u, 3u + ind);                                                                                      \
+            const uint32_t k8 = 8u << ind, val = hw_bfe(e, k8, k8) + hw_bfe(lo, L, x);   /* literal byte | length - 3 | distance - 1 (an end-of-block entry asks for 7 bits: given back below) */ \
+            const uint32_t lenb = hw_bfe(e, 7u, 1u) & ~ind;            /* 1: a length code (or the end of the block) */                                     \
+            const uint32_t litv = (lenb | ind) ^ 1u;                   /* 1: a literal */                                                                  \
+            HW_TAKE(L + x);                                                                                                                               \
+            if (PASS == 1) {                                                                                                                              \
+                /* both rings are written every time; a cursor moves only when the symbol was what the ring holds */                                      \
+                *HW_LRING_AT(smem, lane, nlit) = (uint8_t)val;                                                                                            \
+                nlit += litv; run += litv;                                                                                                                \
+                *HW_TRING_AT(smem, lane, ntok) = (run << 23) | ((want3p - 3u) << 15) | val;                                                               \
+                mbytes += ind * want3p;                                                                                                                   \
+            }                                                                                                                                             \
+            /* the rare cases in one test: the end of the block, and (pass 1) a match behind 511 literals or more, whose token was not right */           \
+            if (HW_ANY((lenb != 0u && (e & 0x70u) == 0x70u) || (PASS == 1 && ind != 0u && run >= DHTS_TOK_PURE))) {                                        \
+                if (lenb != 0u && (e & 0x70u) == 0x70u) { flags |= HWF_EOB; stopv = 0; pos -= 7u; }                                                       \
+                else if (PASS == 1 && ind != 0u && run >= DHTS_TOK_PURE) {                                                                                \
+                    while (run >= DHTS_TOK_PURE) {                 /* "511 literals, no match" tokens in front of the match's own */                      \
+                        HW_PUSH_TOK(DHTS_TOK_PURE << 23); run -= DHTS_TOK_PURE;                                                                           \
+                        if (ntok - tfl >= 4u) HW_FLUSH_TOK();                                                                                             \
+                    }                                                                                                                                     \
+                    *HW_TRING_AT(smem, lane, ntok) = (run << 23) | ((want3p - 3u) << 15) | val;                                                           \
+                }                                                                                                                                         \
+            }                                                                                                                                             \
+            if (PASS == 1) { ntok += ind; run &= ind - 1u; }                                                                                              \
+            want3p = lenb ? val + 3u : want3p;                                                                                                            \
+            ind = lenb & (flags ^ HWF_EOB);                            /* (bit 0 of flags is HWF_EOB: a lane that has just seen it has no distance to read) */ \
+        }                                                                                                                                                 \
+    } while (0)
+    hw_u32x4 inq; inq.x = 0; inq.y = 0; inq.z = 0; inq.w = 0;
+    while (pos < stopv || ind != 0u) {
+#if defined(HOSTSIM_W) && defined(HW_STATS)
+        g_hw_it[lane]++;
+#endif
+        // stage points as in the per-unit loop below: six symbols take at most 21 bytes
+        if (wcommit - widx < 8u) {
+            const uint32_t *gp = in32 + 4u * gnext; hw_u32x4 now; HW_LOAD16(now, gp); HW_LOAD16_WAIT(now);
+            *HW_IRING_AT(smem, lane, 4u * gnext) = now.x; *HW_IRING_AT(smem, lane, 4u * gnext + 1u) = now.y; *HW_IRING_AT(smem, lane, 4u * gnext + 2u) = now.z; *HW_IRING_AT(smem, lane, 4u * gnext + 3u) = now.w;
+            gnext++; wcommit += 4u;
+        }
+        const bool req = gnext - (widx >> 2) < 4u;
+        if (req) { const uint32_t *gp = in32 + 4u * gnext; HW_LOAD16(inq, gp); }
+        HW_SYM(); HW_SYM(); HW_SYM(); HW_SYM(); HW_SYM(); HW_SYM();
+        HW_LOAD16_WAIT(inq);
+        if (req) {
+            *HW_IRING_AT(smem, lane, 4u * gnext) = inq.x; *HW_IRING_AT(smem, lane, 4u * gnext + 1u) = inq.y; *HW_IRING_AT(smem, lane, 4u * gnext + 2u) = inq.z; *HW_IRING_AT(smem, lane, 4u * gnext + 3u) = inq.w;
+            gnext++; wcommit += 4u;
+        }
+        if (PASS == 1) {
+            // at most three new tokens and six new literals since the last stage point (a match with a very long literal run flushes for itself)
+            if (ntok - tfl >= 4u) HW_FLUSH_TOK();
+            if (nlit - lfl >= 16u) HW_FLUSH_LIT();
+        }
+    }
+#undef HW_SYM
+#else
+    hw_u32x4 inq; inq.x = 0; inq.y = 0; inq.z = 0; inq.w = 0;
     while (pos < stopv) {
 #if defined(HOSTSIM_W) && defined(HW_STATS)
         g_hw_it[lane]++;
@@ -354,6 +435,7 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
             if (nlit - lfl >= 16u) HW_FLUSH_LIT();
         }
     }
+#endif
     if (!(flags & HWF_EOB) && pos > limit_bits) flags |= HWF_BAD;            // ran off the payload (a true stream ends with its end-of-block symbol)
     if (PASS == 1) {
         // what is still in the rings: whole pieces first, then single entries (nothing is ever stored beyond the lane's counts)

@@ -116,5 +116,31 @@ def main():
                                   "first_query_s": round(runs[0], 3), "warm_query_s": round(warm, 4), "records_per_s": round(rows / warm, 1), "bgzf_GBps": round(size / warm / 1e9, 3)}), flush=True)
 
 
+def main_producers():
+    """host-side contention of several producers in one process: DHTS_DEVICES=0,0,..,0 runs k producers -- each with its
+    own context, staging threads, pinned arenas and byte window of ONE file -- against a single GPU, so what changes with k is the HOST side:
+    fill threads, pinned-pool mutex, page-cache reads.  Fixed-width columns (the device is not the limit) and all 13 columns, file resident
+    in the page cache, DHTS_FILE_CACHE=0 (every query stages its windows again)."""
+    n = int(os.environ.get("N_RECORDS", "8000000"))
+    d = tempfile.mkdtemp(prefix="dhts_prod_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    bam = os.path.join(d, "p.bam"); synth.bam_segment(n, seed=11)[0].tofile(bam)
+    size = os.path.getsize(bam)
+    try:
+        for cols, proj in (("fixed-width", [1, 3, 4, 7, 8]), ("all 13", None)):
+            for k in (1, 2, 4, 8):
+                for thr in (8, 16, 32):
+                    env = {"DHTS_DEVICES": ",".join(["0"] * k), "DHTS_THREADS": str(thr), "DHTS_FILE_CACHE": "0"}
+                    rows, dt, runs = run("read_bam", bam, proj=proj, threads=thr, repeat=4, env=env)
+                    assert rows == n, (rows, n)
+                    best = min(runs[1:])
+                    print(json.dumps({"producers_on_one_gpu": k, "DHTS_THREADS": thr, "columns": cols, "records_per_s": round(n / best, 1), "seconds": round(best, 4),
+                                      "GBps_bgzf": round(size / best / 1e9, 2), "records": n, "file_bytes": size, "nproc": len(os.sched_getaffinity(0))}), flush=True)
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "producers":
+        main_producers(); sys.exit(0)
     main()
