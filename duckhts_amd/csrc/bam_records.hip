@@ -238,14 +238,17 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 
 // ---- generic multi-array exclusive scan (u32 in; u32 or u64 out), 3 launches for up to 8 arrays at once ----
 #define SCAN_ITEMS 4096     /* per workgroup: 256 threads x 16 */
-struct ScanArgs { const uint32_t *in[8]; uint32_t *out32[8]; uint64_t *out64[8]; uint64_t *partial[8]; uint64_t *total[8]; int64_t n; int narr; };
+struct ScanArgs { const uint32_t *in[8]; uint32_t *out32[8]; uint64_t *out64[8]; uint64_t *partial[8]; uint64_t *total[8]; int64_t n; int narr;
+                  const unsigned long long *n_dev; };   // n_dev: the element count lives on the device (at most n, the launch's size): a batch whose row count the host has not seen
+__device__ __forceinline__ int64_t scan_n(const ScanArgs &a) { if (!a.n_dev) return a.n; const int64_t d = (int64_t)*a.n_dev; return d < a.n ? d : a.n; }
 
 extern "C" __global__ void __launch_bounds__(256) scan_reduce(ScanArgs a) {
     __shared__ uint32_t sh[256];
     const int arr = blockIdx.y; const uint32_t *in = a.in[arr];
     int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS;
+    const int64_t n = scan_n(a);
     uint32_t s = 0;
-    for (int k = 0; k < 16; k++) { int64_t i = base + k * 256 + threadIdx.x; if (i < a.n) s += in[i]; }
+    for (int k = 0; k < 16; k++) { int64_t i = base + k * 256 + threadIdx.x; if (i < n) s += in[i]; }
     sh[threadIdx.x] = s; __syncthreads();
     for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
     if (threadIdx.x == 0) a.partial[arr][blockIdx.x] = sh[0];
@@ -271,16 +274,17 @@ extern "C" __global__ void __launch_bounds__(256) scan_apply(ScanArgs a) {
     __shared__ uint32_t sh[256];
     const int arr = blockIdx.y; const uint32_t *in = a.in[arr]; uint32_t *o32 = a.out32[arr]; uint64_t *o64 = a.out64[arr];
     int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS + (int64_t)threadIdx.x * 16;
+    const int64_t n = scan_n(a);
     uint32_t v[16]; uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { int64_t i = base + k; v[k] = i < a.n ? in[i] : 0; s += v[k]; }
+    for (int k = 0; k < 16; k++) { int64_t i = base + k; v[k] = i < n ? in[i] : 0; s += v[k]; }
     sh[threadIdx.x] = s; __syncthreads();
     for (int d = 1; d < 256; d <<= 1) { uint32_t t = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
     uint64_t run = a.partial[arr][blockIdx.x] + sh[threadIdx.x] - s;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         int64_t i = base + k;
-        if (i <= a.n) { if (o32) o32[i] = (uint32_t)run; if (o64) o64[i] = run; }     // i == n writes the total (off[n])
+        if (i <= n) { if (o32) o32[i] = (uint32_t)run; if (o64) o64[i] = run; }     // i == n writes the total (off[n])
         run += v[k];
     }
 }

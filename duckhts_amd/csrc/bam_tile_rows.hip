@@ -26,10 +26,6 @@
 #define TR_ST_INCL 2u                    /* value = bytes of tiles 0..t (inclusive prefix) */
 #define TR_LOOK_STRIDE 8u                /* u64 words per tile (five used: one 64-byte line per tile) */
 #define TR_LOOK_HDR 8u                   /* u64 words in front of the granules: word 0 = the ticket counter */
-// flags in res[14]
-#define TR_F_ROWS 1ull                   /* the row arrays are too small for this batch */
-#define TR_F_HEAP 2ull                   /* a string arena is too small */
-#define TR_F_TIMEOUT 4ull                /* look-back wait expired (internal error) */
 
 struct RowsCaps { uint64_t heap[5]; int64_t rows; };     // heap order: QNAME, CIGAR, SEQ, QUAL, READ_GROUP_ID
 struct RowsStr { uint32_t *off[5]; uint8_t *heap[5]; uint32_t *alen_qual, *seq_chars; };

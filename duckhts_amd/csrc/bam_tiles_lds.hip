@@ -14,6 +14,10 @@
 #endif
 #define TL_RECS (TL_TILE / 32u)            /* >= records per tile (36-byte minimum for BAM, 32 for BCF) */
 #define TL_HALO 1024u
+// flags in res[14] of a batch whose rows are queued without the host in between (dhts_bam_scan.inc: rows_queue)
+#define TR_F_ROWS 1ull                   /* the row arrays are too small for this batch */
+#define TR_F_HEAP 2ull                   /* a string arena is too small */
+#define TR_F_TIMEOUT 4ull                /* look-back wait expired (bam_tile_rows; internal error) */
 
 // global-memory accessor (records that do not fit the staged window)
 struct GSrc {
@@ -401,6 +405,12 @@ bam_tile_unpack(BamStream st, BamDict dict, int64_t ntiles, TileOut out, const u
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
     if (t >= ntiles || (uint64_t)t > res[3]) return;
+    // nrows < 0: the host has not seen the row count yet (the batch runs without a round trip in between): it is res[0], and the row arrays
+    // hold -nrows - 1 rows (sized from the previous batches); a batch that needs more raises TR_F_ROWS in res[14] and writes nothing
+    if (nrows < 0) {
+        const int64_t cap = -nrows - 1; nrows = (int64_t)res[0];
+        if (nrows > cap) { if (t == 0 && lane == 0) atomicOr((unsigned long long *)res + 14, TR_F_ROWS); return; }
+    }
     const uint64_t first = out.first[t];
     const uint32_t n = out.count[t];
     if (first == NONE64 || n == 0) return;
@@ -508,6 +518,10 @@ bam_tile_strings(BamStream st, int64_t ntiles, TileOut out, const uint32_t *rowb
     const bool w0 = tid < 64;
     const int64_t t = blockIdx.x;
     if (t >= ntiles || (uint64_t)t > res[3]) return;
+    if (nrows_all < 0) {          // the row count is on the device (see bam_tile_unpack); rows_guard has said whether everything fits
+        if (res[14] & (TR_F_ROWS | TR_F_HEAP)) return;
+        nrows_all = nrows = (int64_t)res[0];
+    }
     const uint32_t n = out.count[t];
     if (out.first[t] == NONE64 || n == 0) return;
     const int64_t row0 = rowbase[t];
@@ -630,6 +644,20 @@ bam_pack_validity(const uint8_t *flag, int64_t nrows, uint64_t *words) {
     if ((threadIdx.x & 63) == 0 && row < nrows) words[row >> 6] = m;
 }
 
+
+// behind the string scans of a batch whose sizes the host has not seen: heap totals against the arenas' room, the batch's first record
+//   res[8..12] = heap bytes (QNAME, CIGAR, SEQ, QUAL, READ_GROUP_ID), res[13] = offset of the first record, res[14] |= TR_F_HEAP
+struct HeapCaps { uint64_t cap[5]; };
+extern "C" __global__ void __launch_bounds__(64)
+bam_rows_guard(unsigned long long *res, const uint64_t *scan_total, HeapCaps caps, const uint32_t *rec_off, int strings) {
+    const int k = threadIdx.x;
+    if (k == 0) res[13] = res[0] > 0 && !(res[14] & TR_F_ROWS) ? (unsigned long long)rec_off[0] : 0ull;
+    if (strings && k < 5) {
+        const unsigned long long t = scan_total[k];
+        res[8 + k] = t;
+        if (caps.cap[k] != ~0ull && t > caps.cap[k]) atomicOr(res + 14, TR_F_HEAP);
+    }
+}
 
 // ---- region predicate -----------------------------------------------------------------------------------
 // keep[row] = 1 iff the record overlaps one of the merged query intervals of its reference:
