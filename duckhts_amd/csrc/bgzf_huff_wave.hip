@@ -273,11 +273,10 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
     // a lane that decodes garbage (wrong start, damaged stream) stops at the end of the payload at the latest; a lane that has seen the
     // end-of-block symbol or an invalid code stops by pulling its limit down to zero
     uint32_t stopv = stop < limit_bits + 64u ? stop : limit_bits + 64u;
-    // ONE unit
-#define HW_UNIT() do {                                                                                                                                \
-        if (pos < stopv) {                                                                                                                                \
+    // one literal / length symbol: entry, fields, the literal ring (pass 1), the bits taken, the end of the block
+#define HW_LL() do {                                                                                                                                  \
             HW_REFILL();                                                                                                                                  \
-            uint32_t e = lut_ll[lo & mask_ll];                                                                                                            \
+            e = lut_ll[lo & mask_ll];                                                                                                                     \
             if (HW_ANY((e & 15u) == 0u)) {                                                                                                                \
                 if ((e & 15u) == 0u) {                                                                                                                    \
                     /* a code longer than the root: second-level table (number in the entry, index = the next stream bits), else canonical arithmetic */\
@@ -287,16 +286,30 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
                 }                                                                                                                                         \
             }                                                                                                                                             \
             const uint32_t L = e & 15u, x = (e >> 4) & 7u;                                                                                                \
-            const uint32_t ext = hw_bfe(lo, L, x);               /* (the end-of-block entry asks for 7 bits: given back below) */                         \
-            const uint32_t islen_m = (uint32_t)((int32_t)(e << 24) >> 31);     /* all ones for a length code / end of block */                          \
+            ext = hw_bfe(lo, L, x);                               /* (the end-of-block entry asks for 7 bits: given back below) */                         \
+            islen_m = (uint32_t)((int32_t)(e << 24) >> 31);       /* all ones for a length code / end of block */                                         \
             if (PASS == 1) {                                                                                                                              \
                 /* the literal ring is written every time; its cursor moves only when the symbol was a literal */                                         \
                 *HW_LRING_AT(smem, lane, nlit) = (uint8_t)(e >> 8);                                                                                       \
                 nlit += 1u + islen_m; run += 1u + islen_m;                                                                                                \
             }                                                                                                                                             \
             HW_TAKE(L + x);                                                                                                                               \
-            const bool iseob = (e & 0xf0u) == 0xf0u;                                                                                                      \
+            iseob = (e & 0xf0u) == 0xf0u;                                                                                                                 \
             if (HW_ANY(iseob)) { if (iseob) { flags |= HWF_EOB; stopv = 0; pos -= 7u; } }                                                                 \
+    } while (0)
+    // ONE step: a literal / length symbol, then the distance of the lanes that hold a length.  -DHW_LL2=1 (round 4, measured and not used:
+    // 9.10 against 9.01 ms per 65,536 blocks, profiles/r04/huff_two_symbols_per_step.txt) gives the lanes whose first symbol was a literal a
+    // SECOND literal / length symbol before the distance half (two thirds of the symbols are literals, and a lane that has decoded one idles
+    // through the distance half): 40 % fewer steps, no less time -- the wave waits on its dependent LDS look-ups, not on its instruction count.
+    // Every piece ends on a unit boundary, so a range boundary lies between units either way.
+#ifndef HW_LL2
+#define HW_LL2 0
+#endif
+#define HW_UNIT() do {                                                                                                                                \
+        if (pos < stopv) {                                                                                                                                \
+            uint32_t e, ext, islen_m; bool iseob;                                                                                                         \
+            HW_LL();                                                                                                                                      \
+            if (HW_LL2 && islen_m == 0u && pos < stopv) HW_LL();                                                                                          \
             if (islen_m != 0u && !iseob) {                                                                                                                \
                 const uint32_t want3 = (e >> 8) + ext;          /* length - 3 */                                                                          \
                 HW_REFILL();                                                                                                                              \
@@ -422,7 +435,11 @@ W_DEV void hw_span(uint8_t *smem, const uint32_t *in32, uint32_t start, uint32_t
         }
         const bool req = gnext - (widx >> 2) < 4u;
         if (req) { const uint32_t *gp = in32 + 4u * gnext; HW_LOAD16(inq, gp); }
+#if HW_LL2
+        HW_UNIT(); HW_UNIT(); HW_UNIT();                     // (three steps of at most 20 + 20 + 28 bits: 26 bytes, within the 28 the ring holds ahead)
+#else
         HW_UNIT(); HW_UNIT(); HW_UNIT(); HW_UNIT();
+#endif
         // stage point: the requested bytes have arrived (the load is four units old; so are the stores of the previous stage point)
         HW_LOAD16_WAIT(inq);
         if (req) {
