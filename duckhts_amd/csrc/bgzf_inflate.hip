@@ -1032,6 +1032,17 @@ bgzf_lz_resolve(const uint8_t *__restrict__ comp, BgzfTable tab, int64_t blk0, i
     } else lz_block(win, crct, ring, comp, tab, bi, m, lit_all + (size_t)s * DHTS_LIT_STRIDE, tok_all + (size_t)s * DHTS_TOK_STRIDE, out, out_base, blk_status);
 }
 
+// Blocks whose decoded length differs from the ISIZE field the block table was built on (phase A has decoded them, status 0): htslib never
+// reads ISIZE (bgzf.c:793-801 checks the CRC only), so such a block is valid there -- the host re-places the blocks from the decoded lengths
+// (dhts_bgzf.inc: isize_repair).  cnt[0] = how many.
+extern "C" __global__ void __launch_bounds__(256)
+bgzf_len_check(const InflateMeta *__restrict__ meta, const uint32_t *__restrict__ isize, int64_t b0, int32_t n, uint32_t *__restrict__ cnt) {
+    const int32_t k = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const bool bad = k < n && meta[k].status == 0 && meta[k].outlen != isize[b0 + k];
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(cnt, (uint32_t)__popcll(m));
+}
+
 // First damaged block of a batch, found on the device so that the host need not read the whole status array (and need not wait for it
 // before it queues the record stage): res[0] = index (relative to blk0) of the first block whose status is not 0, res[1] = that status,
 // res[2] = index of the first block marked DHTS_BLK_ERR_SCRATCH; 0xffffffff = none.  One workgroup.

@@ -191,6 +191,7 @@ struct dhts_ctx {
     DevBuf stg_lit, stg_tok, wave_ctr;             // wave kernel: staging slices of the resident workgroups, block counter
     DevBuf wg_lit[2], wg_tok[2], stg2_lit, stg2_tok;  // the workgroups' own literal / token areas ([1], stg2_*: fused launches on stream_b)
     DevBuf blk_off; bool huff_packed = false;      // packed phase-A scratch: per-block offsets into `lit` (used as the pool)
+    int64_t isize_repaired = 0;                    // blocks whose table entry was replaced by their decoded length (isize_repair)
     bool pool_full_pending = false;                // the next phase-A range is the repeat of one that overflowed the packed scratch
     int64_t pool_per_block = 65536 + 4096;         // room per block in the packed scratch (a retry after DHTS_BLK_ERR_SCRATCH uses the full 152 KiB)
     DevBuf sg_cnt, sg_base, sg_cand, sg_hits;      // block discovery scratch

@@ -18,9 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def damage(data, rnd):
-    """flip 1-3 random bits after the first 200 bytes (so that most files still open).  ISIZE fields are left alone: the GPU path
-    trusts ISIZE for placing blocks (that is what lets shards start without decoding their predecessors) and reports a block whose
-    inflated length disagrees as an error, whereas htslib -- and the oracle -- never look at ISIZE (deviation (i))."""
+    """flip 1-3 random bits after the first 200 bytes (so that most files still open).  ISIZE fields are left alone here (a damaged ISIZE
+    with a good CRC is not damage to htslib, the oracle or -- since round 4 -- the GPU path: --isize covers that)."""
     import struct
     b = bytearray(data)
     isize = set()
@@ -47,7 +46,7 @@ def main():
     ap.add_argument("--scans", action="store_true", help="per seed: N-way block-range shards, a self-built BAI driving region queries, the overlap join, a projection mask")
     ap.add_argument("--bgzip", action="store_true", help="per seed: an input of random texture and size through the device compressor; every member checked with zlib, the whole with the library's own inflate")
     ap.add_argument("--vcfregions", action="store_true", help="per seed: a sorted bgzipped VCF with symbolic alleles / SVLEN / END / gVCF LEN, the tabix writer (TBI or CSI), random region queries vs the oracle's tabix interval rule")
-    ap.add_argument("--isize", action="store_true", help="per seed: hostile ISIZE trailer values (bit flips, 0xFFFFxxxx, > 64 KiB) on random blocks: the scan must end at that block with the rows before it intact")
+    ap.add_argument("--isize", action="store_true", help="per seed: hostile ISIZE trailer values (bit flips, 0xFFFFxxxx, > 64 KiB) on random blocks: htslib never reads ISIZE, so the scan must return what the clean file returns")
     ap.add_argument("--vcf", action="store_true", help="per seed: a VCF TEXT file (sites-only or with samples, plain or BGZF) of lines made from a grammar and then damaged character by character, wide or tidy, random batch sizes")
     ap.add_argument("--corrupt", action="store_true", help="flip 1-3 random bytes of each BAM / BCF file: the rows before the damage and the error sign must still agree")
     args = ap.parse_args()
@@ -88,15 +87,14 @@ def main():
             mb = rnd.choice([0, 1, 2, 5])
             got = {}
             try:
+                # htslib never reads ISIZE (bgzf.c:793-801: the CRC decides): the file reads like the clean one -- the block table is re-placed
+                # from the decoded lengths (round 4; rounds 1-3 ended the stream at such a block)
                 got = duckhts_amd.read_bam(bytes(data), max_blocks=mb)
-                if hit:
-                    if not (got["status"] < 0 and got["n_rows"] <= clean["n_rows"]):
-                        msgs.append(f"isize damage in block {min(hit)} of {len(blocks)} not reported: status {got['status']} rows {got['n_rows']}/{clean['n_rows']}")
-                elif got["status"] < 0 or got["n_rows"] != clean["n_rows"]:
-                    msgs.append("undamaged file differs")
+                if got["status"] < 0 or got["n_rows"] != clean["n_rows"]:
+                    msgs.append(f"a file with wrong ISIZE fields {sorted(set(hit))} of {len(blocks)} blocks differs from the clean one: status {got['status']} rows {got['n_rows']}/{clean['n_rows']}")
                 for kk in duckhts_amd.BAM_COLUMNS:
                     if list(got[kk]) != list(clean[kk][:got["n_rows"]]):
-                        msgs.append(f"column {kk} is not a prefix of the clean scan")
+                        msgs.append(f"column {kk} differs from the clean scan")
             except duckhts_amd.DhtsError as e:
                 msgs.append(f"raised {e}")
             done += 1
