@@ -328,7 +328,7 @@ def main():
         lz_n = max(ktimes["lz_resolve"][1], 1)
         # HBM traffic of the inflate stage from the committed PMC passes (rocprofv3 cannot wrap itself): bytes per BGZF block
         # measured on full-size launches of this same workload (profiles/<round>/pmc_traffic_*.json), times the blocks of one step
-        traffic, traffic_src, traffic_detail = None, None, None
+        traffic, traffic_src, traffic_detail, traffic_hash = None, None, None, None
         try:
             import re as _re
             cand = sorted((f for r_ in sorted(os.listdir(os.path.join(ROOT, "profiles"))) for f in
@@ -336,6 +336,10 @@ def main():
                           key=lambda f: (os.path.basename(os.path.dirname(f)), [int(t) for t in _re.findall(r"\d+", os.path.basename(f))]))   # latest round, highest version
             if cand:
                 pjd = json.load(open(cand[-1]))
+                # the counters belong to the kernels they were measured on: the file carries a hash of the inflate kernels' sources
+                import hashlib
+                hk = hashlib.sha256(b"".join(open(os.path.join(ROOT, "duckhts_amd", "csrc", f), "rb").read() for f in ("bgzf_huff_wave.hip", "bgzf_inflate.hip"))).hexdigest()[:16]
+                traffic_hash = {"measured_on": pjd.get("kernel_source_sha256"), "current": hk, "match": pjd.get("kernel_source_sha256") == hk}
                 pj = pjd["per_block"]
                 per_blk = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in pj.values())
                 per_blk_raw = sum(v["fetch_bytes_raw"] + v["write_bytes"] for v in pj.values())
@@ -362,7 +366,7 @@ def main():
             "unpack": dict(_pk(raw_bytes * frac_of_file + float(out_bytes), t3_ms), kernels="bam_tile_unpack + scans + bam_tile_strings", bytes="U + O"),
         }
         roof = {"bound": "hbm", "kernel": "bgzf_huff_decode_wave+bgzf_lz_resolve (inflate stage)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src, "traffic_detail": traffic_detail,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "bytes per step (both kernels)", "traffic_source": traffic_src, "traffic_kernel_sources": traffic_hash, "traffic_detail": traffic_detail,
                 "ms_per_step": round(inflate_ms_step, 3), "bytes_per_step": int(bytes_per_step),
                 "lz_resolve_ms_per_launch": round(ktimes["lz_resolve"][0] / lz_n, 4), "lz_resolve_bytes_per_launch": int(bytes_per_step * args.steps / lz_n),
                 "path_frac": round(value * (C_ + 2 * U + O) / 1e9 / HBM_PEAK_GBPS / max(args.gpus, 1), 5), "per_kernel": per_kernel}
@@ -475,7 +479,7 @@ def main():
             for l in r.stdout.splitlines():
                 if l.startswith("{"):
                     d = json.loads(l)
-                    out[d.get("query", str(len(out)))] = {k: d[k] for k in ("value", "unit", "rows_per_s", "ms_per_step", "bgzf_GBps", "projected_columns", "index_windows", "blocks_scanned", "index_build_s", "rows_out", "pairs_out", "pairs_per_s", "cpu_baseline", "config") if k in d and d[k] is not None}
+                    out[d.get("query", str(len(out)))] = {k: d[k] for k in ("value", "unit", "rows_per_s", "ms_per_step", "bgzf_GBps", "projected_columns", "index_windows", "blocks_scanned", "index_build_s", "rows_out", "pairs_out", "pairs_per_s", "cpu_baseline", "config", "roofline", "kernels", "output_bytes_per_record") if k in d and d[k] is not None}
             return out
         except Exception as e:                                   # (a bench line without these legs is still a bench line)
             return {"error": repr(e)[:300]}

@@ -295,6 +295,7 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16
             const uint64_t left64 = st.ulen - tb;
             const uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;      // bytes of the stream from the tile's first byte on
             bool general = false;
+#ifdef TL_STRICT_WALK
             while (rel < lim) {
                 if (rel + 64u > win) { general = true; break; }
                 uint32_t v; __builtin_memcpy(&v, buf + rel + 4u * (uint32_t)(lane & 15), 4);      // the core as dwords across lanes 0..8
@@ -313,6 +314,22 @@ bam_tile_scan(BamStream st, uint64_t start0, int64_t ntiles, TileOut out, uint16
                 if (lane == 0 && cnt < TL_RECS) rl[cnt] = (uint16_t)rel;
                 cnt++; rel += 4u + (uint32_t)b;
             }
+#else
+            // Round 4: the hop needs block_size only.  The core tests of bam_read1 (lengths that fit the body, reference ids in range: the
+            // strict form above, ~45 scalar instructions per hop) are made again for every row by the row pass (rec_check_t, full), which
+            // reports the first invalid row; rows are cut there either way, and a chain that started on a wrong speculation is replaced by
+            // the repair rounds whatever it walked over.  What the walk must not do is leave the stream (the incomplete test) or stand still
+            // (block_size < 32).  tools/soak.py --corrupt compares the rows and the error sign of damaged files with the oracle.
+            while (rel < lim) {
+                if (rel + 4u > win) { general = true; break; }
+                uint32_t v; __builtin_memcpy(&v, buf + rel, 4);                              // (every lane reads the same word: an LDS broadcast)
+                const int32_t b = (int32_t)__builtin_amdgcn_readfirstlane((int)v);
+                if (b < 32) { err = 1; break; }
+                if (left - rel - 4u < (uint32_t)b) { if (st.final_batch) err = 1; break; }     // the record runs past the stream: incomplete
+                if (lane == 0 && cnt < TL_RECS) rl[cnt] = (uint16_t)rel;
+                cnt++; rel += 4u + (uint32_t)b;
+            }
+#endif
             o = tb + rel;
             if (general && err == 0) {
                 while (o < te) {

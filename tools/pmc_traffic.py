@@ -60,6 +60,13 @@ def main():
         res["per_block"][k] = {"launch_blocks": blocks_f / max(fl[1], 1), "fetch_bytes_raw": fl[0] * 1024 / blocks_f,
                                "fetch_bytes_corrected": fl[0] * 1024 * 2 / blocks_f, "write_bytes": wl[0] * 1024 / blocks_w,
                                "launches_sampled": fl[1], "blocks_sampled": blocks_f}
+    # which kernels these counters belong to: a hash of the inflate kernels' sources (bench.py reports whether it still matches)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        res["kernel_source_sha256"] = hashlib.sha256(b"".join(open(os.path.join(root, "duckhts_amd", "csrc", f), "rb").read() for f in ("bgzf_huff_wave.hip", "bgzf_inflate.hip"))).hexdigest()[:16]
+    except OSError:
+        res["kernel_source_sha256"] = None
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(f"{k:32s} n={v['launches']:5d} fetch/launch={v['fetch_bytes_per_launch'] / 1e6:10.2f} MB write/launch={v['write_bytes_per_launch'] / 1e6:10.2f} MB")
