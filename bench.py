@@ -447,13 +447,18 @@ def main():
     operator = None
     if not args.no_operator and world == 1:
         host = os.path.join(ROOT, "tests", "minihost", "minihost")
-        thr = max(1, min(8, ncpu - 2))
+        thr = max(1, min(16, ncpu - 2))                       # (16 = one GPU's share of the box's cores; profiles/r04/fill_threads_r04.jsonl: 132 M records/s with 8 fill threads, 182 M with 16 and 32)
+        qual_mode = {}
         def host_run(extra_env, repeats):
-            env = dict(os.environ, DHTS_THREADS=str(thr), **extra_env)
+            env = dict(os.environ, DHTS_THREADS=str(thr), DHTS_TRACE="1", **extra_env)
             r = subprocess.run([host, duckhts_amd.LIB_PATH, "read_bam", path, "-t", str(thr), "-r", str(repeats)], capture_output=True, text=True, env=env)
             if r.returncode != 0:
                 return None, (r.stdout + r.stderr)[-300:]
             assert int(r.stdout.split("OK rows=")[1].split()[0]) == n_records
+            for l in r.stderr.splitlines():                    # how QUAL crossed PCIe (data-dependent: the batch's own alphabet)
+                if "QUAL over PCIe:" in l:
+                    w = l.split("QUAL over PCIe:")[1].split()
+                    qual_mode.update({"batches_2bit": int(w[0]), "batches_4bit": int(w[5]), "batches_as_characters": int(w[9])})
             return [float(l.split("seconds=")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("RUN ")], None
         # (a) every query reads the file and copies it to the device (DHTS_FILE_CACHE=0); (b) default: the file staged by the first query
         # is still resident in HBM when the second one runs
@@ -461,6 +466,7 @@ def main():
         if runs:
             operator = {"records_per_s": round(n_records / runs[-1], 1), "bgzf_GBps": round(file_bytes / runs[-1] / 1e9, 3), "seconds": round(runs[-1], 3),
                         "first_query_seconds": round(runs[0], 3), "includes": "pread+H2D+scan+D2H+fill", "columns": 13, "DHTS_THREADS": thr,
+                        "qual_over_pcie": dict(qual_mode, note="QUAL crosses PCIe as 2- / 4-bit codes when a batch holds at most 4 / 16 distinct characters (this synthetic file: 4 quality bins, as current Illumina instruments write; a file with more distinct qualities travels as characters and gains nothing here), SEQ as the file's 4-bit codes"),
                         "how": "read_bam(path) through duckhts_init_c_api driven by the mini DuckDB host (tests/minihost), second query of one process, DHTS_FILE_CACHE=0"}
             runs2, err2 = host_run({}, 3)          # (the second query re-sizes the pinned arenas once: batches are full-size from the start when nothing is staged)
             if runs2:

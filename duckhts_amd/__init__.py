@@ -32,7 +32,7 @@ class BamBatch(C.Structure):
                 ("tlen", C.c_void_p), ("tid", C.c_void_p), ("mtid", C.c_void_p), ("rg_idx", C.c_void_p),
                 ("rg_valid", C.c_void_p),
                 ("qname", StrCol), ("cigar", StrCol), ("seq", StrCol), ("qual", StrCol), ("rg", StrCol),
-                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("reserved2", C.c_int32), ("aux_map", C.c_void_p), ("tag_cols", C.c_void_p),
+                ("first_rec_uoff", C.c_uint64), ("end_uoff", C.c_uint64), ("n_tag_cols", C.c_int32), ("qual_bits", C.c_int32), ("aux_map", C.c_void_p), ("tag_cols", C.c_void_p),
                 ("ov_off", C.c_void_p), ("ov_ids", C.c_void_p), ("n_ov", C.c_uint64)]
 
 
@@ -78,7 +78,7 @@ EXPORTS = ["dhts_abi_version", "dhts_device_count", "dhts_create", "dhts_destroy
            "dhts_kernel_time_reset", "dhts_set_timing", "dhts_bcf_open", "dhts_bcf_info_get", "dhts_bcf_set_projection", "dhts_bcf_set_block_range", "dhts_bcf_set_region", "dhts_bcf_load_index",
            "dhts_bcf_rewind", "dhts_bcf_next_batch",
            "dhts_open_path_range", "dhts_open_path_shard", "dhts_bam_set_file_shard", "dhts_bam_header_bytes", "dhts_voffset",
-           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_bcf_build_index", "dhts_bgzf_wrap", "dhts_bgzf_compress", "dhts_bgzip_file", "dhts_bgunzip_file", "dhts_bcf_is_text", "dhts_bam_set_seq_packed", "dhts_bcf_header_bytes", "dhts_bcf_region_segments", "dhts_set_super_blocks", "dhts_bam_build_index_csi", "dhts_tabix_build_index", "dhts_bcf_batch_host_bytes", "dhts_bcf_batch_fetch", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch", "dhts_bam_batch_fetch_begin", "dhts_bam_batch_fetch_wait", "dhts_bcf_batch_fetch_begin", "dhts_bcf_batch_fetch_wait", "dhts_device_numa_node", "dhts_bind_thread_to_node", "dhts_bind_thread_near_device"]
+           "dhts_host_alloc", "dhts_host_free", "dhts_release_pools", "dhts_device_mem_info", "dhts_shard_window", "dhts_bcf_build_index", "dhts_bgzf_wrap", "dhts_bgzf_compress", "dhts_bgzip_file", "dhts_bgunzip_file", "dhts_bcf_is_text", "dhts_bam_set_seq_packed", "dhts_bcf_header_bytes", "dhts_bcf_region_segments", "dhts_set_super_blocks", "dhts_bam_build_index_csi", "dhts_tabix_build_index", "dhts_bcf_batch_host_bytes", "dhts_bcf_batch_fetch", "dhts_resident_from_cache", "dhts_bam_region_segments", "dhts_open_path_segments", "dhts_open_path_async", "dhts_stage_wait", "dhts_bgzf_index_staged", "dhts_blocks_ahead", "dhts_bam_batch_host_bytes", "dhts_bam_batch_fetch", "dhts_bam_batch_fetch_begin", "dhts_bam_batch_fetch_wait", "dhts_bcf_batch_fetch_begin", "dhts_bcf_batch_fetch_wait", "dhts_device_numa_node", "dhts_bind_thread_to_node", "dhts_bind_thread_near_device", "dhts_bam_set_qual_packed"]
 
 
 def lib():

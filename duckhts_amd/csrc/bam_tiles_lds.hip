@@ -676,6 +676,52 @@ bam_rows_guard(unsigned long long *res, const uint64_t *scan_total, HeapCaps cap
     }
 }
 
+// ---- QUAL over PCIe by the batch's own alphabet (dhts_bam_set_qual_packed; the read-back of dhts_fetch.inc) ---------------------------------
+// qual_presence: which characters occur in the heap -- 128 bits for the ASCII range (a quality + 33 is at most 126, '*' is 42) and one flag
+// for anything above (a quality beyond 93: the batch then travels as characters).  qual_pack: 16 characters per lane through a 256-entry code
+// table in LDS into 2- / 4-bit codes, little end first; the heap is dense, so the code stream ignores row boundaries and the consumer finds
+// character k at bit k * bits.
+extern "C" __global__ void __launch_bounds__(256)
+qual_presence(const uint8_t *__restrict__ q, uint64_t n, unsigned long long *__restrict__ mask3) {
+    __shared__ unsigned long long sm[3];
+    if (threadIdx.x < 3) sm[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long lo = 0, hi = 0; uint32_t big = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16u) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (i + 16 <= n) { const uint4 v = *(const uint4 *)(q + i); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else { const uint8_t first = q[i]; for (uint64_t k = i; k < i + 16; k++) w[(k - i) >> 2] |= (uint32_t)(k < n ? q[k] : first) << (8 * ((k - i) & 3)); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const unsigned long long bit = 1ull << (b & 63u);
+            lo |= (b & 64u) ? 0ull : bit; hi |= (b & 64u) ? bit : 0ull; big |= b >> 7;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo |= __shfl_xor(lo, d, 64); hi |= __shfl_xor(hi, d, 64); big |= __shfl_xor(big, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicOr(&sm[0], lo); atomicOr(&sm[1], hi); atomicOr(&sm[2], (unsigned long long)big); }
+    __syncthreads();
+    if (threadIdx.x < 3 && sm[threadIdx.x]) atomicOr(mask3 + threadIdx.x, sm[threadIdx.x]);
+}
+struct QualCodes { uint8_t code[128]; };            // character (< 128) -> code
+template <int BITS> __global__ void __launch_bounds__(256)
+qual_pack(const uint8_t *__restrict__ q, uint64_t n, QualCodes lut, uint8_t *__restrict__ dst) {
+    __shared__ uint8_t code[128];
+    if (threadIdx.x < 128) code[threadIdx.x] = lut.code[threadIdx.x];
+    __syncthreads();
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    if (i >= n) return;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (i + 16 <= n) { const uint4 v = *(const uint4 *)(q + i); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+    else for (uint64_t k = i; k < n; k++) w[(k - i) >> 2] |= (uint32_t)q[k] << (8 * ((k - i) & 3));
+    unsigned long long out = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) out |= (unsigned long long)code[(w[k >> 2] >> (8 * (k & 3))) & 0x7fu] << (BITS * k);
+    if (BITS == 2) { const uint32_t o32 = (uint32_t)out; __builtin_memcpy(dst + i / 4, &o32, 4); }       // (the stream is padded to whole 16-character groups)
+    else __builtin_memcpy(dst + i / 2, &out, 8);
+}
+
 // ---- region predicate -----------------------------------------------------------------------------------
 // keep[row] = 1 iff the record overlaps one of the merged query intervals of its reference:
 //   end > iv.beg && iv.end > beg, beg = pos, end = bam_endpos (htslib sam.c:668-673: pos + reference length of the effective

@@ -248,6 +248,7 @@ struct dhts_ctx {
     // VCF text: a region names a sequence of the tabix index (tbx_name2id), so it is resolved when the index arrives (dhts_bcf_load_index)
     std::vector<uint8_t> idx_cache; uint64_t idx_cache_len = 0, idx_cache_n = 0; const uint8_t *idx_cache_src = nullptr; uint8_t idx_cache_key[128] = {0};   // the last BGZF index, inflated
     bool seq_packed = false; DevBuf seq_chars;
+    bool qual_packed = false; DevBuf q_mask, q_pack; uint8_t q_syms[2][16];       // dhts_bam_set_qual_packed: QUAL crosses PCIe as 2- / 4-bit codes of the batch's own alphabet (dhts_fetch.inc)
     DevBuf z_in, z_slots, z_sizes, z_offs, z_out, z_tok;                           // bgzip: raw chunk, per-block slots / sizes / offsets, packed blocks
     bool bcf_rg_pending = false; std::string bcf_rg_tok; int32_t bcf_rg_itid = -1; std::vector<std::string> tbx_names;
     DevBuf b_keep, b_map, b_sel;

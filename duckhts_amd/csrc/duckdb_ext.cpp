@@ -81,6 +81,7 @@ struct HostBatch {
     int64_t n = 0; int status = 0;
     std::vector<HostTag> tags;
     std::vector<uint8_t> aux_valid; std::vector<uint32_t> aux_off; std::vector<std::string> aux_key, aux_val;
+    std::vector<uint32_t> qual_lut;   // QUAL as 2- / 4-bit codes (dhts_bam_batch.qual_bits): code byte -> its 4 / 2 characters, built when the batch's bytes have landed
     // parallel mode
     int64_t next = 0; int readers = 0; bool retired = false;
 };
@@ -110,6 +111,7 @@ struct BamScan {
 };
 struct BamLocal {
     std::vector<char> seq_tmp;         // packed SEQ expands here before it is assigned
+    std::vector<char> qual_tmp;        // packed QUAL: a row that starts inside a code byte is expanded here first
     bool done = false;
     HostBatch *cur = nullptr; Producer *cur_owner = nullptr; int64_t pos = 0, end = 0;     // rows [pos, end) of `cur` are this worker's
 };
@@ -299,6 +301,28 @@ static int fetch_optional(dhts_ctx *c, BamScan *g, const dhts_bam_batch &b, Host
 }
 
 // producer thread: one GPU, one scan context, one block range of the file
+// QUAL as codes of the batch's own alphabet (dhts_bam_batch.qual_bits = 2 / 4): qual.bytes = 16-byte symbol table + code stream, character k
+// of the heap at bit k * bits.  The table of a batch: code byte -> its 4 (2-bit) or 2 (4-bit) characters.
+static void build_qual_lut(HostBatch *hb) {
+    hb->qual_lut.clear();
+    const dhts_bam_batch &b = hb->b;
+    if (!b.qual_bits || !b.qual.bytes) return;
+    const uint8_t *sym = b.qual.bytes;
+    hb->qual_lut.resize(256);
+    for (uint32_t v = 0; v < 256; v++) {
+        if (b.qual_bits == 2) hb->qual_lut[v] = (uint32_t)sym[v & 3] | ((uint32_t)sym[(v >> 2) & 3] << 8) | ((uint32_t)sym[(v >> 4) & 3] << 16) | ((uint32_t)sym[v >> 6] << 24);
+        else hb->qual_lut[v] = (uint32_t)sym[v & 15] | ((uint32_t)sym[v >> 4] << 8);
+    }
+}
+// characters [off, off + n) of the heap -> out[0, n) (out has room for n + 8)
+static inline void expand_qual(const uint8_t *stream, int bits, const uint32_t *lut, uint32_t off, uint32_t n, char *out, std::vector<char> &tmp) {
+    const uint32_t per = bits == 2 ? 4u : 2u, first = off / per, skip = off % per, nb = (skip + n + per - 1) / per;
+    char *w = out;
+    if (skip) { if (tmp.size() < (size_t)nb * per + 8) tmp.resize((size_t)nb * per + 8 + n / 2); w = tmp.data(); }
+    if (bits == 2) for (uint32_t k = 0; k < nb; k++) { const uint32_t v = lut[stream[first + k]]; memcpy(w + 4 * k, &v, 4); }
+    else for (uint32_t k = 0; k < nb; k++) { const uint16_t v = (uint16_t)lut[stream[first + k]]; memcpy(w + 2 * k, &v, 2); }
+    if (skip) memcpy(out, w + skip, n);
+}
 static void producer_main(BamScan *g, Producer *p) {
     BamBind *bind = g->bind;
     static const bool trace = getenv("DHTS_TRACE") != nullptr;       // stage timings of every producer on stderr
@@ -314,6 +338,7 @@ static void producer_main(BamScan *g, Producer *p) {
     dhts_ctx *c = dhts_create(p->device);
     if (!c) { fail_with("read_bam: no MI355X (gfx950) device available; this build has no CPU fallback"); return; }
     dhts_set_super_blocks(c, 196608);                    // a scratch the device pool keeps from query to query (29 GB instead of 67 GB for a 10 GB file)
+    { static const bool env_qraw = getenv("DHTS_QUAL_PACKED") && atoi(getenv("DHTS_QUAL_PACKED")) == 0; dhts_bam_set_qual_packed(c, env_qraw ? 0 : 1); }         // QUAL crosses PCIe as 2- / 4-bit codes when the batch holds at most 4 / 16 different characters
     { static const bool env_unpacked = getenv("DHTS_SEQ_PACKED") && atoi(getenv("DHTS_SEQ_PACKED")) == 0; dhts_bam_set_seq_packed(c, env_unpacked ? 0 : 1); }   // SEQ crosses PCIe as 4-bit codes, the fill threads expand it
     const double t_created = now_s() - t_start; double t_staged = 0;
     int rc;
@@ -361,8 +386,10 @@ static void producer_main(BamScan *g, Producer *p) {
     static const int64_t env_mb = getenv("DHTS_BATCH_BLOCKS") ? atoll(getenv("DHTS_BATCH_BLOCKS")) : 0;
     const int64_t max_blocks = env_mb > 0 ? env_mb : 4096;       // ~270 MB of inflated stream per batch: the engine gets its first chunk early and the stages overlap
     HostBatch *pending = nullptr; int pending_slot = 0, slot_no = 0;
+    int64_t n_qual[3] = {0, 0, 0};                               // batches whose QUAL crossed PCIe as 2-bit codes / 4-bit codes / characters
     auto publish = [&](HostBatch *hb, int sl) -> bool {
         if (dhts_bam_batch_fetch_wait(c, sl) != 0) return false;
+        build_qual_lut(hb);
         { std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
         g->cv_ready.notify_all();
         return true;
@@ -400,11 +427,12 @@ static void producer_main(BamScan *g, Producer *p) {
                 std::string m = hb->arena || !need ? dhts_error(c) : "read_bam: out of pinned host memory"; dhts_destroy(c); fail_with(m); return;
             }
             hb->n = b.n_rows; hb->status = b.status; hb->next = 0; hb->readers = 0; hb->retired = false;
+            if (g->colmask & (1u << DHTS_BAM_QUAL)) n_qual[hb->b.qual_bits == 2 ? 0 : hb->b.qual_bits == 4 ? 1 : 2]++;
             if (!p->has_rows) { p->has_rows = true; p->first_v = dhts_voffset(c, b.first_rec_uoff); }
             p->end_v = dhts_voffset(c, b.end_uoff);
             if (pending && !publish(pending, pending_slot)) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
             pending = nullptr;
-            if (env_serial) { std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
+            if (env_serial) { build_qual_lut(hb); std::lock_guard<std::mutex> lk(g->mu); p->ready.push_back(hb); }
             else { pending = hb; pending_slot = slot_no; slot_no ^= 1; }
             if (env_serial) g->cv_ready.notify_all();
             t_fetch += now_s() - tb2;
@@ -415,6 +443,8 @@ static void producer_main(BamScan *g, Producer *p) {
     if (pending && !publish(pending, pending_slot)) { std::string m = dhts_error(c); dhts_destroy(c); fail_with(m); return; }
     dhts_destroy(c);
     if (trace) { uint64_t mc = 0, mb = 0; double ms = 0; dhts_debug_malloc_stats(&mc, &mb, &ms); fprintf(stderr, "[dhts] hipMalloc calls the pool could not serve so far in this process: %llu, %.2f GB, %.3f s\n", (unsigned long long)mc, 1e-9 * (double)mb, ms); }
+    if (trace && (n_qual[0] + n_qual[1] + n_qual[2])) fprintf(stderr, "[dhts] producer %d QUAL over PCIe: %lld batches as 2-bit codes, %lld as 4-bit codes, %lld as characters (the batch's own alphabet: <= 4 / <= 16 / more distinct characters)\n",
+                       p->rank, (long long)n_qual[0], (long long)n_qual[1], (long long)n_qual[2]);
     if (trace) fprintf(stderr, "[dhts] producer %d/%d dev %d: context %.4f s, staged at %.4f s%s, block table %.4f s, header %.4f s, open+index+header %.4f s, %lld batches %lld rows: device %.3f s, waiting for a free host slot %.3f s, read-back %.3f s, waiting for staged bytes %.3f s, %lld table extensions %.3f s, total %.3f s\n",
                        p->rank, p->world, p->device, t_created, t_staged, from_cache ? " (file still resident in HBM)" : "", t_idx, t_hdr, t_open, (long long)n_batches, (long long)n_rows, t_gpu, t_slot, t_fetch, t_wait, (long long)n_index, t_index, now_s() - t_start);
     { std::lock_guard<std::mutex> lk(g->mu); p->done = true; }
@@ -608,7 +638,19 @@ static void bam_read_function(duckdb_function_info info, duckdb_data_chunk outpu
                     }
                 }
                 break;
-            case DHTS_BAM_QUAL: put_str(b.qual); break;
+            case DHTS_BAM_QUAL:
+                if (!b.qual_bits) { put_str(b.qual); break; }
+                {   // the batch carries codes of its own alphabet: expand here (qual_to_string's characters, bam_reader.c:577-600, were made on the device)
+                    duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;
+                    const uint8_t *stream = b.qual.bytes + 16; const uint32_t *lut = hb->qual_lut.data();
+                    for (idx_t r = 0; r < take; r++) {
+                        const uint32_t n = b.qual.len[s + r];
+                        if (l->seq_tmp.size() < (size_t)n + 40) l->seq_tmp.resize((size_t)n + 40 + n / 2);
+                        expand_qual(stream, b.qual_bits, lut, b.qual.off[s + r], n, l->seq_tmp.data(), l->qual_tmp);
+                        if (!inl_string(d + r, l->seq_tmp.data(), n)) assign_len(vec, row_count + r, l->seq_tmp.data(), n);
+                    }
+                }
+                break;
             case DHTS_BAM_READ_GROUP_ID: {
                 duckdb_string_t *d = (duckdb_string_t *)get_data(vec) + row_count;
                 for (idx_t r = 0; r < take; r++) {

@@ -105,7 +105,9 @@ typedef struct {
     uint64_t first_rec_uoff; /* absolute inflated-stream offset of the first row's record        */
     uint64_t end_uoff;       /* absolute inflated-stream offset just past the last row's record  */
     int32_t n_tag_cols;      /* standard-tag columns selected by dhts_bam_set_tag_columns         */
-    int32_t reserved2;
+    int32_t qual_bits;       /* host batches only (dhts_bam_batch_fetch*, after dhts_bam_set_qual_packed): 0 = qual.bytes are the characters; 2 / 4 =
+                              * qual.bytes is a 16-byte symbol table followed by the heap's characters as 2- / 4-bit codes, little end first:
+                              * character k of the heap = table[(stream[k * bits / 8] >> (k * bits % 8)) & mask]; off / len count characters */
     const dhts_aux_map *aux_map; /* NULL unless dhts_bam_set_aux_map enabled it                       */
     const dhts_col *tag_cols;/* host array; BIGINT scalars in fixed (8 B), VARCHAR in off/bytes, LIST(BIGINT) in off/child_fixed (8 B words) */
     const uint32_t *ov_off;  /* overlap join (dhts_bam_set_overlap_intervals): n_rows+1 offsets into ov_ids, NULL when off */
@@ -292,6 +294,10 @@ typedef struct {
 
 int dhts_bcf_open(dhts_ctx *, int tidy_format);                      /* header + dictionaries + schema; positions the scan at the first record */
 int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
+/* QUAL over PCIe by the batch's own alphabet: when on, dhts_bam_batch_fetch / _fetch_begin look at which characters the batch's QUAL heap holds
+ * (one pass on the device) and ship 2 bits per character when there are at most 4, 4 bits when at most 16 (binned base qualities: current Illumina
+ * instruments write 4-8 distinct values), the characters themselves otherwise; dhts_bam_batch.qual_bits says which.  The batch in HBM is unchanged. */
+void dhts_bam_set_qual_packed(dhts_ctx *, int on);
 void dhts_bam_set_seq_packed(dhts_ctx *, int on);                    /* SEQ stays 4 bits per base in the batch: (l + 1) / 2 bytes per row, high nibble first, "=ACMGRSVTWYHKDBN"; len = bases, 0 = "*" */
 void dhts_set_super_blocks(dhts_ctx *, int64_t n_blocks);             /* phase A look-ahead (default 524,288 blocks = 67 GB of scratch for a 10 GB file); the table functions use 196,608 */
 int dhts_bcf_is_text(const dhts_ctx *);                              /* after dhts_bcf_open: 0 binary BCF, 1 bgzipped VCF text, 2 plain VCF text */

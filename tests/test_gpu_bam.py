@@ -619,6 +619,78 @@ def test_packed_seq_and_overlapped_fetch_at_the_c_abi():
         ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("alphabet, bits", [(b"#,:", 2), (b"!\"#$%&'()*+,-./0", 4), (None, 0)])
+def test_qual_over_pcie_as_codes_of_the_batch_alphabet(alphabet, bits):
+    """dhts_bam_set_qual_packed: the read-back (dhts_bam_batch_fetch and _fetch_begin / _wait) looks at which characters the batch's QUAL heap holds
+    and ships 2 bits per character for at most 4 different ones, 4 bits for at most 16, the characters themselves otherwise; decoded on the host,
+    the strings are those of the oracle (rows whose QUAL is "*" included: the star is a character of the heap, the fourth / sixteenth here)"""
+    import ctypes as C
+    import random
+    import bamwriter as bw
+    rnd = random.Random(7)
+    recs = []
+    for i in range(3000):
+        n = rnd.choice([0, 1, 37, 100, 150, 151])
+        if alphabet is None:
+            q = bytes(rnd.randrange(33, 127) for _ in range(n)).decode()
+        else:
+            q = bytes(rnd.choice(alphabet) for _ in range(n)).decode()
+        seq = "".join(rnd.choice("ACGT") for _ in range(n)) if n else "*"
+        recs.append(bw.record(qname=f"r{i}", tid=0, pos=i * 10, cigar=f"{n}M" if n else "*", seq=seq, qual=(None if (n and i % 17 == 0) else q) if n else None))
+    data = bw.bam_bytes([("a", 1_000_000)], recs, text="@HD\tVN:1.6\n@SQ\tSN:a\tLN:1000000\n")
+    exp = orc.bam_read(data)
+    L = duckhts_amd.lib()
+    L.dhts_bam_set_qual_packed.argtypes = [C.c_void_p, C.c_int]; L.dhts_bam_set_qual_packed.restype = None
+    L.dhts_bam_batch_host_bytes.restype = C.c_uint64; L.dhts_bam_batch_host_bytes.argtypes = [C.c_void_p, C.c_uint32]
+    L.dhts_host_alloc.restype = C.c_void_p; L.dhts_host_alloc.argtypes = [C.c_uint64]; L.dhts_host_free.argtypes = [C.c_void_p]
+    L.dhts_bam_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.dhts_bam_batch_fetch_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.dhts_bam_batch_fetch_wait.argtypes = [C.c_void_p, C.c_int]
+
+    def decode(hb):
+        n = hb.n_rows
+        off = np.ctypeslib.as_array(C.cast(hb.qual.off, C.POINTER(C.c_uint32)), (n + 1,)); ln = np.ctypeslib.as_array(C.cast(hb.qual.len, C.POINTER(C.c_uint32)), (n,))
+        raw = np.ctypeslib.as_array(C.cast(hb.qual.bytes, C.POINTER(C.c_uint8)), (int(hb.qual.nbytes),))
+        if hb.qual_bits == 0:
+            return [raw[off[i]:off[i] + ln[i]].tobytes() for i in range(n)]
+        sym, stream, bts = raw[:16], raw[16:], hb.qual_bits
+        out = []
+        for i in range(n):
+            ks = np.arange(int(off[i]), int(off[i]) + int(ln[i]), dtype=np.int64)
+            codes = (stream[ks * bts // 8] >> ((ks * bts) % 8).astype(np.uint8)) & ((1 << bts) - 1)
+            out.append(sym[codes].tobytes())
+        return out
+
+    for overlapped in (False, True):
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(data); ctx.bgzf_index(); ctx.bam_open()
+            L.dhts_bam_set_qual_packed(ctx.h, 1)
+            quals, arenas = [], []
+            while True:
+                b = ctx.next_batch(0)
+                if b.n_rows:
+                    assert b.qual_bits == 0                      # the batch in HBM is unchanged
+                    need = L.dhts_bam_batch_host_bytes(C.byref(b), 0x1FFF)
+                    arena = L.dhts_host_alloc(need); arenas.append(arena)
+                    hb = duckhts_amd.BamBatch()
+                    if overlapped:
+                        assert L.dhts_bam_batch_fetch_begin(ctx.h, C.byref(b), 0x1FFF, arena, need, C.byref(hb), 0) == 0, ctx.L.dhts_error(ctx.h)
+                        assert L.dhts_bam_batch_fetch_wait(ctx.h, 0) == 0
+                    else:
+                        assert L.dhts_bam_batch_fetch(ctx.h, C.byref(b), 0x1FFF, arena, need, C.byref(hb)) == 0, ctx.L.dhts_error(ctx.h)
+                    assert hb.qual_bits == bits, (hb.qual_bits, bits)
+                    quals += decode(hb)
+                if b.status != 0:
+                    break
+            assert quals == list(exp["QUAL"])
+            for a in arenas:
+                L.dhts_host_free(a)
+        finally:
+            ctx.close()
+
+
 # ---- next-batch prefetch: a caller that changes the batch size invalidates the prefetched phase B ---------------------------
 @pytest.mark.gpu
 def test_varying_batch_sizes_discard_the_prefetch(monkeypatch):
