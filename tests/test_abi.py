@@ -33,7 +33,7 @@ def test_library_exports_nothing_the_headers_do_not_declare():
     assert exported, "no dynamic symbols?"
     assert not (exported - declared), f"exported but not declared in include/: {sorted(exported - declared)}"
     diag_only = {"dhts_debug_diag", "dhts_debug_hw_diag", "dhts_debug_tr_diag"}      # defined by -DDHTS_DIAG / -DHW_DIAG / -DTR_DIAG builds only
-    missing = {n for n in declared - exported - diag_only if n.startswith(("dhts_", "duckhts_", "register_read_", "duckdb_ext_api"))}
+    missing = {n for n in declared - exported - diag_only if n.startswith(("dhts_", "duckhts_", "register_", "duckdb_ext_api"))}
     assert not missing, f"declared but not exported: {sorted(missing)}"
     for n in ("duckhts_init_c_api", "register_read_bam_function", "register_read_bcf_function", "duckdb_ext_api"):
         assert n in exported

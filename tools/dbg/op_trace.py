@@ -16,8 +16,8 @@ bench.generate_file(path, synth, 42, 4_000_000, reps, min(os.cpu_count() or 1, 3
 host = os.path.join(ROOT, "tests", "minihost", "minihost")
 try:
     for env_extra, tag in (({"DHTS_FILE_CACHE": "0"}, "file read every query"), ({}, "file resident after the first query")):
-        env = dict(os.environ, DHTS_THREADS="8", DHTS_TRACE="1", **env_extra)
-        r = subprocess.run([host, duckhts_amd.LIB_PATH, "read_bam", path, "-t", "8", "-r", "3"], capture_output=True, text=True, env=env)
+        env = dict(os.environ, DHTS_THREADS=os.environ.get("OP_THREADS", "16"), DHTS_TRACE="1", **env_extra)
+        r = subprocess.run([host, duckhts_amd.LIB_PATH, "read_bam", path, "-t", os.environ.get("OP_THREADS", "16"), "-r", "3"], capture_output=True, text=True, env=env)
         print(f"==== {tag} ({os.path.getsize(path) / 1e9:.2f} GB)")
         print(r.stdout[-600:]); print(r.stderr[-2500:])
 finally:
