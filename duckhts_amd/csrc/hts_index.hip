@@ -197,45 +197,53 @@ struct IndexAcc {
     }
     // the same passes as bam_index_rows over host arrays (text formats): every row [beg, end) 0-based on sequence tid (< 0: unplaced),
     // vafter = the virtual offset behind it
-    bool add_rows(const int32_t *tid, const int64_t *beg_in, const int64_t *end_in, const uint64_t *vafter, const uint8_t *mapped, int64_t n) {
-        if (n <= 0) return true;
-        std::vector<uint32_t> bin((size_t)n); std::vector<int64_t> bw((size_t)n), ew((size_t)n), b0((size_t)n);
-        const int64_t maxpos = 1ll << (g.min_shift + 3 * g.n_lvls);
+    // One row of the passes, the state of the row in front of it carried in `last`.  Returns the violation flags of the row (0: none); a row
+    // with an interval violation (IDX_ROW_ERRS) leaves the tables untouched.
+    static constexpr uint32_t IDX_ROW_ERRS = IDX_ERR_MAXPOS | IDX_ERR_ENDBEG | IDX_ERR_TIDRANGE;
+    inline uint32_t push_row(int32_t tid, int64_t beg, int64_t end, uint64_t vafter, bool mapped, int64_t maxpos) {
         uint32_t e = 0;
-        for (int64_t i = 0; i < n; i++) {                        // interval, bin, windows
-            int64_t beg = beg_in[i], end = end_in[i];
-            if (tid[i] < 0) { beg = -1; end = 0; }
-            if (tid[i] >= 0 && !(beg <= maxpos && end <= maxpos)) e |= IDX_ERR_MAXPOS;
-            if (end < beg) e |= IDX_ERR_ENDBEG;
-            if (tid[i] >= n_ref) { if (!grow) e |= IDX_ERR_TIDRANGE; else ensure_ref(tid[i]); }
-            b0[(size_t)i] = beg;
-            const int64_t cb = beg < 0 ? 0 : beg, ce = end <= 0 ? 1 : end;
-            bin[(size_t)i] = idx_reg2bin(tid[i] < 0 ? beg : cb, tid[i] < 0 ? end : ce, g);
-            bw[(size_t)i] = cb >> g.min_shift; ew[(size_t)i] = tid[i] >= 0 ? (ce - 1) >> g.min_shift : -1;
+        if (tid < 0) { beg = -1; end = 0; }
+        if (tid >= 0 && !(beg <= maxpos && end <= maxpos)) e |= IDX_ERR_MAXPOS;
+        if (end < beg) e |= IDX_ERR_ENDBEG;
+        if (tid >= n_ref) { if (!grow) e |= IDX_ERR_TIDRANGE; else ensure_ref(tid); }
+        if (e) return e;
+        const int64_t cb = beg < 0 ? 0 : beg, ce = end <= 0 ? 1 : end;
+        const uint32_t bin = idx_reg2bin(tid < 0 ? beg : cb, tid < 0 ? end : ce, g);
+        const int64_t bw = cb >> g.min_shift, ew = tid >= 0 ? (ce - 1) >> g.min_shift : -1;
+        const bool hp = last.any != 0;
+        const bool new_tid = !hp || last.tid != tid;
+        const uint64_t vb = last.v;
+        if (hp && !new_tid && tid >= 0 && last.beg > beg) e |= IDX_ERR_UNSORTED;      // last.beg: the clamped begin of a placed row (hts_idx_push's last_coor, hts.c:2620-2633)
+        if (hp && new_tid && tid >= 0 && last.tid < 0) e |= IDX_ERR_NOCOOR;
+        if (new_tid || last.bin != bin) runs.push_back({tid, bin, vb});
+        if (tid >= 0) {
+            if (new_tid) tid_runs[(size_t)tid]++;
+            std::vector<uint64_t> &l = lin[(size_t)tid];
+            if ((int64_t)l.size() < ew + 1) l.resize((size_t)ew + 1, ~0ull);
+            int64_t w0 = bw; if (!new_tid && last.e >= w0) w0 = last.e + 1;
+            for (int64_t w = w0; w <= ew; w++) if (vb < l[(size_t)w]) l[(size_t)w] = vb;
+            (mapped ? nmap : nunmap)[(size_t)tid]++;
+        } else n_nocoor++;
+        last.any = 1; last.tid = tid; last.bin = bin; last.beg = tid >= 0 ? cb : beg; last.e = ew; last.v = vafter;
+        return e;
+    }
+    // A batch of rows reports like the device passes do: an interval violation anywhere in the batch comes before an order violation.
+    struct BatchErr { uint32_t row = 0, order = 0; };
+    inline void note(BatchErr &b, uint32_t e) { b.row |= e & IDX_ROW_ERRS; b.order |= e & ~IDX_ROW_ERRS; }
+    bool batch_ok(const BatchErr &b) { if (b.row) { err = err_text(b.row); return false; } if (b.order) { err = err_text(b.order); return false; } return true; }
+    int64_t maxpos() const { return 1ll << (g.min_shift + 3 * g.n_lvls); }
+    // the same passes as bam_index_rows over host arrays (text formats): every row [beg, end) 0-based on sequence tid (< 0: unplaced),
+    // vafter = the virtual offset behind it
+    bool add_rows(const int32_t *tid, const int64_t *beg_in, const int64_t *end_in, const uint64_t *vafter, const uint8_t *mapped, int64_t n) {
+        BatchErr be; const int64_t mp = maxpos();
+        for (int64_t i = 0; i < n; i++) { const uint32_t e = push_row(tid[i], beg_in[i], end_in[i], vafter[i], mapped[i] != 0, mp); if (e) { note(be, e); if (e & IDX_ROW_ERRS) break; } }
+        if (be.row) for (int64_t i = 0; i < n; i++) {                  // (the whole batch's interval violations decide the message)
+            int64_t b = beg_in[i], e2 = end_in[i]; if (tid[i] < 0) { b = -1; e2 = 0; }
+            if (tid[i] >= 0 && !(b <= mp && e2 <= mp)) be.row |= IDX_ERR_MAXPOS;
+            if (e2 < b) be.row |= IDX_ERR_ENDBEG;
+            if (tid[i] >= n_ref && !grow) be.row |= IDX_ERR_TIDRANGE;
         }
-        if (e) { err = err_text(e); return false; }
-        for (int64_t i = 0; i < n; i++) {                        // neighbours: runs, order, the linear index, counts
-            const bool hp = i > 0 || last.any;
-            const int32_t pt = i > 0 ? tid[i - 1] : last.tid; const uint32_t pb = i > 0 ? bin[(size_t)i - 1] : last.bin;
-            int64_t pbeg = i > 0 ? b0[(size_t)i - 1] : last.beg; const int64_t pe = i > 0 ? ew[(size_t)i - 1] : last.e;
-            if (pt >= 0 && pbeg < 0) pbeg = 0;                   // hts_idx_push's last_coor is the clamped begin (hts.c:2620-2633)
-            const uint64_t vb = i > 0 ? vafter[i - 1] : last.v;
-            const bool new_tid = !hp || pt != tid[i];
-            if (hp && !new_tid && tid[i] >= 0 && pbeg > b0[(size_t)i]) e |= IDX_ERR_UNSORTED;
-            if (hp && new_tid && tid[i] >= 0 && pt < 0) e |= IDX_ERR_NOCOOR;
-            if (new_tid || pb != bin[(size_t)i]) runs.push_back({tid[i], bin[(size_t)i], vb});
-            if (tid[i] >= 0) {
-                if (new_tid) tid_runs[(size_t)tid[i]]++;
-                std::vector<uint64_t> &l = lin[(size_t)tid[i]];
-                if ((int64_t)l.size() < ew[(size_t)i] + 1) l.resize((size_t)ew[(size_t)i] + 1, ~0ull);
-                int64_t w0 = bw[(size_t)i]; if (!new_tid && pe >= w0) w0 = pe + 1;
-                for (int64_t w = w0; w <= ew[(size_t)i]; w++) if (vb < l[(size_t)w]) l[(size_t)w] = vb;
-                (mapped[i] ? nmap : nunmap)[(size_t)tid[i]]++;
-            } else n_nocoor++;
-        }
-        last.any = 1; last.tid = tid[n - 1]; last.bin = bin[(size_t)n - 1]; last.beg = b0[(size_t)n - 1]; last.e = ew[(size_t)n - 1]; last.v = vafter[n - 1];
-        if (e) { err = err_text(e); return false; }
-        return true;
+        return batch_ok(be);
     }
     // run table -> bins.  vfinal: where the reader stands after the last record (the address of the trailing empty block, or the file's end).
     // Array passes, linear in the number of runs.  What they rest on: positions ascend within a sequence (checked by the row passes), so on
