@@ -303,6 +303,7 @@ struct BcfCellArgs {
     const BcfColDev *cols;
     const uint32_t *sel;          // region filter: compacted list of kept record ids (nullptr = every record)
     uint32_t ncols;
+    uint32_t n_vep; const uint32_t *vep_cols;   // n_vep > 0: the BK_VEP columns (indices into cols) are evaluated by bcf_vep_wave, a wave per row and column; bcf_cells leaves them alone
 };
 
 __device__ __forceinline__ uint32_t cstr_len(const uint8_t *p, uint32_t n) { uint32_t l = 0; while (l < n && p[l]) l++; return l; }
@@ -343,6 +344,7 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
     if (row >= a.nrows) return;
     const BcfColDev cd = a.cols[colb];
     if (WRITE && cd.sa_cnt < 0 && cd.sa_bytes < 0) return;
+    if (cd.kind == BK_VEP && a.n_vep) return;
     const uint8_t *u = st.u;
     int64_t rec = a.tidy ? row / a.n_smp : row;
     if (a.sel) rec = a.sel[rec];
@@ -547,6 +549,145 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
         if (cd.sa_bytes >= 0) a.lens[(size_t)cd.sa_bytes * a.ostride + row] = nbytes;
     } else if (row == a.nrows - 1 && cd.child_off && cd.sa_cnt >= 0 && cd.sa_bytes >= 0) {
         // closing offset of the child string table
+        cd.child_off[a.offs[(size_t)cd.sa_cnt * a.ostride + a.nrows]] = a.offs[(size_t)cd.sa_bytes * a.ostride + a.nrows];
+    }
+}
+
+// ---- VEP_<field> columns of long annotation strings: a wave per (row, column) -----------------------------------------------------------------
+// The BK_VEP case of bcf_cells walks the annotation string with one lane: a chain of dependent byte reads as long as the string (gnomAD:
+// ~9 KB, forty transcripts), one row per lane and 15,000 rows per batch -- fewer workgroups than the chip has CUs.  Here the wave finds the
+// ',' between transcripts 16 bytes per lane (positions collected in LDS, in order), then every lane takes one transcript: the '|' in front of
+// the wanted field is found by counting them eight bytes at a time, the field is trimmed / converted as in bcf_cells, and the elements are
+// placed by a scan over the wave.  Same rules (src/vep_parser.c:207-326), same outputs.
+#define VEP_WSEP 2048u
+__device__ __forceinline__ uint64_t vep_eq8(const uint8_t *s, uint32_t p, uint32_t end, uint64_t pat) {       // 0x80 in byte k: s[p + k] == pattern byte, p + k < end (reads 8 bytes: the stream is padded)
+    uint64_t v; __builtin_memcpy(&v, s + p, 8);
+    const uint64_t x = v ^ pat;
+    uint64_t z = ~(((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x | 0x7f7f7f7f7f7f7f7full);
+    if (p + 8 > end) z &= end > p ? (~0ull >> (8 * (p + 8 - end))) : 0ull;
+    return z;
+}
+template <bool WRITE>
+__global__ void __launch_bounds__(64) bcf_vep_wave(BcfStream st, BcfCellArgs a) {
+    __shared__ uint32_t sep[VEP_WSEP];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t colb = a.vep_cols[blockIdx.x % a.n_vep];
+    const int64_t row = (int64_t)(blockIdx.x / a.n_vep);
+    if (row >= a.nrows) return;
+    const BcfColDev cd = a.cols[colb];
+    const uint8_t *u = st.u;
+    int64_t rec = a.tidy ? row / a.n_smp : row;
+    if (a.sel) rec = a.sel[rec];
+    const uint64_t o = a.rec_off[rec];
+    uint32_t cnt = 0, nbytes = 0; bool valid = true;
+    uint32_t cbase = 0, bbase = 0;
+    if (WRITE) {
+        if (cd.sa_cnt >= 0) cbase = a.offs[(size_t)cd.sa_cnt * a.ostride + row];
+        if (cd.sa_bytes >= 0) bbase = a.offs[(size_t)cd.sa_bytes * a.ostride + row];
+    }
+    auto c_isspace = [](uint8_t ch) { return ch == ' ' || (ch >= 9 && ch <= 13); };
+    const uint32_t d = a.dir[(size_t)(2 + cd.slot) * a.stride + rec];
+    int n = 0, t = 0; uint64_t p = o + d;
+    if ((cd.flags & BF_NULL_ALWAYS) || (a.tidy && row % a.n_smp != 0) || !d) valid = false;
+    else { bcf_dec_size(u, p, n, t); if (n <= 0) valid = false; }
+    if (valid) {
+        const uint8_t *s = u + p;
+        // the C string's length: the first NUL, 16 bytes per lane
+        uint32_t l = (uint32_t)n;
+        for (uint32_t base = 0; base < (uint32_t)n; base += 1024u) {
+            const uint32_t q = base + lane * 16u;
+            const uint64_t z = q < (uint32_t)n ? (vep_eq8(s, q, (uint32_t)n, 0) | 0) : 0ull, z2 = q + 8 < (uint32_t)n ? vep_eq8(s, q + 8, (uint32_t)n, 0) : 0ull;
+            const uint32_t first = z ? q + (uint32_t)(__builtin_ctzll(z) >> 3) : z2 ? q + 8u + (uint32_t)(__builtin_ctzll(z2) >> 3) : 0xffffffffu;
+            const unsigned long long hit = __ballot(first != 0xffffffffu);
+            if (hit) { l = (uint32_t)__shfl((int)first, __builtin_ctzll(hit)); break; }
+        }
+        uint32_t seg = 0, nsep = 0;                                           // seg: where the first transcript of the collected stretch begins
+        for (uint32_t base = 0;; base += 1024u) {
+            const bool last = base + 1024u >= l;
+            if (base < l) {
+                const uint32_t q = base + lane * 16u;
+                const uint64_t z = q < l ? vep_eq8(s, q, l, 0x2c2c2c2c2c2c2c2cull) : 0ull, z2 = q + 8 < l ? vep_eq8(s, q + 8, l, 0x2c2c2c2c2c2c2c2cull) : 0ull;
+                uint32_t m = 0;                                               // bit k: s[q + k] == ','
+#pragma unroll
+                for (int k = 0; k < 8; k++) m |= (uint32_t)((z >> (8 * k + 7)) & 1ull) << k | (uint32_t)((z2 >> (8 * k + 7)) & 1ull) << (8 + k);
+                uint32_t x = (uint32_t)__builtin_popcount(m), inc = x;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, dd); if ((int)lane >= dd) inc += y; }
+                uint32_t at = nsep + inc - x;
+                for (; m; m &= m - 1) sep[at++] = q + (uint32_t)__builtin_ctz(m);
+                nsep += (uint32_t)__shfl((int)inc, 63);
+            }
+            if (last) { if (lane == 0) sep[nsep] = l; nsep++; }                // the last transcript ends where the string does
+            if (!last && nsep + 1025u <= VEP_WSEP) continue;
+            __syncthreads();
+            for (uint32_t k0 = 0; k0 < nsep; k0 += 64u) {                      // a transcript per lane; empty pieces do not count (strtok_r)
+                const uint32_t k = k0 + lane;
+                const uint32_t i0 = k < nsep ? (k ? sep[k - 1] + 1u : seg) : 0u, e = k < nsep ? sep[k] : 0u;
+                const bool piece = k < nsep && e > i0;
+                uint32_t f0 = i0, f1 = i0; bool have = piece;
+                if (piece) {
+                    int need = cd.vep_field;                                   // '|' to pass; fewer fields than asked for = missing
+                    while (need > 0 && f0 < e) {
+                        uint64_t z = vep_eq8(s, f0, e, 0x7c7c7c7c7c7c7c7cull);
+                        const int c8 = __builtin_popcountll(z);
+                        if (c8 < need) { need -= c8; f0 += 8; continue; }
+                        for (int j = 1; j < need; j++) z &= z - 1;
+                        f0 += (uint32_t)(__builtin_ctzll(z) >> 3) + 1u; need = 0;
+                    }
+                    if (need > 0) have = false;
+                    else {
+                        if (f0 > e) f0 = e;
+                        f1 = f0;
+                        for (;;) { if (f1 >= e) { f1 = e; break; } const uint64_t z = vep_eq8(s, f1, e, 0x7c7c7c7c7c7c7c7cull); if (z) { f1 += (uint32_t)(__builtin_ctzll(z) >> 3); break; } f1 += 8; }
+                        while (f0 < f1 && c_isspace(s[f0])) f0++;
+                        while (f1 > f0 + 1 && c_isspace(s[f1 - 1])) f1--;
+                    }
+                }
+                const uint32_t tl = have ? f1 - f0 : 0;
+                const bool miss = tl == 0 || (tl == 1 && s[f0] == '.');
+                const uint32_t my_b = (piece && cd.htype != 1 && !miss) ? tl : 0u, my_c = piece ? 1u : 0u;
+                uint32_t ic = my_c, ib = my_b;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)ic, dd), y2 = (uint32_t)__shfl_up((int)ib, dd); if ((int)lane >= dd) { ic += y; ib += y2; } }
+                const uint32_t tot_c = (uint32_t)__shfl((int)ic, 63), tot_b = (uint32_t)__shfl((int)ib, 63);
+                if (WRITE && piece) {
+                    const uint32_t ci = cbase + cnt + ic - my_c, bo = bbase + nbytes + ib - my_b;
+                    cd.child_valid[ci] = miss ? 0 : 1;
+                    if (cd.htype == 1) {                                       // Integer: (int32_t)strtol(token, &end, 10), INT32_MIN unless the whole token is a number (vep_parse_int :207-220)
+                        uint32_t w = 0;
+                        if (!miss) {
+                            uint32_t q = f0; const bool neg = s[q] == '-'; if (s[q] == '-' || s[q] == '+') q++;
+                            uint64_t acc = 0; bool sat = false, ok = q < f1;
+                            for (; q < f1; q++) {
+                                const uint32_t dg = (uint32_t)s[q] - '0'; if (dg > 9) { ok = false; break; }
+                                if (acc > (0x7fffffffffffffffull - dg) / 10) sat = true; else acc = acc * 10 + dg;
+                            }
+                            if (!ok) w = 0x80000000u;
+                            else if (sat || (neg ? acc > 0x8000000000000000ull : acc > 0x7fffffffffffffffull)) w = neg ? 0u : 0xffffffffu;
+                            else w = (uint32_t)(neg ? (uint64_t)0 - acc : acc);
+                        }
+                        cd.child_fixed[ci] = w;
+                    } else {
+                        cd.child_off[ci] = bo;
+                        for (uint32_t j = 0; j < my_b; j++) cd.bytes[bo + j] = s[f0 + j];
+                    }
+                }
+                cnt += tot_c; nbytes += tot_b;
+            }
+            seg = sep[nsep - 1] + 1u;
+            __syncthreads();
+            nsep = 0;
+            if (last) break;
+        }
+        if (cnt == 0) valid = false;
+    }
+    if (lane != 0) return;
+    if (!WRITE) {
+        cd.valid[row] = valid ? 1 : 0;
+        if (!valid) { cnt = 0; nbytes = 0; }
+        if (cd.sa_cnt >= 0) a.lens[(size_t)cd.sa_cnt * a.ostride + row] = cnt;
+        if (cd.sa_bytes >= 0) a.lens[(size_t)cd.sa_bytes * a.ostride + row] = nbytes;
+    } else if (row == a.nrows - 1 && cd.child_off && cd.sa_cnt >= 0 && cd.sa_bytes >= 0) {
         cd.child_off[a.offs[(size_t)cd.sa_cnt * a.ostride + a.nrows]] = a.offs[(size_t)cd.sa_bytes * a.ostride + a.nrows];
     }
 }

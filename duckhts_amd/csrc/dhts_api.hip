@@ -175,6 +175,7 @@ struct dhts_ctx {
     const uint8_t *last_bcf_u = nullptr;   // where the records of the last read_bcf batch live (inflated stream or, for text, v_out)
     bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
     bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
+    DevBuf v_keep, v_endsv; uint64_t proj_gen = 1, keep_gen = 0; int32_t keep_none = 0; bool keep_all = true;   // VCF text: the INFO keys the projection reads (VcfArgs::info_keep)
     DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ, vd_id_ftyp, vd_ctg_hash, vd_id_hash, v_tok_off, v_tok_bytes, v_tok_bits;
     uint32_t v_undef_cap = 65536, v_patch_cap = 1u << 20;      // entries the device may record per batch; grown (and the pass repeated) when a batch needs more
     uint32_t vd_ctg_hmask = 0, vd_id_hmask = 0;
@@ -343,8 +344,10 @@ dhts_ctx *dhts_create(int device_id) {
         hipFuncSetAttribute((const void *)bgzf_huff_decode, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return nullptr;     // no gfx950 code object for this device
     }
-    (void)hipFuncSetAttribute((const void *)vcf_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void *)vcf_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)vcf_encode<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)vcf_encode<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)vcf_encode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)vcf_encode<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VCF_LDS_BYTES);
     hipLaunchKernelGGL(crc_const_init, dim3(1), dim3(64), 0, c->stream);      // per-device CRC constants (idempotent)
     if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     return c;

@@ -29,6 +29,13 @@ struct VcfArgs {
     unsigned long long *first_bad;
     uint32_t *counters;                                     // [0] undefined names, [1] patches
     VcfUndef *undef; uint32_t undef_cap; VcfPatch *patch; uint32_t patch_cap;
+    // projection pushdown into the encoder: bit `id` of info_keep set = a projected column reads INFO key `id` (nullptr: every key is kept).
+    // A key outside the set is looked up (names without a definition are reported whatever is projected) and counted towards the
+    // 65535-entry limit, but its value is neither parsed nor written and the record's n_info counts the kept fields only; nothing in an
+    // INFO value can fail a line (vcf_parse_info turns what it cannot convert into a missing value), so the rows are the same.
+    // info_none: no INFO key is kept at all (the write pass skips INFO).
+    const uint32_t *info_keep; int32_t info_none, pad_keep;
+    uint32_t *endsv;                                        // wave kernel: [2 * line] where the values of the line's first END= / SVLEN= fields begin (0xffffffff: none), measure pass -> write pass
 };
 
 // Line index of a batch: chunks of 4 KiB (one workgroup, 16 bytes per lane, coalesced); newline count per chunk, an exclusive scan over
@@ -382,21 +389,58 @@ bed_intervals(const uint8_t *__restrict__ u, const uint32_t *__restrict__ line_o
 }
 
 // One INFO field u[key, fend) -- the text between two ';' --: key[=value] (vcf_parse_info, vcf.c:3744-3985).  Returns 0 for an empty key (the
-// field is skipped and does not count), else 1.  QUIET: a measure pass that leaves no record of undefined names (the write pass of the wave
+// field is skipped and does not count), 1 for a field that was measured / written, 2 for a field outside the projection (VcfArgs::info_keep).  QUIET: a measure pass that leaves no record of undefined names (the write pass of the wave
 // kernel measures again to place its fields).
 // DEFER: a string value longer than VCF_DEFER_MIN is given its place but not copied; (*d_src, *d_dst, *d_len) tell the caller what is left to do
 // (the wave kernel copies such a value with all its lanes).
 #define VCF_DEFER_MIN 96u
-template <bool WRITE, bool QUIET, bool DEFER = false>
+// The key of a field with its first 32 bytes in registers (REGKEY: u is the stream itself, which is padded, so the four 8-byte loads -- in
+// flight together -- may run past the field): the '=' by a zero-byte test on the words, the hash and the comparison with the table's name
+// from the registers.  A walk byte by byte is a chain of dependent loads, forty of them for a 20-character key; this is four chains of
+// one.  Returns false when the key is longer than the 32 bytes (the caller walks).
+__device__ __forceinline__ bool vcf_key_regs(const VcfDictDev &d, const uint8_t *u, const uint32_t key, const uint32_t fend, uint32_t *kend_out, int *k_out) {
+    uint64_t w[4];
+    __builtin_memcpy(w, u + key, 32);
+    const uint32_t flen = fend - key;
+    uint32_t pe = 32;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+        const uint64_t x = w[q] ^ 0x3d3d3d3d3d3d3d3dull, z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;      // (the lowest flagged byte is exact)
+        if (z) pe = (uint32_t)(8 * q) + (uint32_t)(__builtin_ctzll(z) >> 3);
+    }
+    if (pe >= 32 && flen > 32) return false;
+    const uint32_t L = pe < flen ? pe : flen;
+    *kend_out = key + L; *k_out = -1;
+    if (L == 0 || d.n <= 0) return true;
+    uint64_t msk[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int nb = (int)L - 8 * q; msk[q] = nb >= 8 ? ~0ull : nb <= 0 ? 0ull : ((1ull << (8 * nb)) - 1ull); w[q] &= msk[q]; }
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < L; i++) h = (h ^ (uint32_t)((w[i >> 3] >> (8 * (i & 7))) & 0xffu)) * 16777619u;
+    for (h &= d.hmask;; h = (h + 1) & d.hmask) {
+        const uint32_t e = d.hash[h];
+        if (!e) return true;
+        const uint32_t o0 = d.off[e - 1], o1 = d.off[e];
+        if (o1 - o0 != L) continue;
+        uint64_t m[4];
+        __builtin_memcpy(m, d.bytes + o0, 32);                                     // (the table's bytes have 64 bytes of slack behind them)
+        if ((((m[0] & msk[0]) ^ w[0]) | ((m[1] & msk[1]) ^ w[1]) | ((m[2] & msk[2]) ^ w[2]) | ((m[3] & msk[3]) ^ w[3])) == 0) { *k_out = (int)(e - 1); return true; }
+    }
+}
+template <bool WRITE, bool QUIET, bool DEFER = false, bool REGKEY = false>
 __device__ __forceinline__ int vcf_info_field(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, const uint32_t key, const uint32_t fend, VcfSink<WRITE> &o,
                                               uint32_t *d_src = nullptr, uint32_t *d_dst = nullptr, uint32_t *d_len = nullptr) {
-    uint32_t kend = key; while (kend < fend && u[kend] != '=') kend++;
+    uint32_t kend = key; int k = -1;
+    if (!REGKEY || !vcf_key_regs(a.ids, u, key, fend, &kend, &k)) {
+        kend = key; while (kend < fend && u[kend] != '=') kend++;
+        if (kend > key) k = vcf_dict_find(a.ids, u + key, kend - key);
+    }
     if (kend == key) return 0;
     const uint32_t val = kend < fend ? kend + 1 : 0xffffffffu, end = fend;
-    const int k = vcf_dict_find(a.ids, u + key, kend - key);
     int ht = 3; int32_t id = 0;
     if (k < 0 || a.ids.ityp[k] == 15) { if (!WRITE && !QUIET) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, key + bias, kend - key, 2u}; } }
     else { ht = a.ids.ityp[k]; id = a.ids.id[k]; }
+    if (a.info_keep && !((a.info_keep[(uint32_t)id >> 5] >> ((uint32_t)id & 31u)) & 1u)) return 2;      // (a name without a definition has id 0 here and a definition of its own in the next round)
     o.key(id);
     if (val == 0xffffffffu) o.b(0x00);
     else if (ht == 0 || ht == 3) {
@@ -450,7 +494,7 @@ vcf_scatter_words(uint8_t *__restrict__ out, const VcfPatch *__restrict__ patch,
 #define VCF_ENC_THREADS 64
 #define VCF_MAXF 32
 #define VCF_WSEP 2048u                                        // ';' positions a wave collects before it parses the fields between them (LDS, 8 KB)
-template <bool WRITE, bool WAVE> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep);
+template <bool WRITE, bool WAVE, bool SMP> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep);
 
 // ---- a wave per line (lines too long for 64 of them to share the LDS staging: gnomAD-style INFO of hundreds of keys) ----------------------------
 // first position in [from, to) that holds ch, else `to`: 16 bytes per lane, a ballot per KiB (the stream is padded, so whole 16-byte words are read)
@@ -488,17 +532,19 @@ __device__ __forceinline__ uint32_t vcf_wave_excl_scan(uint32_t v, uint32_t *tot
 }
 // The line stays where it lies (HBM / L2): staging it in LDS was measured and bought nothing -- the parse is a chain of dependent byte reads
 // either way, and what hides their latency is the number of waves per CU, which 8 KB of LDS per wave leaves at twenty.
-template <bool WRITE>
+// SMP: the file has sample columns.  The sites-only instantiations carry none of the FORMAT code, whose per-key arrays would otherwise take
+// the kernel to 300 registers and one wave per SIMD.
+template <bool WRITE, bool SMP>
 __global__ void __launch_bounds__(64) vcf_encode_wave(VcfArgs a) {
     __shared__ uint32_t sep[VCF_WSEP];
     const int64_t li = blockIdx.x;
-    if (li < a.nlines) vcf_encode_line<WRITE, true>(a, li, a.u, 0u, sep);
+    if (li < a.nlines) vcf_encode_line<WRITE, true, SMP>(a, li, a.u, 0u, sep);
 }
 
 // The lines of a workgroup are consecutive in the text: their span is staged in LDS with coalesced 16-byte loads and parsed from there (a
 // lane walks its line byte by byte); a span that does not fit is parsed from HBM.  Two separate calls, so that the LDS copy is reached
 // through LDS instructions: a pointer that may be either kind becomes a flat access, and flat accesses to LDS fault on this system.
-template <bool WRITE>
+template <bool WRITE, bool SMP>
 __global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t vcf_lds[];
     const int64_t li0 = (int64_t)blockIdx.x * blockDim.x, li = li0 + threadIdx.x;
@@ -509,8 +555,8 @@ __global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
     if (staged) {
         for (uint32_t q = threadIdx.x * 16u; s0 + q < s1; q += blockDim.x * 16u) *(uint4 *)(vcf_lds + q) = *(const uint4 *)(a.u + s0 + q);   // (the stream is padded: reading up to 15 bytes past s1 is safe)
         __syncthreads();
-        if (li < a.nlines) vcf_encode_line<WRITE, false>(a, li, vcf_lds, s0, nullptr);
-    } else if (li < a.nlines) vcf_encode_line<WRITE, false>(a, li, a.u, 0u, nullptr);
+        if (li < a.nlines) vcf_encode_line<WRITE, false, SMP>(a, li, vcf_lds, s0, nullptr);
+    } else if (li < a.nlines) vcf_encode_line<WRITE, false, SMP>(a, li, a.u, 0u, nullptr);
 }
 
 // every position below is relative to `bias` (the start of the staged span, or 0): u[] is either the LDS copy or the stream itself
@@ -518,7 +564,7 @@ __global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
 // then hit one address, and `lead` keeps the records of undefined names and patches single --; what is long is shared out: the searches for
 // the line's NUL and INFO's end (vcf_wave_find), and INFO, whose ';' are collected 16 bytes per lane and whose fields are then parsed one per
 // lane, measured, placed by a scan of the sizes and written.
-template <bool WRITE, bool WAVE>
+template <bool WRITE, bool WAVE, bool SMP>
 __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep) {
     const bool lead = !WAVE || (threadIdx.x & 63u) == 0;
     const uint32_t l0 = a.line_off[li] - bias;
@@ -542,7 +588,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
     }
     uint32_t w_pe = 0xffffffffu, w_ps = 0xffffffffu;                                                  // WAVE: where the values of END= / SVLEN= begin
     if (nf < 8) bad = true;
-    int32_t rid = 0; int64_t pos = 0; uint32_t n_allele = 1, n_info = 0, qbits = 0x7F800001u; int32_t rlen = 0;
+    int32_t rid = 0; int64_t pos = 0; uint32_t n_allele = 1, n_info = 0, n_info_all = 0, qbits = 0x7F800001u; int32_t rlen = 0;      // n_info: fields kept (the record's count); n_info_all: fields met (the limit's)
     if (!bad) {
         // CHROM
         const int k = vcf_dict_find(a.ctg, u + fs[0], fe[0] - fs[0]);
@@ -599,7 +645,9 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         // INFO
         if (!(fe[7] - fs[7] == 1 && u[fs[7]] == '.')) {
             uint32_t e7 = fe[7]; if (e7 > fs[7] && u[e7 - 1] == ';') e7--;
-            if (WAVE) {
+            if (WAVE && WRITE && a.info_none) {                                                      // nothing of INFO is projected: the measure pass has seen every field (and left END= / SVLEN=)
+                w_pe = a.endsv[2 * li]; w_ps = a.endsv[2 * li + 1];
+            } else if (WAVE) {
                 const uint32_t lane = threadIdx.x & 63u;
                 uint32_t seg = fs[7], nsep = 0;                                                       // seg: where the first field of the collected stretch begins
                 for (uint32_t base = fs[7] & ~15u;; base += 1024u) {
@@ -619,27 +667,31 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                         const uint32_t key = have ? (k ? sep[k - 1] + 1u : seg) : 0u, fend = have ? sep[k] : 0u;
                         VcfSink<false> ms; ms.p = nullptr; ms.n = 0;
                         int cnt = 0;
-                        if (have) cnt = WRITE ? vcf_info_field<false, true>(a, li, u, bias, key, fend, ms) : vcf_info_field<false, false>(a, li, u, bias, key, fend, ms);
+                        if (have) cnt = WRITE ? vcf_info_field<false, true, false, true>(a, li, u, bias, key, fend, ms) : vcf_info_field<false, false, false, true>(a, li, u, bias, key, fend, ms);
                         uint32_t tot_n, tot_c;
-                        const uint32_t off = vcf_wave_excl_scan(ms.n, &tot_n), before = vcf_wave_excl_scan((uint32_t)cnt, &tot_c);
-                        if (__ballot(have && n_info + before == 65535u)) bad = true;
+                        // one scan for both counts: fields met (low half) and fields kept (high half), at most 64 of either
+                        const uint32_t off = vcf_wave_excl_scan(ms.n, &tot_n), both = vcf_wave_excl_scan((cnt ? 1u : 0u) | (cnt == 1 ? 0x10000u : 0u), &tot_c);
+                        if (__ballot(have && n_info_all + (both & 0xffffu) == 65535u)) bad = true;
                         if (WRITE) {
                             uint32_t d_src = 0, d_dst = 0, d_len = 0;
-                            if (have && !bad) { VcfSink<WRITE> ws; ws.p = o.p; ws.n = o.n + off; vcf_info_field<WRITE, false, true>(a, li, u, bias, key, fend, ws, &d_src, &d_dst, &d_len); }
+                            if (have && !bad && cnt == 1) { VcfSink<WRITE> ws; ws.p = o.p; ws.n = o.n + off; vcf_info_field<WRITE, false, true, true>(a, li, u, bias, key, fend, ws, &d_src, &d_dst, &d_len); }
                             for (unsigned long long big = __ballot(d_len != 0); big; big &= big - 1) {      // long strings: all lanes copy, a byte each per step
                                 const int l = __builtin_ctzll(big);
                                 const uint32_t src = (uint32_t)__shfl((int)d_src, l), dst = (uint32_t)__shfl((int)d_dst, l), len = (uint32_t)__shfl((int)d_len, l);
-                                for (uint32_t i = lane; i < len; i += 64u) o.p[dst + i] = u[src + i];
+                                uint32_t i = lane * 8u;                                              // eight bytes per lane and step (unaligned 8-byte loads and stores), the tail a byte per lane
+                                for (; i + 8u <= len; i += 512u) { uint64_t v; __builtin_memcpy(&v, u + src + i, 8); __builtin_memcpy(o.p + dst + i, &v, 8); }
+                                i = (len & ~7u) + lane;
+                                if (i < len) o.p[dst + i] = u[src + i];
                             }
                         }
-                        if (WRITE) {                                                                  // the first fields that begin with END= / SVLEN= (vcf_tabix_end)
+                        if (!WRITE || !a.endsv) {                                                     // the first fields that begin with END= / SVLEN= (vcf_tabix_end)
                             const bool is_e = have && fend - key >= 4 && u[key] == 'E' && u[key + 1] == 'N' && u[key + 2] == 'D' && u[key + 3] == '=';
                             const bool is_s = have && fend - key >= 6 && u[key] == 'S' && u[key + 1] == 'V' && u[key + 2] == 'L' && u[key + 3] == 'E' && u[key + 4] == 'N' && u[key + 5] == '=';
                             const unsigned long long be = __ballot(is_e), bs = __ballot(is_s);
                             if (be && w_pe == 0xffffffffu) w_pe = (uint32_t)__shfl((int)key, __builtin_ctzll(be)) + 4u;
                             if (bs && w_ps == 0xffffffffu) w_ps = (uint32_t)__shfl((int)key, __builtin_ctzll(bs)) + 6u;
                         }
-                        o.n += tot_n; n_info += tot_c;
+                        o.n += tot_n; n_info += tot_c >> 16; n_info_all += tot_c & 0xffffu;
                         if (bad) break;
                     }
                     seg = sep[nsep - 1] + 1u;
@@ -647,11 +699,14 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                     nsep = 0;
                     if (last || bad) break;
                 }
-            } else
+                if (!WRITE && a.endsv && lane == 0) { a.endsv[2 * li] = w_pe; a.endsv[2 * li + 1] = w_ps; }
+                if (WRITE && a.endsv) { w_pe = a.endsv[2 * li]; w_ps = a.endsv[2 * li + 1]; }
+            } else if (!(WRITE && a.info_none))                                                      // (nothing of INFO projected: the measure pass has seen every field)
             for (uint32_t key = fs[7];;) {                                                           // fields between ';' (kstrtok)
                 uint32_t fend = key; while (fend < e7 && u[fend] != ';') fend++;
-                if (n_info == 65535) { bad = true; break; }
-                n_info += (uint32_t)vcf_info_field<WRITE, false>(a, li, u, bias, key, fend, o);
+                if (n_info_all == 65535) { bad = true; break; }
+                const int got = vcf_info_field<WRITE, false>(a, li, u, bias, key, fend, o);
+                n_info += got == 1; n_info_all += got != 0;
                 if (fend >= e7) break;
                 key = fend + 1;
             }
@@ -660,7 +715,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
     if (WAVE && WRITE && !bad) rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1, true, w_pe, w_ps) - pos);
     // FORMAT + sample columns (vcf_parse_format vcf.c:3686-3742; steps 3137-3684): per-sample text A:B:C becomes per-field arrays
     uint32_t n_fmt_kept = 0, n_sample = 0; const uint32_t indiv0 = o.n;
-    if (!bad && a.n_smp > 0 && fe[7] < l1) {
+    if (SMP && !bad && a.n_smp > 0 && fe[7] < l1) {
         const uint32_t fp = fe[7] + 1; uint32_t fq = fp; while (fq < l1 && u[fq] != '\t') fq++;
         if (fq >= l1) bad = true;                                                                     // "FORMAT column with no sample columns"
         else if (fq - fp == 1 && u[fp] == '.') n_sample = (uint32_t)a.n_smp;                          // FORMAT ".": nothing to parse, the sample columns are not looked at

@@ -303,6 +303,50 @@ def test_gpu_projection_and_sample_columns():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_gpu_projection_reaches_the_text_encoder(wave, monkeypatch):
+    """the INFO keys the projected columns read are all the encoder writes into the records it makes (VcfArgs::info_keep): every projection
+    gives the columns of the full read -- a single key, the annotation tag behind a VEP_ column, no INFO column at all (rows, POS, and the
+    END= / SVLEN= interval behind a region filter), random subsets --, names without a definition are still reported, the 65535-entry
+    limit still counts every field"""
+    import random
+    import duckhts_amd
+    monkeypatch.setenv("DHTS_VCF_WAVE", wave)
+    txt = _long_info_lines(120, seed=8)
+    exp = orc.bcf_read(txt)
+    names = [c["name"] for c in exp["cols"]]
+    rnd = random.Random(5)
+    info_cols = [n for n in names if n.startswith("INFO_")]
+    projections = [["POS"], ["CHROM", "POS", "REF", "ALT", "QUAL", "FILTER"], ["INFO_END"], ["VEP_SYMBOL"], ["INFO_vep", "POS"], ["VEP_Consequence", "INFO_SVLEN", "ID"]]
+    projections += [rnd.sample(info_cols, k) + ["POS"] for k in (1, 3, 40)] + [info_cols]
+    for want in projections:
+        for kw in ({}, {"max_blocks": 1}):
+            got = duckhts_amd.read_bcf(txt, columns=[names.index(w) for w in want], **kw)
+            d = orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": [exp["by_name"][w] for w in want]}, got)
+            assert d is None, (want[:4], d)
+    # a region filter on a projection without INFO columns: the interval comes from END= / SVLEN= all the same
+    import bamwriter
+    from test_vcf_region import build_index
+    z = bamwriter.bgzf_file(txt, payload=20000)
+    raw, tbi = build_index(z, 0)                                         # (the index build projects nothing)
+    full = duckhts_amd.read_bcf(z, region="22:3000-9000", index=tbi)
+    part = duckhts_amd.read_bcf(z, region="22:3000-9000", index=tbi, columns=[names.index("POS")])
+    assert part["n_rows"] == full["n_rows"] > 0
+    monkeypatch.setenv("DHTS_VCF_KEEP", "0")                             # every key encoded whatever is projected: the same index
+    assert build_index(z, 0)[0] == raw
+    monkeypatch.delenv("DHTS_VCF_KEEP")
+    assert orc.bcf_cols_diff({"n_rows": full["n_rows"], "cols": [c for c in full["cols"] if c["name"] == "POS"]}, part) is None
+    # 65535 INFO entries are too many whatever is projected (vcf_parse_info counts every field)
+    hdr = "##fileformat=VCFv4.2\n##contig=<ID=1>\n##INFO=<ID=A,Number=1,Type=Integer,Description=\"x\">\n##INFO=<ID=B,Number=0,Type=Flag,Description=\"x\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    many = (hdr + "1\t5\t.\tA\tC\t.\t.\tA=1\n1\t6\t.\tA\tC\t.\t.\t" + ";".join(["B"] * 65536) + "\n1\t7\t.\tA\tC\t.\t.\tA=2\n").encode()
+    e2 = orc.bcf_read(many)
+    n2 = [c["name"] for c in e2["cols"]]
+    for want in (["POS"], ["INFO_A"], n2):
+        g2 = duckhts_amd.read_bcf(many, columns=[n2.index(w) for w in want])
+        assert g2["n_rows"] == e2["n_rows"] and (g2["status"] == 1) == (e2["status"] == 0), (want[:3], g2["n_rows"], e2["n_rows"], g2["status"], e2["status"])
+
+
+@pytest.mark.gpu
 def test_gpu_vcf_text_through_the_table_function(tmp_path):
     """the reference's own queries on its own files: read_bcf('test_vep.vcf') (plain text) and read_bcf('no_contig.vcf.gz')"""
     from test_duckdb_surface import compare_bcf, run_host

@@ -153,6 +153,54 @@ def test_gpu_edge_cases(name, data, tidy):
     _check(data, tidy)
 
 
+def _long_vep(n, seed=4):
+    """annotation strings of up to thousands of transcripts: empty pieces, short transcripts, white space, '.', numbers that do and do not parse"""
+    import random
+    rnd = random.Random(seed)
+    fmt = "Allele|Consequence|SYMBOL|DISTANCE|STRAND|gnomAD_AF|HGVSc"
+    hdr = ["##fileformat=VCFv4.2", "##contig=<ID=1,length=1000000>",
+           '##INFO=<ID=CSQ,Number=.,Type=String,Description="Consequence annotations from Ensembl VEP. Format: %s">' % fmt, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    out = ["\n".join(hdr)]
+    for r in range(n):
+        ntr = rnd.choice([0, 1, 2, 40, 70, 130, 1100, 2300] if r % 9 == 0 else [1, 3, 20, 40])
+        trs = []
+        for _ in range(ntr):
+            k = rnd.random()
+            if k < 0.05:
+                trs.append("")
+            elif k < 0.1:
+                trs.append("|".join(["A"] * rnd.randrange(1, 4)))
+            else:
+                trs.append("|".join([rnd.choice("ACGT"), rnd.choice(["missense_variant", " intron_variant ", ".", ""]), "GENE%d" % rnd.randrange(900),
+                                     rnd.choice(["", "12", "-7", "+3", "1x", " 44 ", "99999999999999999999", "."]), rnd.choice(["1", "-1", ""]),
+                                     rnd.choice(["", "0.25", "1e-5", "."]), "x" * rnd.choice([0, 1, 7, 8, 9, 30, 200])] + (["extra"] if k > 0.95 else [])))
+        info = "CSQ=" + ",".join(trs) if (ntr or r % 2) else "."
+        if r % 13 == 0:
+            info = "CSQ=,,,"
+        out.append("1\t%d\t.\tA\tC\t.\t.\t%s" % (100 + r, info))
+    return ("\n".join(out) + "\n").encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_gpu_vep_wave_per_row(wave, fixture, monkeypatch):
+    """bcf_vep_wave (a wave per row and VEP column, a transcript per lane) and the lane-per-row form of bcf_cells, each forced onto the
+    fixture, the edge cases and long annotation strings: the same columns as the oracle's"""
+    import duckhts_amd
+    monkeypatch.setenv("DHTS_VEP_WAVE", wave)
+    _check(fixture[0])
+    _check(fixture[0], max_blocks=1)
+    for name, data, tidy in vep_cases.edge_cases():
+        _check(data, tidy)
+    txt = _long_vep(120)
+    exp, got = _check(txt)
+    assert max(len(x) for x in orc.bcf_col_py(got["by_name"]["VEP_SYMBOL"]) if x is not None) >= 1000
+    names = [c["name"] for c in exp["cols"]]
+    for want in (["VEP_DISTANCE"], ["VEP_HGVSc", "POS", "VEP_Allele"], ["VEP_gnomAD_AF", "VEP_STRAND"]):
+        sub = duckhts_amd.read_bcf(txt, columns=[names.index(w) for w in want], max_blocks=1)
+        assert orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": [exp["by_name"][w] for w in want]}, sub) is None, want
+
+
 @pytest.mark.gpu
 def test_gpu_projection_of_vep_columns(fixture):
     import duckhts_amd
