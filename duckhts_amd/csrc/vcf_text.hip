@@ -492,9 +492,12 @@ vcf_scatter_words(uint8_t *__restrict__ out, const VcfPatch *__restrict__ patch,
 
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
-#define VCF_MAXF 32
+#define VCF_MAXF 32                                           // FORMAT keys of a line in the lane-per-line encoder (more: the batch goes to the wave encoder)
+#define VCF_MAXF_WAVE 255                                     // htslib's MAX_N_FMT (vcf.c:3134)
+struct VcfFmtLds { int32_t key[VCF_MAXF_WAVE + 1]; uint32_t mx_l[VCF_MAXF_WAVE + 1], mx_m[VCF_MAXF_WAVE + 1], mx_g[VCF_MAXF_WAVE + 1], fsz[VCF_MAXF_WAVE + 1], fat[VCF_MAXF_WAVE + 1]; uint8_t ht[VCF_MAXF_WAVE + 1], flg[VCF_MAXF_WAVE + 1]; };
 #define VCF_WSEP 2048u                                        // ';' positions a wave collects before it parses the fields between them (LDS, 8 KB)
-template <bool WRITE, bool WAVE, bool SMP> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep);
+struct VcfFmtLds;
+template <bool WRITE, bool WAVE, bool SMP> __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep, VcfFmtLds *fl);
 
 // ---- a wave per line (lines too long for 64 of them to share the LDS staging: gnomAD-style INFO of hundreds of keys) ----------------------------
 // first position in [from, to) that holds ch, else `to`: 16 bytes per lane, a ballot per KiB (the stream is padded, so whole 16-byte words are read)
@@ -537,8 +540,10 @@ __device__ __forceinline__ uint32_t vcf_wave_excl_scan(uint32_t v, uint32_t *tot
 template <bool WRITE, bool SMP>
 __global__ void __launch_bounds__(64) vcf_encode_wave(VcfArgs a) {
     __shared__ uint32_t sep[VCF_WSEP];
+    __shared__ uint32_t fl_words[SMP ? (sizeof(VcfFmtLds) + 3) / 4 : 1];                             // (the sites-only kernels do not pay for the tables)
+    VcfFmtLds *fl = (VcfFmtLds *)fl_words;
     const int64_t li = blockIdx.x;
-    if (li < a.nlines) vcf_encode_line<WRITE, true, SMP>(a, li, a.u, 0u, sep);
+    if (li < a.nlines) vcf_encode_line<WRITE, true, SMP>(a, li, a.u, 0u, sep, fl);
 }
 
 // The lines of a workgroup are consecutive in the text: their span is staged in LDS with coalesced 16-byte loads and parsed from there (a
@@ -555,8 +560,8 @@ __global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
     if (staged) {
         for (uint32_t q = threadIdx.x * 16u; s0 + q < s1; q += blockDim.x * 16u) *(uint4 *)(vcf_lds + q) = *(const uint4 *)(a.u + s0 + q);   // (the stream is padded: reading up to 15 bytes past s1 is safe)
         __syncthreads();
-        if (li < a.nlines) vcf_encode_line<WRITE, false, SMP>(a, li, vcf_lds, s0, nullptr);
-    } else if (li < a.nlines) vcf_encode_line<WRITE, false, SMP>(a, li, a.u, 0u, nullptr);
+        if (li < a.nlines) vcf_encode_line<WRITE, false, SMP>(a, li, vcf_lds, s0, nullptr, nullptr);
+    } else if (li < a.nlines) vcf_encode_line<WRITE, false, SMP>(a, li, a.u, 0u, nullptr, nullptr);
 }
 
 // every position below is relative to `bias` (the start of the staged span, or 0): u[] is either the LDS copy or the stream itself
@@ -564,8 +569,127 @@ __global__ void __launch_bounds__(VCF_ENC_THREADS) vcf_encode(VcfArgs a) {
 // then hit one address, and `lead` keeps the records of undefined names and patches single --; what is long is shared out: the searches for
 // the line's NUL and INFO's end (vcf_wave_find), and INFO, whose ';' are collected 16 bytes per lane and whose fields are then parsed one per
 // lane, measured, placed by a scan of the sizes and written.
+// ---- the sample columns (vcf_parse_format vcf.c:3686-3742; steps 3137-3684), one sample at a time: the serial encoder walks them in a row, the wave encoder a sample per lane ----
+// max3 of one sample column u[r, e) (e: its tab, or the line's end): the widths of its fields into mx_l / mx_m / mx_g (ATOMIC: LDS tables shared
+// by the lanes of a wave).  false: more fields than FORMAT names ("Incorrect number of FORMAT fields").
+template <bool ATOMIC>
+__device__ __forceinline__ bool vcf_fmt_widths(const uint8_t *u, uint32_t r, const uint32_t e, const int n_fmt, const uint8_t *flg, uint32_t *mx_l, uint32_t *mx_m, uint32_t *mx_g) {
+    auto up = [&](uint32_t *p, uint32_t v) { if (ATOMIC) { if (*p < v) atomicMax(p, v); } else if (*p < v) *p = v; };
+    int j = 0; uint32_t r_start = r, m = 1, g = 1;
+    for (;;) {
+        while (r < e && u[r] != ',' && u[r] != '/' && u[r] != ':' && u[r] != '|') r++;
+        const uint8_t ch = r < e ? u[r] : 0;
+        if (ch == ',') m++;
+        else if (ch == '|' || ch == '/') { if (flg[j] & 1) g++; }
+        else {
+            const uint32_t l = r - r_start; r_start = r;                          // (from the second field on the ':' in front counts, as in htslib)
+            up(mx_m + j, m); up(mx_l + j, l); if (flg[j] & 1) up(mx_g + j, g);
+            m = g = 1;
+            if (ch == ':') { j++; if (j >= n_fmt) return false; }
+            else break;
+        }
+        if (r >= e) break;
+        r++;
+    }
+    return true;
+}
+// fill5 of one sample column u[t, end) of a line that ends at lend: every field validated (measure pass) and stored at its place fat[field] + fsz[field] * m (write pass).
+// Returns true when the column is an error.
+template <bool WRITE>
+__device__ __forceinline__ bool vcf_fmt_fill_sample(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t t, const uint32_t end, const uint32_t lend, const uint32_t m, const int n_fmt,
+                                                    const uint8_t *ht, const uint8_t *flg, const uint32_t *fsz, const uint32_t *fat, uint8_t *op) {
+    bool bad = false;
+    int j = 0;
+    while (t < lend) {                                                            // (lend: the line's end -- the walk looks at a field behind a ':' even when the column ends there, unless the line does too)
+        const int z = j++;
+        const uint32_t at = fat[z] + fsz[z] * m;
+        auto put32 = [&](uint32_t idx, uint32_t v) { if (WRITE) __builtin_memcpy(op + at + 4 * idx, &v, 4); };
+        auto ch = [&](uint32_t p) -> uint8_t { return p < end ? u[p] : (uint8_t)0; };                                // a sample column is a C string (end: its tab, or the line's end)
+        if (flg[z] & 2) { while (ch(t) != ':' && ch(t)) t++; }
+        else if (ht[z] == 3 && (flg[z] & 1)) {                                        // GT: ([/|])?val([/|]val)*, val = digits or '.'
+            uint32_t is_phased = 0, maxv = 0, x0 = 0; bool unreadable = false; int l = 0, ploidy = 0, anyunphased = 0, prfx = 0, unknown1 = 0;
+            if (a.v44 && (ch(t) == '|' || ch(t) == '/')) { is_phased = ch(t) == '|'; t++; prfx = 1; }
+            for (;; ++t) {
+                ploidy++;
+                uint32_t xv;
+                if (ch(t) == '.') { ++t; xv = is_phased; if (l == 0) unknown1 = 1; }
+                else {
+                    const uint32_t tt = t; uint64_t n = 0;
+                    if (ch(t) == '+') t++;
+                    while (ch(t) >= '0' && ch(t) <= '9') n = n * 10 + (uint64_t)(ch(t++) - '0');
+                    const uint32_t val = (uint32_t)n;
+                    unreadable |= tt == t;
+                    if (maxv < val) maxv = val;
+                    xv = (val + 1) << 1 | is_phased;
+                }
+                if (l == 0) x0 = xv; else put32((uint32_t)l, xv);
+                l++;
+                anyunphased |= (ploidy != 1) && !is_phased;
+                is_phased = ch(t) == '|';
+                if (ch(t) != '|' && ch(t) != '/') break;
+            }
+            if (!prfx) { if (ploidy == 1) { if (!unknown1) x0 |= 1; } else x0 |= anyunphased ? 0u : 1u; }
+            if (maxv > (0x7fffffffu >> 1) - 1 || unreadable) { bad = true; break; }
+            put32(0, x0);
+            for (; (uint32_t)l < fsz[z] >> 2; ++l) put32((uint32_t)l, 0x80000001u);
+        } else if (ht[z] == 3) {
+            uint32_t l = 0;
+            for (; ch(t) != ':' && ch(t); ++t, ++l) if (WRITE) op[at + l] = u[t];
+            if (WRITE) for (; l < fsz[z]; l++) op[at + l] = 0;
+        } else if (ht[z] == 1) {
+            uint32_t l = 0;
+            for (;; ++t) {
+                if (ch(t) == '.') { put32(l++, 0x80000000u); ++t; }
+                else {
+                    uint32_t te = t; bool neg = false, over = false; uint64_t n = 0, limit = (1ull << 63) - 1;
+                    if (ch(te) == '-') { limit++; neg = true; te++; } else if (ch(te) == '+') te++;
+                    for (; ch(te) >= '0' && ch(te) <= '9'; te++) { const uint32_t d = ch(te) - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
+                    const int64_t v = neg ? (int64_t)(0 - n) : (int64_t)n;
+                    put32(l++, (te == t || over || v < -2147483640ll || v > 2147483647ll) ? 0x80000000u : (uint32_t)(int32_t)v);
+                    t = te;
+                }
+                if (ch(t) != ',') break;
+            }
+            for (; l < fsz[z] >> 2; ++l) put32(l, 0x80000001u);
+        } else {
+            uint32_t l = 0;
+            for (;; ++t) {
+                const uint8_t c1 = ch(t + 1);
+                if (ch(t) == '.' && !(c1 >= '0' && c1 <= '9')) { put32(l++, 0x7F800001u); ++t; }
+                else {
+                    uint32_t tok_end = t; while (ch(tok_end) && ch(tok_end) != ',' && ch(tok_end) != ':') tok_end++;
+                    double d; uint32_t e;
+                    if (tok_end == t) put32(l++, 0u);                               // an empty value: strtod converts nothing and returns 0.0
+                    else if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { put32(l++, __float_as_uint(__double2float_rn(d))); t += e; }
+                    else {
+                        // strtod's forms: the host converts (write pass) and checks that the number ends where the token ends (measure pass)
+                        if (!WRITE) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, tok_end - t, 4u}; }
+                        else { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + at + 4 * l, 2u}; }
+                        put32(l++, 0u);
+                        t = tok_end;
+                    }
+                }
+                if (ch(t) != ',') break;
+            }
+            for (; l < fsz[z] >> 2; ++l) put32(l, 0x7F800002u);
+        }
+        if (ch(t) == 0) break;
+        else if (ch(t) == ':') t++;
+        else { bad = true; break; }                                                   // "Invalid character"
+    }
+    if (bad) return true;
+    for (; j < n_fmt; ++j) {                                                          // trailing fields the sample leaves out
+        if (flg[j] & 2) continue;
+        const uint32_t at = fat[j] + fsz[j] * m;
+        if (!WRITE) continue;
+        if (ht[j] == 3 && !(flg[j] & 1)) { for (uint32_t l = 0; l < fsz[j]; l++) op[at + l] = l == 0 ? '.' : 0; }
+        else for (uint32_t l = 0; l < fsz[j] >> 2; l++) { const uint32_t w = l == 0 ? (ht[j] == 2 ? 0x7F800001u : 0x80000000u) : (ht[j] == 2 ? 0x7F800002u : 0x80000001u); __builtin_memcpy(op + at + 4 * l, &w, 4); }
+    }
+    return false;
+}
+
 template <bool WRITE, bool WAVE, bool SMP>
-__device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep) {
+__device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t li, const uint8_t *u, const uint32_t bias, uint32_t *sep, VcfFmtLds *fl) {
     const bool lead = !WAVE || (threadIdx.x & 63u) == 0;
     const uint32_t l0 = a.line_off[li] - bias;
     uint32_t l1 = ((li + 1 == a.nlines && a.last_open) ? (uint32_t)a.text_end : a.line_off[li + 1] - 1) - bias;
@@ -713,19 +837,25 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
         }
     }
     if (WAVE && WRITE && !bad) rlen = (int32_t)(vcf_tabix_end(u, pos, fs[3], fe[3], fs[4], fe[4], fs[7], fe[7], fe[7] < l1 ? fe[7] + 1 : l1, l1, true, w_pe, w_ps) - pos);
-    // FORMAT + sample columns (vcf_parse_format vcf.c:3686-3742; steps 3137-3684): per-sample text A:B:C becomes per-field arrays
+    // FORMAT + sample columns (vcf_parse_format vcf.c:3686-3742; steps 3137-3684): per-sample text A:B:C becomes per-field arrays.  The tables of
+    // the FORMAT keys (up to htslib's 255, MAX_N_FMT) live in LDS for the wave encoder -- which then takes the sample columns a sample per lane --
+    // and in private arrays of VCF_MAXF for the lane-per-line encoder, which hands a line with more keys to the wave encoder (counters[2]).
     uint32_t n_fmt_kept = 0, n_sample = 0; const uint32_t indiv0 = o.n;
     if (SMP && !bad && a.n_smp > 0 && fe[7] < l1) {
         const uint32_t fp = fe[7] + 1; uint32_t fq = fp; while (fq < l1 && u[fq] != '\t') fq++;
         if (fq >= l1) bad = true;                                                                     // "FORMAT column with no sample columns"
         else if (fq - fp == 1 && u[fp] == '.') n_sample = (uint32_t)a.n_smp;                          // FORMAT ".": nothing to parse, the sample columns are not looked at
         else {
-            // dict2: the keys
-            int32_t key[VCF_MAXF]; uint8_t ht[VCF_MAXF], flg[VCF_MAXF]; uint32_t mx_l[VCF_MAXF], mx_m[VCF_MAXF], mx_g[VCF_MAXF], fsz[VCF_MAXF], fat[VCF_MAXF];   // flg: 1 = GT, 2 = dropped duplicate
+            constexpr int MAXF = WAVE ? VCF_MAXF_WAVE : VCF_MAXF, NP = WAVE ? 1 : VCF_MAXF;
+            int32_t key_p[NP]; uint8_t ht_p[NP], flg_p[NP]; uint32_t mx_l_p[NP], mx_m_p[NP], mx_g_p[NP], fsz_p[NP], fat_p[NP];      // flg: 1 = GT, 2 = dropped duplicate
+            int32_t *key = WAVE ? fl->key : key_p; uint8_t *ht = WAVE ? fl->ht : ht_p, *flg = WAVE ? fl->flg : flg_p;
+            uint32_t *mx_l = WAVE ? fl->mx_l : mx_l_p, *mx_m = WAVE ? fl->mx_m : mx_m_p, *mx_g = WAVE ? fl->mx_g : mx_g_p, *fsz = WAVE ? fl->fsz : fsz_p, *fat = WAVE ? fl->fat : fat_p;
+            const uint32_t lane = WAVE ? (threadIdx.x & 63u) : 0u;
+            // dict2: the keys (every lane of a wave alike: the stores hit one address with one value)
             int n_fmt = 0;
             for (uint32_t t = fp;;) {
                 uint32_t c = t; while (c < fq && u[c] != ':') c++;
-                if (n_fmt >= VCF_MAXF) { bad = true; break; }                                       // (htslib allows 255 identifiers; this encoder 32)
+                if (n_fmt >= MAXF) { if (!WAVE) a.counters[2] = 1u; bad = true; break; }              // (the lane-per-line encoder: the batch goes to the wave encoder; there: htslib's own limit)
                 const int k = vcf_dict_find(a.ids, u + t, c - t);
                 key[n_fmt] = 0; ht[n_fmt] = 3;
                 if (k < 0 || a.ids.ftyp[k] == 15) {
@@ -738,36 +868,59 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                 if (c >= fq) break;
                 t = c + 1;
             }
+            if (WAVE) __syncthreads();
             const uint32_t body = fq + 1, end = l1;
+            // The sample columns of a wave: the tabs of [body, end) collected 16 bytes per lane into `sep` (a stretch at a time), then a column per
+            // lane.  A column that starts at the line's end does not count (the serial walk stops there); columns behind the header's samples are
+            // not looked at.  fn(column's start, its end, its number) returns true on an error.
+            auto wave_columns = [&](auto &&fn) -> uint32_t {
+                uint32_t seg = body, nsep = 0, done = 0;
+                for (uint32_t base = body & ~15u;; base += 1024u) {
+                    const bool last = base + 1024u >= end;
+                    if (base < end) {
+                        const uint32_t p = base + lane * 16u;
+                        uint32_t m = p < end ? vcf_eq_mask16(u, p, body, end, 0x09090909u) : 0u, tot;
+                        uint32_t at = nsep + vcf_wave_excl_scan((uint32_t)__builtin_popcount(m), &tot);
+                        for (; m; m &= m - 1) sep[at++] = p + (uint32_t)__builtin_ctz(m);
+                        nsep += tot;
+                    }
+                    if (last) { if (lane == 0) sep[nsep] = end; nsep++; }
+                    if (!last && nsep + 1025u <= VCF_WSEP) continue;
+                    __syncthreads();
+                    uint32_t ncol = nsep;
+                    if (last && (nsep > 1 ? sep[nsep - 2] + 1u : seg) >= end) ncol--;               // the column that would start at the line's end
+                    if (ncol > (uint32_t)a.n_smp - done) ncol = (uint32_t)a.n_smp - done;
+                    for (uint32_t k0 = 0; k0 < ncol && !bad; k0 += 64u) {
+                        const uint32_t k = k0 + lane; const bool have = k < ncol;
+                        bool err = false;
+                        if (have) err = fn(k ? sep[k - 1] + 1u : seg, sep[k], done + k);
+                        if (__ballot(err)) bad = true;
+                    }
+                    done += ncol;
+                    seg = sep[nsep - 1] + 1u;
+                    __syncthreads();
+                    nsep = 0;
+                    if (last || bad || done >= (uint32_t)a.n_smp) break;
+                }
+                return done;
+            };
             // max3: widths of every field over the samples
             if (!bad) {
-                uint32_t r = body, l = 0, m = 1, g = 1;
-                while (r < end && !bad) {
-                    int j = 0; uint32_t r_start = r;
-                    for (;;) {
-                        while (r < end && u[r] != '\t' && u[r] != ',' && u[r] != '/' && u[r] != ':' && u[r] != '|') r++;
-                        const uint8_t ch = r < end ? u[r] : 0;
-                        if (ch == ',') m++;
-                        else if (ch == '|' || ch == '/') { if (flg[j] & 1) g++; }
-                        else {
-                            l = r - r_start; r_start = r;
-                            if (mx_m[j] < m) mx_m[j] = m;
-                            if (mx_l[j] < l) mx_l[j] = l;
-                            if ((flg[j] & 1) && mx_g[j] < g) mx_g[j] = g;
-                            l = 0; m = g = 1;
-                            if (ch == ':') { j++; if (j >= n_fmt) { bad = true; break; } }             // "Incorrect number of FORMAT fields"
-                            else break;
-                        }
-                        if (r >= end) break;
-                        r++;
+                if (WAVE) n_sample = wave_columns([&](uint32_t s, uint32_t e, uint32_t) { return !vcf_fmt_widths<true>(u, s, e, n_fmt, flg, mx_l, mx_m, mx_g); });
+                else {
+                    uint32_t r = body;
+                    while (r < end && !bad) {
+                        uint32_t e = r; while (e < end && u[e] != '\t') e++;
+                        if (!vcf_fmt_widths<false>(u, r, e, n_fmt, flg, mx_l, mx_m, mx_g)) bad = true;
+                        n_sample++;
+                        if (n_sample == (uint32_t)a.n_smp) break;
+                        r = e + 1;
                     }
-                    n_sample++;
-                    if (n_sample == (uint32_t)a.n_smp) break;
-                    r++;
                 }
             }
             // alloc4: slot sizes, duplicates, and where every field's array sits in the indiv block
-            if (!bad) {
+            if (WAVE) __syncthreads();
+            if (!bad && (!WAVE || lane == 0)) {
                 for (int j = 0; j < n_fmt; j++) {
                     if (!mx_m[j]) mx_m[j] = 1;
                     if (ht[j] == 3) fsz[j] = (flg[j] & 1) ? mx_g[j] << 2 : mx_l[j];
@@ -776,106 +929,28 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                 }
                 for (int i = 1; i < n_fmt && !bad; i++) for (int j = 0; j < i; j++) if (!(flg[j] & 2) && key[i] == key[j] && ht[i] != 15) { flg[i] |= 2; break; }
             }
+            if (WAVE) { __syncthreads(); bad = __shfl((int)bad, 0) != 0; }
             if (!bad && n_sample != (uint32_t)a.n_smp) bad = true;                                   // check7 (fill5 errors found below are errors either way)
             if (!bad) {
-                for (int j = 0; j < n_fmt; j++) {
+                for (int j = 0; j < n_fmt; j++) {                                                     // (a wave: every lane alike; lane 0 keeps the places)
                     if (flg[j] & 2) continue;
                     n_fmt_kept++;
                     o.key(key[j]);
                     if (ht[j] == 3 && !(flg[j] & 1)) o.size(fsz[j], 7); else o.size(fsz[j] >> 2, ht[j] == 2 ? 5 : 3);
-                    fat[j] = o.n; o.n += fsz[j] * n_sample;
+                    if (!WAVE || lane == 0) fat[j] = o.n;
+                    o.n += fsz[j] * n_sample;
                 }
+                if (WAVE) __syncthreads();
                 // fill5: every sample, field by field (validated in the measure pass, stored in the write pass)
-                uint32_t t = body; uint32_t m = 0;
-                while (t < end && !bad) {
-                    if (m == (uint32_t)a.n_smp) break;
-                    int j = 0;
-                    while (t < end) {
-                        const int z = j++;
-                        const uint32_t at = fat[z] + fsz[z] * m;
-                        auto put32 = [&](uint32_t idx, uint32_t v) { if (WRITE) { const uint32_t keep = o.n; o.n = at + 4 * idx; o.w32(v); o.n = keep; } };
-                        auto ch = [&](uint32_t p) -> uint8_t { return (p < end && u[p] != '\t') ? u[p] : (uint8_t)0; };       // a sample column is a C string
-                        if (flg[z] & 2) { while (ch(t) != ':' && ch(t)) t++; }
-                        else if (ht[z] == 3 && (flg[z] & 1)) {                                        // GT: ([/|])?val([/|]val)*, val = digits or '.'
-                            uint32_t is_phased = 0, maxv = 0, x0 = 0; bool unreadable = false; int l = 0, ploidy = 0, anyunphased = 0, prfx = 0, unknown1 = 0;
-                            if (a.v44 && (ch(t) == '|' || ch(t) == '/')) { is_phased = ch(t) == '|'; t++; prfx = 1; }
-                            for (;; ++t) {
-                                ploidy++;
-                                uint32_t xv;
-                                if (ch(t) == '.') { ++t; xv = is_phased; if (l == 0) unknown1 = 1; }
-                                else {
-                                    const uint32_t tt = t; uint64_t n = 0;
-                                    if (ch(t) == '+') t++;
-                                    while (ch(t) >= '0' && ch(t) <= '9') n = n * 10 + (uint64_t)(ch(t++) - '0');
-                                    const uint32_t val = (uint32_t)n;
-                                    unreadable |= tt == t;
-                                    if (maxv < val) maxv = val;
-                                    xv = (val + 1) << 1 | is_phased;
-                                }
-                                if (l == 0) x0 = xv; else put32((uint32_t)l, xv);
-                                l++;
-                                anyunphased |= (ploidy != 1) && !is_phased;
-                                is_phased = ch(t) == '|';
-                                if (ch(t) != '|' && ch(t) != '/') break;
-                            }
-                            if (!prfx) { if (ploidy == 1) { if (!unknown1) x0 |= 1; } else x0 |= anyunphased ? 0u : 1u; }
-                            if (maxv > (0x7fffffffu >> 1) - 1 || unreadable) { bad = true; break; }
-                            put32(0, x0);
-                            for (; (uint32_t)l < fsz[z] >> 2; ++l) put32((uint32_t)l, 0x80000001u);
-                        } else if (ht[z] == 3) {
-                            uint32_t l = 0;
-                            for (; ch(t) != ':' && ch(t); ++t, ++l) if (WRITE) o.p[at + l] = u[t];
-                            if (WRITE) for (; l < fsz[z]; l++) o.p[at + l] = 0;
-                        } else if (ht[z] == 1) {
-                            uint32_t l = 0;
-                            for (;; ++t) {
-                                if (ch(t) == '.') { put32(l++, 0x80000000u); ++t; }
-                                else {
-                                    uint32_t te = t; bool neg = false, over = false; uint64_t n = 0, limit = (1ull << 63) - 1;
-                                    if (ch(te) == '-') { limit++; neg = true; te++; } else if (ch(te) == '+') te++;
-                                    for (; ch(te) >= '0' && ch(te) <= '9'; te++) { const uint32_t d = ch(te) - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
-                                    const int64_t v = neg ? (int64_t)(0 - n) : (int64_t)n;
-                                    put32(l++, (te == t || over || v < -2147483640ll || v > 2147483647ll) ? 0x80000000u : (uint32_t)(int32_t)v);
-                                    t = te;
-                                }
-                                if (ch(t) != ',') break;
-                            }
-                            for (; l < fsz[z] >> 2; ++l) put32(l, 0x80000001u);
-                        } else {
-                            uint32_t l = 0;
-                            for (;; ++t) {
-                                const uint8_t c1 = ch(t + 1);
-                                if (ch(t) == '.' && !(c1 >= '0' && c1 <= '9')) { put32(l++, 0x7F800001u); ++t; }
-                                else {
-                                    uint32_t tok_end = t; while (ch(tok_end) && ch(tok_end) != ',' && ch(tok_end) != ':') tok_end++;
-                                    double d; uint32_t e;
-                                    if (tok_end == t) put32(l++, 0u);                               // an empty value: strtod converts nothing and returns 0.0
-                                    else if (vcf_str2dbl_fast(u + t, tok_end - t, &d, &e) == 0) { put32(l++, __float_as_uint(__double2float_rn(d))); t += e; }
-                                    else {
-                                        // strtod's forms: the host converts (write pass) and checks that the number ends where the token ends (measure pass)
-                                        if (!WRITE) { if (lead) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, tok_end - t, 4u}; } }
-                                        else if (lead) { const uint32_t q = atomicAdd(&a.counters[1], 1u); if (q < a.patch_cap) a.patch[q] = {t + bias, tok_end - t, a.rec_off[li] + at + 4 * l, 2u}; }
-                                        put32(l++, 0u);
-                                        t = tok_end;
-                                    }
-                                }
-                                if (ch(t) != ',') break;
-                            }
-                            for (; l < fsz[z] >> 2; ++l) put32(l, 0x7F800002u);
-                        }
-                        if (ch(t) == 0) break;
-                        else if (ch(t) == ':') t++;
-                        else { bad = true; break; }                                                   // "Invalid character"
+                if (WAVE) (void)wave_columns([&](uint32_t s, uint32_t e, uint32_t m) { return vcf_fmt_fill_sample<WRITE>(a, li, u, bias, s, e, end, m, n_fmt, ht, flg, fsz, fat, o.p); });
+                else {
+                    uint32_t t = body, m = 0;
+                    while (t < end && !bad) {
+                        if (m == (uint32_t)a.n_smp) break;
+                        uint32_t e = t; while (e < end && u[e] != '\t') e++;
+                        if (vcf_fmt_fill_sample<WRITE>(a, li, u, bias, t, e, end, m, n_fmt, ht, flg, fsz, fat, o.p)) { bad = true; break; }
+                        m++; t = e + 1;
                     }
-                    if (bad) break;
-                    for (; j < n_fmt; ++j) {                                                          // trailing fields the sample leaves out
-                        if (flg[j] & 2) continue;
-                        const uint32_t at = fat[j] + fsz[j] * m;
-                        if (!WRITE) continue;
-                        if (ht[j] == 3 && !(flg[j] & 1)) { for (uint32_t l = 0; l < fsz[j]; l++) o.p[at + l] = l == 0 ? '.' : 0; }
-                        else for (uint32_t l = 0; l < fsz[j] >> 2; l++) { const uint32_t keep = o.n; o.n = at + 4 * l; o.w32(l == 0 ? (ht[j] == 2 ? 0x7F800001u : 0x80000000u) : (ht[j] == 2 ? 0x7F800002u : 0x80000001u)); o.n = keep; }
-                    }
-                    m++; t++;
                 }
                 if (!bad && n_sample == 0) { o.n = indiv0; n_fmt_kept = 0; }
             }

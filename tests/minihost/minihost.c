@@ -78,7 +78,9 @@ static duckdb_value h_bind_get_named(duckdb_bind_info i, const char *name) {
     return NULL;                                   /* unset named parameter */
 }
 static void h_bind_add_result_column(duckdb_bind_info i, const char *n, duckdb_logical_type t) {
-    Bind *b = i; LType *lt = t; snprintf(b->colname[b->ncol], 256, "%s", n); b->colchild[b->ncol] = lt->child ? lt->child->id : 0; b->coltype[b->ncol++] = lt->id; }
+    Bind *b = i; LType *lt = t;
+    if (b->ncol >= 1024) { if (!b->has_err) { snprintf(b->err, sizeof(b->err), "mini host: more than 1024 result columns"); b->has_err = 1; } return; }   /* (a limit of this test harness, not of the extension) */
+    snprintf(b->colname[b->ncol], 256, "%s", n); b->colchild[b->ncol] = lt->child ? lt->child->id : 0; b->coltype[b->ncol++] = lt->id; }
 static void h_bind_set_bind_data(duckdb_bind_info i, void *d, duckdb_delete_callback_t del) { Bind *b = i; b->bind_data = d; b->bind_del = del; }
 static void h_bind_set_error(duckdb_bind_info i, const char *e) { Bind *b = i; snprintf(b->err, sizeof(b->err), "%s", e); b->has_err = 1; }
 static void *h_init_get_bind_data(duckdb_init_info i) { return ((Init *)i)->b->bind_data; }

@@ -346,6 +346,46 @@ def test_gpu_projection_reaches_the_text_encoder(wave, monkeypatch):
         assert g2["n_rows"] == e2["n_rows"] and (g2["status"] == 1) == (e2["status"] == 0), (want[:3], g2["n_rows"], e2["n_rows"], g2["status"], e2["status"])
 
 
+def _many_format_keys(n_keys, n_smp=3, n_lines=5, declared=True):
+    import random
+    rnd = random.Random(n_keys)
+    hdr = ["##fileformat=VCFv4.2", "##contig=<ID=1>", '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">']
+    keys = ["GT"] + ["F%03d" % i for i in range(n_keys - 1)]
+    types = {}
+    for k in keys[1:]:
+        types[k] = rnd.choice(["Integer", "Float", "String"])
+        if declared or rnd.random() < 0.5:
+            hdr.append('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="x">' % (k, rnd.choice(["1", "."]), types[k]))
+    hdr.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("S%d" % i for i in range(n_smp)))
+    out = ["\n".join(hdr)]
+    for r in range(n_lines):
+        cols = []
+        for _ in range(n_smp):
+            vals = [rnd.choice(["0/1", "1|1", "./.", "0"])]
+            for k in keys[1:rnd.randrange(1, len(keys) + 1)]:
+                vals.append({"Integer": rnd.choice(["7", "1,2,3", ".", "-5"]), "Float": rnd.choice(["0.5", "1e-3,2", ".", "nan"]), "String": rnd.choice(["ab", "", "x,y", "."])}[types[k]])
+            cols.append(":".join(vals))
+        out.append("1\t%d\t.\tA\tC\t.\t.\t.\t%s\t%s" % (10 + r, ":".join(keys), "\t".join(cols)))
+    return ("\n".join(out) + "\n").encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave", [None, "0", "1"])
+def test_gpu_up_to_255_format_keys(wave, monkeypatch):
+    """htslib keeps 255 FORMAT identifiers per line (MAX_N_FMT, vcf.c:3134); the lane-per-line encoder keeps tables for 32 and hands a batch with
+    more to the wave encoder, whose tables live in LDS; the 256th key is an error in both"""
+    if wave is not None:
+        monkeypatch.setenv("DHTS_VCF_WAVE", wave)
+    for n_keys in (31, 32, 33, 40, 255):
+        exp, got = _check(_many_format_keys(n_keys))
+        assert exp["status"] == 0 and exp["n_rows"] == 5, n_keys
+    _check(_many_format_keys(60, declared=False))                         # names without a definition among them
+    exp, got = _check(_many_format_keys(256))
+    assert exp["status"] < 0 and exp["n_rows"] == 0
+    mixed = _many_format_keys(20, n_lines=4) + b"\n".join(_many_format_keys(90, n_lines=3).split(b"\n")[-4:])   # (same samples; the keys of the second file are not declared in the first)
+    _check(mixed)
+
+
 @pytest.mark.gpu
 def test_gpu_vcf_text_through_the_table_function(tmp_path):
     """the reference's own queries on its own files: read_bcf('test_vep.vcf') (plain text) and read_bcf('no_contig.vcf.gz')"""

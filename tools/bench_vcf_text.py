@@ -164,6 +164,74 @@ def main_region():
                               "staging": "header + index windows" if sparse == "1" else "whole file (DHTS_SPARSE=0)", "warm_query_s": round(warm, 4), "first_query_s": round(runs[0], 3)}), flush=True)
 
 
+def generate_samples_shape(path, n, n_smp, seed=3):
+    """a cohort call set: GT:DP:GQ:AD:PL for n_smp samples per line (1000 Genomes / gVCF-merge shape: the line's length is the samples')"""
+    rnd = random.Random(seed)
+    hdr = ["##fileformat=VCFv4.2", '##FILTER=<ID=LowQual,Description="x">', '##INFO=<ID=AC,Number=A,Type=Integer,Description="x">', '##INFO=<ID=AF,Number=A,Type=Float,Description="x">',
+           '##INFO=<ID=AN,Number=1,Type=Integer,Description="x">', '##INFO=<ID=DP,Number=1,Type=Integer,Description="x">',
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="x">', '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="x">', '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="x">',
+           '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="x">', '##FORMAT=<ID=PL,Number=G,Type=Integer,Description="x">', "##contig=<ID=20,length=64444167>",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("S%05d" % i for i in range(n_smp))]
+    pool = []
+    for _ in range(400):
+        gt = rnd.choice(["0|0", "0|0", "0|0", "0|1", "1|0", "1|1", "./."])
+        if gt == "./.":
+            pool.append("./.:.:.:.:.")
+        else:
+            a, b = rnd.randrange(40), rnd.randrange(30)
+            pool.append("%s:%d:%d:%d,%d:%d,%d,%d" % (gt, a + b, rnd.randrange(100), a, b, rnd.randrange(300), rnd.randrange(300), rnd.randrange(300)))
+    with open(path, "wb") as f:
+        buf = ["\n".join(hdr) + "\n"]; pos = 60000; nbuf = 0
+        for k in range(n):
+            pos += rnd.randrange(1, 300)
+            ref = rnd.choice("ACGT"); alt = rnd.choice([x for x in "ACGT" if x != ref])
+            line = "20\t%d\t.\t%s\t%s\t%d\tPASS\tAC=%d;AF=%.4f;AN=%d;DP=%d\tGT:DP:GQ:AD:PL\t%s\n" % (pos, ref, alt, rnd.randrange(9000), rnd.randrange(2 * n_smp), rnd.random(), 2 * n_smp,
+                                                                                                   rnd.randrange(50 * n_smp), "\t".join(rnd.choices(pool, k=n_smp)))
+            buf.append(line); nbuf += len(line)
+            if nbuf >= 32 << 20:
+                f.write(bamwriter.bgzf_file("".join(buf).encode(), eof=False, level=6)); buf = []; nbuf = 0
+        f.write(bamwriter.bgzf_file("".join(buf).encode(), eof=True, level=6))
+    return n
+
+
+def main_samples():
+    """the scan through the library (tidy_format: a row per record and sample), columns left in HBM; the mini host stops at 1024 result columns"""
+    n_smp = int(sys.argv[2]) if len(sys.argv) > 2 else 2504
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+    d = tempfile.mkdtemp(dir="/tmp")
+    path = os.path.join(d, "cohort_like.vcf.gz")
+    t0 = time.time()
+    generate_samples_shape(path, n, n_smp)
+    size = os.path.getsize(path)
+    print(json.dumps({"generated": path, "records": n, "samples": n_smp, "compressed_bytes": size, "seconds": round(time.time() - t0, 1)}), flush=True)
+    for tidy, qn, proj in ((False, "COUNT(*) (wide)", ["CHROM"]), (False, "CHROM,POS,REF,ALT,INFO_AF (wide)", ["CHROM", "POS", "REF", "ALT", "INFO_AF"]),
+                           (True, "tidy: CHROM,POS,SAMPLE_ID,FORMAT_GT,FORMAT_DP,FORMAT_GQ,FORMAT_AD,FORMAT_PL", ["CHROM", "POS", "SAMPLE_ID", "FORMAT_GT", "FORMAT_DP", "FORMAT_GQ", "FORMAT_AD", "FORMAT_PL"])):
+        ctx = duckhts_amd.Context(0)
+        try:
+            ctx.open(path); ctx.bgzf_index()
+            sc = duckhts_amd.BcfScan(ctx, tidy=tidy)
+            sc.set_projection(proj)
+            times = []
+            for rep in range(4):
+                ctx.L.dhts_sync(ctx.h); t0 = time.perf_counter()
+                if rep:
+                    sc.rewind()
+                rows = 0
+                while True:
+                    b = sc.next_batch(0)
+                    rows += b.n_rows
+                    if b.status != 0:
+                        assert b.status > 0, b.status
+                        break
+                ctx.L.dhts_sync(ctx.h); times.append(time.perf_counter() - t0)
+            warm = sorted(times[1:])[1]
+            assert rows == n * (n_smp if tidy else 1), rows
+            print(json.dumps({"scan": "read_bcf on a cohort-shaped vcf.gz (%d samples), file resident, columns left in HBM" % n_smp, "query": qn, "rows": rows, "first_s": round(times[0], 3),
+                              "warm_s": round(warm, 4), "records_per_s": round(n / warm, 1), "genotypes_per_s": round(n * n_smp / warm, 1), "compressed_MBps": round(size / warm / 1e6, 1)}), flush=True)
+        finally:
+            ctx.close()
+
+
 def main_gnomad():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
     d = tempfile.mkdtemp(dir="/tmp")
@@ -185,6 +253,8 @@ def main_gnomad():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "gnomad":
         main_gnomad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "samples":
+        main_samples()
     elif len(sys.argv) > 1 and sys.argv[1] == "region":
         main_region()
     else:
