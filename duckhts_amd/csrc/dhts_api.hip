@@ -9,6 +9,7 @@
 #include "bam_tile_rows.hip"
 #include "bcf_records.hip"
 #include "vcf_text.hip"
+#include "gzip_serial.hip"
 #include "bam_tags.hip"
 #include "bgzf_deflate.hip"
 #include "hts_index.hip"
@@ -173,6 +174,9 @@ struct dhts_ctx {
     struct Seg { uint64_t res_off, file_off, len; };
     std::vector<Seg> segs;
     const uint8_t *last_bcf_u = nullptr;   // where the records of the last read_bcf batch live (inflated stream or, for text, v_out)
+    bool gz_any = false;               // bgunzip: a plain-gzip file is inflated whatever it holds
+    bool gz_plain = false, gz_error = false;   // the file is plain (non-BGZF) gzip: gz_out holds what its members inflate to and serves as the uncompressed text; gz_error: the stream ends in an error behind those bytes
+    DevBuf gz_out; uint64_t gz_len = 0;
     bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
     bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
     DevBuf v_keep, v_endsv; uint64_t proj_gen = 1, keep_gen = 0; int32_t keep_none = 0; bool keep_all = true;   // VCF text: the INFO keys the projection reads (VcfArgs::info_keep)
@@ -393,7 +397,7 @@ static void stop_stager(dhts_ctx *c) {
 }
 static void reset_file_state(dhts_ctx *c) {
     stop_stager(c);
-    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false; c->segs.clear(); c->cache_hit = false; c->plain_text = false; c->vcf_text = false;
+    c->huff_b0 = c->huff_nb = 0; c->file_off = 0; c->file_size = 0; c->seg_split = 0; c->seg_file_off = 0; c->partial_tail = false; c->segs.clear(); c->cache_hit = false; c->gz_plain = c->gz_error = false; c->gz_len = 0; c->plain_text = false; c->vcf_text = false;
     c->n_blocks = 0; c->bgzf_status = 0; c->bam_open = false; c->carry_len = 0; c->next_block = 0; c->stream_done = false; c->first_batch = true;
     c->h_coff.clear(); c->h_clen.clear(); c->h_isize.clear(); c->h_uoff.clear();
 }
