@@ -26,7 +26,14 @@ struct BcfStream {
     const uint8_t *id_ok;         // n_ids: dictionary id present
     const int16_t *info_slot;     // n_ids: schema INFO field index of a dictionary id, -1 if none
     const int16_t *fmt_slot;      // n_ids: schema FORMAT field index, -1 if none
+    const int32_t *pos_hi;        // VCF text: bits 32.. of every record's 0-based position (htslib keeps 64-bit positions for text, vcf.c:4052-4063; the BCF2 core in the record holds the low word); nullptr for BCF
 };
+// 0-based position of record `rec` at u + o (BCF: the core's word, 0xffffffff = -1, vcf.c:1895-1896)
+__device__ __forceinline__ int64_t bcf_pos64(const BcfStream &st, const uint8_t *u, uint64_t o, int64_t rec) {
+    uint32_t lo; __builtin_memcpy(&lo, u + o + 12, 4);
+    if (st.pos_hi) return (int64_t)(((uint64_t)(uint32_t)st.pos_hi[rec] << 32) | lo);
+    return lo == 0xffffffffu ? -1 : (int64_t)lo;
+}
 
 __device__ __constant__ uint8_t BCF_SHIFT[16] = {0, 0, 1, 2, 3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // vcf.c:91
 
@@ -370,7 +377,7 @@ __global__ void __launch_bounds__(256) bcf_cells(BcfStream st, BcfCellArgs a) {
 
     switch (cd.kind) {
     case BK_CHROM: if (!WRITE) ((int32_t *)cd.fixed)[row] = (int32_t)ldu32(u + o + 8); break;
-    case BK_POS: if (!WRITE) { const uint32_t p32 = ldu32(u + o + 12); ((int64_t *)cd.fixed)[row] = p32 == 0xffffffffu ? 0 : (int64_t)p32 + 1; } break;   // vcf.c:1895-1896
+    case BK_POS: if (!WRITE) ((int64_t *)cd.fixed)[row] = bcf_pos64(st, u, o, rec) + 1; break;   // vcf.c:1895-1896
     case BK_QUAL: if (!WRITE) {
             const uint32_t b = ldu32(u + o + 20);
             if (b == 0x7F800001u) { valid = false; ((uint64_t *)cd.fixed)[row] = 0; }           // NULL, payload 0.0 (bcf_reader.c:1427-1434)
@@ -692,13 +699,14 @@ __global__ void __launch_bounds__(64) bcf_vep_wave(BcfStream st, BcfCellArgs a) 
     }
 }
 
-// rid, pos, rlen of every record (the three int32 behind the two length words), packed for the index writer
+// rid, pos, rlen of every record (the three int32 behind the two length words) and the position's high word, packed for the index writer
 extern "C" __global__ void __launch_bounds__(256)
-bcf_index_rows(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t nrec, uint32_t *__restrict__ out) {
+bcf_index_rows(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t nrec, const int32_t *__restrict__ pos_hi, uint32_t *__restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const uint64_t o = rec_off[r];
-    out[3 * r] = ldu32(u + o + 8); out[3 * r + 1] = ldu32(u + o + 12); out[3 * r + 2] = ldu32(u + o + 16);
+    out[4 * r] = ldu32(u + o + 8); out[4 * r + 1] = ldu32(u + o + 12); out[4 * r + 2] = ldu32(u + o + 16);
+    out[4 * r + 3] = pos_hi ? (uint32_t)pos_hi[r] : (out[4 * r + 1] == 0xffffffffu ? 0xffffffffu : 0u);          // bits 32.. of the position (text), the sign of BCF's -1
 }
 
 // ---- region predicate (bcf_itr_querys -> hts_itr_next hts.c:4287-4300 over bcf_readrec vcf.c:2267-2276) ----------------------
@@ -712,8 +720,7 @@ bcf_region_keep(BcfStream st, const uint32_t *rec_off, const uint32_t *dir, int6
     uint32_t k = 0;
     if (all) k = 1;
     else if ((int32_t)ldu32(u + o + 8) == tid) {
-        const uint32_t p32 = ldu32(u + o + 12);
-        const int64_t beg = p32 == 0xffffffffu ? -1 : (int64_t)p32;
+        const int64_t beg = bcf_pos64(st, u, o, r);
         int64_t rlen = (int32_t)ldu32(u + o + 16);
         if (rlen < 0) { rlen = 0; const uint32_t d = dir[r]; if (d) { uint64_t p = o + d; int n, t; bcf_dec_size(u, p, n, t); rlen = n > 0 ? (int64_t)cstr_len(u + p, (uint32_t)n) : 0; } }
         const int64_t end = beg + rlen;

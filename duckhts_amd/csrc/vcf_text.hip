@@ -35,6 +35,7 @@ struct VcfArgs {
     // INFO value can fail a line (vcf_parse_info turns what it cannot convert into a missing value), so the rows are the same.
     // info_none: no INFO key is kept at all (the write pass skips INFO).
     const uint32_t *info_keep; int32_t info_none, pad_keep;
+    int32_t *pos_hi;                                        // [line] bits 32.. of the record's 0-based position (hts_pos_t is 64 bits wide for text, vcf.c:4052-4063)
     uint32_t *endsv;                                        // wave kernel: [2 * line] where the values of the line's first END= / SVLEN= fields begin (0xffffffff: none), measure pass -> write pass
 };
 
@@ -725,7 +726,6 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
             for (; v < fe[1] && u[v] >= '0' && u[v] <= '9'; v++) { const uint32_t d = u[v] - '0'; if (over) continue; if (n < limit / 10 || (n == limit / 10 && d <= limit % 10)) n = n * 10 + d; else over = true; }
             if (over || v != fe[1]) bad = true;
             pos = (int64_t)n - 1;
-            if (pos >= 0x7fffffffll) bad = true;                                                     // (the BCF2 core holds 32-bit positions)
         }
     }
     if (!bad) {
@@ -961,7 +961,8 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
     const uint32_t total = o.n;
     o.n = 0;
     o.w32(indiv0 - 8); o.w32(total - indiv0);                                                        // l_shared (core + shared block), l_indiv
-    o.w32((uint32_t)rid); o.w32((uint32_t)(int32_t)pos); o.w32((uint32_t)rlen);
+    o.w32((uint32_t)rid); o.w32((uint32_t)(uint64_t)pos); o.w32((uint32_t)rlen);                      // (the core holds the position's low word; text keeps 64-bit positions: the high word goes beside the records)
+    if (a.pos_hi) a.pos_hi[li] = (int32_t)(pos >> 32);
     o.w32(qbits);
     o.w32(n_info | (n_allele << 16)); o.w32((n_sample & 0xffffffu) | (n_fmt_kept << 24));
 }

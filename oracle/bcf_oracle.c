@@ -403,6 +403,7 @@ typedef struct {
     int gt_id;
     int64_t n_rows, n_recs;
     buf_t rec_rid, rec_pos, rec_rlen;      /* per emitted record: contig id, 0-based pos, rlen (region-oracle inputs) */
+    const int32_t *pos_hi; size_t n_pos_hi;   /* VCF text: bits 32.. of every record's 0-based position, in record order (hts_pos_t is 64 bits wide: vcf.c:4052-4063) */
 } scan_t;
 
 static void scan_free(scan_t *s)
@@ -634,6 +635,7 @@ static int scan_records(scan_t *s, const uint8_t *u, size_t ulen, size_t pos, in
         shared_len -= 24;
         int32_t rid = rd_i32(x + 8);
         int64_t rpos = rd_u32(x + 12); if (rpos == 0xFFFFFFFFll) rpos = -1;
+        if (s->pos_hi && (size_t)s->n_recs < s->n_pos_hi) rpos = (int64_t)(((uint64_t)(uint32_t)s->pos_hi[s->n_recs] << 32) | rd_u32(x + 12));
         uint32_t qbits = rd_u32(x + 20);
         int n_info = x[24] | x[25] << 8, n_allele = x[26] | x[27] << 8;
         uint32_t n_sample = rd_u32(x + 28) & 0xffffff; int n_fmt = x[31];
@@ -1103,7 +1105,7 @@ static int vcf_format_to_bcf(hdr_t *h, char *rest, buf_t *in, int *n_fmt_out, in
 }
 
 /* one line -> one BCF2 record appended to `out`; < 0: the line is an error (the scan ends before it) */
-static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
+static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out, buf_t *pos_hi)
 {
     char *f[8]; int nf = 0; char *p = line; char *rest = NULL;                /* rest: FORMAT column and what follows it (NULL when there are only eight columns) */
     for (;;) {                                                                /* kstrtok on '\t': empty tokens count, all eight are required */
@@ -1123,7 +1125,6 @@ static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
     uint64_t pos1 = str2uint(f[1], &e, 62, &failed);
     if (failed || *e) { free(sh.p); return -1; }
     int64_t pos = (int64_t)pos1 - 1;
-    if (pos >= 0x7fffffffLL) { free(sh.p); return -1; }                        /* (restatement limit: the BCF2 core holds 32-bit positions) */
     /* ID, REF, ALT */
     if (strcmp(f[2], ".")) enc_vchar(&sh, strlen(f[2]), f[2]); else enc_size(&sh, 0, 7);
     enc_vchar(&sh, strlen(f[3]), f[3]);
@@ -1210,7 +1211,8 @@ static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
     if (rest && h->n_smp > 0 && vcf_format_to_bcf(h, rest, &in, &n_fmt, &n_sample) < 0) { free(sh.p); free(in.p); return -1; }
     uint32_t l_shared = 24 + (uint32_t)sh.n, l_indiv = (uint32_t)in.n, w;
     buf_push(out, &l_shared, 4); buf_push(out, &l_indiv, 4);
-    int32_t i32 = rid; buf_push(out, &i32, 4); i32 = (int32_t)pos; buf_push(out, &i32, 4); buf_push(out, &rlen, 4); buf_push(out, &qbits, 4);
+    int32_t i32 = rid; buf_push(out, &i32, 4); i32 = (int32_t)(uint32_t)(uint64_t)pos; buf_push(out, &i32, 4); buf_push(out, &rlen, 4); buf_push(out, &qbits, 4);      /* the core takes the low word */
+    { int32_t hi = (int32_t)(pos >> 32); buf_push(pos_hi, &hi, 4); }
     w = (uint32_t)n_info | ((uint32_t)n_allele << 16); buf_push(out, &w, 4);
     w = ((uint32_t)n_sample & 0xffffff) | ((uint32_t)n_fmt << 24); buf_push(out, &w, 4);
     buf_push(out, sh.p, sh.n); buf_push(out, in.p, in.n);
@@ -1219,7 +1221,7 @@ static int vcf_line_to_bcf(hdr_t *h, char *line, buf_t *out)
 }
 
 /* text stream -> header (parsed into s->h, schema built) + BCF2 record bytes; returns ORC_BCF_* or 0; *bad = 1 when a line failed */
-static int vcf_text_load(scan_t *s, const uint8_t *u, size_t ulen, buf_t *recs, int *bad)
+static int vcf_text_load(scan_t *s, const uint8_t *u, size_t ulen, buf_t *recs, buf_t *pos_hi, int *bad)
 {
     buf_t txt = { 0 }; size_t pos = 0; int have_sample_line = 0;
     char *line = NULL;
@@ -1244,7 +1246,7 @@ static int vcf_text_load(scan_t *s, const uint8_t *u, size_t ulen, buf_t *recs, 
     for (;;) {
         NEXT_LINE(ok);
         if (!ok) break;
-        if (vcf_line_to_bcf(&s->h, line, recs) < 0) { *bad = 1; break; }
+        if (vcf_line_to_bcf(&s->h, line, recs, pos_hi) < 0) { *bad = 1; break; }
     }
     free(line);
     #undef NEXT_LINE
@@ -1264,10 +1266,12 @@ int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, ui
     const uint8_t *u = is_bgzf ? bz.data : file; size_t ulen = is_bgzf ? bz.len : flen;
     if (ulen >= 16 && !memcmp(u, "##fileformat=VCF", 16)) {                     /* text VCF (hts_detect_format) */
         scan_t s; memset(&s, 0, sizeof s); s.tidy = tidy;
-        buf_t recs = { 0 }; int bad = 0;
-        int rc = vcf_text_load(&s, u, ulen, &recs, &bad);
-        if (rc < 0) { free(recs.p); scan_free(&s); orc_bgzf_free(&bz); return rc; }
+        buf_t recs = { 0 }, phi = { 0 }; int bad = 0;
+        int rc = vcf_text_load(&s, u, ulen, &recs, &phi, &bad);
+        if (rc < 0) { free(recs.p); free(phi.p); scan_free(&s); orc_bgzf_free(&bz); return rc; }
+        s.pos_hi = (const int32_t *)phi.p; s.n_pos_hi = phi.n / 4;
         int status = scan_records(&s, recs.p, recs.n, 0, materialise);
+        s.pos_hi = NULL;
         if (status == 0 && bad) status = -2;
         if (status == 0 && is_bgzf && bz.status < 0) status = bz.status;
         if (n_rows) *n_rows = s.n_rows;
@@ -1279,7 +1283,7 @@ int orc_bcf_read(const uint8_t *file, size_t flen, int tidy, int materialise, ui
             { uint64_t nrec = (uint64_t)s.n_recs; buf_push(&o, &nrec, 8); buf_push(&o, s.rec_rid.p, s.rec_rid.n); buf_push(&o, s.rec_pos.p, s.rec_pos.n); buf_push(&o, s.rec_rlen.p, s.rec_rlen.n); }
             *blob = o.p; *blob_len = o.n;
         }
-        free(recs.p); scan_free(&s); orc_bgzf_free(&bz);
+        free(recs.p); free(phi.p); scan_free(&s); orc_bgzf_free(&bz);
         return status;
     }
     if (!is_bgzf || ulen < 9 || memcmp(u, "BCF\2\2", 5)) { orc_bgzf_free(&bz); return ORC_BCF_EHDR; }

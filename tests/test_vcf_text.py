@@ -96,7 +96,7 @@ def test_undefined_names_get_dummy_definitions():
     assert t2["n_rows"] == 160 and _col(t2, "CHROM")[:4] == _col(t, "CHROM")
 
 
-@pytest.mark.parametrize("name,rows", [("bad_pos", 3), ("bad_pos_overflow", 3), ("pos_too_large_for_bcf", 3), ("too_few_columns", 3), ("empty_line", 3),
+@pytest.mark.parametrize("name,rows", [("bad_pos", 3), ("bad_pos_overflow", 3), ("pos_beyond_62_bits", 3), ("too_few_columns", 3), ("empty_line", 3),
                                        ("undefined_contig_with_bad_name", 3), ("nul_in_line", 2)])
 def test_the_first_bad_line_ends_the_scan(name, rows):
     t = orc.bcf_read(dict(CASES)[name])

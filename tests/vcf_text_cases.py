@@ -123,7 +123,11 @@ def all_cases():
                [("chrUn1", "lowq7", "NEWKEY1"), ("c8rUn1", "Xowq7", "NxWKEY1"), ("2hrUn1", "lXwq7", "XEWKEY1"), ("chrUn1", "lowq7", "NEWKEY1"), ("xbrUn", "loXq7x", "NEWKEY1"),
                 ("abrUn", "lowq7x", "NEXKEY1"), ("chr_unplaced_1", "filter_name_15", "INFO_KEY_13_"), ("chr_unplXced_1", "fXlter_name_15", "INFO_XEY_13_"),
                 ("Xhr_unplaced_1", "filter_nXme_15", "XNFO_KEY_13_"), ("c8rUn1", "Xowq7", "NxWKEY1"), ("chr_unplaced_1", "filter_name_15", "INFO_KEY_13_")])]))]
-    for name, bad in (("bad_pos", L(pos="1x")), ("bad_pos_overflow", L(pos="9223372036854775807")), ("pos_too_large_for_bcf", L(pos=2147483648)), ("too_few_columns", "chr1\t5\t.\tA\tT\t.\tPASS"),
+    # positions beyond 32 bits: hts_pos_t is 64 bits wide and vcf_parse takes up to 62 (vcf.c:4052-4063): POS 0 (the telomere: -1), the edges of the
+    # 32-bit words, END= / SVLEN= behind them, a sample column
+    out.append(("positions_beyond_32_bits", text([L(pos=p, info=i) for p, i in ((0, "."), (2147483647, "DP=1"), (2147483648, "END=2147483999"), (4294967295, "."), (4294967296, "DP=2"), (4294967297, "END=4294968000"),
+                                                                                (1 << 40, "DP=3"), ((1 << 62) - 1, "."), (1 << 62, "DP=4"), (5, "."))])))
+    for name, bad in (("bad_pos", L(pos="1x")), ("bad_pos_overflow", L(pos="9223372036854775807")), ("pos_beyond_62_bits", L(pos=(1 << 62) + 1)), ("too_few_columns", "chr1\t5\t.\tA\tT\t.\tPASS"),
                       ("empty_line", ""), ("undefined_contig_with_bad_name", L(chrom="a,b>")), ("empty_filter_name", L(flt="q10;;s50"))):
         out.append((name, text(FIELDS[:3] + [bad] + FIELDS[3:6])))
     out.append(("nul_in_line", text([L(pos=1, info="DP=1"), L(pos=2, info="DP=2\0;AF=0.5"), L(pos=3, vid="a\0b", info="DP=3")])))
