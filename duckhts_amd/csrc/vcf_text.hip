@@ -493,7 +493,7 @@ vcf_scatter_words(uint8_t *__restrict__ out, const VcfPatch *__restrict__ patch,
 
 #define VCF_LDS_BYTES 40960u
 #define VCF_ENC_THREADS 64
-#define VCF_MAXF 32                                           // FORMAT keys of a line in the lane-per-line encoder (more: the batch goes to the wave encoder)
+#define VCF_MAXF 16                                           // FORMAT keys of a line in the lane-per-line encoder (more: the batch goes to the wave encoder)
 #define VCF_MAXF_WAVE 255                                     // htslib's MAX_N_FMT (vcf.c:3134)
 struct VcfFmtLds { int32_t key[VCF_MAXF_WAVE + 1]; uint32_t mx_l[VCF_MAXF_WAVE + 1], mx_m[VCF_MAXF_WAVE + 1], mx_g[VCF_MAXF_WAVE + 1], fsz[VCF_MAXF_WAVE + 1], fat[VCF_MAXF_WAVE + 1]; uint8_t ht[VCF_MAXF_WAVE + 1], flg[VCF_MAXF_WAVE + 1]; };
 #define VCF_WSEP 2048u                                        // ';' positions a wave collects before it parses the fields between them (LDS, 8 KB)
