@@ -224,10 +224,18 @@ def main():
                     l = "".join(b).replace("\n", "")
                 lines.append(l)
             raw = V.text(lines, hdr=hdr, eol=rnd.choice(["\n", "\n", "\r\n"]), last_eol=rnd.random() < 0.8)
-            data = raw if rnd.random() < 0.4 else bw.bgzf_file(raw, payload=rnd.choice([500, 3000, 65280]), level=rnd.choice([1, 6]))
+            kind = rnd.random()
+            if kind < 0.3:
+                data = raw
+            elif kind < 0.45:                                # plain (non-BGZF) gzip, one member or several: read through the serial device decoder; the oracle gets the text
+                import gzip as _gz
+                cuts_ = sorted(rnd.sample(range(1, max(2, len(raw))), rnd.choice([0, 0, 1, 3]))) if len(raw) > 4 else []
+                data = b"".join(_gz.compress(raw[a:b], rnd.choice([0, 1, 6, 9])) for a, b in zip([0] + cuts_, cuts_ + [len(raw)]))
+            else:
+                data = bw.bgzf_file(raw, payload=rnd.choice([500, 3000, 65280]), level=rnd.choice([1, 6]))
             tidy = smp and rnd.random() < 0.3
             try:
-                exp = orc.bcf_read(data, tidy)
+                exp = orc.bcf_read(raw if 0.3 <= kind < 0.45 else data, tidy)
                 got = duckhts_amd.read_bcf(data, tidy=tidy, max_blocks=rnd.choice([0, 1, 2, 5]))
                 d = orc.bcf_cols_diff(exp, got)
                 if d is not None:
