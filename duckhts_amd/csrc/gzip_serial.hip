@@ -159,6 +159,7 @@ gz_inflate_serial(const uint8_t *__restrict__ in, unsigned long long in_len, uin
     }
     if (threadIdx.x != 0) return;
     // ---- the decoder
+    const unsigned long long t_clk0 = clock64(), t_rt0 = wall_clock64();
     GzIn src; src.ring = in_ring; src.sh = &sh; src.n = in_len; src.have = 0;
     GzBits b; b.src = &src; b.n = in_len; b.p = 0; b.buf = 0; b.cnt = 0;
     unsigned long long pos = 0, pub = 0, flushed = 0;       // output position; the one last published; out_flushed as last seen
@@ -298,6 +299,7 @@ gz_inflate_serial(const uint8_t *__restrict__ in, unsigned long long in_len, uin
     GZ_ST(sh.final_pos, pos);
     GZ_ST(sh.done, 1u);
     res->out_len = pos; res->in_used = used; res->n_members = n_mem; res->status = status;
+    { const unsigned long long dc = clock64() - t_clk0, dr = wall_clock64() - t_rt0; res->pad[0] = (uint32_t)(dc >> 10); res->pad[1] = (uint32_t)(dr >> 10); }     // shader cycles / 1024, 100 MHz ticks / 1024 (DHTS_TRACE: what the lone decoder wave cost)
 }
 
 // CRC-32 state (from 0, no final xor) of out[off[i], off[i] + len[i]): a lane per range, byte-wise through the first table of g_crcc
