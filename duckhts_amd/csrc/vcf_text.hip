@@ -34,7 +34,9 @@ struct VcfArgs {
     // 65535-entry limit, but its value is neither parsed nor written and the record's n_info counts the kept fields only; nothing in an
     // INFO value can fail a line (vcf_parse_info turns what it cannot convert into a missing value), so the rows are the same.
     // info_none: no INFO key is kept at all (the write pass skips INFO).
-    const uint32_t *info_keep; int32_t info_none, pad_keep;
+    const uint32_t *info_keep; int32_t info_none;
+    int32_t fmt_none;                                       // no FORMAT column is projected: the sample columns are validated by the measure pass (a line that fails there ends the scan, whatever is
+                                                            // projected) and left out of the records: the write pass does not look at them
     int32_t *pos_hi;                                        // [line] bits 32.. of the record's 0-based position (hts_pos_t is 64 bits wide for text, vcf.c:4052-4063)
     uint32_t *endsv;                                        // wave kernel: [2 * line] where the values of the line's first END= / SVLEN= fields begin (0xffffffff: none), measure pass -> write pass
 };
@@ -841,7 +843,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
     // the FORMAT keys (up to htslib's 255, MAX_N_FMT) live in LDS for the wave encoder -- which then takes the sample columns a sample per lane --
     // and in private arrays of VCF_MAXF for the lane-per-line encoder, which hands a line with more keys to the wave encoder (counters[2]).
     uint32_t n_fmt_kept = 0, n_sample = 0; const uint32_t indiv0 = o.n;
-    if (SMP && !bad && a.n_smp > 0 && fe[7] < l1) {
+    if (SMP && !bad && a.n_smp > 0 && fe[7] < l1 && !(WRITE && a.fmt_none)) {
         const uint32_t fp = fe[7] + 1; uint32_t fq = fp; while (fq < l1 && u[fq] != '\t') fq++;
         if (fq >= l1) bad = true;                                                                     // "FORMAT column with no sample columns"
         else if (fq - fp == 1 && u[fp] == '.') n_sample = (uint32_t)a.n_smp;                          // FORMAT ".": nothing to parse, the sample columns are not looked at
@@ -956,6 +958,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
             }
         }
     }
+    if (SMP && a.fmt_none && !bad) { o.n = indiv0; n_fmt_kept = 0; n_sample = 0; }                      // (validated above in the measure pass; the record carries no sample data)
     if (bad) { atomicMin(a.first_bad, (unsigned long long)li); if (!WRITE) a.rec_len[li] = 0; return; }
     if (!WRITE) { a.rec_len[li] = o.n; return; }
     const uint32_t total = o.n;

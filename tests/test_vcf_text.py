@@ -346,6 +346,30 @@ def test_gpu_projection_reaches_the_text_encoder(wave, monkeypatch):
         assert g2["n_rows"] == e2["n_rows"] and (g2["status"] == 1) == (e2["status"] == 0), (want[:3], g2["n_rows"], e2["n_rows"], g2["status"], e2["status"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_gpu_projection_without_format_columns_still_validates_the_samples(wave, monkeypatch):
+    """no FORMAT column projected: the encoder leaves the sample data out of the records it makes (VcfArgs::fmt_none), but the measure pass has
+    walked every sample column -- a line whose samples do not parse ends the scan whatever is projected -- and tidy mode still has a row per
+    record and sample"""
+    import duckhts_amd
+    monkeypatch.setenv("DHTS_VCF_WAVE", wave)
+    names_of = lambda t: [c["name"] for c in t["cols"]]
+    for name, data in CASES:
+        if not name.startswith("samples"):
+            continue
+        for tidy in (False, True):
+            exp = orc.bcf_read(data, tidy)
+            if not exp["cols"]:
+                continue
+            names = names_of(exp)
+            for want in (["POS"], ["CHROM", "POS", "REF", "ALT", "QUAL", "FILTER"] + [n for n in names if n.startswith("INFO_")][:2], ["SAMPLE_ID", "POS"] if "SAMPLE_ID" in names else ["ID"]):
+                got = duckhts_amd.read_bcf(data, tidy=tidy, columns=[names.index(w) for w in want], max_blocks=1 if len(data) > 3000 else 0)
+                d = orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": [exp["by_name"][w] for w in want]}, got)
+                assert d is None, (name, tidy, want, d)
+                assert (got["status"] == 1) == (exp["status"] == 0), (name, tidy, want, got["status"], exp["status"])
+
+
 def _many_format_keys(n_keys, n_smp=3, n_lines=5, declared=True):
     import random
     rnd = random.Random(n_keys)
