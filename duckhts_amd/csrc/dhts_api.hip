@@ -180,7 +180,7 @@ struct dhts_ctx {
     bool plain_text = false;          // the file is not BGZF: its bytes ARE the stream (text VCF); the "block table" cuts it into 65,280-byte pieces
     bool vcf_text = false;            // read_bcf on VCF text (vcf_text.hip)
     DevBuf v_pos_hi;                   // VCF text: the high words of the batch's 0-based positions (BcfStream::pos_hi)
-    DevBuf v_keep, v_endsv; uint64_t proj_gen = 1, keep_gen = 0; int32_t keep_none = 0, fmt_none = 0; bool keep_all = true;   // VCF text: the INFO keys the projection reads (VcfArgs::info_keep)
+    DevBuf v_keep, v_endsv; uint64_t proj_gen = 1, keep_gen = 0; int32_t keep_none = 0, fmt_none = 0; bool keep_all = true, fmt_keep_all = true; DevBuf v_fkeep;   // VCF text: the INFO keys the projection reads (VcfArgs::info_keep)
     DevBuf v_cnt, v_base, v_line_off, v_rec_len, v_out, v_ctr, v_undef, v_patch, vd_ctg_off, vd_ctg_bytes, vd_ctg_id, vd_id_off, vd_id_bytes, vd_id_id, vd_id_typ, vd_id_ftyp, vd_ctg_hash, vd_id_hash, v_tok_off, v_tok_bytes, v_tok_bits;
     uint32_t v_undef_cap = 65536, v_patch_cap = 1u << 20;      // entries the device may record per batch; grown (and the pass repeated) when a batch needs more
     uint32_t vd_ctg_hmask = 0, vd_id_hmask = 0;

@@ -35,6 +35,8 @@ struct VcfArgs {
     // INFO value can fail a line (vcf_parse_info turns what it cannot convert into a missing value), so the rows are the same.
     // info_none: no INFO key is kept at all (the write pass skips INFO).
     const uint32_t *info_keep; int32_t info_none;
+    const uint32_t *fmt_keep;                               // bit `id` set = a projected column reads FORMAT key `id` (nullptr: every key is kept): another key's values are validated by the
+                                                            // measure pass and left out of the record (as a repeated key's are, without the validation, in htslib and here)
     int32_t fmt_none;                                       // no FORMAT column is projected: the sample columns are validated by the measure pass (a line that fails there ends the scan, whatever is
                                                             // projected) and left out of the records: the write pass does not look at them
     int32_t *pos_hi;                                        // [line] bits 32.. of the record's 0-based position (hts_pos_t is 64 bits wide for text, vcf.c:4052-4063)
@@ -608,7 +610,7 @@ __device__ __forceinline__ bool vcf_fmt_fill_sample(const VcfArgs &a, const int6
         const uint32_t at = fat[z] + fsz[z] * m;
         auto put32 = [&](uint32_t idx, uint32_t v) { if (WRITE) __builtin_memcpy(op + at + 4 * idx, &v, 4); };
         auto ch = [&](uint32_t p) -> uint8_t { return p < end ? u[p] : (uint8_t)0; };                                // a sample column is a C string (end: its tab, or the line's end)
-        if (flg[z] & 2) { while (ch(t) != ':' && ch(t)) t++; }
+        if ((flg[z] & 2) || (WRITE && (flg[z] & 4))) { while (ch(t) != ':' && ch(t)) t++; }                 // a repeated key; a key outside the projection (the measure pass has validated its values)
         else if (ht[z] == 3 && (flg[z] & 1)) {                                        // GT: ([/|])?val([/|]val)*, val = digits or '.'
             uint32_t is_phased = 0, maxv = 0, x0 = 0; bool unreadable = false; int l = 0, ploidy = 0, anyunphased = 0, prfx = 0, unknown1 = 0;
             if (a.v44 && (ch(t) == '|' || ch(t) == '/')) { is_phased = ch(t) == '|'; t++; prfx = 1; }
@@ -682,7 +684,7 @@ __device__ __forceinline__ bool vcf_fmt_fill_sample(const VcfArgs &a, const int6
     }
     if (bad) return true;
     for (; j < n_fmt; ++j) {                                                          // trailing fields the sample leaves out
-        if (flg[j] & 2) continue;
+        if (flg[j] & 6) continue;
         const uint32_t at = fat[j] + fsz[j] * m;
         if (!WRITE) continue;
         if (ht[j] == 3 && !(flg[j] & 1)) { for (uint32_t l = 0; l < fsz[j]; l++) op[at + l] = l == 0 ? '.' : 0; }
@@ -865,6 +867,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
                     if (!WRITE && lead) { const uint32_t q = atomicAdd(&a.counters[0], 1u); if (q < a.undef_cap) a.undef[q] = {(uint32_t)li, t + bias, c - t, 3u}; }
                 } else { key[n_fmt] = a.ids.id[k]; ht[n_fmt] = a.ids.ftyp[k]; }
                 flg[n_fmt] = (c - t == 2 && u[t] == 'G' && u[t + 1] == 'T') ? 1 : 0;
+                if (a.fmt_keep && !((a.fmt_keep[(uint32_t)key[n_fmt] >> 5] >> ((uint32_t)key[n_fmt] & 31u)) & 1u)) flg[n_fmt] |= 4;      // flg: 4 = outside the projection
                 mx_l[n_fmt] = mx_m[n_fmt] = mx_g[n_fmt] = 0;
                 n_fmt++;
                 if (c >= fq) break;
@@ -935,7 +938,7 @@ __device__ __forceinline__ void vcf_encode_line(const VcfArgs &a, const int64_t 
             if (!bad && n_sample != (uint32_t)a.n_smp) bad = true;                                   // check7 (fill5 errors found below are errors either way)
             if (!bad) {
                 for (int j = 0; j < n_fmt; j++) {                                                     // (a wave: every lane alike; lane 0 keeps the places)
-                    if (flg[j] & 2) continue;
+                    if (flg[j] & 6) continue;
                     n_fmt_kept++;
                     o.key(key[j]);
                     if (ht[j] == 3 && !(flg[j] & 1)) o.size(fsz[j], 7); else o.size(fsz[j] >> 2, ht[j] == 2 ? 5 : 3);

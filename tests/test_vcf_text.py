@@ -349,7 +349,7 @@ def test_gpu_projection_reaches_the_text_encoder(wave, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("wave", ["0", "1"])
 def test_gpu_projection_without_format_columns_still_validates_the_samples(wave, monkeypatch):
-    """no FORMAT column projected: the encoder leaves the sample data out of the records it makes (VcfArgs::fmt_none), but the measure pass has
+    """no FORMAT column projected, or some: the encoder leaves the sample data (the other keys' values) out of the records it makes (VcfArgs::fmt_none / fmt_keep), but the measure pass has
     walked every sample column -- a line whose samples do not parse ends the scan whatever is projected -- and tidy mode still has a row per
     record and sample"""
     import duckhts_amd
@@ -363,7 +363,9 @@ def test_gpu_projection_without_format_columns_still_validates_the_samples(wave,
             if not exp["cols"]:
                 continue
             names = names_of(exp)
-            for want in (["POS"], ["CHROM", "POS", "REF", "ALT", "QUAL", "FILTER"] + [n for n in names if n.startswith("INFO_")][:2], ["SAMPLE_ID", "POS"] if "SAMPLE_ID" in names else ["ID"]):
+            fmt = [n for n in names if n.startswith("FORMAT_")]
+            some_fmt = [[fmt[0]], [fmt[-1], "POS"], fmt[1:4:2] + ["ID"]] if len(fmt) >= 4 else ([[fmt[0]]] if fmt else [])     # a subset of the FORMAT keys: the others are validated, not written (VcfArgs::fmt_keep)
+            for want in [["POS"], ["CHROM", "POS", "REF", "ALT", "QUAL", "FILTER"] + [n for n in names if n.startswith("INFO_")][:2], ["SAMPLE_ID", "POS"] if "SAMPLE_ID" in names else ["ID"]] + some_fmt:
                 got = duckhts_amd.read_bcf(data, tidy=tidy, columns=[names.index(w) for w in want], max_blocks=1 if len(data) > 3000 else 0)
                 d = orc.bcf_cols_diff({"n_rows": exp["n_rows"], "cols": [exp["by_name"][w] for w in want]}, got)
                 assert d is None, (name, tidy, want, d)

@@ -205,6 +205,7 @@ def main_samples():
     size = os.path.getsize(path)
     print(json.dumps({"generated": path, "records": n, "samples": n_smp, "compressed_bytes": size, "seconds": round(time.time() - t0, 1)}), flush=True)
     for tidy, qn, proj in ((False, "COUNT(*) (wide)", ["CHROM"]), (False, "CHROM,POS,REF,ALT,INFO_AF (wide)", ["CHROM", "POS", "REF", "ALT", "INFO_AF"]),
+                           (True, "tidy: CHROM,POS,SAMPLE_ID,FORMAT_GT", ["CHROM", "POS", "SAMPLE_ID", "FORMAT_GT"]),
                            (True, "tidy: CHROM,POS,SAMPLE_ID,FORMAT_GT,FORMAT_DP,FORMAT_GQ,FORMAT_AD,FORMAT_PL", ["CHROM", "POS", "SAMPLE_ID", "FORMAT_GT", "FORMAT_DP", "FORMAT_GQ", "FORMAT_AD", "FORMAT_PL"])):
         ctx = duckhts_amd.Context(0)
         try:
