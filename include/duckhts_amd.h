@@ -300,7 +300,7 @@ int dhts_bcf_info_get(const dhts_ctx *, dhts_bcf_info *out);
 void dhts_bam_set_qual_packed(dhts_ctx *, int on);
 void dhts_bam_set_seq_packed(dhts_ctx *, int on);                    /* SEQ stays 4 bits per base in the batch: (l + 1) / 2 bytes per row, high nibble first, "=ACMGRSVTWYHKDBN"; len = bases, 0 = "*" */
 void dhts_set_super_blocks(dhts_ctx *, int64_t n_blocks);             /* phase A look-ahead (default 524,288 blocks = 67 GB of scratch for a 10 GB file); the table functions use 196,608 */
-int dhts_bcf_is_text(const dhts_ctx *);                              /* after dhts_bcf_open: 0 binary BCF, 1 bgzipped VCF text, 2 plain VCF text */
+int dhts_bcf_is_text(const dhts_ctx *);                              /* after dhts_bcf_open: 0 binary BCF, 1 bgzipped VCF text, 2 plain VCF text (also: VCF text inside plain, non-BGZF gzip -- inflated by the serial device decoder at open, bgzf.c:828-905) */
 int dhts_bcf_set_projection(dhts_ctx *, const int32_t *col_ids, int32_t n);   /* default: every schema column */
 int dhts_bcf_set_block_range(dhts_ctx *, int64_t b0, int64_t b1, int speculative_start);
 /* ONE region of read_bcf(region := 'a,b,...'): the reference chains single-region iterators in the order given (src/bcf_reader.c:
@@ -349,7 +349,8 @@ int64_t dhts_tabix_build_index(dhts_ctx *, int preset, int sc, int bc, int ec, i
  * EOF block appended.  level 0 stores; -1 and 1..9 all select the one compressing setting.  The bytes are not zlib's bytes (no two DEFLATE
  * implementations agree); every reader returns the input.
  * dhts_bgzf_compress: host buffer -> host buffer; returns the size, or an upper bound when out is NULL / cap is below that bound.
- * dhts_bgzip_file / dhts_bgunzip_file: 0, -2 cannot open input (or not BGZF), -3 cannot open output, -4 read / block error, -5 write error. */
+ * dhts_bgzip_file / dhts_bgunzip_file: 0, -2 cannot open input (or gzip without a block to read), -3 cannot open output, -4 read / block error, -5 write error.
+ * bgunzip reads what bgzf_read reads: BGZF, plain gzip (any content; serial device decoder), and files that are not gzip at all (handed through). */
 int64_t dhts_bgzf_compress(dhts_ctx *, const void *raw, uint64_t n, int level, void *out, uint64_t cap);
 int dhts_bgzip_file(dhts_ctx *, const char *in_path, const char *out_path, int level, int64_t *bytes_in, int64_t *bytes_out);
 int dhts_bgunzip_file(dhts_ctx *, const char *in_path, const char *out_path, int64_t *bytes_in, int64_t *bytes_out);
